@@ -1,0 +1,230 @@
+"""ctypes binding of the C ABI declared in include/agarcl_batch.h (libagarcl_hip.so).
+
+The HIP engine is the only implementation this package ships: if the shared library is missing or
+no HIP device is present, loading/creating fails loudly -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_SO = os.path.join(_HERE, "libagarcl_hip.so")
+
+E_UNSUPPORTED = -3
+
+
+class AgarclError(RuntimeError):
+    """Raised for every non-zero return of the C ABI (the reference raises RuntimeError through
+    pybind11 for EngineException / EnvironmentException)."""
+
+    def __init__(self, code, msg):
+        super().__init__("agarcl error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("num_agents", C.c_int32), ("ticks_per_step", C.c_int32), ("arena_size", C.c_int32),
+        ("pellet_regen", C.c_int32), ("num_pellets", C.c_int32), ("num_viruses", C.c_int32),
+        ("num_bots", C.c_int32), ("reward_type", C.c_int32), ("c_death", C.c_int32),
+        ("mode_number", C.c_int32), ("dt", C.c_double), ("cap_cells", C.c_int32),
+        ("cap_viruses", C.c_int32), ("cap_foods", C.c_int32), ("reserved", C.c_int32 * 5),
+    ]
+
+
+# every symbol include/agarcl_batch.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("agarcl_last_error", C.c_char_p, []),
+    ("agarcl_device_count", C.c_int, []),
+    ("agarcl_create", C.c_int, [C.POINTER(Config), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    ("agarcl_destroy", C.c_int, [C.c_void_p]),
+    ("agarcl_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("agarcl_sync", C.c_int, [C.c_void_p]),
+    ("agarcl_seed", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    ("agarcl_reset", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    ("agarcl_set_actions", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    ("agarcl_step", C.c_int, [C.c_void_p, C.c_int32]),
+    ("agarcl_tick", C.c_int, [C.c_void_p, C.c_int32]),
+    ("agarcl_set_targets", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("agarcl_respawn_dead", C.c_int, [C.c_void_p]),
+    ("agarcl_rewards_dev", C.c_void_p, [C.c_void_p]),
+    ("agarcl_dones_dev", C.c_void_p, [C.c_void_p]),
+    ("agarcl_masses_dev", C.c_void_p, [C.c_void_p]),
+    ("agarcl_flags_dev", C.c_void_p, [C.c_void_p]),
+    ("agarcl_get_rewards", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("agarcl_get_dones", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("agarcl_get_masses", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("agarcl_get_flags", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("agarcl_get_counts", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("agarcl_get_events", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
+    ("agarcl_grid_obs", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]),
+    ("agarcl_dump_arena", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
+    ("agarcl_load_arena", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
+    ("agarcl_num_arenas", C.c_int, [C.c_void_p]),
+    ("agarcl_players_per_arena", C.c_int, [C.c_void_p]),
+    ("agarcl_state_bytes", C.c_int64, [C.c_void_p]),
+]
+
+
+def bind(cdll):
+    """Attach prototypes for every declared symbol; raises AttributeError if one is missing."""
+    for name, res, args in SYMBOLS:
+        fn = getattr(cdll, name)
+        fn.restype = res
+        fn.argtypes = args
+    return cdll
+
+
+_hip = None
+
+
+def hip_lib():
+    """The product library.  Fails loudly when it has not been built (python -c 'import
+    __graft_entry__ as g; g.build()' or agarcl_amd/build.py)."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_SO):
+            raise AgarclError(-4, "HIP extension %s is missing -- build it with agarcl_amd/build.py "
+                                  "(there is no CPU fallback)" % HIP_SO)
+        _hip = bind(C.CDLL(HIP_SO))
+    return _hip
+
+
+def _ptr(x):
+    """host numpy array or raw device pointer (int) -> void*"""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    return C.c_void_p(x.ctypes.data)
+
+
+class BatchedEngine:
+    """Thin object wrapper over one agarcl_env (N arenas stepped in lock-step)."""
+
+    def __init__(self, num_arenas, num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True,
+                 num_pellets=1000, num_viruses=0, num_bots=0, reward_type=1, c_death=0, mode=0, dt=1.0 / 30,
+                 device=0, cap_cells=0, cap_viruses=0, cap_foods=0, lib=None):
+        self.L = lib if lib is not None else hip_lib()
+        self.cfg = Config(num_agents, ticks_per_step, arena_size, int(bool(pellet_regen)), num_pellets, num_viruses,
+                          num_bots, int(reward_type), c_death, mode, dt, cap_cells, cap_viruses, cap_foods)
+        self.h = C.c_void_p()
+        self.num_arenas = num_arenas
+        self.num_agents = num_agents
+        self.dt = dt
+        self._chk(self.L.agarcl_create(C.byref(self.cfg), num_arenas, device, C.byref(self.h)))
+        self.players = self.L.agarcl_players_per_arena(self.h)
+        self._blob = np.zeros(1 << 16, dtype=np.uint32)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise AgarclError(rc, (self.L.agarcl_last_error() or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.agarcl_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- control ------------------------------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        self._chk(self.L.agarcl_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def sync(self):
+        self._chk(self.L.agarcl_sync(self.h))
+
+    def seed(self, seeds=None, base_seed=0):
+        if seeds is not None:
+            seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+            assert seeds.shape == (self.num_arenas,)
+        self._chk(self.L.agarcl_seed(self.h, _ptr(seeds), base_seed))
+
+    def reset(self, mask=None, reset_ids=False):
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+            assert mask.shape == (self.num_arenas,)
+        self._chk(self.L.agarcl_reset(self.h, _ptr(mask), int(reset_ids)))
+
+    def set_actions(self, dxdy, act):
+        """host arrays: dxdy [A, n_agents, 2] f32, act [A, n_agents] i32"""
+        dxdy = np.ascontiguousarray(dxdy, dtype=np.float32).reshape(self.num_arenas, self.num_agents, 2)
+        act = np.ascontiguousarray(act, dtype=np.int32).reshape(self.num_arenas, self.num_agents)
+        self._chk(self.L.agarcl_set_actions(self.h, _ptr(dxdy), _ptr(act), 0))
+
+    def set_actions_device(self, dxdy_ptr, act_ptr):
+        """raw HBM pointers (ints); buffers must outlive the next step()"""
+        self._chk(self.L.agarcl_set_actions(self.h, C.c_void_p(dxdy_ptr), C.c_void_p(act_ptr), 1))
+
+    def step(self, ticks=0):
+        self._chk(self.L.agarcl_step(self.h, ticks))
+
+    def tick(self, ticks=1):
+        self._chk(self.L.agarcl_tick(self.h, ticks))
+
+    def set_targets(self, txy, act):
+        txy = np.ascontiguousarray(txy, dtype=np.float32).reshape(self.num_arenas, self.players, 2)
+        act = np.ascontiguousarray(act, dtype=np.int32).reshape(self.num_arenas, self.players)
+        self._chk(self.L.agarcl_set_targets(self.h, _ptr(txy), _ptr(act)))
+
+    def respawn_dead(self):
+        self._chk(self.L.agarcl_respawn_dead(self.h))
+
+    # -- results ------------------------------------------------------------------------------
+    def rewards(self):
+        out = np.zeros((self.num_arenas, self.num_agents), dtype=np.float64)
+        self._chk(self.L.agarcl_get_rewards(self.h, _ptr(out)))
+        return out
+
+    def dones(self):
+        out = np.zeros((self.num_arenas, self.num_agents), dtype=np.uint8)
+        self._chk(self.L.agarcl_get_dones(self.h, _ptr(out)))
+        return out.astype(bool)
+
+    def masses(self):
+        out = np.zeros((self.num_arenas, self.num_agents), dtype=np.int32)
+        self._chk(self.L.agarcl_get_masses(self.h, _ptr(out)))
+        return out
+
+    def flags(self):
+        out = np.zeros(self.num_arenas, dtype=np.uint32)
+        self._chk(self.L.agarcl_get_flags(self.h, _ptr(out)))
+        return out
+
+    def counts(self):
+        out = np.zeros((self.num_arenas, 4), dtype=np.int32)
+        self._chk(self.L.agarcl_get_counts(self.h, _ptr(out)))
+        return out
+
+    def events(self, cap=256, cap_v=16):
+        n = np.zeros((self.num_arenas, 2), dtype=np.int32)
+        pe = np.full((self.num_arenas, cap), -1, dtype=np.int32)
+        ve = np.full((self.num_arenas, cap_v), -1, dtype=np.int32)
+        self._chk(self.L.agarcl_get_events(self.h, _ptr(n), _ptr(pe), cap, _ptr(ve), cap_v))
+        return n, pe, ve
+
+    def device_ptrs(self):
+        return {"rewards": self.L.agarcl_rewards_dev(self.h), "dones": self.L.agarcl_dones_dev(self.h),
+                "masses": self.L.agarcl_masses_dev(self.h), "flags": self.L.agarcl_flags_dev(self.h)}
+
+    def state_bytes(self):
+        return int(self.L.agarcl_state_bytes(self.h))
+
+    # -- state exchange -------------------------------------------------------------------------
+    def dump(self, arena=0):
+        n = self.L.agarcl_dump_arena(self.h, arena, _ptr(self._blob), len(self._blob))
+        if n < -1000:
+            self._blob = np.zeros(-n, dtype=np.uint32)
+            n = self.L.agarcl_dump_arena(self.h, arena, _ptr(self._blob), len(self._blob))
+        if n < 0:
+            self._chk(n)
+        return self._blob[:n].copy()
+
+    def load(self, blob, arena=0):
+        blob = np.ascontiguousarray(blob, dtype=np.uint32)
+        self._chk(self.L.agarcl_load_arena(self.h, arena, _ptr(blob), len(blob)))

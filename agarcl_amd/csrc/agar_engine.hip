@@ -1,0 +1,507 @@
+// libagarcl_hip.so -- HIP kernels (gfx950) and the C ABI of include/agarcl_batch.h.
+//
+// One 64-lane wavefront per arena (grid = num_arenas single-wave workgroups): a launch steps all
+// arenas in lock-step; per-arena state is staged HBM -> LDS once per launch, all `ticks` ticks of a
+// step() run out of LDS, and the changed state is written back once.  No torch types cross this ABI.
+//
+// Build (product):   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared ...   (see build.py)
+// Build (test-only): g++ -x c++ -DAGAR_CPU_EMU ...   -> tests/_build/libagarcl_emu.so: the same wave-level
+//                    source with lanes executed as loops, used by CPU tests to diff kernel logic against
+//                    the oracle.  agarcl_amd never loads it.
+#ifndef AGAR_CPU_EMU
+#include <hip/hip_runtime.h>
+#endif
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/agarcl_batch.h"
+#include "agar_core.inl"
+
+// ---- thread-local error string -------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string &m) { g_err = m; return code; }
+extern "C" const char *agarcl_last_error(void) { return g_err.c_str(); }
+
+// ---- memory / launch abstraction -----------------------------------------------------------------
+#ifdef AGAR_CPU_EMU
+typedef void *ag_stream_t;
+static void *dmalloc(size_t n) { return calloc(1, n ? n : 1); }
+static void dfree(void *p) { free(p); }
+static int h2d(void *d, const void *h, size_t n, ag_stream_t) { memcpy(d, h, n); return 0; }
+static int d2h(void *h, const void *d, size_t n, ag_stream_t) { memcpy(h, d, n); return 0; }
+static int dsync(ag_stream_t) { return 0; }
+#else
+typedef hipStream_t ag_stream_t;
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(AGARCL_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+static void *dmalloc(size_t n) { void *p = nullptr; if (hipMalloc(&p, n ? n : 1) != hipSuccess) return nullptr; (void)hipMemset(p, 0, n ? n : 1); return p; }
+static void dfree(void *p) { if (p) (void)hipFree(p); }
+static int h2d(void *d, const void *h, size_t n, ag_stream_t s) { return hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
+static int d2h(void *h, const void *d, size_t n, ag_stream_t s) { return hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
+static int dsync(ag_stream_t s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
+#endif
+
+struct agarcl_env {
+  agarcl_config cfg;
+  AgDims d; AgParams g; AgState s;
+  int device;
+  ag_stream_t stream; bool own_stream;
+  size_t lds_bytes;
+  std::vector<void *> allocs;
+  float *d_act_dxdy; int32_t *d_act;  // env-owned action buffers (host-copy path)
+  float *lut_r, *lut_ms, *lut_ss, *lut_anti;
+};
+
+// ---- kernels ----------------------------------------------------------------------------------------
+#ifdef AGAR_CPU_EMU
+template <class F> static void for_each_arena(agarcl_env *e, F f) {
+  std::vector<unsigned char> lds(e->lds_bytes + 64);
+  for (int a = 0; a < e->d.A; a++) {
+    AgCtx c; c.d = e->d; c.g = e->g;
+    ag_bind_lds(c, lds.data()); ag_bind_arena(c, e->s, a);
+    f(c);
+  }
+}
+#else
+extern __shared__ __align__(16) unsigned char ag_lds[];
+#define AG_KERNEL_PROLOGUE AgCtx c; c.d = d; c.g = g; ag_bind_lds(c, ag_lds); ag_bind_arena(c, s, (int)blockIdx.x);
+
+__global__ void __launch_bounds__(64) k_step(AgState s, AgDims d, AgParams g, int ticks, int with_env) {
+  AG_KERNEL_PROLOGUE
+  arena_load(c, s);
+  env_step(c, s, ticks, with_env != 0);
+  arena_store(c, s);
+}
+__global__ void __launch_bounds__(64) k_reset(AgState s, AgDims d, AgParams g, const uint8_t *mask, int reset_ids) {
+  if (mask && !mask[blockIdx.x]) return;
+  AG_KERNEL_PROLOGUE
+  arena_load(c, s);
+  env_reset(c, reset_ids);
+  arena_store(c, s);
+}
+__global__ void __launch_bounds__(64) k_respawn(AgState s, AgDims d, AgParams g) {
+  AG_KERNEL_PROLOGUE
+  arena_load(c, s);
+  respawn_dead(c);
+  arena_store(c, s);
+}
+__global__ void k_set_word(int32_t *base, int stride, int n, int value) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) base[(size_t)i * stride] = value;
+}
+#endif
+
+static int launch_step(agarcl_env *e, int ticks, int with_env) {
+#ifdef AGAR_CPU_EMU
+  for_each_arena(e, [&](AgCtx &c) { arena_load(c, e->s); env_step(c, e->s, ticks, with_env != 0); arena_store(c, e->s); });
+#else
+  hipLaunchKernelGGL(k_step, dim3(e->d.A), dim3(64), e->lds_bytes, e->stream, e->s, e->d, e->g, ticks, with_env);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+static int launch_reset(agarcl_env *e, const uint8_t *mask_dev, const uint8_t *mask_host, int reset_ids) {
+#ifdef AGAR_CPU_EMU
+  (void)mask_dev;
+  for_each_arena(e, [&](AgCtx &c) { if (mask_host && !mask_host[c.arena]) return; arena_load(c, e->s); env_reset(c, reset_ids); arena_store(c, e->s); });
+#else
+  (void)mask_host;
+  hipLaunchKernelGGL(k_reset, dim3(e->d.A), dim3(64), e->lds_bytes, e->stream, e->s, e->d, e->g, mask_dev, reset_ids);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+// ---- host helpers -------------------------------------------------------------------------------------
+template <class T> static T *alloc(agarcl_env *e, size_t n) { T *p = (T *)dmalloc(n * sizeof(T)); if (p) e->allocs.push_back(p); return p; }
+
+static void mt_seed_host(uint64_t *mt, uint64_t seed) {  // std::mt19937_64::seed
+  mt[0] = seed;
+  for (int i = 1; i < 312; i++) mt[i] = 6364136223846793005ULL * (mt[i - 1] ^ (mt[i - 1] >> 62)) + (uint64_t)i;
+}
+
+static int set_mode(AgParams &g, int mode) {  // R: Engine.hpp:367-416
+  switch (mode) {
+    case 0: case 4: g.mass_decay = 1; g.squared = 0; g.regen = 1; g.agent_mass = 25; return 0;
+    case 1: g.mass_decay = 0; g.squared = 1; g.regen = 0; g.agent_mass = 25; return 0;
+    case 2: g.mass_decay = 1; g.squared = 1; g.regen = 0; g.agent_mass = 25; return 0;
+    case 3: g.mass_decay = 0; g.squared = 0; g.regen = 1; g.agent_mass = 25; return 0;
+    case 5: set_mode(g, 2); g.agent_mass = 1000; return 0;
+    case 6: set_mode(g, 4); g.agent_mass = 1000; return 0;
+    case 7: case 8: case 9: case 10: set_mode(g, 4); return 0;
+    default: return -1;
+  }
+}
+
+extern "C" int agarcl_device_count(void) {
+#ifdef AGAR_CPU_EMU
+  return 1;
+#else
+  int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n;
+#endif
+}
+
+extern "C" int agarcl_destroy(agarcl_env *e) {
+  if (!e) return AGARCL_OK;
+#ifndef AGAR_CPU_EMU
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  if (e->own_stream) (void)hipStreamDestroy(e->stream);
+#endif
+  for (void *p : e->allocs) dfree(p);
+  delete e;
+  return AGARCL_OK;
+}
+
+extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32_t device, agarcl_env **out) {
+  if (!cfg || !out || num_arenas <= 0) return fail(AGARCL_E_INVALID, "agarcl_create: bad arguments");
+  if (cfg->num_agents < 1 || cfg->ticks_per_step < 1 || cfg->arena_size < 8 || cfg->num_pellets < 0 || cfg->num_viruses < 0 || cfg->num_bots < 0)
+    return fail(AGARCL_E_INVALID, "agarcl_create: invalid environment arguments");
+  AgParams g; memset(&g, 0, sizeof(g));
+  if (set_mode(g, cfg->mode_number) != 0) return fail(AGARCL_E_MODE, "Invalid mode number");
+  // Scope of the HIP path this round: one RL agent per arena, no scripted bots.
+  if (cfg->num_bots > 0 && (cfg->mode_number == 0 || cfg->mode_number > 6))
+    return fail(AGARCL_E_UNSUPPORTED, "agarcl_create: scripted bots are not implemented on the HIP path yet (num_bots must be 0; modes 7-10 need a bot)");
+  if (cfg->mode_number > 6) return fail(AGARCL_E_UNSUPPORTED, "agarcl_create: modes 7-10 add a scripted bot, not implemented on the HIP path yet");
+  if (cfg->num_agents != 1) return fail(AGARCL_E_UNSUPPORTED, "agarcl_create: multi-agent arenas (cell-eats-cell) are not implemented on the HIP path yet");
+#ifndef AGAR_CPU_EMU
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(AGARCL_E_HIP, "agarcl_create: no HIP device available (the HIP engine has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(AGARCL_E_INVALID, "agarcl_create: bad device index");
+  HIPCHK(hipSetDevice(device));
+#endif
+  agarcl_env *e = new agarcl_env();
+  e->cfg = *cfg; e->device = device; e->own_stream = true; e->d_act_dxdy = nullptr; e->d_act = nullptr;
+#ifdef AGAR_CPU_EMU
+  e->stream = nullptr;
+#else
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(AGARCL_E_HIP, "hipStreamCreate failed"); }
+#endif
+  double dt = cfg->dt > 0 ? cfg->dt : 1.0 / 30.0;
+  g.W = (float)cfg->arena_size;
+  g.target_pellets = cfg->num_pellets; g.target_viruses = cfg->num_viruses; g.mode = cfg->mode_number;
+  g.dt = (float)dt; g.dt10 = (float)(dt * 10);
+  g.recomb_ticks = (int)ceil(10.0 / dt - 1e-9);
+  g.reward_type = cfg->reward_type != 0; g.c_death = cfg->c_death;
+  // grid dims exactly as the reference computes them in float (Engine.hpp:964-965, 1210-1211)
+  g.pgw = g.pgh = (int)((g.W + (float)AG_PELLET_GRID - 1.0f) / (float)AG_PELLET_GRID);
+  g.vgw = g.vgh = (int)((g.W + (float)AG_VIRUS_GRID - 1.0f) / (float)AG_VIRUS_GRID);
+  AgDims d;
+  d.A = num_arenas; d.n_agents = cfg->num_agents; d.P = cfg->num_agents + cfg->num_bots;
+  d.CC = cfg->cap_cells > 0 ? cfg->cap_cells : 32;
+  int npel = cfg->num_pellets;
+  if (g.squared) { int pps = (int)(g.W / 2.0f); npel = 4 * pps; }
+  d.PC = ((npel > 0 ? npel : 1) + 63) / 64 * 64;
+  d.VC = cfg->cap_viruses > 0 ? cfg->cap_viruses : cfg->num_viruses + 64;
+  d.FC = cfg->cap_foods > 0 ? cfg->cap_foods : 256;
+  if (d.P > AG_MAX_PLAYERS) { agarcl_destroy(e); return fail(AGARCL_E_UNSUPPORTED, "too many players per arena"); }
+  if (d.CC > 64 || d.CC < 16) { agarcl_destroy(e); return fail(AGARCL_E_INVALID, "cap_cells must be in [16, 64]"); }
+  e->d = d; e->g = g;
+  e->lds_bytes = ag_lds_bytes(d);
+  if (e->lds_bytes > 160 * 1024) { agarcl_destroy(e); return fail(AGARCL_E_UNSUPPORTED, "arena does not fit the 160 KiB LDS of a CU (too many pellets)"); }
+  AgState &s = e->s; memset(&s, 0, sizeof(s));
+  size_t A = (size_t)d.A;
+  s.pel_x = alloc<float>(e, A * d.PC); s.pel_y = alloc<float>(e, A * d.PC); s.pel_id = alloc<int32_t>(e, A * d.PC);
+  s.vir_x = alloc<float>(e, A * d.VC); s.vir_y = alloc<float>(e, A * d.VC); s.vir_vx = alloc<float>(e, A * d.VC); s.vir_vy = alloc<float>(e, A * d.VC);
+  s.vir_mass = alloc<int32_t>(e, A * d.VC); s.vir_hits = alloc<int32_t>(e, A * d.VC); s.vir_id = alloc<int32_t>(e, A * d.VC);
+  s.food_x = alloc<float>(e, A * d.FC); s.food_y = alloc<float>(e, A * d.FC); s.food_vx = alloc<float>(e, A * d.FC); s.food_vy = alloc<float>(e, A * d.FC); s.food_id = alloc<int32_t>(e, A * d.FC);
+  size_t NC = A * d.P * d.CC;
+  s.cell_x = alloc<float>(e, NC); s.cell_y = alloc<float>(e, NC); s.cell_vx = alloc<float>(e, NC); s.cell_vy = alloc<float>(e, NC); s.cell_sx = alloc<float>(e, NC); s.cell_sy = alloc<float>(e, NC);
+  s.cell_m = alloc<uint32_t>(e, NC); s.cell_id = alloc<int32_t>(e, NC); s.cell_dl = alloc<uint32_t>(e, NC);
+  s.pl = alloc<int32_t>(e, A * d.P * PL_WORDS); s.vticks = alloc<int32_t>(e, A * d.P * AG_VT_CAP); s.ar = alloc<int32_t>(e, A * AR_WORDS);
+  s.mt = alloc<uint64_t>(e, A * 312); s.rnd = alloc<int32_t>(e, A * 35);
+  s.rewards = alloc<double>(e, A * d.n_agents); s.dones = alloc<uint8_t>(e, A * d.n_agents); s.masses = alloc<int32_t>(e, A * d.n_agents);
+  s.counts = alloc<int32_t>(e, A * 4); s.ev_p = alloc<int32_t>(e, A * AG_EV_CAP); s.ev_v = alloc<int32_t>(e, A * AG_EVV_CAP);
+  e->d_act_dxdy = alloc<float>(e, A * d.n_agents * 2); e->d_act = alloc<int32_t>(e, A * d.n_agents);
+  e->lut_r = alloc<float>(e, AG_LUT_SIZE); e->lut_ms = alloc<float>(e, AG_LUT_SIZE); e->lut_ss = alloc<float>(e, AG_LUT_SIZE); e->lut_anti = alloc<float>(e, AG_ANTI_LUT);
+  if (!e->lut_anti || !s.ev_v || !s.mt || !s.cell_dl) { agarcl_destroy(e); return fail(AGARCL_E_NOMEM, "device allocation failed"); }
+  s.lut_r = e->lut_r; s.lut_ms = e->lut_ms; s.lut_ss = e->lut_ss; s.lut_anti = e->lut_anti;
+  s.act_dxdy = nullptr; s.act = nullptr;
+  {  // mass -> fp32 tables: the reference's double-precision islands, evaluated with the host libm
+     // (core/utils.hpp:8-11; Engine.hpp:1296-1302; Engine.hpp:567)
+    std::vector<float> r(AG_LUT_SIZE), ms(AG_LUT_SIZE), ss(AG_LUT_SIZE), an(AG_ANTI_LUT);
+    for (int m = 0; m < AG_LUT_SIZE; m++) {
+      double area = (double)(unsigned)m / 1.0;
+      r[m] = (float)sqrt(area / 3.14159265358979323846);
+      ms[m] = (float)(300.0 / pow((double)(unsigned)m, 0.439));
+      double v = 3.0 * pow((double)ms[m], 1.2);
+      double cl = (v < 130.0) ? v : 130.0; cl = (cl < 20.0) ? 20.0 : cl;
+      ss[m] = (float)cl;
+    }
+    for (int k = 0; k < AG_ANTI_LUT; k++) an[k] = (float)pow(1.1, (double)k);
+    if (h2d(e->lut_r, r.data(), r.size() * 4, e->stream) || h2d(e->lut_ms, ms.data(), ms.size() * 4, e->stream) ||
+        h2d(e->lut_ss, ss.data(), ss.size() * 4, e->stream) || h2d(e->lut_anti, an.data(), an.size() * 4, e->stream)) { agarcl_destroy(e); return fail(AGARCL_E_HIP, "LUT upload failed"); }
+  }
+  {  // initial arena words: id counter 1 (first entity id 2, core/Ball.hpp:18,97), identity player order
+    std::vector<int32_t> ar(A * AR_WORDS, 0);
+    for (size_t a = 0; a < A; a++) { ar[a * AR_WORDS + AR_IDC] = 1; ar[a * AR_WORDS + AR_MTIDX] = 312; for (int p = 0; p < d.P; p++) ar[a * AR_WORDS + AR_ORDER0 + p] = p; }
+    if (h2d(s.ar, ar.data(), ar.size() * 4, e->stream)) { agarcl_destroy(e); return fail(AGARCL_E_HIP, "state upload failed"); }
+  }
+  *out = e;
+  // the reference constructor resets once (BaseEnvironment.hpp:66)
+  int rc = agarcl_seed(e, nullptr, 5489u);
+  if (rc == 0) rc = agarcl_reset(e, nullptr, 1);
+  if (rc != 0) { agarcl_destroy(e); *out = nullptr; return rc; }
+  return AGARCL_OK;
+}
+
+extern "C" int agarcl_set_stream(agarcl_env *e, void *hip_stream) {
+  if (!e) return fail(AGARCL_E_INVALID, "null env");
+#ifndef AGAR_CPU_EMU
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (hip_stream) { if (e->own_stream) (void)hipStreamDestroy(e->stream); e->stream = (hipStream_t)hip_stream; e->own_stream = false; }
+  else if (!e->own_stream) { HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)); e->own_stream = true; }
+#else
+  (void)hip_stream;
+#endif
+  return AGARCL_OK;
+}
+extern "C" int agarcl_sync(agarcl_env *e) {
+  if (!e) return fail(AGARCL_E_INVALID, "null env");
+  return dsync(e->stream) ? fail(AGARCL_E_HIP, "stream synchronize failed") : AGARCL_OK;
+}
+
+extern "C" int agarcl_seed(agarcl_env *e, const uint32_t *seeds_host, uint32_t base_seed) {
+  if (!e) return fail(AGARCL_E_INVALID, "null env");
+  size_t A = (size_t)e->d.A;
+  std::vector<uint64_t> mt(A * 312);
+  for (size_t a = 0; a < A; a++) mt_seed_host(&mt[a * 312], (uint64_t)(seeds_host ? seeds_host[a] : base_seed + (uint32_t)a));
+  if (h2d(e->s.mt, mt.data(), mt.size() * 8, e->stream)) return fail(AGARCL_E_HIP, "seed upload failed");
+#ifdef AGAR_CPU_EMU
+  for (size_t a = 0; a < A; a++) e->s.ar[a * AR_WORDS + AR_MTIDX] = 312;
+#else
+  HIPCHK(hipSetDevice(e->device));
+  hipLaunchKernelGGL(k_set_word, dim3((e->d.A + 255) / 256), dim3(256), 0, e->stream, e->s.ar + AR_MTIDX, AR_WORDS, e->d.A, 312);
+  HIPCHK(hipGetLastError());
+#endif
+  return AGARCL_OK;
+}
+
+extern "C" int agarcl_reset(agarcl_env *e, const uint8_t *mask_host, int32_t reset_ids) {
+  if (!e) return fail(AGARCL_E_INVALID, "null env");
+  uint8_t *mask_dev = nullptr;
+#ifndef AGAR_CPU_EMU
+  HIPCHK(hipSetDevice(e->device));
+  if (mask_host) {
+    mask_dev = (uint8_t *)dmalloc((size_t)e->d.A);
+    if (!mask_dev) return fail(AGARCL_E_NOMEM, "mask alloc failed");
+    if (h2d(mask_dev, mask_host, (size_t)e->d.A, e->stream)) { dfree(mask_dev); return fail(AGARCL_E_HIP, "mask upload failed"); }
+  }
+#endif
+  int rc = launch_reset(e, mask_dev, mask_host, reset_ids);
+  if (mask_dev) { dsync(e->stream); dfree(mask_dev); }
+  return rc;
+}
+
+extern "C" int agarcl_set_actions(agarcl_env *e, const float *dxdy, const int32_t *act, int32_t on_device) {
+  if (!e || !dxdy || !act) return fail(AGARCL_E_INVALID, "agarcl_set_actions: null pointer");
+  size_t n = (size_t)e->d.A * e->d.n_agents;
+  if (on_device) { e->s.act_dxdy = dxdy; e->s.act = act; return AGARCL_OK; }
+  if (h2d(e->d_act_dxdy, dxdy, n * 8, e->stream) || h2d(e->d_act, act, n * 4, e->stream)) return fail(AGARCL_E_HIP, "action upload failed");
+  e->s.act_dxdy = e->d_act_dxdy; e->s.act = e->d_act;
+  return AGARCL_OK;
+}
+
+extern "C" int agarcl_step(agarcl_env *e, int32_t ticks) {
+  if (!e) return fail(AGARCL_E_INVALID, "null env");
+#ifndef AGAR_CPU_EMU
+  HIPCHK(hipSetDevice(e->device));
+#endif
+  return launch_step(e, ticks > 0 ? ticks : e->cfg.ticks_per_step, 1);
+}
+extern "C" int agarcl_tick(agarcl_env *e, int32_t ticks) {
+  if (!e) return fail(AGARCL_E_INVALID, "null env");
+#ifndef AGAR_CPU_EMU
+  HIPCHK(hipSetDevice(e->device));
+#endif
+  return launch_step(e, ticks > 0 ? ticks : 1, 0);
+}
+
+extern "C" int agarcl_set_targets(agarcl_env *e, const float *txy_host, const int32_t *act_host) {
+  if (!e || !txy_host || !act_host) return fail(AGARCL_E_INVALID, "agarcl_set_targets: null pointer");
+  size_t n = (size_t)e->d.A * e->d.P;
+  std::vector<int32_t> pl(n * PL_WORDS);
+  if (d2h(pl.data(), e->s.pl, pl.size() * 4, e->stream)) return fail(AGARCL_E_HIP, "download failed");
+  for (size_t i = 0; i < n; i++) {
+    memcpy(&pl[i * PL_WORDS + PL_TX], &txy_host[2 * i], 4); memcpy(&pl[i * PL_WORDS + PL_TY], &txy_host[2 * i + 1], 4);
+    pl[i * PL_WORDS + PL_ACTION] = act_host[i];
+  }
+  if (h2d(e->s.pl, pl.data(), pl.size() * 4, e->stream)) return fail(AGARCL_E_HIP, "upload failed");
+  return AGARCL_OK;
+}
+
+extern "C" int agarcl_respawn_dead(agarcl_env *e) {
+  if (!e) return fail(AGARCL_E_INVALID, "null env");
+#ifdef AGAR_CPU_EMU
+  for_each_arena(e, [&](AgCtx &c) { arena_load(c, e->s); respawn_dead(c); arena_store(c, e->s); });
+#else
+  HIPCHK(hipSetDevice(e->device));
+  hipLaunchKernelGGL(k_respawn, dim3(e->d.A), dim3(64), e->lds_bytes, e->stream, e->s, e->d, e->g);
+  HIPCHK(hipGetLastError());
+#endif
+  return AGARCL_OK;
+}
+
+extern "C" const double *agarcl_rewards_dev(agarcl_env *e) { return e ? e->s.rewards : nullptr; }
+extern "C" const uint8_t *agarcl_dones_dev(agarcl_env *e) { return e ? e->s.dones : nullptr; }
+extern "C" const int32_t *agarcl_masses_dev(agarcl_env *e) { return e ? e->s.masses : nullptr; }
+extern "C" const uint32_t *agarcl_flags_dev(agarcl_env *e) { return e ? (const uint32_t *)(e->s.ar + AR_FLAGS) : nullptr; }
+
+#define GETTER(name, field, type, count) \
+  extern "C" int name(agarcl_env *e, type *out) { \
+    if (!e || !out) return fail(AGARCL_E_INVALID, #name ": null pointer"); \
+    return d2h(out, e->s.field, (size_t)(count) * sizeof(type), e->stream) ? fail(AGARCL_E_HIP, #name ": copy failed") : AGARCL_OK; }
+GETTER(agarcl_get_rewards, rewards, double, e->d.A * e->d.n_agents)
+GETTER(agarcl_get_dones, dones, uint8_t, e->d.A * e->d.n_agents)
+GETTER(agarcl_get_masses, masses, int32_t, e->d.A * e->d.n_agents)
+GETTER(agarcl_get_counts, counts, int32_t, e->d.A * 4)
+
+extern "C" int agarcl_get_flags(agarcl_env *e, uint32_t *out) {
+  if (!e || !out) return fail(AGARCL_E_INVALID, "agarcl_get_flags: null pointer");
+  std::vector<int32_t> ar((size_t)e->d.A * AR_WORDS);
+  if (d2h(ar.data(), e->s.ar, ar.size() * 4, e->stream)) return fail(AGARCL_E_HIP, "copy failed");
+  for (int a = 0; a < e->d.A; a++) out[a] = (uint32_t)ar[(size_t)a * AR_WORDS + AR_FLAGS];
+  return AGARCL_OK;
+}
+
+extern "C" int agarcl_get_events(agarcl_env *e, int32_t *n_events_host, int32_t *pellet_idx_host, int32_t cap, int32_t *virus_idx_host, int32_t cap_v) {
+  if (!e || !n_events_host) return fail(AGARCL_E_INVALID, "agarcl_get_events: null pointer");
+  size_t A = (size_t)e->d.A;
+  std::vector<int32_t> ar(A * AR_WORDS), evp(A * AG_EV_CAP), evv(A * AG_EVV_CAP);
+  if (d2h(ar.data(), e->s.ar, ar.size() * 4, e->stream) || d2h(evp.data(), e->s.ev_p, evp.size() * 4, e->stream) || d2h(evv.data(), e->s.ev_v, evv.size() * 4, e->stream))
+    return fail(AGARCL_E_HIP, "copy failed");
+  for (size_t a = 0; a < A; a++) {
+    int np = ar[a * AR_WORDS + AR_NEVP], nv = ar[a * AR_WORDS + AR_NEVV];
+    n_events_host[2 * a] = np; n_events_host[2 * a + 1] = nv;
+    if (pellet_idx_host) for (int i = 0; i < np && i < cap && i < AG_EV_CAP; i++) pellet_idx_host[a * cap + i] = evp[a * AG_EV_CAP + i];
+    if (virus_idx_host) for (int i = 0; i < nv && i < cap_v && i < AG_EVV_CAP; i++) virus_idx_host[a * cap_v + i] = evv[a * AG_EVV_CAP + i];
+  }
+  return AGARCL_OK;
+}
+
+extern "C" int agarcl_num_arenas(agarcl_env *e) { return e ? e->d.A : 0; }
+extern "C" int agarcl_players_per_arena(agarcl_env *e) { return e ? e->d.P : 0; }
+
+// ---- state blobs (oracle/BLOB_FORMAT.md) ------------------------------------------------------------------
+namespace {
+struct ArenaHost {
+  std::vector<int32_t> ar, pl, vt;
+  std::vector<float> px, py, vx, vy, vvx, vvy, fx, fy, fvx, fvy, cx, cy, cvx, cvy, csx, csy;
+  std::vector<int32_t> pid, vm, vh, vid, fid, cid; std::vector<uint32_t> cm, cdl;
+};
+template <class T> int pull(agarcl_env *e, std::vector<T> &h, const T *dev, size_t off, size_t n) { h.resize(n); return n ? d2h(h.data(), dev + off, n * sizeof(T), e->stream) : 0; }
+template <class T> int push(agarcl_env *e, const std::vector<T> &h, T *dev, size_t off) { return h.empty() ? 0 : h2d(dev + off, h.data(), h.size() * sizeof(T), e->stream); }
+}  // namespace
+
+extern "C" int agarcl_dump_arena(agarcl_env *e, int32_t arena, uint32_t *buf, int32_t cap) {
+  if (!e || !buf || arena < 0 || arena >= e->d.A) return fail(AGARCL_E_INVALID, "agarcl_dump_arena: bad arguments");
+  const AgDims &d = e->d; const AgState &s = e->s; size_t a = (size_t)arena; ArenaHost h; int rc = 0;
+  rc |= pull(e, h.ar, s.ar, a * AR_WORDS, AR_WORDS); rc |= pull(e, h.pl, s.pl, a * d.P * PL_WORDS, (size_t)d.P * PL_WORDS); rc |= pull(e, h.vt, s.vticks, a * d.P * AG_VT_CAP, (size_t)d.P * AG_VT_CAP);
+  if (rc) return fail(AGARCL_E_HIP, "copy failed");
+  size_t np = (size_t)h.ar[AR_NPEL], nv = (size_t)h.ar[AR_NVIR], nf = (size_t)h.ar[AR_NFOOD];
+  rc |= pull(e, h.px, s.pel_x, a * d.PC, np); rc |= pull(e, h.py, s.pel_y, a * d.PC, np); rc |= pull(e, h.pid, s.pel_id, a * d.PC, np);
+  rc |= pull(e, h.vx, s.vir_x, a * d.VC, nv); rc |= pull(e, h.vy, s.vir_y, a * d.VC, nv); rc |= pull(e, h.vvx, s.vir_vx, a * d.VC, nv); rc |= pull(e, h.vvy, s.vir_vy, a * d.VC, nv);
+  rc |= pull(e, h.vm, s.vir_mass, a * d.VC, nv); rc |= pull(e, h.vh, s.vir_hits, a * d.VC, nv); rc |= pull(e, h.vid, s.vir_id, a * d.VC, nv);
+  rc |= pull(e, h.fx, s.food_x, a * d.FC, nf); rc |= pull(e, h.fy, s.food_y, a * d.FC, nf); rc |= pull(e, h.fvx, s.food_vx, a * d.FC, nf); rc |= pull(e, h.fvy, s.food_vy, a * d.FC, nf); rc |= pull(e, h.fid, s.food_id, a * d.FC, nf);
+  size_t nc = (size_t)d.P * d.CC, co = a * nc;
+  rc |= pull(e, h.cx, s.cell_x, co, nc); rc |= pull(e, h.cy, s.cell_y, co, nc); rc |= pull(e, h.cvx, s.cell_vx, co, nc); rc |= pull(e, h.cvy, s.cell_vy, co, nc);
+  rc |= pull(e, h.csx, s.cell_sx, co, nc); rc |= pull(e, h.csy, s.cell_sy, co, nc); rc |= pull(e, h.cm, s.cell_m, co, nc); rc |= pull(e, h.cid, s.cell_id, co, nc); rc |= pull(e, h.cdl, s.cell_dl, co, nc);
+  if (rc) return fail(AGARCL_E_HIP, "copy failed");
+  std::vector<uint32_t> o;
+  auto F = [&](float f) { uint32_t u; memcpy(&u, &f, 4); o.push_back(u); };
+  o.push_back(0x31524741u); o.push_back((uint32_t)h.ar[AR_TICKS]); o.push_back((uint32_t)h.ar[AR_IDC]); o.push_back((uint32_t)h.ar[AR_NEXT_PID]);
+  o.push_back((uint32_t)np); o.push_back((uint32_t)nv); o.push_back((uint32_t)nf); o.push_back((uint32_t)d.P);
+  for (float v : h.px) F(v); for (float v : h.py) F(v); for (int32_t v : h.pid) o.push_back((uint32_t)v);
+  for (float v : h.vx) F(v); for (float v : h.vy) F(v); for (float v : h.vvx) F(v); for (float v : h.vvy) F(v);
+  for (int32_t v : h.vm) o.push_back((uint32_t)v); for (int32_t v : h.vh) o.push_back((uint32_t)v); for (int32_t v : h.vid) o.push_back((uint32_t)v);
+  for (float v : h.fx) F(v); for (float v : h.fy) F(v); for (float v : h.fvx) F(v); for (float v : h.fvy) F(v); for (int32_t v : h.fid) o.push_back((uint32_t)v);
+  uint32_t clock = (uint32_t)h.ar[AR_CLOCK];
+  for (int k = 0; k < d.P; k++) {
+    int p = h.ar[AR_ORDER0 + k]; const int32_t *P = &h.pl[(size_t)p * PL_WORDS];
+    o.push_back((uint32_t)P[PL_PID]); o.push_back(P[PL_KIND] != 0 ? 1u : 0u); o.push_back((uint32_t)P[PL_NCELLS]); o.push_back((uint32_t)P[PL_ACTION]);
+    o.push_back((uint32_t)P[PL_TX]); o.push_back((uint32_t)P[PL_TY]); o.push_back((uint32_t)P[PL_SPLIT_CD]); o.push_back((uint32_t)P[PL_FEED_CD]);
+    o.push_back((uint32_t)P[PL_ELAPSED]); o.push_back((uint32_t)P[PL_LAST_DECAY]); o.push_back((uint32_t)P[PL_ANTI_TEAM]);
+    o.push_back((uint32_t)P[PL_FOOD_EATEN]); o.push_back((uint32_t)P[PL_HIGHEST_MASS]); o.push_back((uint32_t)P[PL_CELLS_EATEN]); o.push_back((uint32_t)P[PL_VIRUSES_EATEN]);
+    o.push_back((uint32_t)P[PL_MIN_MASS]); o.push_back((uint32_t)P[PL_NVTICKS]);
+    for (int i = 0; i < P[PL_NVTICKS]; i++) o.push_back((uint32_t)h.vt[(size_t)p * AG_VT_CAP + i]);
+    for (int i = 0; i < P[PL_NCELLS]; i++) {
+      size_t q = (size_t)p * d.CC + i;
+      F(h.cx[q]); F(h.cy[q]); F(h.cvx[q]); F(h.cvy[q]); F(h.csx[q]); F(h.csy[q]);
+      o.push_back(h.cm[q]); o.push_back((uint32_t)h.cid[q]);
+      o.push_back(h.cdl[q] > clock ? h.cdl[q] - clock : 0u);
+    }
+  }
+  if ((int64_t)o.size() > cap) return -(int)o.size() - 1000;
+  memcpy(buf, o.data(), o.size() * 4);
+  return (int)o.size();
+}
+
+extern "C" int agarcl_load_arena(agarcl_env *e, int32_t arena, const uint32_t *b, int32_t words) {
+  if (!e || !b || arena < 0 || arena >= e->d.A || words < 8 || b[0] != 0x31524741u) return fail(AGARCL_E_INVALID, "agarcl_load_arena: bad arguments");
+  const AgDims &d = e->d; const AgState &s = e->s; size_t a = (size_t)arena; ArenaHost h;
+  uint32_t np = b[4], nv = b[5], nf = b[6], npl = b[7];
+  if ((int)npl != d.P) return fail(AGARCL_E_INVALID, "agarcl_load_arena: player count mismatch");
+  if ((int)np > d.PC || (int)nv > d.VC || (int)nf > d.FC) return fail(AGARCL_E_CAPACITY, "agarcl_load_arena: blob exceeds arena capacities");
+  if (pull(e, h.ar, s.ar, a * AR_WORDS, AR_WORDS) || pull(e, h.pl, s.pl, a * d.P * PL_WORDS, (size_t)d.P * PL_WORDS)) return fail(AGARCL_E_HIP, "copy failed");
+  h.vt.assign((size_t)d.P * AG_VT_CAP, 0);
+  auto U2F = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+  const uint32_t *p = b + 8;
+  h.ar[AR_TICKS] = (int32_t)b[1]; h.ar[AR_IDC] = (int32_t)b[2]; h.ar[AR_NEXT_PID] = (int32_t)b[3];
+  h.ar[AR_NPEL] = (int32_t)np; h.ar[AR_NVIR] = (int32_t)nv; h.ar[AR_NFOOD] = (int32_t)nf;
+  for (uint32_t i = 0; i < np; i++) { h.px.push_back(U2F(p[i])); h.py.push_back(U2F(p[np + i])); h.pid.push_back((int32_t)p[2 * np + i]); }
+  p += 3 * np;
+  for (uint32_t i = 0; i < nv; i++) { h.vx.push_back(U2F(p[i])); h.vy.push_back(U2F(p[nv + i])); h.vvx.push_back(U2F(p[2 * nv + i])); h.vvy.push_back(U2F(p[3 * nv + i]));
+    h.vm.push_back((int32_t)p[4 * nv + i]); h.vh.push_back((int32_t)p[5 * nv + i]); h.vid.push_back((int32_t)p[6 * nv + i]); }
+  p += 7 * nv;
+  for (uint32_t i = 0; i < nf; i++) { h.fx.push_back(U2F(p[i])); h.fy.push_back(U2F(p[nf + i])); h.fvx.push_back(U2F(p[2 * nf + i])); h.fvy.push_back(U2F(p[3 * nf + i])); h.fid.push_back((int32_t)p[4 * nf + i]); }
+  p += 5 * nf;
+  size_t nc = (size_t)d.P * d.CC;
+  h.cx.assign(nc, 0); h.cy.assign(nc, 0); h.cvx.assign(nc, 0); h.cvy.assign(nc, 0); h.csx.assign(nc, 0); h.csy.assign(nc, 0); h.cm.assign(nc, 0); h.cid.assign(nc, 0); h.cdl.assign(nc, 0);
+  uint32_t clock = (uint32_t)h.ar[AR_CLOCK];
+  for (int k = 0; k < d.P; k++) {
+    int slot = h.ar[AR_ORDER0 + k]; int32_t *P = &h.pl[(size_t)slot * PL_WORDS];
+    if ((int32_t)p[0] != P[PL_PID]) return fail(AGARCL_E_INVALID, "agarcl_load_arena: pid / iteration order mismatch");
+    uint32_t ncell = p[2];
+    if ((int)ncell > d.CC) return fail(AGARCL_E_CAPACITY, "agarcl_load_arena: too many cells");
+    P[PL_NCELLS] = (int32_t)ncell; P[PL_ACTION] = (int32_t)p[3]; P[PL_TX] = (int32_t)p[4]; P[PL_TY] = (int32_t)p[5]; P[PL_SPLIT_CD] = (int32_t)p[6]; P[PL_FEED_CD] = (int32_t)p[7];
+    P[PL_ELAPSED] = (int32_t)p[8]; P[PL_LAST_DECAY] = (int32_t)p[9]; P[PL_ANTI_TEAM] = (int32_t)p[10]; P[PL_FOOD_EATEN] = (int32_t)p[11]; P[PL_HIGHEST_MASS] = (int32_t)p[12];
+    P[PL_CELLS_EATEN] = (int32_t)p[13]; P[PL_VIRUSES_EATEN] = (int32_t)p[14]; P[PL_MIN_MASS] = (int32_t)p[15];
+    uint32_t nt = p[16];
+    if (nt > AG_VT_CAP) return fail(AGARCL_E_CAPACITY, "agarcl_load_arena: too many virus ticks");
+    P[PL_NVTICKS] = (int32_t)nt;
+    for (uint32_t i = 0; i < nt; i++) h.vt[(size_t)slot * AG_VT_CAP + i] = (int32_t)p[17 + i];
+    p += 17 + nt;
+    for (uint32_t i = 0; i < ncell; i++, p += 9) {
+      size_t q = (size_t)slot * d.CC + i;
+      h.cx[q] = U2F(p[0]); h.cy[q] = U2F(p[1]); h.cvx[q] = U2F(p[2]); h.cvy[q] = U2F(p[3]); h.csx[q] = U2F(p[4]); h.csy[q] = U2F(p[5]);
+      h.cm[q] = p[6] > AG_CELL_MIN_SIZE ? p[6] : AG_CELL_MIN_SIZE; h.cid[q] = (int32_t)p[7]; h.cdl[q] = clock + p[8];
+    }
+  }
+  if (p - b != words) return fail(AGARCL_E_INVALID, "agarcl_load_arena: blob length mismatch");
+  int rc = 0;
+  rc |= push(e, h.ar, s.ar, a * AR_WORDS); rc |= push(e, h.pl, s.pl, a * d.P * PL_WORDS); rc |= push(e, h.vt, s.vticks, a * d.P * AG_VT_CAP);
+  rc |= push(e, h.px, s.pel_x, a * d.PC); rc |= push(e, h.py, s.pel_y, a * d.PC); rc |= push(e, h.pid, s.pel_id, a * d.PC);
+  rc |= push(e, h.vx, s.vir_x, a * d.VC); rc |= push(e, h.vy, s.vir_y, a * d.VC); rc |= push(e, h.vvx, s.vir_vx, a * d.VC); rc |= push(e, h.vvy, s.vir_vy, a * d.VC);
+  rc |= push(e, h.vm, s.vir_mass, a * d.VC); rc |= push(e, h.vh, s.vir_hits, a * d.VC); rc |= push(e, h.vid, s.vir_id, a * d.VC);
+  rc |= push(e, h.fx, s.food_x, a * d.FC); rc |= push(e, h.fy, s.food_y, a * d.FC); rc |= push(e, h.fvx, s.food_vx, a * d.FC); rc |= push(e, h.fvy, s.food_vy, a * d.FC); rc |= push(e, h.fid, s.food_id, a * d.FC);
+  size_t co = a * nc;
+  rc |= push(e, h.cx, s.cell_x, co); rc |= push(e, h.cy, s.cell_y, co); rc |= push(e, h.cvx, s.cell_vx, co); rc |= push(e, h.cvy, s.cell_vy, co);
+  rc |= push(e, h.csx, s.cell_sx, co); rc |= push(e, h.csy, s.cell_sy, co); rc |= push(e, h.cm, s.cell_m, co); rc |= push(e, h.cid, s.cell_id, co); rc |= push(e, h.cdl, s.cell_dl, co);
+  return rc ? fail(AGARCL_E_HIP, "upload failed") : AGARCL_OK;
+}
+
+extern "C" int64_t agarcl_state_bytes(agarcl_env *e) {
+  if (!e) return 0;
+  // streaming model (DESIGN.md / SURVEY.md 8d): pellet (x,y) read + cells r/w + player r/w + action in / result out
+  return 8LL * e->cfg.num_pellets + 12LL * e->cfg.num_viruses + 72LL * 1 + 112LL * e->d.P + 24LL * e->d.n_agents;
+}
+
+extern "C" int agarcl_grid_obs(agarcl_env *e, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t *, int32_t *) {
+  if (!e) return fail(AGARCL_E_INVALID, "null env");
+  return fail(AGARCL_E_UNSUPPORTED, "agarcl_grid_obs: not implemented yet");
+}

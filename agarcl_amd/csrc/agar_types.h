@@ -1,0 +1,91 @@
+// Shared host/device definitions of the batched engine's HBM-resident SoA state.
+// Layout rationale: DESIGN.md "Data layout in HBM".
+#pragma once
+#include <stdint.h>
+
+// game constants: /root/reference/agario/core/settings.hpp:5-50, core/Entities.hpp:9-18
+#define AG_CELL_MIN_SIZE 25u
+#define AG_CELL_SPLIT_MINIMUM 50u
+#define AG_SPLIT_DECEL 80.0f
+#define AG_FOOD_SPEED 100.0f
+#define AG_FOOD_DECEL 80.0f
+#define AG_CELL_POP_SIZE 25u
+#define AG_PLAYER_CELL_LIMIT 14
+#define AG_FOOD_HITS 7
+#define AG_MAX_MASS 22500u
+#define AG_NEW_MASS_NO_SPLIT 22000u
+#define AG_ANTI_TEAM_TICKS 3600
+#define AG_PELLET_MASS 1u
+#define AG_FOOD_MASS 10u
+#define AG_VIRUS_MASS 100u
+#define AG_PELLET_GRID 510
+#define AG_VIRUS_GRID 25
+
+// per-player int32 words ([A][P][PL_WORDS]); floats are bit-cast
+enum {
+  PL_NCELLS = 0, PL_ACTION, PL_TX, PL_TY, PL_SPLIT_CD, PL_FEED_CD, PL_ELAPSED, PL_LAST_DECAY, PL_ANTI_TEAM,
+  PL_FOOD_EATEN, PL_HIGHEST_MASS, PL_CELLS_EATEN, PL_VIRUSES_EATEN, PL_MIN_MASS, PL_NVTICKS, PL_PID, PL_KIND,
+  PL_WORDS = 20
+};
+// per-arena int32 words ([A][AR_WORDS])
+enum {
+  AR_TICKS = 0, AR_CLOCK, AR_IDC, AR_NEXT_PID, AR_NPEL, AR_NVIR, AR_NFOOD, AR_FLAGS, AR_MTIDX,
+  AR_NEVP, AR_NEVV, AR_DONE, AR_RESPAWNED, AR_ORDER0 /* P slots of player order follow */,
+  AR_WORDS = 32
+};
+#define AG_MAX_PLAYERS (AR_WORDS - AR_ORDER0)
+#define AG_EV_CAP 256   // pellet eat events per arena-tick
+#define AG_EVV_CAP 16   // virus eat events per arena-tick (<= players)
+#define AG_CAND_CAP 128 // pellet candidates per cell in the ordered slow path
+#define AG_VT_CAP 32    // virus_eaten_ticks kept per player
+#define AG_LUT_SIZE (1 << 19)
+#define AG_ANTI_LUT 64
+
+struct AgDims {
+  int A;         // arenas
+  int P;         // player slots per arena (agents + bots)
+  int n_agents;  // RL-controlled players per arena
+  int CC;        // cell capacity per player
+  int PC;        // pellet capacity per arena (multiple of 64)
+  int VC;        // virus capacity
+  int FC;        // food capacity
+};
+
+struct AgParams {
+  float W;                 // arena width == height
+  int target_pellets, target_viruses;
+  int mass_decay, squared, agent_mass, regen, mode;  // Engine.hpp:362-416
+  float dt, dt10;          // (float)dt and (float)(dt*10) (Engine.hpp:613,674)
+  int recomb_ticks;        // 10 s in ticks
+  int reward_type, c_death;
+  int pgw, pgh, vgw, vgh;  // pellet / virus grid dims (Engine.hpp:964-965,1210-1211)
+};
+
+struct AgState {
+  // pellets [A][PC]
+  float *pel_x, *pel_y; int32_t *pel_id;
+  // viruses [A][VC]
+  float *vir_x, *vir_y, *vir_vx, *vir_vy; int32_t *vir_mass, *vir_hits, *vir_id;
+  // foods [A][FC]
+  float *food_x, *food_y, *food_vx, *food_vy; int32_t *food_id;
+  // cells [A][P][CC]
+  float *cell_x, *cell_y, *cell_vx, *cell_vy, *cell_sx, *cell_sy;
+  uint32_t *cell_m; int32_t *cell_id; uint32_t *cell_dl;
+  int32_t *pl;      // [A][P][PL_WORDS]
+  int32_t *vticks;  // [A][P][AG_VT_CAP]
+  int32_t *ar;      // [A][AR_WORDS]
+  uint64_t *mt;     // [A][312]
+  int32_t *rnd;     // [A][35] glibc rand() state (bots / colour draws)
+  // inputs
+  const float *act_dxdy;  // [A][n_agents][2]
+  const int32_t *act;     // [A][n_agents]
+  // outputs
+  double *rewards;        // [A][n_agents]
+  uint8_t *dones;         // [A][n_agents]
+  int32_t *masses;        // [A][n_agents]
+  int32_t *counts;        // [A][4]
+  int32_t *ev_p;          // [A][AG_EV_CAP]
+  int32_t *ev_v;          // [A][AG_EVV_CAP]
+  // read-only tables (mass -> fp32), host generated (Engine.hpp:1296-1302, core/utils.hpp:8-11)
+  const float *lut_r, *lut_ms, *lut_ss, *lut_anti;
+};

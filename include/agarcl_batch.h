@@ -1,0 +1,139 @@
+/* agarcl_batch.h -- C ABI of the MI355X-native batched Agar.io engine (libagarcl_hip.so).
+ *
+ * Drop-in boundary.  The reference exposes ONE arena per object through the pybind11 module `agarcl`
+ * (/root/reference/environment/bindings.cpp:94-376).  Nothing in the reference calls a C ABI today;
+ * these entry points are what a maintainer binds instead of the C++ classes (INTEGRATION.md shows
+ * the pybind11 stub).  Each function cites the reference interface it replaces.  All arenas of one
+ * `agarcl_env` are stepped in lock-step by one kernel launch; the reference's single-arena classes
+ * are the num_arenas == 1 case.
+ *
+ * Conventions: every call returns 0 on success or a negative AGARCL_E_* code and never throws;
+ * agarcl_last_error() returns a thread-local message (the reference throws EngineException /
+ * EnvironmentException, Engine.hpp:25-27, BaseEnvironment.hpp:19-21 -> Python RuntimeError).
+ * Not re-entrant per env; distinct envs may be used from distinct threads.
+ * Pointers named *_dev are device (HBM) pointers, *_host are host pointers.
+ */
+#ifndef AGARCL_BATCH_H
+#define AGARCL_BATCH_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGARCL_OK 0
+#define AGARCL_E_INVALID (-1)     /* bad argument (e.g. action count mismatch, BaseEnvironment.hpp:142-144) */
+#define AGARCL_E_MODE (-2)        /* invalid mode number (Engine.hpp:413-414) */
+#define AGARCL_E_UNSUPPORTED (-3) /* configuration the HIP path does not implement yet (fails loudly) */
+#define AGARCL_E_HIP (-4)         /* HIP runtime error / no device */
+#define AGARCL_E_NOMEM (-5)
+#define AGARCL_E_CAPACITY (-6)    /* blob does not fit the arena capacities */
+
+/* per-arena sticky flag bits (agarcl_get_flags): a fixed-capacity SoA array overflowed -- the arena
+ * has diverged from the unbounded std::vector semantics of the reference and must be reset. */
+#define AGARCL_F_CELLS_OVERFLOW 1u
+#define AGARCL_F_FOODS_OVERFLOW 2u
+#define AGARCL_F_VIRUSES_OVERFLOW 4u
+#define AGARCL_F_EVENTS_OVERFLOW 8u
+#define AGARCL_F_VTICKS_OVERFLOW 16u
+#define AGARCL_F_MASS_LUT_OVERFLOW 32u
+#define AGARCL_F_PELLETS_OVERFLOW 64u
+
+/* Mirrors the positional constructor arguments of GridEnvironment / BaseEnvironment
+ * (bindings.cpp:102; BaseEnvironment.hpp:36-67) plus the engine time step and SoA capacities. */
+typedef struct agarcl_config {
+  int32_t num_agents;     /* RL-controlled players per arena */
+  int32_t ticks_per_step; /* Engine::tick calls per step() (BaseEnvironment.hpp:93-94) */
+  int32_t arena_size;     /* square arena (BaseEnvironment.hpp:54) */
+  int32_t pellet_regen;
+  int32_t num_pellets;
+  int32_t num_viruses;
+  int32_t num_bots;
+  int32_t reward_type;    /* 0: reward = mass, 1: reward = mass difference (BaseEnvironment.hpp:116-121) */
+  int32_t c_death;
+  int32_t mode_number;    /* Engine.hpp:367-416 */
+  double dt;              /* seconds per tick; 0 -> DEFAULT_DT = 1/30 (BaseEnvironment.hpp:14) */
+  int32_t cap_cells;      /* cells per player, 0 -> 32 (reference: unbounded vector, nominal limit 14) */
+  int32_t cap_viruses;    /* 0 -> num_viruses + 64 */
+  int32_t cap_foods;      /* 0 -> 256 */
+  int32_t reserved[5];
+} agarcl_config;
+
+typedef struct agarcl_env agarcl_env;
+
+const char *agarcl_last_error(void);
+int agarcl_device_count(void);
+
+/* replaces: GridEnvironment(...) ctor, bindings.cpp:102 (one object per arena).  Like the reference
+ * ctor (BaseEnvironment.hpp:66) it performs one reset() (seed 5489-like default; call
+ * agarcl_seed + agarcl_reset for reproducible episodes). */
+int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32_t device, agarcl_env **out);
+/* replaces: object destruction / close(), bindings.cpp:134 */
+int agarcl_destroy(agarcl_env *env);
+/* use an existing HIP stream (hipStream_t) for all launches and copies; NULL = the env's own stream */
+int agarcl_set_stream(agarcl_env *env, void *hip_stream);
+int agarcl_sync(agarcl_env *env);
+
+/* replaces: seed(int), bindings.cpp:103 -> Engine::seed, Engine.hpp:242-245.  seeds_host[num_arenas];
+ * NULL -> arena i gets base_seed + i. */
+int agarcl_seed(agarcl_env *env, const uint32_t *seeds_host, uint32_t base_seed);
+/* replaces: reset(), bindings.cpp:130 -> BaseEnvironment::reset, BaseEnvironment.hpp:179-204.
+ * mask_host[num_arenas] (nullable = all).  reset_ids != 0 restarts the arena's entity-id counter
+ * (the reference's is process-global and never restarts, core/Ball.hpp:15). */
+int agarcl_reset(agarcl_env *env, const uint8_t *mask_host, int32_t reset_ids);
+
+/* replaces: take_actions(list[(dx,dy,a)]), bindings.cpp:117-119 -> BaseEnvironment.hpp:141-176.
+ * dxdy[num_arenas][num_agents][2] f32, act[num_arenas][num_agents] i32 (0 none, 1 feed, 2 split:
+ * core/types.hpp:59-61).  on_device != 0: the pointers are HBM pointers and no copy is made -- they
+ * must stay valid until the next agarcl_step has been enqueued. */
+int agarcl_set_actions(agarcl_env *env, const float *dxdy, const int32_t *act, int32_t on_device);
+/* replaces: step() -> list[float], bindings.cpp:132 -> BaseEnvironment::step, BaseEnvironment.hpp:89-122.
+ * ticks <= 0 -> ticks_per_step.  Asynchronous on the env's stream. */
+int agarcl_step(agarcl_env *env, int32_t ticks);
+/* engine-level tick without the env's action/reward logic (Engine::tick, Engine.hpp:208-240);
+ * targets/actions as last set via agarcl_set_targets. */
+int agarcl_tick(agarcl_env *env, int32_t ticks);
+/* absolute targets (Player::target/action, core/Player.hpp:26-27) for every player slot:
+ * txy[num_arenas][players][2], act[num_arenas][players]; host pointers. */
+int agarcl_set_targets(agarcl_env *env, const float *txy_host, const int32_t *act_host);
+/* BaseEnvironment::repsawn_all_players (BaseEnvironment.hpp:73-81) */
+int agarcl_respawn_dead(agarcl_env *env);
+
+/* results of the last step, HBM-resident: rewards f64[num_arenas][num_agents] (vector<double>,
+ * BaseEnvironment.hpp:31,116-121), dones u8[...] (BaseEnvironment.hpp:206), masses i32[...],
+ * flags u32[num_arenas] */
+const double *agarcl_rewards_dev(agarcl_env *env);
+const uint8_t *agarcl_dones_dev(agarcl_env *env);
+const int32_t *agarcl_masses_dev(agarcl_env *env);
+const uint32_t *agarcl_flags_dev(agarcl_env *env);
+/* synchronising host copies */
+int agarcl_get_rewards(agarcl_env *env, double *out_host);
+int agarcl_get_dones(agarcl_env *env, uint8_t *out_host);
+int agarcl_get_masses(agarcl_env *env, int32_t *out_host);
+int agarcl_get_flags(agarcl_env *env, uint32_t *out_host);
+/* live entity counts of the last step: i32[num_arenas][4] = pellets, viruses, foods, cells(all players) */
+int agarcl_get_counts(agarcl_env *env, int32_t *out_host);
+/* eat events of the LAST tick executed, per arena (pellets_to_remove / viruses_to_remove order,
+ * Engine.hpp:992,1243): n_events i32[num_arenas][2], pellet_idx i32[num_arenas][cap] */
+int agarcl_get_events(agarcl_env *env, int32_t *n_events_host, int32_t *pellet_idx_host, int32_t cap,
+                      int32_t *virus_idx_host, int32_t cap_v);
+
+/* replaces: configure_observation(dict) + observation_shape() + get_state() of GridEnvironment,
+ * bindings.cpp:104-116,133 -> GridObservation::add_frame, GridEnvironment.hpp:91-123.
+ * Writes i32[num_arenas][num_agents][C][G][G] into out_dev (HBM); returns C through *channels. */
+int agarcl_grid_obs(agarcl_env *env, int32_t grid_size, int32_t observe_cells, int32_t observe_others,
+                    int32_t observe_viruses, int32_t observe_pellets, int32_t *out_dev, int32_t *channels);
+
+/* full-state exchange for parity tests and snapshots (layout: oracle/BLOB_FORMAT.md); synchronising */
+int agarcl_dump_arena(agarcl_env *env, int32_t arena, uint32_t *buf_host, int32_t cap_words);
+int agarcl_load_arena(agarcl_env *env, int32_t arena, const uint32_t *blob_host, int32_t words);
+
+/* introspection */
+int agarcl_num_arenas(agarcl_env *env);
+int agarcl_players_per_arena(agarcl_env *env);
+/* HBM bytes the engine reads+writes per arena-tick under the streaming model of DESIGN.md */
+int64_t agarcl_state_bytes(agarcl_env *env);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGARCL_BATCH_H */
