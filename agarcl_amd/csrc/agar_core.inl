@@ -42,9 +42,13 @@ AG_DEV unsigned ag_uniu(unsigned v) { return (unsigned)__builtin_amdgcn_readfirs
 AG_DEV float ag_unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 // make lane-0 / other-lane stores to LDS+HBM visible to the whole wave before it continues
 AG_DEV void ag_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
-AG_DEV float ag_sqrtf(float x) { return __fsqrt_rn(x); }   // IEEE correctly rounded
-AG_DEV float ag_divf(float a, float b) { return __fdiv_rn(a, b); }
+// IEEE correctly rounded: built with -fhip-fp32-correctly-rounded-divide-sqrt (build.py); NOT __fsqrt_rn,
+// which ROCm's headers map to the approximate __ocml_native_sqrt_f32.
+AG_DEV float ag_sqrtf(float x) { return __builtin_sqrtf(x); }
+AG_DEV float ag_divf(float a, float b) { return a / b; }
 #endif
+
+#include "agar_libm.inl"
 
 // ---- collectives --------------------------------------------------------------------------------
 #ifdef AGAR_CPU_EMU
@@ -366,7 +370,7 @@ AG_DEV void v_decelerate(float &dx, float &dy, float decel, float dt) {
   if (fabsf(ddy * dt) <= fabsf(dy)) { float t = ddy * dt; dy -= t; } else dy = 0.0f;
 }
 AG_DEV float v_direction(float dx, float dy) {  // R: types.hpp:167-174
-  float angle = atanf(ag_divf(dx, dy));
+  float angle = ag_atanf(ag_divf(dx, dy));
   if (dx < 0) { if (dy > 0) angle = (float)((double)angle + 3.14159265358979323846); else angle = (float)((double)angle - 3.14159265358979323846); }
   return angle;
 }
@@ -587,7 +591,7 @@ AG_DEV bool virus_collisions(AgCtx &c, int p, int n, int create_limit, bool can_
         float inc = (float)(2 * 3.14159265358979323846 * j / num_new);
         float dvel = theta + inc;
         float ang = theta + dvel;
-        float svx = sp * cosf(ang), svy = sp * sinf(ang);
+        float svx = sp * ag_cosf(ang), svy = sp * ag_sinf(ang);
         unsigned rem = pop - AG_CELL_POP_SIZE * (unsigned)j;  // each earlier new cell took min(rem, 25)
         unsigned cmass = rem < AG_CELL_POP_SIZE ? rem : AG_CELL_POP_SIZE;
         put_created(c, nc0 + j, virx, viry, cvx, cvy, svx, svy, cmass, idc + 1 + j, dl);
