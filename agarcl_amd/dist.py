@@ -1,0 +1,67 @@
+"""Multi-GPU sharding: arenas are independent, so they shard contiguously across ranks with NO
+data-path collective inside the tick.  The only exchange is gathering per-step results (reward +
+done, 8 bytes per arena) to rank 0 -- RCCL over xGMI on GPUs ("nccl" backend), gloo in CPU tests.
+
+There is no counterpart in the reference (single process, one arena); the closest thing is its thread
+pool running independent engines (/root/reference/agario/bots/benchmark.cpp:146-168).
+"""
+
+
+def shard_bounds(total, world_size, rank):
+    """Contiguous block [lo, hi) of `total` arenas owned by `rank` (first ranks take the remainder)."""
+    base, rem = divmod(total, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def arena_seeds(base_seed, lo, hi):
+    """Per-arena seeds depend on the GLOBAL arena index only, so results are independent of how many
+    GPUs the job is sharded over."""
+    import numpy as np
+    return (base_seed + np.arange(lo, hi, dtype=np.int64)).astype(np.uint32)
+
+
+class ResultGatherer:
+    """Double-buffered asynchronous gather of (reward, done) rows to rank 0.
+
+    pack(k, rewards, dones) copies this step's results into slot k % depth on the current stream and
+    starts a gather; the collective overlaps the next step's kernel.  Buffers are float32 [A_local, 2].
+    Works with any torch.distributed backend (nccl == RCCL on ROCm, gloo on CPU)."""
+
+    def __init__(self, n_local, device, depth=2, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.depth = depth
+        self.send = [torch.zeros((n_local, 2), dtype=torch.float32, device=device) for _ in range(depth)]
+        self.recv = None
+        if self.rank == 0:
+            self.recv = [[torch.zeros((n_local, 2), dtype=torch.float32, device=device) for _ in range(self.world)]
+                         for _ in range(depth)]
+        self.work = [None] * depth
+        self.n_local = n_local
+
+    def pack(self, k, rewards, dones):
+        s = k % self.depth
+        if self.work[s] is not None:
+            self.work[s].wait()
+        buf = self.send[s]
+        buf[:, 0].copy_(rewards.reshape(-1))
+        buf[:, 1].copy_(dones.reshape(-1))
+        self.work[s] = self.dist.gather(buf, self.recv[s] if self.rank == 0 else None, dst=0, group=self.group,
+                                        async_op=True)
+        return s
+
+    def wait_all(self):
+        for i, w in enumerate(self.work):
+            if w is not None:
+                w.wait()
+                self.work[i] = None
+
+    def gathered(self, slot):
+        """rank 0: float32 [world * n_local, 2] of the given slot (after its work completed)."""
+        if self.rank != 0:
+            return None
+        return self.torch.cat(self.recv[slot], dim=0)

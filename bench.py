@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""Headline benchmark: env-steps/s (arenas x engine ticks per second) of the batched HIP engine.
+
+Workload = BASELINE.json configs[1] / SURVEY.md 8(d) "C2": 4096 arenas per GPU, each 1000x1000,
+1000 pellets, 0 viruses, 1 agent, no bots, pellet regen, mode 0, dt = 1/30, 4 ticks per env step,
+action "none", (dx,dy) ~ U(-1,1)^2 pre-generated in HBM, arena seeds = 10000 + global arena index.
+A bench "step" is one agarcl_step launch = 4 engine ticks of every arena.
+
+    python bench.py --gpus 1 --steps 400 --warmup 40
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the roofline / cpu_baseline fields).
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ARENAS_PER_GPU = 4096
+CFG = dict(num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True, num_pellets=1000, num_viruses=0,
+           num_bots=0, reward_type=1, c_death=0, mode_number=0)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
+
+
+def cpu_baseline(seconds_budget=12.0):
+    """The same per-arena workload on the host cores, timed on a bounded sample.
+    kind "reference": oracle/_ref/libagar_ref.so = the unmodified reference engine (prebuilt from
+    /root/reference); otherwise kind "port": the plain-C restatement."""
+    cores = os.cpu_count() or 1
+    try:
+        from oracle import refbind
+        use_ref = refbind.available()
+    except Exception:
+        use_ref = False
+    if use_ref:
+        from oracle import refbind as B
+        mk = lambda: B.RefEnv(num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True, num_pellets=1000,
+                              num_viruses=0, num_bots=0, reward_type=1, c_death=0, mode=0)
+        kind = "reference"
+    else:
+        from oracle import orabind as B
+        if not B.available():
+            B.build()
+        mk = lambda: B.OraEnv(num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True, num_pellets=1000,
+                              num_viruses=0, num_bots=0, reward_type=1, c_death=0, mode=0)
+        kind = "port"
+    # calibrate on one core
+    e = mk(); e.seed(10000); e.reset(True)
+    t0 = time.perf_counter(); e.run_random(4000, policy_seed=1, allow_actions=False); dt1 = time.perf_counter() - t0
+    rate1 = 4000 / dt1
+    ticks_each = max(4000, int(rate1 * seconds_budget * 0.8 / 2))  # 2 arenas per thread
+    done = [0] * cores
+
+    def worker(w):
+        for j in range(2):
+            env = mk(); env.seed(10000 + w * 2 + j); env.reset(True)
+            done[w] += env.run_random(ticks_each, policy_seed=w * 2 + j + 1, allow_actions=False)
+            env.close()
+    th = [threading.Thread(target=worker, args=(w,)) for w in range(cores)]
+    t0 = time.perf_counter()
+    for t in th: t.start()
+    for t in th: t.join()
+    el = time.perf_counter() - t0
+    total = sum(done)
+    return {"value": total / el, "unit": "env-steps/s", "cores": cores, "kind": kind,
+            "sample": "%d arenas x %d ticks of the C2 workload, one engine per host thread (%d threads, ctypes releases "
+                      "the GIL); single-core rate %.0f ticks/s" % (2 * cores, ticks_each, cores, rate1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--arenas", type=int, default=ARENAS_PER_GPU, help="arenas per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import numpy as np
+    from agarcl_amd.vec_env import VecEnvironment
+    from agarcl_amd import dist as agdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    A = args.arenas
+    K, Wm = args.steps, args.warmup
+    lo, hi = rank * A, (rank + 1) * A  # weak scaling: every GPU owns `A` arenas
+    env = VecEnvironment(A, device=local_rank, **CFG)
+    env.seed(agdist.arena_seeds(10000, lo, hi))
+    env.reset(reset_ids=True)
+
+    # synthetic random policy, resident in HBM before the timed region: counter-based per (arena, step)
+    g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
+    dxdy = (torch.rand((K + Wm, A, 1, 2), generator=g, device=dev, dtype=torch.float32) * 2.0 - 1.0).contiguous()
+    act = torch.zeros((K + Wm, A, 1), dtype=torch.int32, device=dev)
+    gather = agdist.ResultGatherer(A, dev) if world > 1 else None
+    eng = env.engine
+
+    def one_step(k):
+        eng.set_actions_device(dxdy[k].data_ptr(), act[k].data_ptr())
+        eng.step(CFG["ticks_per_step"])
+        if gather is not None:
+            gather.pack(k, env.rewards, env.dones_u8)
+
+    for k in range(Wm):
+        one_step(k)
+    if gather is not None:
+        gather.wait_all()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for k in range(Wm, Wm + K):
+        one_step(k)
+    ev1.record()
+    if gather is not None:
+        gather.wait_all()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / K  # HIP events on the launch stream: avg per launch incl. gaps
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    flags = eng.flags()
+    counts = eng.counts().astype(np.float64).mean(axis=0)  # pellets, viruses, foods, cells per arena
+    ticks = CFG["ticks_per_step"]
+    value = world * A * ticks * K / elapsed
+    if rank == 0:
+        # algorithmic bytes per arena-tick, SURVEY.md 8(d): 8 N_p + 12 N_v + 72 N_c + 40 N_f + 112 P + 24 A
+        b_tick = 8 * counts[0] + 12 * counts[1] + 72 * counts[3] + 40 * counts[2] + 112 * 1 + 24 * 1
+        bytes_per_launch = b_tick * A * ticks
+        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec (arenas x ticks/s)", "value": value, "unit": "env-steps/s", "n_gpus": world,
+            "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: %d arenas/GPU x 1 agent, 1000x1000 arena, 1000 pellets, 0 viruses, mode 0, "
+                                   "4 ticks/step, random (dx,dy), action none" % A,
+                       "arenas_total": world * A, "ticks_per_step": ticks,
+                       "parallelism": "arena-sharded x%d, per-step reward/done gather to rank 0" % world if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_step", "kernel_ms": kernel_ms, "algorithmic_bytes_per_arena_tick": b_tick},
+            "capacity_flags_raised": int((flags != 0).sum()),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,49 @@
+import ctypes
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long-running CPU test")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    from oracle import orabind
+    orabind.build()
+    return orabind
+
+
+@pytest.fixture(scope="session")
+def ref_lib():
+    """The real reference engine (oracle/_ref/libagar_ref.so); built here when /root/reference exists."""
+    from oracle import refbind
+    if os.path.isdir("/root/reference/agario"):
+        subprocess.check_call(["make", "-s", "-f", os.path.join(ROOT, "oracle", "Makefile"), "ref"], cwd=os.path.join(ROOT, "oracle"))
+    if not refbind.available():
+        pytest.skip("reference build not available")
+    return refbind
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    """TEST-ONLY host build of the kernel source (lanes as loops); never used by the product."""
+    subprocess.check_call(["make", "-s", "-f", os.path.join(ROOT, "tests", "emu", "Makefile")], cwd=ROOT)
+    from agarcl_amd import _capi
+    return _capi.bind(ctypes.CDLL(os.path.join(ROOT, "tests", "_build", "libagarcl_emu.so")))
+
+
+@pytest.fixture(scope="session")
+def hip_engine_cls():
+    from agarcl_amd import _capi
+    _capi.hip_lib()
+    return _capi.BatchedEngine

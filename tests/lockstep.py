@@ -92,3 +92,93 @@ def run_batched_lockstep(engine, oracles, steps, seeds, policy_seed=1, allow_act
                     if not np.array_equal(ed[a], oracles[a].dones()):
                         return False, "step %d: arena %d: dones differ" % (t, a)
     return True, "ok"
+
+
+# ---- golden fixture replay -------------------------------------------------------------------------
+class EngineAsEnv:
+    """Adapts agarcl_amd._capi.BatchedEngine (one arena) to the RefEnv/OraEnv env-level API."""
+
+    def __init__(self, engine_cls, lib=None, **cfg):
+        kw = dict(cfg)
+        self.num_agents = kw.get("num_agents", 1)
+        self.e = engine_cls(1, lib=lib, **kw) if lib is not None else engine_cls(1, **kw)
+
+    def seed(self, s):
+        self.e.seed(np.asarray([s], dtype=np.uint32))
+
+    def reset(self, reset_ids=True):
+        self.e.reset(reset_ids=reset_ids)
+
+    def take_actions(self, dxdy, act):
+        self.e.set_actions(np.asarray(dxdy, np.float32).reshape(1, self.num_agents, 2), np.asarray(act, np.int32).reshape(1, self.num_agents))
+
+    def step(self):
+        self.e.step(0)
+        return self.e.rewards()[0]
+
+    def dones(self):
+        return self.e.dones()[0]
+
+    def dump(self):
+        return self.e.dump(0)
+
+    def load(self, b):
+        self.e.load(b, 0)
+
+    def flags(self):
+        return int(self.e.flags()[0])
+
+
+def golden_crc(b):
+    import zlib
+    f = b.view(np.float32)
+    c = b.copy()
+    m = blob._is_float_word_mask(b) & np.isnan(f)
+    c[m] = 0x7FC00000
+    return zlib.crc32(c.tobytes()) & 0xFFFFFFFF
+
+
+def replay_golden(path, make_env):
+    """Replays one tests/golden/*.npz on `make_env(**cfg)`; returns (ok, message)."""
+    import json
+    z = np.load(path, allow_pickle=False)
+    cfg = json.loads(str(z["cfg"]))
+    env = make_env(**cfg)
+    seed = int(z["seed"])
+    if seed >= 0:
+        env.seed(seed)
+    env.reset(True)
+    env.load(z["blob0"])
+    d = blob.diff(z["blob0"], env.dump())
+    if d:
+        return False, "initial state does not round-trip: " + d
+    acts = z["actions"]
+    cps = set(int(c) for c in z["checkpoints"])
+    for t in range(acts.shape[0]):
+        env.take_actions(acts[t, :, :2], acts[t, :, 2].astype(np.int32))
+        r = env.step()
+        b = env.dump()
+        if t in cps:
+            d = blob.diff(z["blob_%d" % t], b)
+            if d:
+                return False, "step %d: %s" % (t, d)
+        if golden_crc(b) != int(z["crcs"][t]):
+            return False, "step %d: state CRC differs from the reference's" % t
+        if not np.array_equal(np.asarray(r, np.float64), z["rewards"][t]):
+            return False, "step %d: rewards %s vs %s" % (t, r, z["rewards"][t])
+        if not np.array_equal(np.asarray(env.dones(), bool), z["dones"][t].astype(bool)):
+            return False, "step %d: dones differ" % t
+    return True, "ok"
+
+
+def golden_files(gpu_capable_only=False):
+    import glob, json, os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    out = []
+    for p in sorted(glob.glob(os.path.join(here, "*.npz"))):
+        if gpu_capable_only:
+            cfg = json.loads(str(np.load(p)["cfg"]))
+            if cfg.get("num_agents", 1) != 1 or cfg.get("num_bots", 0) != 0 or cfg.get("mode", 0) > 6:
+                continue
+        out.append(p)
+    return out

@@ -1,0 +1,63 @@
+"""N > 1 path on CPU: arena sharding + the per-step (reward, done) gather to rank 0, world_size 2, gloo."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from agarcl_amd import dist as agdist
+
+
+def test_shard_bounds_cover_exactly():
+    for total in (1, 7, 4096, 32768, 50001):
+        for world in (1, 2, 3, 8):
+            spans = [agdist.shard_bounds(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_seeds_independent_of_world_size():
+    full = agdist.arena_seeds(10000, 0, 64)
+    parts = np.concatenate([agdist.arena_seeds(10000, *agdist.shard_bounds(64, 4, r)) for r in range(4)])
+    assert np.array_equal(full, parts)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_local = 6
+    g = agdist.ResultGatherer(n_local, torch.device("cpu"), depth=2)
+    ok = True
+    for k in range(5):
+        lo = rank * n_local
+        rewards = torch.arange(lo, lo + n_local, dtype=torch.float64).reshape(n_local, 1) + 100.0 * k
+        dones = ((torch.arange(lo, lo + n_local) + k) % 3 == 0).to(torch.uint8).reshape(n_local, 1)
+        slot = g.pack(k, rewards, dones)
+        g.wait_all()
+        if rank == 0:
+            got = g.gathered(slot)
+            exp_r = torch.arange(0, world * n_local, dtype=torch.float32) + 100.0 * k
+            exp_d = ((torch.arange(0, world * n_local) + k) % 3 == 0).to(torch.float32)
+            ok = ok and torch.equal(got[:, 0], exp_r) and torch.equal(got[:, 1], exp_d)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        q.put(ok)
+
+
+def test_result_gather_world2_gloo():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get() is True

@@ -1,0 +1,166 @@
+"""Parity tests proper: the HIP engine (through the C ABI, on a real MI355X) against the C oracle on the
+same seeded inputs, against the golden vectors recorded from the real reference, and -- at BASELINE.json's
+full size (4096 arenas) -- through size-independent properties.  Bar: bit-exact (ints AND fp32 words)."""
+import os
+
+import numpy as np
+import pytest
+
+from lockstep import EngineAsEnv, golden_files, replay_golden, run_batched_lockstep, policy
+
+pytestmark = pytest.mark.gpu
+
+C2 = dict(arena_size=1000, num_pellets=1000, num_viruses=0, mode=0)
+C3 = dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode=0)
+C3M6 = dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode=6)
+
+
+@pytest.mark.parametrize("path", golden_files(gpu_capable_only=True), ids=lambda p: os.path.basename(p)[:-4])
+def test_hip_matches_reference_golden(hip_engine_cls, path):
+    ok, msg = replay_golden(path, lambda **cfg: EngineAsEnv(hip_engine_cls, **cfg))
+    assert ok, msg
+
+
+@pytest.mark.parametrize("cfg,steps,sticky", [
+    (C2, 400, 4), (C3, 400, 4), (C3M6, 1000, 16), (C3M6, 600, 3),
+    (dict(arena_size=250, num_pellets=500, num_viruses=10, mode=6), 1000, 8),
+    (dict(arena_size=300, num_pellets=300, num_viruses=5, mode=5), 600, 8),
+    (dict(arena_size=300, num_pellets=300, num_viruses=5, mode=1), 300, 8),
+    (dict(arena_size=300, num_pellets=300, num_viruses=5, mode=2), 300, 8),
+    (dict(arena_size=1200, num_pellets=800, num_viruses=15, mode=3), 300, 8),
+    (dict(arena_size=60, num_pellets=200, num_viruses=0, mode=0), 300, 8),   # "trivial" difficulty-like tiny arena
+    (dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode=6, reward_type=0), 200, 8),
+])
+def test_hip_vs_oracle_lockstep(hip_engine_cls, oracle_lib, cfg, steps, sticky):
+    A = 16
+    eng = hip_engine_cls(A, **cfg)
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    ok, msg = run_batched_lockstep(eng, oras, steps, seeds=np.arange(500, 500 + A), sticky=sticky, every=5)
+    eng.close()
+    assert ok, "%s: %s" % (cfg, msg)
+
+
+def test_masked_reset_and_reseed(hip_engine_cls, oracle_lib):
+    """reset(mask) touches only the selected arenas; ids keep growing like the reference's global counter."""
+    A = 8
+    eng = hip_engine_cls(A, **C3M6)
+    oras = [oracle_lib.OraEnv(**C3M6) for _ in range(A)]
+    seeds = np.arange(40, 40 + A).astype(np.uint32)
+    ok, msg = run_batched_lockstep(eng, oras, 40, seeds=seeds, sticky=8, every=40)
+    assert ok, msg
+    mask = np.array([1, 0, 0, 1, 0, 1, 0, 0], dtype=np.uint8)
+    eng.reset(mask, reset_ids=False)
+    for a in range(A):
+        if mask[a]:
+            oras[a].reset(False)
+    from oracle import blob
+    for a in range(A):
+        assert blob.diff(oras[a].dump(), eng.dump(a)) is None, "arena %d after masked reset" % a
+    for t in range(40):
+        dxdy = np.zeros((A, 1, 2), np.float32); act = np.zeros((A, 1), np.int32)
+        for a in range(A):
+            dd, aa = policy(9 + a, t, 1, True, 8); dxdy[a, 0] = dd[0]; act[a, 0] = aa[0]
+        eng.set_actions(dxdy, act); eng.step()
+        for a in range(A):
+            oras[a].take_actions(dxdy[a], act[a]); oras[a].step()
+    for a in range(A):
+        assert blob.diff(oras[a].dump(), eng.dump(a)) is None, "arena %d after continuing" % a
+    eng.close()
+
+
+def test_events_match_oracle(hip_engine_cls, oracle_lib):
+    """eat events (pellets_to_remove / viruses_to_remove order, Engine.hpp:992,1243) bit-exact per tick."""
+    cfg = dict(arena_size=250, num_pellets=500, num_viruses=10, mode=6)
+    A = 8
+    eng = hip_engine_cls(A, **cfg)
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    seeds = np.arange(70, 70 + A).astype(np.uint32)
+    eng.seed(seeds); eng.reset(reset_ids=True)
+    for o, s in zip(oras, seeds):
+        o.seed(int(s)); o.reset(True)
+    total = 0
+    for t in range(200):
+        eng.tick(1)
+        n, pe, ve = eng.events()
+        for a in range(A):
+            oras[a].tick()
+            ope, ove = oras[a].last_events()
+            assert np.array_equal(ope, pe[a, :n[a, 0]]), (t, a)
+            assert np.array_equal(ove, ve[a, :n[a, 1]]), (t, a)
+            total += len(ope) + len(ove)
+    assert total > 50
+    eng.close()
+
+
+def test_full_size_properties_4096(hip_engine_cls, oracle_lib):
+    """BASELINE config 2 at full size (4096 arenas): (i) a sample of arenas equals the oracle run alone on
+    the same seed (batch independence), (ii) two identical runs are bitwise identical (determinism),
+    (iii) conservation: without decay-free ... mass gained == pellets eaten, pellet count <= target,
+    entity ids unique and below the id counter."""
+    from oracle import blob
+    A, steps = 4096, 50
+    rng = np.random.RandomState(3)
+    dx = rng.uniform(-1, 1, size=(steps, A, 1, 2)).astype(np.float32)
+    act = np.zeros((A, 1), np.int32)
+    runs = []
+    for rep in range(2):
+        eng = hip_engine_cls(A, **C2)
+        eng.seed(None, 10000); eng.reset(reset_ids=True)
+        tot_reward = np.zeros((A, 1))
+        for t in range(steps):
+            eng.set_actions(dx[t], act); eng.step()
+            tot_reward += eng.rewards()
+        assert not eng.flags().any()
+        sample = [0, 1, 63, 64, 1000, 2047, 4095]
+        runs.append(([eng.dump(a) for a in sample], eng.masses().copy(), eng.counts().copy(), tot_reward))
+        if rep == 0:
+            for a, b in zip(sample, runs[0][0]):
+                o = oracle_lib.OraEnv(**C2); o.seed(10000 + a); o.reset(True)
+                for t in range(steps):
+                    o.take_actions(dx[t, a], act[a]); o.step()
+                assert blob.diff(o.dump(), b) is None, "arena %d differs from the oracle run alone" % a
+                d = blob.parse(b)
+                ids = np.concatenate([d["pellet_id"], d["virus_id"], d["food_id"], d["players"][0]["cell_id"]])
+                assert len(np.unique(ids)) == len(ids) and ids.max() <= d["id_counter"]
+        eng.close()
+    for b0, b1 in zip(runs[0][0], runs[1][0]):
+        assert np.array_equal(b0, b1)
+    assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+    masses, counts, tot_reward = runs[0][1], runs[0][2], runs[0][3]
+    assert (counts[:, 0] <= 1000).all() and (counts[:, 3] == 1).all()
+    # reward_type 1: the rewards of an episode sum to (final mass - initial mass)
+    assert np.array_equal(tot_reward[:, 0], masses[:, 0] - 25.0)
+
+
+def test_mode6_full_size_vs_oracle_sample(hip_engine_cls, oracle_lib):
+    """BASELINE config 3 (full ruleset) at 4096 arenas: sampled arenas vs the oracle after 60 steps."""
+    from oracle import blob
+    A, steps = 4096, 60
+    eng = hip_engine_cls(A, **C3M6)
+    eng.seed(None, 777); eng.reset(reset_ids=True)
+    acts = []
+    for t in range(steps):
+        rng = np.random.RandomState(1000 + t // 8)
+        dxdy = rng.uniform(-1, 1, size=(A, 1, 2)).astype(np.float32)
+        a = rng.randint(0, 3, size=(A, 1)).astype(np.int32)
+        acts.append((dxdy, a))
+        eng.set_actions(dxdy, a); eng.step()
+    assert not eng.flags().any()
+    for arena in (0, 5, 777, 4095):
+        o = oracle_lib.OraEnv(**C3M6); o.seed(777 + arena); o.reset(True)
+        for dxdy, a in acts:
+            o.take_actions(dxdy[arena], a[arena]); o.step()
+        assert blob.diff(o.dump(), eng.dump(arena)) is None, "arena %d" % arena
+    eng.close()
+
+
+def test_error_paths(hip_engine_cls):
+    from agarcl_amd._capi import AgarclError
+    with pytest.raises(AgarclError):
+        hip_engine_cls(1, mode=11)                      # Engine.hpp:413-414 "Invalid mode number"
+    with pytest.raises(AgarclError):
+        hip_engine_cls(1, num_bots=2, mode=0)           # loud, not a silent fallback
+    e = hip_engine_cls(2, **C2)
+    with pytest.raises(Exception):
+        e.set_actions(np.zeros((3, 1, 2), np.float32), np.zeros((3, 1), np.int32))
+    e.close()

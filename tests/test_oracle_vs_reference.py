@@ -1,0 +1,61 @@
+"""Pins the C restatement (oracle/agar_oracle.c) against the REAL reference engine compiled from
+/root/reference (oracle/_ref/libagar_ref.so): same seeds, same actions, every tick, word for word."""
+import pytest
+from lockstep import run_lockstep
+
+CASES = [
+    # (env kwargs, ticks, sticky)  -- SURVEY.md 8(d) configs C1..C3 + modes / bots / multi-agent
+    (dict(num_agents=1, arena_size=1000, num_pellets=1000, num_viruses=0, mode=0), 1500, 4),
+    (dict(num_agents=1, arena_size=1000, num_pellets=1000, num_viruses=25, mode=0), 1500, 4),
+    (dict(num_agents=1, arena_size=1000, num_pellets=1000, num_viruses=25, mode=6), 3000, 16),
+    (dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0), 3000, 4),
+    (dict(num_agents=3, arena_size=250, num_pellets=500, num_viruses=10, mode=6), 2500, 8),
+    (dict(num_agents=1, arena_size=300, num_pellets=300, num_viruses=5, mode=5), 1500, 8),
+    (dict(num_agents=1, arena_size=300, num_pellets=300, num_viruses=5, mode=1), 800, 8),
+    (dict(num_agents=1, arena_size=300, num_pellets=300, num_viruses=5, mode=2), 800, 8),
+    (dict(num_agents=1, arena_size=1200, num_pellets=600, num_viruses=12, mode=3), 800, 8),
+    (dict(num_agents=1, arena_size=200, num_pellets=500, num_viruses=5, num_bots=1, mode=7), 1500, 8),
+    (dict(num_agents=1, arena_size=200, num_pellets=500, num_viruses=5, num_bots=1, mode=8), 1500, 8),
+    (dict(num_agents=1, arena_size=200, num_pellets=500, num_viruses=5, num_bots=1, mode=9), 1500, 8),
+    (dict(num_agents=1, arena_size=200, num_pellets=500, num_viruses=5, num_bots=1, mode=10), 1500, 8),
+    (dict(num_agents=14, arena_size=300, num_pellets=300, num_viruses=5, mode=0), 300, 8),  # 14th insert rehashes the player map
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+@pytest.mark.parametrize("seed", [1, 42])
+def test_lockstep_bit_exact(ref_lib, oracle_lib, case, seed):
+    cfg, ticks, sticky = CASES[case]
+    r = ref_lib.RefEnv(**cfg)
+    o = oracle_lib.OraEnv(**cfg)
+    ok, msg = run_lockstep([r, o], ticks, seed, policy_seed=seed + 5, sticky=sticky)
+    assert ok, "%s seed %d: %s" % (cfg, seed, msg)
+
+
+def test_bench_dt_60hz(ref_lib, oracle_lib):
+    """bench/main.cpp path: dt = 1/60 (600-tick recombine timer)."""
+    cfg = dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0, dt=1.0 / 60)
+    r = ref_lib.RefEnv(**cfg); o = oracle_lib.OraEnv(**cfg)
+    ok, msg = run_lockstep([r, o], 3000, 42, policy_seed=7, sticky=4)
+    assert ok, msg
+
+
+def test_env_step_rewards_dones(ref_lib, oracle_lib):
+    """BaseEnvironment::step rewards / dones (BaseEnvironment.hpp:89-122) incl. mode-3 done and reward_type 0."""
+    import numpy as np
+    from lockstep import policy
+    from oracle import blob
+    for cfg in (dict(num_agents=1, arena_size=300, num_pellets=400, num_viruses=4, mode=0, reward_type=1),
+                dict(num_agents=2, arena_size=300, num_pellets=400, num_viruses=4, mode=6, reward_type=0),
+                dict(num_agents=1, arena_size=300, num_pellets=400, num_viruses=4, mode=3, reward_type=1),
+                dict(num_agents=1, arena_size=200, num_pellets=300, num_viruses=3, num_bots=1, mode=9, reward_type=1)):
+        r = ref_lib.RefEnv(**cfg); o = oracle_lib.OraEnv(**cfg)
+        for e in (r, o):
+            e.seed(5); e.reset(True)
+        for t in range(400):
+            dxdy, act = policy(3, t, cfg["num_agents"], True, 8)
+            r.take_actions(dxdy, act); o.take_actions(dxdy, act)
+            assert np.array_equal(r.step(), o.step()), (cfg, t)
+            assert np.array_equal(r.dones(), o.dones()), (cfg, t)
+            if t % 20 == 0:
+                assert blob.diff(r.dump(), o.dump()) is None
