@@ -134,7 +134,7 @@ class BatchedEngine:
 
     # -- control ------------------------------------------------------------------------------
     def set_stream(self, stream_ptr):
-        self._chk(self.L.agarcl_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
+        self._chk(self.L.agarcl_set_stream(self.h, C.c_void_p(int(stream_ptr))))
 
     def sync(self):
         self._chk(self.L.agarcl_sync(self.h))

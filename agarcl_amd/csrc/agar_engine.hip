@@ -254,8 +254,9 @@ extern "C" int agarcl_set_stream(agarcl_env *e, void *hip_stream) {
 #ifndef AGAR_CPU_EMU
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->stream));
-  if (hip_stream) { if (e->own_stream) (void)hipStreamDestroy(e->stream); e->stream = (hipStream_t)hip_stream; e->own_stream = false; }
-  else if (!e->own_stream) { HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)); e->own_stream = true; }
+  // adopt the caller's stream; NULL is the legacy default stream (what torch.cuda.current_stream() is by default)
+  if (e->own_stream) (void)hipStreamDestroy(e->stream);
+  e->stream = (hipStream_t)hip_stream; e->own_stream = false;
 #else
   (void)hip_stream;
 #endif

@@ -31,7 +31,16 @@ def cpu_baseline(seconds_budget=12.0):
     """The same per-arena workload on the host cores, timed on a bounded sample.
     kind "reference": oracle/_ref/libagar_ref.so = the unmodified reference engine (prebuilt from
     /root/reference); otherwise kind "port": the plain-C restatement."""
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:  # cgroup v2 CPU quota (containers report the host's CPU count otherwise)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(float(q) / float(per))))
+    except Exception:
+        pass
     try:
         from oracle import refbind
         use_ref = refbind.available()
@@ -53,14 +62,19 @@ def cpu_baseline(seconds_budget=12.0):
     e = mk(); e.seed(10000); e.reset(True)
     t0 = time.perf_counter(); e.run_random(4000, policy_seed=1, allow_actions=False); dt1 = time.perf_counter() - t0
     rate1 = 4000 / dt1
-    ticks_each = max(4000, int(rate1 * seconds_budget * 0.8 / 2))  # 2 arenas per thread
+    chunk = 2000
     done = [0] * cores
+    deadline = time.perf_counter() + seconds_budget
 
-    def worker(w):
-        for j in range(2):
-            env = mk(); env.seed(10000 + w * 2 + j); env.reset(True)
-            done[w] += env.run_random(ticks_each, policy_seed=w * 2 + j + 1, allow_actions=False)
-            env.close()
+    def worker(w):  # one engine per thread at a time (the reference's BotEvaluator pattern), time-bounded
+        j = 0
+        while time.perf_counter() < deadline:
+            env = mk(); env.seed(10000 + w * 64 + j); env.reset(True)
+            for _ in range(10):
+                done[w] += env.run_random(chunk, policy_seed=w * 64 + j + 1, allow_actions=False)
+                if time.perf_counter() >= deadline:
+                    break
+            env.close(); j += 1
     th = [threading.Thread(target=worker, args=(w,)) for w in range(cores)]
     t0 = time.perf_counter()
     for t in th: t.start()
@@ -68,8 +82,9 @@ def cpu_baseline(seconds_budget=12.0):
     el = time.perf_counter() - t0
     total = sum(done)
     return {"value": total / el, "unit": "env-steps/s", "cores": cores, "kind": kind,
-            "sample": "%d arenas x %d ticks of the C2 workload, one engine per host thread (%d threads, ctypes releases "
-                      "the GIL); single-core rate %.0f ticks/s" % (2 * cores, ticks_each, cores, rate1)}
+            "sample": "%.0f s of the C2 workload (1000x1000, 1000 pellets, 1 agent, random dx/dy, action none), one engine "
+                      "per host thread, %d threads, %d arena-ticks in total; single-thread rate %.0f ticks/s"
+                      % (seconds_budget, cores, total, rate1)}
 
 
 def main():

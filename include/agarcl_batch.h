@@ -69,7 +69,8 @@ int agarcl_device_count(void);
 int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32_t device, agarcl_env **out);
 /* replaces: object destruction / close(), bindings.cpp:134 */
 int agarcl_destroy(agarcl_env *env);
-/* use an existing HIP stream (hipStream_t) for all launches and copies; NULL = the env's own stream */
+/* adopt an existing HIP stream (hipStream_t) for all launches and copies; NULL = the legacy default
+ * stream.  Until called, the env uses a private non-blocking stream. */
 int agarcl_set_stream(agarcl_env *env, void *hip_stream);
 int agarcl_sync(agarcl_env *env);
 
