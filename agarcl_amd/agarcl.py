@@ -1,0 +1,99 @@
+"""Single-arena classes with the names, positional constructor signatures and method names of the
+reference's pybind11 module `agarcl` (/root/reference/environment/bindings.cpp:94-376), backed by the
+HIP engine through the C ABI (num_arenas == 1).  `from agarcl_amd import agarcl` stands in for
+`import agarcl` in gym_agario-style code.
+
+Errors follow the reference: every failure is a RuntimeError (AgarclError subclasses it).
+"""
+import numpy as np
+
+from . import _capi
+
+# the OpenGL ScreenEnvironment is outside the hot path
+has_screen_env = False
+
+
+class _Environment:
+    def __init__(self, num_agents, ticks_per_step, arena_size, pellet_regen, num_pellets, num_viruses, num_bots,
+                 reward_type, c_death=0, mode_number=0, device=0):
+        self._num_agents = int(num_agents)
+        self._engine = _capi.BatchedEngine(1, int(num_agents), int(ticks_per_step), int(arena_size), bool(pellet_regen),
+                                           int(num_pellets), int(num_viruses), int(num_bots), int(bool(reward_type)) if isinstance(reward_type, bool) else int(reward_type),
+                                           int(c_death), int(mode_number), device=device)
+
+    def seed(self, s):                       # bindings.cpp:103
+        self._engine.seed(np.asarray([int(s) & 0xFFFFFFFF], dtype=np.uint32))
+
+    def reset(self):                         # bindings.cpp:130
+        self._engine.reset(reset_ids=False)
+
+    def take_actions(self, actions):         # bindings.cpp:50-64,117-119
+        actions = list(actions)
+        if len(actions) != self._num_agents:  # BaseEnvironment.hpp:142-144
+            raise RuntimeError("Number of actions (%d) does not match number of agents (%d)" % (len(actions), self._num_agents))
+        dxdy = np.array([[float(a[0]), float(a[1])] for a in actions], dtype=np.float32)
+        act = np.array([int(a[2]) for a in actions], dtype=np.int32)
+        self._engine.set_actions(dxdy, act)
+
+    def step(self):                          # bindings.cpp:132 -> list[float]
+        self._engine.step(0)
+        return [float(r) for r in self._engine.rewards()[0]]
+
+    def dones(self):                         # bindings.cpp:116 -> list[bool]
+        return [bool(d) for d in self._engine.dones()[0]]
+
+    def render(self):
+        pass
+
+    def close(self):
+        self._engine.close()
+
+    def save_env_state(self, path):
+        """Binary state blob (oracle/BLOB_FORMAT.md) instead of the reference's JSON."""
+        np.save(path, self._engine.dump(0))
+
+    def load_env_state(self, path):
+        self._engine.load(np.load(path), 0)
+
+
+class GridEnvironment(_Environment):
+    """agarcl.GridEnvironment (bindings.cpp:99-135)."""
+
+    def __init__(self, num_agents, ticks_per_step, arena_size, pellet_regen, num_pellets, num_viruses, num_bots,
+                 reward_type=0, c_death=0, mode_number=0):
+        # GridEnvironment forwards c_death = 0 to its base (GridEnvironment.hpp:369-372)
+        super().__init__(num_agents, ticks_per_step, arena_size, pellet_regen, num_pellets, num_viruses, num_bots,
+                         reward_type, 0, mode_number)
+        self._obs_cfg = None
+
+    def configure_observation(self, config):  # bindings.cpp:104-114
+        self._obs_cfg = dict(num_frames=int(config.get("num_frames", 1)), grid_size=int(config.get("grid_size", 128)),
+                             observe_cells=bool(config.get("observe_cells", True)), observe_others=bool(config.get("observe_others", True)),
+                             observe_viruses=bool(config.get("observe_viruses", True)), observe_pellets=bool(config.get("observe_pellets", True)))
+
+    def _channels(self):
+        c = self._obs_cfg
+        return c["num_frames"] * (1 + c["observe_cells"] + 2 * c["observe_others"] + 2 * c["observe_viruses"] + 2 * c["observe_pellets"])
+
+    def observation_shape(self):             # bindings.cpp:115
+        if self._obs_cfg is None:
+            raise RuntimeError("GridObservation was not configured.")  # GridEnvironment.hpp:72-88
+        g = self._obs_cfg["grid_size"]
+        return (self._channels(), g, g)
+
+    def get_state(self):                     # bindings.cpp:67-91,133: one owned int32 (C,G,G) array per agent
+        if self._obs_cfg is None:
+            raise RuntimeError("GridObservation was not configured.")
+        c = self._obs_cfg
+        obs = self._engine.grid_obs(c["grid_size"], c["observe_cells"], c["observe_others"], c["observe_viruses"], c["observe_pellets"])
+        return [obs[0, i].copy() for i in range(self._num_agents)]
+
+
+class ScreenEnvironment:
+    def __init__(self, *a, **k):
+        raise RuntimeError("agarcl was not compiled to include ScreenEnvironment (has_screen_env is False)")
+
+
+class GoBiggerEnvironment:
+    def __init__(self, *a, **k):
+        raise RuntimeError("GoBiggerEnvironment is not provided by the HIP engine (SURVEY.md section 8f, row N3)")
