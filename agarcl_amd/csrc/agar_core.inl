@@ -1,19 +1,21 @@
 // Wave-level Agar.io engine: ONE 64-lane wavefront simulates ONE arena.
 //
 // Programming discipline (what makes the code both a CDNA4 kernel and checkable on a host):
-//   * code outside AG_LANES/AG_SERIAL is *wave-uniform* scalar code (same value in every lane;
-//     the compiler keeps it in SGPRs where it can prove uniformity -- collectives end in
-//     readfirstlane for that reason);
+//   * code outside AG_LANES / AG_SERIAL is *wave-uniform* scalar code (same value in every lane).
+//     Per-arena and per-player scalars live in "uniform blocks" (UBlock): ONE VGPR whose lane k holds
+//     word k, read with v_readlane / written with v_writelane -- no LDS round trip on the hot path;
 //   * AG_LANES(i, n) bodies are the data-parallel parts: lane-private temporaries only, all
-//     communication through LDS/HBM;
-//   * collectives (wave_sum / wave_min / wave_any / wave_compact) are the only cross-lane ops:
-//     ballot + popcount prefix for ordered compaction, xor-shuffle trees for reductions;
-//   * AG_SERIAL sections replay the reference's order-dependent semantics on lane 0.
+//     communication through LDS / HBM;
+//   * collectives are the only cross-lane ops: wave_count / wave_any (ballot + popcount), wave_compact
+//     (ballot + popcount(mask & lanemask_lt): ordered stream compaction), wave_min/max/sum (DPP row_shr +
+//     row_bcast scan, result read from lane 63);
+//   * AG_SERIAL sections replay the reference's order-dependent semantics on lane 0 and hand scalar
+//     results back through a small LDS mailbox (rare paths only).
 // The reference semantics being reproduced are cited as "R:" (paths under /root/reference).
 //
-// Compiled for gfx950 by agar_engine.hip.  tests/emu/ compiles the same text with
-// -DAGAR_CPU_EMU into a *test-only* host library (lanes become loops) so that kernel logic can be
-// diffed against the oracle without a GPU; the product never loads that build.
+// Compiled for gfx950 by agar_engine.hip.  tests/emu/ compiles the same text with -DAGAR_CPU_EMU into a
+// *test-only* host library (lanes become loops) so that kernel logic can be diffed against the oracle
+// without a GPU; the product never loads that build.
 #pragma once
 #include "agar_types.h"
 #include <limits.h>
@@ -25,23 +27,25 @@
 #define AG_DEV static inline
 #define AG_LANES(i, n) for (int i = 0; i < (n); ++i)
 #define AG_SERIAL if (true)
-#define AG_LANE0 true
 AG_DEV int ag_uni(int v) { return v; }
 AG_DEV unsigned ag_uniu(unsigned v) { return v; }
 AG_DEV float ag_unif(float v) { return v; }
-AG_DEV void ag_fence() {}
+AG_DEV void ag_mem_fence() {}
+AG_DEV void ag_lds_order() {}
 AG_DEV float ag_sqrtf(float x) { return sqrtf(x); }
 AG_DEV float ag_divf(float a, float b) { return a / b; }
 #else
 #define AG_DEV __device__ __forceinline__
 #define AG_LANES(i, n) for (int i = (int)threadIdx.x; i < (n); i += 64)
 #define AG_SERIAL if (threadIdx.x == 0)
-#define AG_LANE0 (threadIdx.x == 0)
 AG_DEV int ag_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 AG_DEV unsigned ag_uniu(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 AG_DEV float ag_unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-// make lane-0 / other-lane stores to LDS+HBM visible to the whole wave before it continues
-AG_DEV void ag_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+// HBM written by one lane and read by another lane of the same wave later on: drain the wave's
+// outstanding vector-memory operations first (single-wave workgroups: same CU, same L1)
+AG_DEV void ag_mem_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+// LDS traffic of one wave is processed in program order; only the compiler must not reorder
+AG_DEV void ag_lds_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 // IEEE correctly rounded: built with -fhip-fp32-correctly-rounded-divide-sqrt (build.py); NOT __fsqrt_rn,
 // which ROCm's headers map to the approximate __ocml_native_sqrt_f32.
 AG_DEV float ag_sqrtf(float x) { return __builtin_sqrtf(x); }
@@ -52,16 +56,31 @@ AG_DEV float ag_divf(float a, float b) { return a / b; }
 
 // ---- collectives --------------------------------------------------------------------------------
 #ifdef AGAR_CPU_EMU
+// (no short-circuiting: functors may have side effects, exactly like on the device)
 template <class F> AG_DEV int wave_sum(int n, F f) { int s = 0; for (int i = 0; i < n; i++) s += f(i); return s; }
+template <class F> AG_DEV int wave_count(int n, F f) { int s = 0; for (int i = 0; i < n; i++) s += f(i) ? 1 : 0; return s; }
 template <class F> AG_DEV unsigned wave_max(int n, F f) { unsigned s = 0; for (int i = 0; i < n; i++) { unsigned v = f(i); if (v > s) s = v; } return s; }
 template <class F> AG_DEV unsigned wave_min(int n, F f) { unsigned s = UINT_MAX; for (int i = 0; i < n; i++) { unsigned v = f(i); if (v < s) s = v; } return s; }
-template <class F> AG_DEV bool wave_any(int n, F f) { for (int i = 0; i < n; i++) if (f(i)) return true; return false; }
+template <class F> AG_DEV bool wave_any(int n, F f) { bool a = false; for (int i = 0; i < n; i++) a = a | (bool)f(i); return a; }
 template <class P, class S> AG_DEV int wave_compact(int n, P pred, S sink) { int c = 0; for (int i = 0; i < n; i++) if (pred(i)) { sink(i, c); c++; } return c; }
 #else
-AG_DEV int wred_add(int v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return __builtin_amdgcn_readfirstlane(v); }
-AG_DEV unsigned wred_max(unsigned v) { for (int o = 32; o > 0; o >>= 1) { unsigned t = (unsigned)__shfl_xor((int)v, o, 64); v = t > v ? t : v; } return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
-AG_DEV unsigned wred_min(unsigned v) { for (int o = 32; o > 0; o >>= 1) { unsigned t = (unsigned)__shfl_xor((int)v, o, 64); v = t < v ? t : v; } return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+// DPP scan (row_shr 1,2,4,8 + row_bcast15/31): lane 63 ends up with the reduction of all 64 lanes.
+#define AG_DPP_STEP(v, ident, OP, ctrl, rmask) { int t_ = __builtin_amdgcn_update_dpp((int)(ident), (int)(v), ctrl, rmask, 0xf, false); v = OP(v, t_); }
+#define AG_DPP_REDUCE(v, ident, OP) \
+  AG_DPP_STEP(v, ident, OP, 0x111, 0xf) AG_DPP_STEP(v, ident, OP, 0x112, 0xf) AG_DPP_STEP(v, ident, OP, 0x114, 0xf) \
+  AG_DPP_STEP(v, ident, OP, 0x118, 0xf) AG_DPP_STEP(v, ident, OP, 0x142, 0xa) AG_DPP_STEP(v, ident, OP, 0x143, 0xc)
+#define AG_OP_ADD(a, b) ((a) + (b))
+#define AG_OP_UMAX(a, b) ((unsigned)(a) > (unsigned)(b) ? (a) : (b))
+#define AG_OP_UMIN(a, b) ((unsigned)(a) < (unsigned)(b) ? (a) : (b))
+AG_DEV int wred_add(int v) { AG_DPP_REDUCE(v, 0, AG_OP_ADD) return __builtin_amdgcn_readlane(v, 63); }
+AG_DEV unsigned wred_max(unsigned u) { int v = (int)u; AG_DPP_REDUCE(v, 0, AG_OP_UMAX) return (unsigned)__builtin_amdgcn_readlane(v, 63); }
+AG_DEV unsigned wred_min(unsigned u) { int v = (int)u; AG_DPP_REDUCE(v, -1, AG_OP_UMIN) return (unsigned)__builtin_amdgcn_readlane(v, 63); }
 template <class F> AG_DEV int wave_sum(int n, F f) { int s = 0; for (int i = (int)threadIdx.x; i < n; i += 64) s += f(i); return wred_add(s); }
+template <class F> AG_DEV int wave_count(int n, F f) {
+  int c = 0;
+  for (int base = 0; base < n; base += 64) { int i = base + (int)threadIdx.x; bool p = (i < n) && f(i); c += __popcll(__ballot(p)); }
+  return c;
+}
 template <class F> AG_DEV unsigned wave_max(int n, F f) { unsigned s = 0; for (int i = (int)threadIdx.x; i < n; i += 64) { unsigned v = f(i); s = v > s ? v : s; } return wred_max(s); }
 template <class F> AG_DEV unsigned wave_min(int n, F f) { unsigned s = UINT_MAX; for (int i = (int)threadIdx.x; i < n; i += 64) { unsigned v = f(i); s = v < s ? v : s; } return wred_min(s); }
 template <class F> AG_DEV bool wave_any(int n, F f) { bool a = false; for (int i = (int)threadIdx.x; i < n; i += 64) a = a | (bool)f(i); return __ballot(a) != 0ull; }
@@ -80,6 +99,21 @@ template <class P, class S> AG_DEV int wave_compact(int n, P pred, S sink) {
 }
 #endif
 
+// ---- uniform block: up to 32 wave-uniform 32-bit words kept in ONE VGPR (lane k = word k) ----------
+#ifdef AGAR_CPU_EMU
+struct UBlock { int w[32]; };
+AG_DEV int ub_get(const UBlock &b, int k) { return b.w[k]; }
+AG_DEV void ub_set(UBlock &b, int k, int v) { b.w[k] = v; }
+AG_DEV void ub_load(UBlock &b, const int *src, int n) { for (int i = 0; i < 32; i++) b.w[i] = i < n ? src[i] : 0; }
+AG_DEV void ub_store(const UBlock &b, int *dst, int n) { for (int i = 0; i < n; i++) dst[i] = b.w[i]; }
+#else
+struct UBlock { int v; };
+AG_DEV int ub_get(const UBlock &b, int k) { return __builtin_amdgcn_readlane(b.v, k); }
+AG_DEV void ub_set(UBlock &b, int k, int v) { b.v = ((int)threadIdx.x == k) ? v : b.v; }
+AG_DEV void ub_load(UBlock &b, const int *src, int n) { int l = (int)threadIdx.x; b.v = l < n ? src[l] : 0; }
+AG_DEV void ub_store(const UBlock &b, int *dst, int n) { int l = (int)threadIdx.x; if (l < n) dst[l] = b.v; }
+#endif
+
 // ---- numerics: C++ std::min/max/clamp on floats with their NaN behaviour (R: core/utils.hpp:19-21)
 AG_DEV float smaxf(float a, float b) { return (a < b) ? b : a; }
 AG_DEV float sminf(float a, float b) { return (b < a) ? b : a; }
@@ -96,119 +130,234 @@ AG_DEV bool touches(float ax, float ay, float ar, float bx, float by, float br) 
 AG_DEV bool can_eat_mass(unsigned a, unsigned b) { return (double)a > (double)b * 1.1; }  // R: Ball.hpp:45-47
 AG_DEV unsigned clamp_mass(unsigned m) { return m > AG_CELL_MIN_SIZE ? m : AG_CELL_MIN_SIZE; }  // R: Entities.hpp:171-177
 
-// per-arena context ------------------------------------------------------------------------------
-struct AgCtx {
-  AgDims d; AgParams g;
-  int arena;
-  // HBM slices of this arena
-  float *gpx, *gpy; int32_t *gpid;
-  float *vx, *vy, *vvx, *vvy; int32_t *vm, *vh, *vid;
-  float *fx, *fy, *fvx, *fvy; int32_t *fid;
-  uint64_t *mt; int32_t *gar; int32_t *gpl; int32_t *gvt;
-  int32_t *gev_p, *gev_v;
-  const float *lut_r, *lut_ms, *lut_ss, *lut_anti;
-  // LDS
-  float *px, *py;                                                    // [PC]
-  float *cx, *cy, *cvx, *cvy, *csx, *csy; unsigned *cm; int *cid; unsigned *cdl;  // [P*CC]
-  float *nx, *ny, *nvx, *nvy, *nsx, *nsy; unsigned *nm; int *nid; unsigned *ndl;  // [CC] created this tick
-  int *S;        // [AR_WORDS] arena scalars
-  int *PLS;      // [P*PL_WORDS] player scalars
-  int *evp, *evv; unsigned *cand; uint64_t *rb; int *tmp;
-  int *ncreated;
+// ---- LDS layout (bytes).  Everything but the pellet base is a compile-time constant for P == 1 -----
+#define L_EVP 0                                   // int[AG_EV_CAP]   pellet eat events of the tick
+#define L_EVV (L_EVP + 4 * AG_EV_CAP)             // int[AG_EVV_CAP]
+#define L_CAND (L_EVV + 4 * AG_EVV_CAP)           // unsigned[AG_CAND_CAP] ordered-replay keys
+#define L_TMP (L_CAND + 4 * AG_CAND_CAP)          // int[64] mailbox / scratch
+#define L_NEW (L_TMP + 4 * 64)                    // created cells [CF_FIELDS][AG_CC]; also the RNG draw buffer (128 x u64)
+#define L_PLS (L_NEW + 4 * CF_FIELDS * AG_CC)     // int[P][PL_WORDS]
+#define CELL_STRIDE (4 * (CF_FIELDS + 3) * AG_CC) // per player: 9 fields + (cached-for mass, radius, max speed)
+#ifdef AGAR_CPU_EMU
+static inline
+#else
+__host__ __device__ inline
+#endif
+size_t ag_lds_layout(int P, int *cells_off) {
+  int co = L_PLS + 4 * P * PL_WORDS;
+  if (cells_off) *cells_off = co;
+  return (size_t)co + (size_t)P * CELL_STRIDE;
+}
+
+struct Cells {  // LDS arrays of one player
+  float *x, *y, *vx, *vy, *sx, *sy; unsigned *m; int *id; unsigned *dl;
+  unsigned *cmc; float *crad, *cms;  // radius / max-speed cache, valid for cell i iff cmc[i] == m[i]
 };
 
-static inline
-#ifndef AGAR_CPU_EMU
-__host__ __device__
+// diagnostic build only (-DAGAR_PROFILE): per-phase shader-clock accumulation, summed into gs->prof
+#if defined(AGAR_PROFILE) && !defined(AGAR_CPU_EMU)
+#define AG_NPROF 16
+#define AG_T(c, k) do { unsigned t_ = (unsigned)__builtin_readcyclecounter(); (c).tacc[k] += t_ - (c).tlast; (c).tlast = t_; } while (0)
+#else
+#define AG_T(c, k) do { } while (0)
 #endif
-size_t ag_lds_bytes(const AgDims &d) {
-  size_t w = 0;
-  w += 2 * (size_t)d.PC;              // px py
-  w += 9 * (size_t)d.P * d.CC;        // cells
-  w += 9 * (size_t)d.CC;              // created
-  w += AR_WORDS + (size_t)d.P * PL_WORDS;
-  w += AG_EV_CAP + AG_EVV_CAP + AG_CAND_CAP;
-  w += 2 * 128;                       // rb (128 x u64)
-  w += 64;                            // tmp
-  w += 4;                             // ncreated + pad
-  return w * 4;
+
+// pellets live in registers: lane l, slot s holds pellet s*64+l; unused entries hold a far-away sentinel
+// so the scan needs no bounds test.  (test-only host build: plain arrays)
+#define AG_PEL_SENTINEL 3.0e38f
+template <int NS> struct Pel {
+#ifdef AGAR_CPU_EMU
+  float x[NS][64], y[NS][64];
+#else
+  float x[NS], y[NS];
+#endif
+};
+#ifdef AGAR_CPU_EMU
+#define AG_PEL_FOR(s, lane, i) for (int s = 0; s < NS; s++) for (int lane = 0, i = s * 64; lane < 64; lane++, i++)
+#define PELX(c, s, lane) (c).pel.x[s][lane]
+#define PELY(c, s, lane) (c).pel.y[s][lane]
+#else
+#define AG_PEL_FOR(s, lane, i) _Pragma("unroll") for (int s = 0; s < NS; s++) for (int lane = (int)threadIdx.x, i = s * 64 + (int)threadIdx.x, once_ = 1; once_; once_ = 0)
+#define PELX(c, s, lane) (c).pel.x[s]
+#define PELY(c, s, lane) (c).pel.y[s]
+#endif
+
+// AV ("all visible"): the pellet grid is at most 2x2 buckets (arena <= 1020), so every bucket is within +-1 of
+// every other and the reference's 3x3 bucket walk visits all pellets: no per-pellet bucket test is needed.
+template <int NS, bool AV> struct AgCtx {
+  Pel<NS> pel;
+#if defined(AGAR_PROFILE) && !defined(AGAR_CPU_EMU)
+  unsigned tacc[AG_NPROF]; unsigned tlast;
+#endif
+  const AgState *gs;
+  const float *act_dxdy; const int32_t *act;
+  int arena, P, PC, cells_off;
+  unsigned char *lds;
+  UBlock S;    // arena words (AR_*): register-resident for the whole launch
+  UBlock PB;   // current player's words (PL_*): valid inside tick_player only; LDS PLS is its home
+  int ncreated;
+  bool pel_dirty;
+};
+
+template <int NS, bool AV> AG_DEV int *L_I(const AgCtx<NS, AV> &c, int off) { return (int *)(c.lds + off); }
+template <int NS, bool AV> AG_DEV int *PLS(const AgCtx<NS, AV> &c, int p) { return (int *)(c.lds + L_PLS) + p * PL_WORDS; }
+template <int NS, bool AV> AG_DEV Cells cells_of(const AgCtx<NS, AV> &c, int p) {
+  float *b = (float *)(c.lds + c.cells_off + p * CELL_STRIDE);
+  Cells k;
+  k.x = b; k.y = b + AG_CC; k.vx = b + 2 * AG_CC; k.vy = b + 3 * AG_CC; k.sx = b + 4 * AG_CC; k.sy = b + 5 * AG_CC;
+  k.m = (unsigned *)(b + 6 * AG_CC); k.id = (int *)(b + 7 * AG_CC); k.dl = (unsigned *)(b + 8 * AG_CC);
+  k.cmc = (unsigned *)(b + 9 * AG_CC); k.crad = b + 10 * AG_CC; k.cms = b + 11 * AG_CC;
+  return k;
 }
-
-AG_DEV void ag_bind_lds(AgCtx &c, void *base) {
-  // rb (u64) first for 8-byte alignment
-  char *p = (char *)base;
-  c.rb = (uint64_t *)p; p += 128 * 8;
-  c.px = (float *)p; p += 4 * (size_t)c.d.PC; c.py = (float *)p; p += 4 * (size_t)c.d.PC;
-  size_t nc = (size_t)c.d.P * c.d.CC;
-  c.cx = (float *)p; p += 4 * nc; c.cy = (float *)p; p += 4 * nc; c.cvx = (float *)p; p += 4 * nc; c.cvy = (float *)p; p += 4 * nc;
-  c.csx = (float *)p; p += 4 * nc; c.csy = (float *)p; p += 4 * nc; c.cm = (unsigned *)p; p += 4 * nc; c.cid = (int *)p; p += 4 * nc; c.cdl = (unsigned *)p; p += 4 * nc;
-  size_t cc = (size_t)c.d.CC;
-  c.nx = (float *)p; p += 4 * cc; c.ny = (float *)p; p += 4 * cc; c.nvx = (float *)p; p += 4 * cc; c.nvy = (float *)p; p += 4 * cc;
-  c.nsx = (float *)p; p += 4 * cc; c.nsy = (float *)p; p += 4 * cc; c.nm = (unsigned *)p; p += 4 * cc; c.nid = (int *)p; p += 4 * cc; c.ndl = (unsigned *)p; p += 4 * cc;
-  c.S = (int *)p; p += 4 * AR_WORDS; c.PLS = (int *)p; p += 4 * (size_t)c.d.P * PL_WORDS;
-  c.evp = (int *)p; p += 4 * AG_EV_CAP; c.evv = (int *)p; p += 4 * AG_EVV_CAP; c.cand = (unsigned *)p; p += 4 * AG_CAND_CAP;
-  c.tmp = (int *)p; p += 4 * 64; c.ncreated = (int *)p; p += 16;
+template <int NS, bool AV> AG_DEV Cells created_of(const AgCtx<NS, AV> &c) {
+  float *b = (float *)(c.lds + L_NEW);
+  Cells k;
+  k.x = b; k.y = b + AG_CC; k.vx = b + 2 * AG_CC; k.vy = b + 3 * AG_CC; k.sx = b + 4 * AG_CC; k.sy = b + 5 * AG_CC;
+  k.m = (unsigned *)(b + 6 * AG_CC); k.id = (int *)(b + 7 * AG_CC); k.dl = (unsigned *)(b + 8 * AG_CC);
+  k.cmc = nullptr; k.crad = nullptr; k.cms = nullptr;
+  return k;
 }
+// HBM slices of this arena (pointer + capacity fetched with scalar loads when a rare path needs them)
+#define G_SLICE(name, type, field, cap) template <int NS, bool AV> AG_DEV type *name(const AgCtx<NS, AV> &c) { return c.gs->field + (size_t)c.arena * (size_t)(cap); }
+G_SLICE(g_pxy, float, pel_xy, 2 * c.PC) G_SLICE(g_pid, int32_t, pel_id, c.PC)
+G_SLICE(g_vx, float, vir_x, c.gs->d.VC) G_SLICE(g_vy, float, vir_y, c.gs->d.VC) G_SLICE(g_vvx, float, vir_vx, c.gs->d.VC) G_SLICE(g_vvy, float, vir_vy, c.gs->d.VC)
+G_SLICE(g_vm, int32_t, vir_mass, c.gs->d.VC) G_SLICE(g_vh, int32_t, vir_hits, c.gs->d.VC) G_SLICE(g_vid, int32_t, vir_id, c.gs->d.VC)
+G_SLICE(g_fx, float, food_x, c.gs->d.FC) G_SLICE(g_fy, float, food_y, c.gs->d.FC) G_SLICE(g_fvx, float, food_vx, c.gs->d.FC) G_SLICE(g_fvy, float, food_vy, c.gs->d.FC)
+G_SLICE(g_fid, int32_t, food_id, c.gs->d.FC)
+G_SLICE(g_mt, uint64_t, mt, 312) G_SLICE(g_ar, int32_t, ar, AR_WORDS)
+template <int NS, bool AV> AG_DEV int32_t *g_pl(const AgCtx<NS, AV> &c) { return c.gs->pl + (size_t)c.arena * c.P * PL_WORDS; }
+template <int NS, bool AV> AG_DEV int32_t *g_vt(const AgCtx<NS, AV> &c, int p) { return c.gs->vticks + ((size_t)c.arena * c.P + p) * AG_VT_CAP; }
+template <int NS, bool AV> AG_DEV uint32_t *g_cells(const AgCtx<NS, AV> &c, int p) { return c.gs->cells + ((size_t)c.arena * c.P + p) * (CF_FIELDS * AG_CC); }
 
-AG_DEV void ag_bind_arena(AgCtx &c, const AgState &s, int a) {
-  c.arena = a;
-  size_t A = (size_t)a;
-  c.gpx = s.pel_x + A * c.d.PC; c.gpy = s.pel_y + A * c.d.PC; c.gpid = s.pel_id + A * c.d.PC;
-  c.vx = s.vir_x + A * c.d.VC; c.vy = s.vir_y + A * c.d.VC; c.vvx = s.vir_vx + A * c.d.VC; c.vvy = s.vir_vy + A * c.d.VC;
-  c.vm = s.vir_mass + A * c.d.VC; c.vh = s.vir_hits + A * c.d.VC; c.vid = s.vir_id + A * c.d.VC;
-  c.fx = s.food_x + A * c.d.FC; c.fy = s.food_y + A * c.d.FC; c.fvx = s.food_vx + A * c.d.FC; c.fvy = s.food_vy + A * c.d.FC; c.fid = s.food_id + A * c.d.FC;
-  c.mt = s.mt + A * 312; c.gar = s.ar + A * AR_WORDS; c.gpl = s.pl + A * c.d.P * PL_WORDS; c.gvt = s.vticks + A * c.d.P * AG_VT_CAP;
-  c.gev_p = s.ev_p + A * AG_EV_CAP; c.gev_v = s.ev_v + A * AG_EVV_CAP;
-  c.lut_r = s.lut_r; c.lut_ms = s.lut_ms; c.lut_ss = s.lut_ss; c.lut_anti = s.lut_anti;
+template <int NS, bool AV> AG_DEV int SR(const AgCtx<NS, AV> &c, int k) { return ub_get(c.S, k); }
+template <int NS, bool AV> AG_DEV void SW(AgCtx<NS, AV> &c, int k, int v) { ub_set(c.S, k, v); }
+template <int NS, bool AV> AG_DEV int PR(const AgCtx<NS, AV> &c, int k) { return ub_get(c.PB, k); }
+template <int NS, bool AV> AG_DEV float PRF(const AgCtx<NS, AV> &c, int k) { return u2f(ub_get(c.PB, k)); }
+template <int NS, bool AV> AG_DEV void PW(AgCtx<NS, AV> &c, int k, int v) { ub_set(c.PB, k, v); }
+template <int NS, bool AV> AG_DEV void flag(AgCtx<NS, AV> &c, unsigned f) { SW(c, AR_FLAGS, SR(c, AR_FLAGS) | (int)f); }
+AG_DEV float lut(const float *t, unsigned m) { return t[m < (unsigned)AG_LUT_SIZE ? m : (unsigned)AG_LUT_SIZE - 1u]; }
+template <int NS, bool AV> AG_DEV float radius_of(const AgCtx<NS, AV> &c, unsigned m) { return lut(c.gs->lut_r, m); }
+// lane-level radius of LDS cell k of `cs`, through the per-cell cache when it is valid
+template <int NS, bool AV> AG_DEV float cell_rad(const AgCtx<NS, AV> &c, const Cells &cs, int k) { unsigned m = cs.m[k]; return cs.cmc[k] == m ? cs.crad[k] : radius_of(c, m); }
+
+// ---- pellet-register collectives: f(x, y, i) over every pellet slot, i = global pellet index ----------
+template <int NS, bool AV, class F> AG_DEV bool pel_any(const AgCtx<NS, AV> &c, F f) {
+  bool a = false;
+  AG_PEL_FOR(s, lane, i) { a = a | (bool)f(PELX(c, s, lane), PELY(c, s, lane), i); }
+#ifdef AGAR_CPU_EMU
+  return a;
+#else
+  return __ballot(a) != 0ull;
+#endif
 }
-
-// uniform reads of the LDS scalar blocks
-AG_DEV int SR(const AgCtx &c, int k) { return ag_uni(c.S[k]); }
-AG_DEV int PR(const AgCtx &c, int p, int k) { return ag_uni(c.PLS[p * PL_WORDS + k]); }
-AG_DEV float PRF(const AgCtx &c, int p, int k) { return u2f(PR(c, p, k)); }
-AG_DEV void SW(AgCtx &c, int k, int v) { AG_SERIAL { c.S[k] = v; } }
-AG_DEV void PW(AgCtx &c, int p, int k, int v) { AG_SERIAL { c.PLS[p * PL_WORDS + k] = v; } }
-AG_DEV void flag(AgCtx &c, unsigned f) { AG_SERIAL { c.S[AR_FLAGS] |= (int)f; } }
-AG_DEV float lut(const AgCtx &c, const float *t, unsigned m) { return t[m < (unsigned)AG_LUT_SIZE ? m : (unsigned)AG_LUT_SIZE - 1u]; }
-AG_DEV float radius_of(const AgCtx &c, unsigned m) { return lut(c, c.lut_r, m); }
-
-// ---- load / store arena state between HBM and LDS ------------------------------------------------
-AG_DEV void arena_load(AgCtx &c, const AgState &s) {
-  AG_LANES(i, AR_WORDS) c.S[i] = c.gar[i];
-  AG_LANES(i, c.d.P * PL_WORDS) c.PLS[i] = c.gpl[i];
-  ag_fence();
-  int np = SR(c, AR_NPEL);
-  AG_LANES(i, np) { c.px[i] = c.gpx[i]; c.py[i] = c.gpy[i]; }
-  size_t cb = (size_t)c.arena * c.d.P * c.d.CC;
-  for (int p = 0; p < c.d.P; p++) {
-    int n = PR(c, p, PL_NCELLS); size_t o = cb + (size_t)p * c.d.CC; int l = p * c.d.CC;
-    AG_LANES(i, n) {
-      c.cx[l + i] = s.cell_x[o + i]; c.cy[l + i] = s.cell_y[o + i]; c.cvx[l + i] = s.cell_vx[o + i]; c.cvy[l + i] = s.cell_vy[o + i];
-      c.csx[l + i] = s.cell_sx[o + i]; c.csy[l + i] = s.cell_sy[o + i]; c.cm[l + i] = s.cell_m[o + i]; c.cid[l + i] = s.cell_id[o + i]; c.cdl[l + i] = s.cell_dl[o + i];
-    }
+template <int NS, bool AV, class F> AG_DEV int pel_count(const AgCtx<NS, AV> &c, F f) {
+#ifdef AGAR_CPU_EMU
+  int n = 0;
+  AG_PEL_FOR(s, lane, i) { n += f(PELX(c, s, lane), PELY(c, s, lane), i) ? 1 : 0; }
+  return n;
+#else
+  int n = 0;
+  AG_PEL_FOR(s, lane, i) { n += __popcll(__ballot((bool)f(PELX(c, s, lane), PELY(c, s, lane), i))); }
+  return n;
+#endif
+}
+// ordered compaction in ascending pellet index: sink(x, y, i, rank)
+template <int NS, bool AV, class F, class S> AG_DEV int pel_compact(const AgCtx<NS, AV> &c, F pred, S sink) {
+  int count = 0;
+#ifdef AGAR_CPU_EMU
+  AG_PEL_FOR(s, lane, i) { if (pred(PELX(c, s, lane), PELY(c, s, lane), i)) { sink(PELX(c, s, lane), PELY(c, s, lane), i, count); count++; } }
+#else
+  const unsigned long long lt = (1ull << threadIdx.x) - 1ull;
+  AG_PEL_FOR(s, lane, i) {
+    bool p = pred(PELX(c, s, lane), PELY(c, s, lane), i);
+    unsigned long long m = __ballot(p);
+    if (p) sink(PELX(c, s, lane), PELY(c, s, lane), i, count + __popcll(m & lt));
+    count += __popcll(m);
   }
-  ag_fence();
+#endif
+  return count;
 }
-AG_DEV void arena_store(AgCtx &c, const AgState &s) {
-  ag_fence();
+// Optimisation barrier: tells the compiler the pellet registers "changed" (no instruction is emitted) so that it
+// recomputes per-pellet distances in each rare-path pass instead of keeping 16+ of them alive across passes.
+template <int NS, bool AV> AG_DEV void pel_launder(AgCtx<NS, AV> &c) {
+#ifndef AGAR_CPU_EMU
+  _Pragma("unroll") for (int s = 0; s < NS; s++) asm volatile("" : "+v"(c.pel.x[s]), "+v"(c.pel.y[s]));
+#endif
+}
+// pellet[dst] = pellet[src] (wave-level; the swap half of the reference's swap-pop that survives)
+template <int NS, bool AV> AG_DEV void pel_move(AgCtx<NS, AV> &c, int dst, int src) {
+#ifdef AGAR_CPU_EMU
+  c.pel.x[dst >> 6][dst & 63] = c.pel.x[src >> 6][src & 63]; c.pel.y[dst >> 6][dst & 63] = c.pel.y[src >> 6][src & 63];
+#else
+  int ss = src >> 6, sl = src & 63, ds = dst >> 6, dl = dst & 63; float vx = 0.0f, vy = 0.0f;
+  _Pragma("unroll") for (int s = 0; s < NS; s++) if (s == ss) { vx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.pel.x[s]), sl)); vy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.pel.y[s]), sl)); }
+  _Pragma("unroll") for (int s = 0; s < NS; s++) if (s == ds && (int)threadIdx.x == dl) { c.pel.x[s] = vx; c.pel.y[s] = vy; }
+#endif
+}
+// uniform read of pellet i
+template <int NS, bool AV> AG_DEV void pel_get(const AgCtx<NS, AV> &c, int i, float &x, float &y) {
+#ifdef AGAR_CPU_EMU
+  x = c.pel.x[i >> 6][i & 63]; y = c.pel.y[i >> 6][i & 63];
+#else
+  int ss = i >> 6, sl = i & 63; x = 0.0f; y = 0.0f;
+  _Pragma("unroll") for (int s = 0; s < NS; s++) if (s == ss) { x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.pel.x[s]), sl)); y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.pel.y[s]), sl)); }
+#endif
+}
+
+// ---- load / store arena state between HBM and LDS / registers -------------------------------------
+template <int NS, bool AV> AG_DEV void arena_load(AgCtx<NS, AV> &c) {
+  ub_load(c.S, g_ar(c), AR_WORDS);
+  const int32_t *gpl = g_pl(c);
+  AG_LANES(i, c.P * PL_WORDS) PLS(c, 0)[i] = gpl[i];
   int np = SR(c, AR_NPEL);
-  AG_LANES(i, np) { c.gpx[i] = c.px[i]; c.gpy[i] = c.py[i]; }
-  size_t cb = (size_t)c.arena * c.d.P * c.d.CC;
+  const float *gxy = g_pxy(c);
+  AG_PEL_FOR(s, lane, i) {  // 8 B per lane, 512 B per wave-instruction, all slots in flight together
+    float x = AG_PEL_SENTINEL, y = AG_PEL_SENTINEL;
+    if (i < np) { x = gxy[2 * i]; y = gxy[2 * i + 1]; }
+    PELX(c, s, lane) = x; PELY(c, s, lane) = y;
+  }
+  ag_lds_order();
+  for (int p = 0; p < c.P; p++) {
+    int n = ag_uni(PLS(c, p)[PL_NCELLS]);
+    Cells cs = cells_of(c, p); const uint32_t *g = g_cells(c, p);
+    AG_LANES(i, n) {
+      cs.x[i] = u2f((int)g[CF_X * AG_CC + i]); cs.y[i] = u2f((int)g[CF_Y * AG_CC + i]); cs.vx[i] = u2f((int)g[CF_VX * AG_CC + i]); cs.vy[i] = u2f((int)g[CF_VY * AG_CC + i]);
+      cs.sx[i] = u2f((int)g[CF_SX * AG_CC + i]); cs.sy[i] = u2f((int)g[CF_SY * AG_CC + i]);
+      cs.m[i] = g[CF_M * AG_CC + i]; cs.id[i] = (int)g[CF_ID * AG_CC + i]; cs.dl[i] = g[CF_DL * AG_CC + i];
+    }
+    // radius / max-speed cache (valid for cell i iff cmc[i] == m[i]); slots past n start invalid (no cell has mass 0)
+    const float *lut_r = c.gs->lut_r, *lut_ms = c.gs->lut_ms;
+    AG_LANES(i, AG_CC) { if (i < n) { unsigned m = g[CF_M * AG_CC + i]; cs.cmc[i] = m; cs.crad[i] = lut(lut_r, m); cs.cms[i] = lut(lut_ms, m); } else cs.cmc[i] = 0u; }
+  }
+  c.pel_dirty = false; c.ncreated = 0;
+  ag_lds_order();
+}
+template <int NS, bool AV> AG_DEV void arena_store(AgCtx<NS, AV> &c) {
+  ag_lds_order();
+  int np = SR(c, AR_NPEL);
+  if (c.pel_dirty) {
+    float *gxy = g_pxy(c);
+    AG_PEL_FOR(s, lane, i) { if (i < np) { gxy[2 * i] = PELX(c, s, lane); gxy[2 * i + 1] = PELY(c, s, lane); } }
+  }
   int total_cells = 0;
-  for (int p = 0; p < c.d.P; p++) {
-    int n = PR(c, p, PL_NCELLS); size_t o = cb + (size_t)p * c.d.CC; int l = p * c.d.CC;
+  for (int p = 0; p < c.P; p++) {
+    int n = ag_uni(PLS(c, p)[PL_NCELLS]);
     total_cells += n;
+    Cells cs = cells_of(c, p); uint32_t *g = g_cells(c, p);
     AG_LANES(i, n) {
-      s.cell_x[o + i] = c.cx[l + i]; s.cell_y[o + i] = c.cy[l + i]; s.cell_vx[o + i] = c.cvx[l + i]; s.cell_vy[o + i] = c.cvy[l + i];
-      s.cell_sx[o + i] = c.csx[l + i]; s.cell_sy[o + i] = c.csy[l + i]; s.cell_m[o + i] = c.cm[l + i]; s.cell_id[o + i] = c.cid[l + i]; s.cell_dl[o + i] = c.cdl[l + i];
+      g[CF_X * AG_CC + i] = (uint32_t)f2u(cs.x[i]); g[CF_Y * AG_CC + i] = (uint32_t)f2u(cs.y[i]); g[CF_VX * AG_CC + i] = (uint32_t)f2u(cs.vx[i]); g[CF_VY * AG_CC + i] = (uint32_t)f2u(cs.vy[i]);
+      g[CF_SX * AG_CC + i] = (uint32_t)f2u(cs.sx[i]); g[CF_SY * AG_CC + i] = (uint32_t)f2u(cs.sy[i]);
+      g[CF_M * AG_CC + i] = cs.m[i]; g[CF_ID * AG_CC + i] = (uint32_t)cs.id[i]; g[CF_DL * AG_CC + i] = cs.dl[i];
     }
   }
-  AG_LANES(i, AR_WORDS) c.gar[i] = c.S[i];
-  AG_LANES(i, c.d.P * PL_WORDS) c.gpl[i] = c.PLS[i];
+  ub_store(c.S, g_ar(c), AR_WORDS);
+  int32_t *gpl = g_pl(c);
+  AG_LANES(i, c.P * PL_WORDS) gpl[i] = PLS(c, 0)[i];
   int nevp = SR(c, AR_NEVP), nevv = SR(c, AR_NEVV);
-  AG_LANES(i, nevp) c.gev_p[i] = c.evp[i];
-  AG_LANES(i, nevv) c.gev_v[i] = c.evv[i];
-  AG_SERIAL { int32_t *cn = s.counts + (size_t)c.arena * 4; cn[0] = np; cn[1] = c.S[AR_NVIR]; cn[2] = c.S[AR_NFOOD]; cn[3] = total_cells; }
+  if (nevp > 0) { int32_t *ge = c.gs->ev_p + (size_t)c.arena * AG_EV_CAP; int lim = nevp < AG_EV_CAP ? nevp : AG_EV_CAP; AG_LANES(i, lim) ge[i] = L_I(c, L_EVP)[i]; }
+  if (nevv > 0) { int32_t *ge = c.gs->ev_v + (size_t)c.arena * AG_EVV_CAP; int lim = nevv < AG_EVV_CAP ? nevv : AG_EVV_CAP; AG_LANES(i, lim) ge[i] = L_I(c, L_EVV)[i]; }
+  int nv = SR(c, AR_NVIR), nf = SR(c, AR_NFOOD);
+  AG_SERIAL { int32_t *cn = c.gs->counts + (size_t)c.arena * 4; cn[0] = np; cn[1] = nv; cn[2] = nf; cn[3] = total_cells; }
 }
 
 // ---- mt19937_64, one generator per arena, state in HBM.  R: GameState.hpp:51, Engine.hpp:1304-1311
@@ -220,9 +369,9 @@ AG_DEV uint64_t mt_mix(uint64_t a, uint64_t b, uint64_t far) {
   uint64_t y = (a & 0xFFFFFFFF80000000ULL) | (b & 0x7FFFFFFFULL);
   return far ^ (y >> 1) ^ ((y & 1ULL) ? 0xB5026F5AA96619E9ULL : 0ULL);
 }
-AG_DEV void mt_twist(AgCtx &c) {  // three dependency phases, each data-parallel across the wave
-  uint64_t *mt = c.mt;
-  ag_fence();
+template <int NS, bool AV> AG_DEV void mt_twist(AgCtx<NS, AV> &c) {  // three dependency phases, each data-parallel across the wave
+  uint64_t *mt = g_mt(c);
+  ag_mem_fence();
   for (int base = 0; base < 156; base += 64) {  // phase 1: reads old values only
     int lim = base + 64 < 156 ? base + 64 : 156;
 #ifdef AGAR_CPU_EMU
@@ -230,9 +379,9 @@ AG_DEV void mt_twist(AgCtx &c) {  // three dependency phases, each data-parallel
 #else
     int i = base + (int)threadIdx.x; uint64_t v = 0;
     if (i < lim) v = mt_mix(mt[i], mt[i + 1], mt[i + 156]);
-    ag_fence();
+    ag_mem_fence();
     if (i < lim) mt[i] = v;
-    ag_fence();
+    ag_mem_fence();
 #endif
   }
   for (int base = 156; base < 311; base += 64) {  // phase 2: far operand is a phase-1 result
@@ -242,26 +391,28 @@ AG_DEV void mt_twist(AgCtx &c) {  // three dependency phases, each data-parallel
 #else
     int i = base + (int)threadIdx.x; uint64_t v = 0;
     if (i < lim) v = mt_mix(mt[i], mt[i + 1], mt[i - 156]);
-    ag_fence();
+    ag_mem_fence();
     if (i < lim) mt[i] = v;
-    ag_fence();
+    ag_mem_fence();
 #endif
   }
   AG_SERIAL { mt[311] = mt_mix(mt[311], mt[0], mt[155]); }
-  ag_fence();
+  ag_mem_fence();
 }
-// fill c.rb[0..n) (n <= 128) with the next n raw 64-bit outputs
-AG_DEV void mt_fill(AgCtx &c, int n) {
+// fill rb[0..n) (n <= 128, LDS) with the next n raw 64-bit outputs
+template <int NS, bool AV> AG_DEV void mt_fill(AgCtx<NS, AV> &c, int n) {
+  uint64_t *rb = (uint64_t *)(c.lds + L_NEW);
   int produced = 0;
   while (produced < n) {
     int idx = SR(c, AR_MTIDX);
     if (idx >= 312) { mt_twist(c); idx = 0; }
     int take = 312 - idx < n - produced ? 312 - idx : n - produced;
-    AG_LANES(j, take) c.rb[produced + j] = mt_temper(c.mt[idx + j]);
+    const uint64_t *mt = g_mt(c);
+    AG_LANES(j, take) rb[produced + j] = mt_temper(mt[idx + j]);
     SW(c, AR_MTIDX, idx + take);
-    ag_fence();
     produced += take;
   }
+  ag_lds_order();
 }
 // std::uniform_real_distribution<float>(0,max) from one raw draw.  R: utils/random.hpp:6-20
 AG_DEV float mt_to_float(uint64_t u, float maxv) {
@@ -272,94 +423,113 @@ AG_DEV float mt_to_float(uint64_t u, float maxv) {
   return v + 0.0f;
 }
 // `count` random_location(radius) draws in sequence; sink(j, x, y).  R: Engine.hpp:143-148
-template <class SINK> AG_DEV void draw_locations(AgCtx &c, int count, float radius, SINK sink) {
-  float two_r = 2.0f * radius; float span = c.g.W - two_r;
+template <int NS, bool AV, class SINK> AG_DEV void draw_locations(AgCtx<NS, AV> &c, int count, float radius, SINK sink) {
+  float two_r = 2.0f * radius; float span = c.gs->g.W - two_r;
+  const uint64_t *rb = (const uint64_t *)(c.lds + L_NEW);
   for (int done = 0; done < count; done += 64) {
     int b = count - done < 64 ? count - done : 64;
     mt_fill(c, 2 * b);
     AG_LANES(j, b) {
-      float x = mt_to_float(c.rb[2 * j], span) + radius;
-      float y = mt_to_float(c.rb[2 * j + 1], span) + radius;
+      float x = mt_to_float(rb[2 * j], span) + radius;
+      float y = mt_to_float(rb[2 * j + 1], span) + radius;
       sink(done + j, x, y);
     }
-    ag_fence();
+    ag_lds_order();
   }
 }
 
 // ---- spawning.  R: Engine.hpp:418-424, 480-485, 426-475, 119-137 -----------------------------------
-AG_DEV void add_pellets(AgCtx &c, int n) {
+template <int NS, bool AV> AG_DEV void add_pellets(AgCtx<NS, AV> &c, int n) {
   if (n <= 0) return;
   int np = SR(c, AR_NPEL), idc = SR(c, AR_IDC);
-  if (np + n > c.d.PC) { flag(c, 64u); n = c.d.PC - np; if (n <= 0) return; }
+  if (np + n > c.PC) { flag(c, 64u); n = c.PC - np; if (n <= 0) return; }
   float r = radius_of(c, AG_PELLET_MASS);
-  draw_locations(c, n, r, [&](int j, float x, float y) { c.px[np + j] = x; c.py[np + j] = y; c.gpid[np + j] = idc + 1 + j; });
+  int32_t *gid = g_pid(c);
+  float *stage = (float *)L_I(c, L_CAND);  // 64 (x,y) pairs; the candidate list is idle during regen
+  float two_r = 2.0f * r; float span = c.gs->g.W - two_r;
+  const uint64_t *rb = (const uint64_t *)(c.lds + L_NEW);
+  for (int done = 0; done < n; done += 64) {  // random_location(r) x n in sequence.  R: Engine.hpp:143-148, 418-424
+    int b = n - done < 64 ? n - done : 64;
+    mt_fill(c, 2 * b);
+    int base = np + done;
+    AG_LANES(j, b) {
+      stage[2 * j] = mt_to_float(rb[2 * j], span) + r;
+      stage[2 * j + 1] = mt_to_float(rb[2 * j + 1], span) + r;
+      gid[base + j] = idc + 1 + done + j;
+    }
+    ag_lds_order();
+    AG_PEL_FOR(s, lane, i) { if (i >= base && i < base + b) { PELX(c, s, lane) = stage[2 * (i - base)]; PELY(c, s, lane) = stage[2 * (i - base) + 1]; } }
+    ag_lds_order();
+  }
   SW(c, AR_NPEL, np + n); SW(c, AR_IDC, idc + n);
-  ag_fence();
+  c.pel_dirty = true;
 }
-AG_DEV void add_viruses(AgCtx &c, int n) {
+template <int NS, bool AV> AG_DEV void add_viruses(AgCtx<NS, AV> &c, int n) {
   if (n <= 0) return;
-  int nv = SR(c, AR_NVIR), idc = SR(c, AR_IDC);
-  if (nv + n > c.d.VC) { flag(c, 4u); n = c.d.VC - nv; if (n <= 0) return; }
+  int nv = SR(c, AR_NVIR), idc = SR(c, AR_IDC), VC = c.gs->d.VC;
+  if (nv + n > VC) { flag(c, 4u); n = VC - nv; if (n <= 0) return; }
   float r = radius_of(c, AG_VIRUS_MASS);
+  float *vx = g_vx(c), *vy = g_vy(c), *vvx = g_vvx(c), *vvy = g_vvy(c); int32_t *vm = g_vm(c), *vh = g_vh(c), *vid = g_vid(c);
   draw_locations(c, n, r, [&](int j, float x, float y) {
-    int k = nv + j; c.vx[k] = x; c.vy[k] = y; c.vvx[k] = 0.0f; c.vvy[k] = 0.0f; c.vm[k] = (int)AG_VIRUS_MASS; c.vh[k] = 0; c.vid[k] = idc + 1 + j; });
+    int k = nv + j; vx[k] = x; vy[k] = y; vvx[k] = 0.0f; vvy[k] = 0.0f; vm[k] = (int)AG_VIRUS_MASS; vh[k] = 0; vid[k] = idc + 1 + j; });
   SW(c, AR_NVIR, nv + n); SW(c, AR_IDC, idc + n);
-  ag_fence();
+  ag_mem_fence();
 }
-AG_DEV void create_squared_pellets(AgCtx &c) {
-  float W = c.g.W;
+template <int NS, bool AV> AG_DEV void create_squared_pellets(AgCtx<NS, AV> &c) {
+  float W = c.gs->g.W;
   float square = ag_divf(W, 2.0f);
   int pps = f2i(square);
   float cx = ag_divf(W, 2.0f), half = ag_divf(square, 2.0f);
   int idc = SR(c, AR_IDC);
   // every generated point lies inside the arena (centre +- W/4), so all 4*pps are kept, in order
   int total = 4 * pps;
-  if (total > c.d.PC) { flag(c, 64u); total = c.d.PC; }
-  AG_LANES(k, total) {
-    int side = k / pps, i = k - side * pps; float t = (float)i * 1.0f; float x, y;
-    if (side == 0) { x = (cx - half) + t; y = cx - half; }
-    else if (side == 1) { x = cx + half; y = (cx - half) + t; }
-    else if (side == 2) { x = (cx + half) - t; y = cx + half; }
-    else { x = cx - half; y = (cx + half) - t; }
-    c.px[k] = x; c.py[k] = y; c.gpid[k] = idc + 1 + k;
+  if (total > c.PC) { flag(c, 64u); total = c.PC; }
+  int32_t *gid = g_pid(c);
+  AG_PEL_FOR(s, lane, k) {
+    if (k < total) {
+      int side = k / pps, i = k - side * pps; float t = (float)i * 1.0f; float x, y;
+      if (side == 0) { x = (cx - half) + t; y = cx - half; }
+      else if (side == 1) { x = cx + half; y = (cx - half) + t; }
+      else if (side == 2) { x = (cx + half) - t; y = cx + half; }
+      else { x = cx - half; y = (cx + half) - t; }
+      PELX(c, s, lane) = x; PELY(c, s, lane) = y; gid[k] = idc + 1 + k;
+    }
   }
   SW(c, AR_NPEL, total); SW(c, AR_IDC, idc + total);
-  ag_fence();
+  c.pel_dirty = true;
+  ag_lds_order();
 }
-AG_DEV void player_kill(AgCtx &c, int p) {  // R: core/Player.hpp:75-86
-  AG_SERIAL {
-    int *P = c.PLS + p * PL_WORDS;
+// Engine::respawn on player slot p, operating on its LDS words (called outside tick_player).
+template <int NS, bool AV> AG_DEV void respawn(AgCtx<NS, AV> &c, int p) {
+  int *P = PLS(c, p);
+  AG_SERIAL {  // Player::kill, R: core/Player.hpp:75-86
     P[PL_NCELLS] = 0; P[PL_MIN_MASS] = (int)AG_CELL_MIN_SIZE; P[PL_SPLIT_CD] = 0; P[PL_FEED_CD] = 0;
     P[PL_ANTI_TEAM] = f2u(1.0f); P[PL_ELAPSED] = 0; P[PL_LAST_DECAY] = 0; P[PL_NVTICKS] = 0;
   }
-  ag_fence();
-}
-AG_DEV void respawn(AgCtx &c, int p) {
-  player_kill(c, p);
-  unsigned pm = (unsigned)(c.g.agent_mass > (int)AG_CELL_MIN_SIZE ? c.g.agent_mass : (int)AG_CELL_MIN_SIZE);
-  float r25 = radius_of(c, AG_CELL_MIN_SIZE);
-  int l = p * c.d.CC;
-  if (SR(c, AR_NPEL) > 0 && c.g.squared) {
-    AG_SERIAL {
-      float x = c.px[0], y = c.py[0]; float t = 2.0f * r25; x += t; y += t;
-      x = sminf(x, c.g.W - r25); y = sminf(y, c.g.W - r25);
-      c.cx[l] = x; c.cy[l] = y;
-    }
+  unsigned pm = (unsigned)(c.gs->g.agent_mass > (int)AG_CELL_MIN_SIZE ? c.gs->g.agent_mass : (int)AG_CELL_MIN_SIZE);
+  float r25 = radius_of(c, AG_CELL_MIN_SIZE), W = c.gs->g.W;
+  Cells cs = cells_of(c, p);
+  if (SR(c, AR_NPEL) > 0 && c.gs->g.squared) {
+    float x, y; pel_get(c, 0, x, y);
+    float t = 2.0f * r25; x += t; y += t;
+    x = sminf(x, W - r25); y = sminf(y, W - r25);
+    AG_SERIAL { cs.x[0] = x; cs.y[0] = y; }
   } else {
-    draw_locations(c, 1, r25, [&](int, float x, float y) { c.cx[l] = x; c.cy[l] = y; });
+    draw_locations(c, 1, r25, [&](int, float x, float y) { cs.x[0] = x; cs.y[0] = y; });
   }
+  int idc = SR(c, AR_IDC) + 1; SW(c, AR_IDC, idc);
+  unsigned clock = (unsigned)SR(c, AR_CLOCK);
   AG_SERIAL {
-    int idc = c.S[AR_IDC] + 1; c.S[AR_IDC] = idc;
-    c.cvx[l] = 0; c.cvy[l] = 0; c.csx[l] = 0; c.csy[l] = 0; c.cm[l] = clamp_mass(pm); c.cid[l] = idc; c.cdl[l] = (unsigned)c.S[AR_CLOCK];
-    c.PLS[p * PL_WORDS + PL_NCELLS] = 1;
+    cs.vx[0] = 0; cs.vy[0] = 0; cs.sx[0] = 0; cs.sy[0] = 0; cs.m[0] = clamp_mass(pm); cs.id[0] = idc; cs.dl[0] = clock; cs.cmc[0] = 0u;
+    P[PL_NCELLS] = 1;
   }
-  ag_fence();
+  ag_lds_order();
 }
 
 // ---- movement.  R: Engine.hpp:609-630, 695-698; core/types.hpp:176-223; Entities.hpp:161-164 ------
-AG_DEV void boundary(const AgCtx &c, float &x, float &y, float r) {
-  x = smaxf(0.0f, clampf(x, r, c.g.W - r));
-  y = smaxf(0.0f, clampf(y, r, c.g.W - r));
+AG_DEV void boundary(float W, float &x, float &y, float r) {
+  x = smaxf(0.0f, clampf(x, r, W - r));
+  y = smaxf(0.0f, clampf(y, r, W - r));
 }
 AG_DEV void v_decelerate(float &dx, float &dy, float decel, float dt) {
   float xr = ag_divf(dx, vmag(dx, dy));
@@ -375,203 +545,215 @@ AG_DEV float v_direction(float dx, float dy) {  // R: types.hpp:167-174
   return angle;
 }
 
-// serial (lane 0) pieces of the self-collision relaxation; operate on LDS cells l+a, l+b
-AG_DEV void cell_move1(AgCtx &c, int k, float dt) {
-  float sx = c.cvx[k] + c.csx[k]; float tx = sx * dt; c.cx[k] += tx;
-  float sy = c.cvy[k] + c.csy[k]; float ty = sy * dt; c.cy[k] += ty;
+// pair-level pieces of the self-collision relaxation (lane-level code on LDS cells a, b of `s`)
+AG_DEV void cell_move1(const Cells &s, int k, float dt) {
+  float sx = s.vx[k] + s.sx[k]; float tx = sx * dt; s.x[k] += tx;
+  float sy = s.vy[k] + s.sy[k]; float ty = sy * dt; s.y[k] += ty;
 }
-AG_DEV void avoid_static_overlap(AgCtx &c, int a, int b) {  // R: Engine.hpp:701-749
-  float dx = c.cx[b] - c.cx[a], dy = c.cy[b] - c.cy[a];
+template <int NS, bool AV> AG_DEV void avoid_static_overlap(const AgCtx<NS, AV> &c, const Cells &s, int a, int b, float W) {  // R: Engine.hpp:701-749
+  float dx = s.x[b] - s.x[a], dy = s.y[b] - s.y[a];
   float dist = vmag(dx, dy);
-  float ra = radius_of(c, c.cm[a]), rb = radius_of(c, c.cm[b]);
+  float ra = cell_rad(c, s, a), rb = cell_rad(c, s, b);
   float target = ra + rb;
   if (dist > target) return;
   float den = fabsf(dx) + fabsf(dy);
   float xr = ag_divf(dx, den), yr = ag_divf(dy, den);
   float depth = target - dist;
-  float a1 = 0.5f, a2 = 0.5f, b1 = 0.5f, b2 = 0.5f; float W = c.g.W;
-  if (c.cx[a] == ra || c.cx[a] == W - ra) { a1 = 1.0f; c.cvx[a] = 0; }
-  if (c.cy[a] == ra || c.cy[a] == W - ra) { a2 = 1.0f; c.cvy[a] = 0; }
-  if (c.cx[b] == rb || c.cx[b] == W - rb) { b1 = 1.0f; c.cvx[b] = 0; }
-  if (c.cy[b] == rb || c.cy[b] == W - rb) { b2 = 1.0f; c.cvy[b] = 0; }
+  float a1 = 0.5f, a2 = 0.5f, b1 = 0.5f, b2 = 0.5f;
+  if (s.x[a] == ra || s.x[a] == W - ra) { a1 = 1.0f; s.vx[a] = 0; }
+  if (s.y[a] == ra || s.y[a] == W - ra) { a2 = 1.0f; s.vy[a] = 0; }
+  if (s.x[b] == rb || s.x[b] == W - rb) { b1 = 1.0f; s.vx[b] = 0; }
+  if (s.y[b] == rb || s.y[b] == W - rb) { b2 = 1.0f; s.vy[b] = 0; }
   float t;
-  t = xr * depth; t = t * a1; c.cx[a] -= t;
-  t = yr * depth; t = t * a2; c.cy[a] -= t;
-  t = xr * depth; t = t * b1; c.cx[b] += t;
-  t = yr * depth; t = t * b2; c.cy[b] += t;
-  boundary(c, c.cx[a], c.cy[a], ra);
-  boundary(c, c.cx[b], c.cy[b], rb);
+  t = xr * depth; t = t * a1; s.x[a] -= t;
+  t = yr * depth; t = t * a2; s.y[a] -= t;
+  t = xr * depth; t = t * b1; s.x[b] += t;
+  t = yr * depth; t = t * b2; s.y[b] += t;
+  boundary(W, s.x[a], s.y[a], ra);
+  boundary(W, s.x[b], s.y[b], rb);
 }
-AG_DEV void separate_cells(AgCtx &c, int a, int b, float tx, float ty) {  // R: Engine.hpp:803-848
-  float dx = c.cx[b] - c.cx[a], dy = c.cy[b] - c.cy[a];
+template <int NS, bool AV> AG_DEV void separate_cells(const AgCtx<NS, AV> &c, const Cells &s, int a, int b, float tx, float ty) {  // R: Engine.hpp:803-848
+  float dx = s.x[b] - s.x[a], dy = s.y[b] - s.y[a];
   float dist = vmag(dx, dy);
-  float target = radius_of(c, c.cm[a]) + radius_of(c, c.cm[b]);
+  float target = cell_rad(c, s, a) + cell_rad(c, s, b);
   if (dist > target) return;
   float den = fabsf(dx) + fabsf(dy);
   float xr = ag_divf(dx, den), yr = ag_divf(dy, den);
-  float diff_a = sqr_dist(tx, ty, c.cx[a], c.cy[a]);
-  float diff_b = sqr_dist(tx, ty, c.cx[b], c.cy[b]);
+  float diff_a = sqr_dist(tx, ty, s.x[a], s.y[a]);
+  float diff_b = sqr_dist(tx, ty, s.x[b], s.y[b]);
   float depth = target - dist;
-  int s1 = c.cm[a] < c.cm[b] ? 1 : -1;
+  int s1 = s.m[a] < s.m[b] ? 1 : -1;
   int s2 = diff_a >= diff_b ? 1 : -1;
-  int s = (s1 == s2) ? s2 : 0;
-  int tc = c.cm[a] < c.cm[b] ? a : b;
-  float fs = (float)s, t;
+  int sg = (s1 == s2) ? s2 : 0;
+  int tc = s.m[a] < s.m[b] ? a : b;
+  float fs = (float)sg, t;
   if (dx >= 0) {
-    t = xr * depth; t = t * fs; c.cx[tc] -= t;
-    if (dy >= 0) { t = yr * depth; t = t * fs; c.cy[tc] -= t; } else { t = yr * depth; t = t * fs; c.cy[tc] += t; }
+    t = xr * depth; t = t * fs; s.x[tc] -= t;
+    if (dy >= 0) { t = yr * depth; t = t * fs; s.y[tc] -= t; } else { t = yr * depth; t = t * fs; s.y[tc] += t; }
   } else {
-    t = xr * depth; t = t * fs; c.cx[tc] += t;
-    if (dy >= 0) { t = yr * depth; t = t * fs; c.cy[tc] -= t; } else { t = yr * depth; t = t * fs; c.cy[tc] += t; }
+    t = xr * depth; t = t * fs; s.x[tc] += t;
+    if (dy >= 0) { t = yr * depth; t = t * fs; s.y[tc] -= t; } else { t = yr * depth; t = t * fs; s.y[tc] += t; }
   }
 }
-AG_DEV void elastic(AgCtx &c, int a, int b, float dx, float dy, float dist) {  // R: Engine.hpp:893-938
+AG_DEV void elastic(const Cells &s, int a, int b, float dx, float dy, float dist) {  // R: Engine.hpp:893-938
   float nx = ag_divf(dx, dist), ny = ag_divf(dy, dist);
   float tx = -ny, ty = nx;
-  float p1 = c.cvx[a] * nx, p2 = c.cvy[a] * ny; float dpN1 = p1 + p2;
-  p1 = c.cvx[b] * nx; p2 = c.cvy[b] * ny; float dpN2 = p1 + p2;
-  p1 = c.cvx[a] * tx; p2 = c.cvy[a] * ty; float dpT1 = p1 + p2;
-  p1 = c.cvx[b] * tx; p2 = c.cvy[b] * ty; float dpT2 = p1 + p2;
-  int m1 = (int)c.cm[a], m2 = (int)c.cm[b];
+  float p1 = s.vx[a] * nx, p2 = s.vy[a] * ny; float dpN1 = p1 + p2;
+  p1 = s.vx[b] * nx; p2 = s.vy[b] * ny; float dpN2 = p1 + p2;
+  p1 = s.vx[a] * tx; p2 = s.vy[a] * ty; float dpT1 = p1 + p2;
+  p1 = s.vx[b] * tx; p2 = s.vy[b] * ty; float dpT2 = p1 + p2;
+  int m1 = (int)s.m[a], m2 = (int)s.m[b];
   float q1 = dpN1 * (float)(m1 - m2);
   float q2 = 2.0f * (float)m2; q2 = q2 * dpN2;
   float v1 = ag_divf(q1 + q2, (float)(m1 + m2));
   q1 = dpN2 * (float)(m2 - m1);
   q2 = 2.0f * (float)m1; q2 = q2 * dpN1;
   float v2 = ag_divf(q1 + q2, (float)(m1 + m2));
-  if (c.cm[a] < c.cm[b]) {
-    float u = tx * dpT1, w = nx * v1; c.cvx[a] = u + w; u = ty * dpT1; w = ny * v1; c.cvy[a] = u + w;
-  } else if (c.cm[a] > c.cm[b]) {
-    float u = tx * dpT2, w = nx * v2; c.cvx[b] = u + w; u = ty * dpT2; w = ny * v2; c.cvy[b] = u + w;
+  if (s.m[a] < s.m[b]) {
+    float u = tx * dpT1, w = nx * v1; s.vx[a] = u + w; u = ty * dpT1; w = ny * v1; s.vy[a] = u + w;
+  } else if (s.m[a] > s.m[b]) {
+    float u = tx * dpT2, w = nx * v2; s.vx[b] = u + w; u = ty * dpT2; w = ny * v2; s.vy[b] = u + w;
   } else {
-    float u = tx * dpT1, w = nx * v1; c.cvx[a] = u + w; u = ty * dpT1; w = ny * v1; c.cvy[a] = u + w;
-    u = tx * dpT2; w = nx * v2; c.cvx[b] = u + w; u = ty * dpT2; w = ny * v2; c.cvy[b] = u + w;
+    float u = tx * dpT1, w = nx * v1; s.vx[a] = u + w; u = ty * dpT1; w = ny * v1; s.vy[a] = u + w;
+    u = tx * dpT2; w = nx * v2; s.vx[b] = u + w; u = ty * dpT2; w = ny * v2; s.vy[b] = u + w;
   }
 }
-AG_DEV bool cells_touch(const AgCtx &c, int a, int b) {
-  return touches(c.cx[a], c.cy[a], radius_of(c, c.cm[a]), c.cx[b], c.cy[b], radius_of(c, c.cm[b]));
+template <int NS, bool AV> AG_DEV bool cells_touch(const AgCtx<NS, AV> &c, const Cells &s, int a, int b) {
+  return touches(s.x[a], s.y[a], cell_rad(c, s, a), s.x[b], s.y[b], cell_rad(c, s, b));
 }
-AG_DEV void prevent_overlap(AgCtx &c, int a, int b, float dt, float tx, float ty) {  // R: Engine.hpp:857-888
-  float dx = c.cx[b] - c.cx[a], dy = c.cy[b] - c.cy[a];
+template <int NS, bool AV> AG_DEV void prevent_overlap(const AgCtx<NS, AV> &c, const Cells &s, int a, int b, float dt, float tx, float ty, float W) {  // R: Engine.hpp:857-888
+  float dx = s.x[b] - s.x[a], dy = s.y[b] - s.y[a];
   float dist = vmag(dx, dy);
-  float target = radius_of(c, c.cm[a]) + radius_of(c, c.cm[b]);
+  float ra = cell_rad(c, s, a), rb = cell_rad(c, s, b);
+  float target = ra + rb;
   if (dist > target) return;
-  float s, t;
-  s = c.cvx[a] + c.csx[a]; t = s * dt; c.cx[a] -= t;
-  s = c.cvy[a] + c.csy[a]; t = s * dt; c.cy[a] -= t;
-  s = c.cvx[b] + c.csx[b]; t = s * dt; c.cx[b] -= t;
-  s = c.cvy[b] + c.csy[b]; t = s * dt; c.cy[b] -= t;
-  elastic(c, a, b, dx, dy, dist);
-  cell_move1(c, a, dt);
-  cell_move1(c, b, dt);
-  if (cells_touch(c, a, b)) {
-    int d = (int)(c.cm[a] - c.cm[b]);
-    if ((d < 0 ? -d : d) <= 10) avoid_static_overlap(c, a, b);
-    else separate_cells(c, a, b, tx, ty);
+  float u, t;
+  u = s.vx[a] + s.sx[a]; t = u * dt; s.x[a] -= t;
+  u = s.vy[a] + s.sy[a]; t = u * dt; s.y[a] -= t;
+  u = s.vx[b] + s.sx[b]; t = u * dt; s.x[b] -= t;
+  u = s.vy[b] + s.sy[b]; t = u * dt; s.y[b] -= t;
+  elastic(s, a, b, dx, dy, dist);
+  cell_move1(s, a, dt);
+  cell_move1(s, b, dt);
+  if (touches(s.x[a], s.y[a], ra, s.x[b], s.y[b], rb)) {
+    int d = (int)(s.m[a] - s.m[b]);
+    if ((d < 0 ? -d : d) <= 10) avoid_static_overlap(c, s, a, b, W);
+    else separate_cells(c, s, a, b, tx, ty);
   }
-  boundary(c, c.cx[a], c.cy[a], radius_of(c, c.cm[a]));
-  boundary(c, c.cx[b], c.cy[b], radius_of(c, c.cm[b]));
+  boundary(W, s.x[a], s.y[a], ra);
+  boundary(W, s.x[b], s.y[b], rb);
 }
-AG_DEV void self_collisions(AgCtx &c, int p, int n) {  // R: Engine.hpp:763-794
-  int l = p * c.d.CC;
+// R: Engine.hpp:763-794.  The reference visits pairs (a,b), a<b, in lexicographic order and every visit
+// touches only cells a and b.  Two visits commute unless they share a cell, and every earlier visit
+// sharing a cell with (a,b) has a smaller a+b; so all pairs with equal a+b are independent and the
+// passes run as 2n-3 "anti-diagonal" levels, one pair per lane -- same result as the sequential sweep.
+template <class F> AG_DEV bool pair_levels(int n, F f) {
+  bool any = false;
+  for (int L = 1; L <= 2 * n - 3; L++) {
+    int a0 = L - (n - 1) > 0 ? L - (n - 1) : 0;
+    int a1 = (L - 1) / 2;  // a < b = L - a  <=>  a <= (L-1)/2
+    any = wave_any(a1 - a0 + 1, [&](int j) { int a = a0 + j; return f(a, L - a); }) || any;
+    ag_lds_order();
+  }
+  return any;
+}
+template <int NS, bool AV> AG_DEV void self_collisions(AgCtx<NS, AV> &c, const Cells &s, int n, float tx, float ty) {
   // wave-parallel any-touch test; when no pair touches the reference's first pass is a no-op
-  bool any = wave_any(n * n, [&](int k) { int a = k / n, b = k - a * n; return a < b && cells_touch(c, l + a, l + b); });
+  bool any = wave_any(n * n, [&](int k) { int a = k / n, b = k - a * n; return a < b && cells_touch(c, s, a, b); });
   if (!any) return;
-  float tx = PRF(c, p, PL_TX), ty = PRF(c, p, PL_TY), dt = c.g.dt;
-  AG_SERIAL {
-    bool overlap = false;
-    for (int iter = 0; iter < 5; iter++) {
-      overlap = false;
-      for (int a = 0; a < n; a++)
-        for (int b = a + 1; b < n; b++)
-          if (cells_touch(c, l + a, l + b)) { overlap = true; prevent_overlap(c, l + a, l + b, dt, tx, ty); }
-      if (!overlap) break;
-    }
-    if (overlap)
-      for (int a = 0; a < n; a++)
-        for (int b = a + 1; b < n; b++)
-          if (cells_touch(c, l + a, l + b)) avoid_static_overlap(c, l + a, l + b);
+  float dt = c.gs->g.dt, W = c.gs->g.W;
+  bool overlap = false;
+  for (int iter = 0; iter < 5; iter++) {
+    overlap = pair_levels(n, [&](int a, int b) { if (!cells_touch(c, s, a, b)) return false; prevent_overlap(c, s, a, b, dt, tx, ty, W); return true; });
+    if (!overlap) break;
   }
-  ag_fence();
+  if (overlap) pair_levels(n, [&](int a, int b) { if (!cells_touch(c, s, a, b)) return false; avoid_static_overlap(c, s, a, b, W); return true; });
 }
-AG_DEV void move_player(AgCtx &c, int p, int n) {
-  int l = p * c.d.CC;
-  float tx = PRF(c, p, PL_TX), ty = PRF(c, p, PL_TY), dt = c.g.dt;
-  AG_LANES(i, n) {
-    int k = l + i;
-    float x = c.cx[k], y = c.cy[k], svx = c.csx[k], svy = c.csy[k]; unsigned m = c.cm[k];
-    float d = tx - x; float vx = 3.0f * d;
-    d = ty - y; float vy = 3.0f * d;
-    float hi = lut(c, c.lut_ms, m);
-    if (vmag(vx, vy) > hi) {  // clamp_speed(0, hi): set_speed re-evaluates speed() after dx changed
-      float f = ag_divf(hi, vmag(vx, vy)); vx *= f;
-      float g = ag_divf(hi, vmag(vx, vy)); vy *= g;
-    }
-    float s = vx + svx; float t = s * dt; x += t;
-    s = vy + svy; t = s * dt; y += t;
-    v_decelerate(svx, svy, AG_SPLIT_DECEL, dt);
-    boundary(c, x, y, radius_of(c, m));
-    c.cx[k] = x; c.cy[k] = y; c.cvx[k] = vx; c.cvy[k] = vy; c.csx[k] = svx; c.csy[k] = svy;
+// Kinematics of ONE cell for one tick (Engine::move_player's loop body, Engine.hpp:616-626).  Shared by the
+// lane-parallel general path and the uniform-register quiet path so both execute the same fp32 sequence.
+AG_DEV void move_one(float &x, float &y, float &vx, float &vy, float &svx, float &svy, float hi, float r, float tx, float ty, float dt, float W) {
+  float d = tx - x; vx = 3.0f * d;
+  d = ty - y; vy = 3.0f * d;
+  if (vmag(vx, vy) > hi) {  // clamp_speed(0, hi): set_speed re-evaluates speed() after dx changed
+    float f = ag_divf(hi, vmag(vx, vy)); vx *= f;
+    float g = ag_divf(hi, vmag(vx, vy)); vy *= g;
   }
-  ag_fence();
-  unsigned mn = wave_min(n, [&](int i) { return c.cm[l + i]; });
-  PW(c, p, PL_MIN_MASS, (int)mn);
-  if (n >= 2) self_collisions(c, p, n);
+  float u = vx + svx; float t = u * dt; x += t;
+  u = vy + svy; t = u * dt; y += t;
+  // (0,0): 0/0 = NaN fails both magnitude tests, so the reference ends with (0,0) again
+  if (!(svx == 0.0f && svy == 0.0f)) v_decelerate(svx, svy, AG_SPLIT_DECEL, dt);
+  boundary(W, x, y, r);
+}
+template <int NS, bool AV> AG_DEV void move_player(AgCtx<NS, AV> &c, const Cells &s, int n) {
+  float tx = PRF(c, PL_TX), ty = PRF(c, PL_TY), dt = c.gs->g.dt, W = c.gs->g.W;
+  const float *lut_r = c.gs->lut_r, *lut_ms = c.gs->lut_ms;
+  AG_LANES(i, n) {
+    float x = s.x[i], y = s.y[i], svx = s.sx[i], svy = s.sy[i]; unsigned m = s.m[i];
+    if (s.cmc[i] != m) { s.cmc[i] = m; s.crad[i] = lut(lut_r, m); s.cms[i] = lut(lut_ms, m); }  // refresh the cache on mass change
+    float hi = s.cms[i], r = s.crad[i], vx, vy;
+    move_one(x, y, vx, vy, svx, svy, hi, r, tx, ty, dt, W);
+    s.x[i] = x; s.y[i] = y; s.vx[i] = vx; s.vy[i] = vy; s.sx[i] = svx; s.sy[i] = svy;
+  }
+  ag_lds_order();
+  unsigned mn = n == 1 ? ag_uniu(s.m[0]) : wave_min(n, [&](int i) { return s.m[i]; });
+  PW(c, PL_MIN_MASS, (int)mn);
+#ifndef AG_ABL_SELFCOL
+  if (n >= 2) self_collisions(c, s, n, tx, ty);
+#endif
 }
 
 // ---- created-cell buffer ---------------------------------------------------------------------------
-AG_DEV void put_created(AgCtx &c, int slot, float x, float y, float vx, float vy, float sx, float sy, unsigned m, int id, unsigned dl) {
-  if (slot >= c.d.CC) return;  // overflow is flagged by the caller
-  c.nx[slot] = x; c.ny[slot] = y; c.nvx[slot] = vx; c.nvy[slot] = vy; c.nsx[slot] = sx; c.nsy[slot] = sy; c.nm[slot] = clamp_mass(m); c.nid[slot] = id; c.ndl[slot] = dl;
+AG_DEV void put_created(const Cells &nw, int slot, float x, float y, float vx, float vy, float sx, float sy, unsigned m, int id, unsigned dl) {
+  if (slot >= AG_CC) return;  // overflow is flagged by the caller
+  nw.x[slot] = x; nw.y[slot] = y; nw.vx[slot] = vx; nw.vy[slot] = vy; nw.sx[slot] = sx; nw.sy[slot] = sy; nw.m[slot] = clamp_mass(m); nw.id[slot] = id; nw.dl[slot] = dl;
 }
 // Engine::cell_split for LDS cell k (lane-level).  R: Engine.hpp:1067-1093.  Caller checked mass >= 50.
-AG_DEV void do_cell_split(AgCtx &c, int k, int slot, int id, float tx, float ty) {
-  unsigned m = c.cm[k];
+template <int NS, bool AV> AG_DEV void do_cell_split(const AgCtx<NS, AV> &c, const Cells &s, const Cells &nw, int k, int slot, int id, float tx, float ty, unsigned dl) {
+  unsigned m = s.m[k];
   unsigned split_mass = m / 2u, remaining = m - split_mass;
-  c.cm[k] = clamp_mass(remaining);
-  float x = c.cx[k], y = c.cy[k];
+  s.m[k] = clamp_mass(remaining);
+  float x = s.x[k], y = s.y[k], W = c.gs->g.W;
   float ddx = tx - x, ddy = ty - y;
   float ax = fabsf(ddx), ay = fabsf(ddy); float n2 = ax * ax, n2b = ay * ay; float nrm = ag_sqrtf(n2 + n2b);
   float dirx = ag_divf(ddx, nrm), diry = ag_divf(ddy, nrm);
-  float r = radius_of(c, c.cm[k]);
+  float r = radius_of(c, s.m[k]);
   float ox = dirx * r, oy = diry * r;
   float lx = x + ox, ly = y + oy;
-  lx = smaxf(0.0f, clampf(lx, r, c.g.W - r));
-  ly = smaxf(0.0f, clampf(ly, r, c.g.W - r));
-  float ss = lut(c, c.lut_ss, split_mass);
+  lx = smaxf(0.0f, clampf(lx, r, W - r));
+  ly = smaxf(0.0f, clampf(ly, r, W - r));
+  float ss = lut(c.gs->lut_ss, split_mass);
   float vx = dirx * ss, vy = diry * ss;
-  unsigned dl = (unsigned)c.S[AR_CLOCK] + (unsigned)c.g.recomb_ticks;
-  put_created(c, slot, lx, ly, vx, vy, vx, vy, split_mass, id, dl);
-  c.cdl[k] = dl;
+  put_created(nw, slot, lx, ly, vx, vy, vx, vy, split_mass, id, dl);
+  s.dl[k] = dl;
 }
 
 // ---- viruses.  R: Engine.hpp:1223-1252 (grid :1207-1221), disrupt :1263-1294 ---------------------------
-AG_DEV bool virus_collisions(AgCtx &c, int p, int n, int create_limit, bool can_eat_virus) {
+template <int NS, bool AV> AG_DEV bool virus_collisions(AgCtx<NS, AV> &c, const Cells &s, int n, int create_limit, bool can_eat_virus) {
   int nv = SR(c, AR_NVIR);
   if (nv == 0) return false;
-  int l = p * c.d.CC;
-  unsigned maxm = wave_max(n, [&](int i) { return c.cm[l + i]; });
+  unsigned maxm = n == 1 ? ag_uniu(s.m[0]) : wave_max(n, [&](int i) { return s.m[i]; });
   if (maxm < 111u) return false;  // virus mass >= 100 and can_eat needs mass > 1.1 * virus mass
-  for (int ci = 0; ci < n; ci++) {
-    int k = l + ci;
-    unsigned m = ag_uniu(c.cm[k]);
+  const float *vx_ = g_vx(c), *vy_ = g_vy(c); const int32_t *vm_ = g_vm(c);
+  int vgw = c.gs->g.vgw, vgh = c.gs->g.vgh; unsigned VC = (unsigned)c.gs->d.VC;
+  for (int k = 0; k < n; k++) {
+    unsigned m = ag_uniu(s.m[k]);
     if (m < 111u) continue;
-    float x = ag_unif(c.cx[k]), y = ag_unif(c.cy[k]);
+    float x = ag_unif(s.x[k]), y = ag_unif(s.y[k]);
     float r = radius_of(c, m);
     int gx = f2i(x) / AG_VIRUS_GRID, gy = f2i(y) / AG_VIRUS_GRID;
-    unsigned VC = (unsigned)c.d.VC;
     unsigned key = wave_min(nv, [&](int vi) -> unsigned {
-      float vx = c.vx[vi], vy = c.vy[vi]; unsigned vmass = (unsigned)c.vm[vi];
+      float vx = vx_[vi], vy = vy_[vi]; unsigned vmass = (unsigned)vm_[vi];
       int bx = f2i(vx) / AG_VIRUS_GRID, by = f2i(vy) / AG_VIRUS_GRID;
       int ddx = bx - gx, ddy = by - gy;
-      bool ok = ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1 && bx >= 0 && bx < c.g.vgw && by >= 0 && by < c.g.vgh;
+      bool ok = ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1 && bx >= 0 && bx < vgw && by >= 0 && by < vgh;
       ok = ok && can_eat_mass(m, vmass) && collides(x, y, r, vx, vy, radius_of(c, vmass));
       return ok ? (unsigned)((ddx + 1) * 3 + (ddy + 1)) * VC + (unsigned)vi : UINT_MAX;
     });
     if (key == UINT_MAX) continue;
     int vi = (int)(key % VC);
     if (can_eat_virus) {
-      AG_SERIAL { c.cm[k] = clamp_mass(m + (unsigned)c.vm[vi]); }
+      unsigned vmass = ag_uniu((unsigned)vm_[vi]);
+      AG_SERIAL { s.m[k] = clamp_mass(m + vmass); }
     } else {
       // disrupt
       unsigned total = m;
@@ -580,13 +762,14 @@ AG_DEV bool virus_collisions(AgCtx &c, int p, int n, int create_limit, bool can_
       unsigned pop = total - nm;
       int num_new = (int)((pop + AG_CELL_POP_SIZE - 1u) / AG_CELL_POP_SIZE);
       if (create_limit < num_new) num_new = create_limit;
-      float cvx = ag_unif(c.cvx[k]), cvy = ag_unif(c.cvy[k]);
+      float cvx = ag_unif(s.vx[k]), cvy = ag_unif(s.vy[k]);
       float theta = v_direction(cvx, cvy);
-      float sp = lut(c, c.lut_ms, AG_CELL_POP_SIZE);
-      float virx = ag_unif(c.vx[vi]), viry = ag_unif(c.vy[vi]);
-      int idc = SR(c, AR_IDC), nc0 = ag_uni(*c.ncreated);
-      unsigned dl = (unsigned)SR(c, AR_CLOCK) + (unsigned)c.g.recomb_ticks;
-      if (nc0 + num_new > c.d.CC) flag(c, 1u);
+      float sp = lut(c.gs->lut_ms, AG_CELL_POP_SIZE);
+      float virx = ag_unif(vx_[vi]), viry = ag_unif(vy_[vi]);
+      int idc = SR(c, AR_IDC), nc0 = c.ncreated;
+      unsigned dl = (unsigned)SR(c, AR_CLOCK) + (unsigned)c.gs->g.recomb_ticks;
+      if (nc0 + num_new > AG_CC) flag(c, 1u);
+      Cells nw = created_of(c);
       AG_LANES(j, num_new) {
         float inc = (float)(2 * 3.14159265358979323846 * j / num_new);
         float dvel = theta + inc;
@@ -594,12 +777,15 @@ AG_DEV bool virus_collisions(AgCtx &c, int p, int n, int create_limit, bool can_
         float svx = sp * ag_cosf(ang), svy = sp * ag_sinf(ang);
         unsigned rem = pop - AG_CELL_POP_SIZE * (unsigned)j;  // each earlier new cell took min(rem, 25)
         unsigned cmass = rem < AG_CELL_POP_SIZE ? rem : AG_CELL_POP_SIZE;
-        put_created(c, nc0 + j, virx, viry, cvx, cvy, svx, svy, cmass, idc + 1 + j, dl);
+        put_created(nw, nc0 + j, virx, viry, cvx, cvy, svx, svy, cmass, idc + 1 + j, dl);
       }
-      AG_SERIAL { c.cm[k] = nm; c.cdl[k] = dl; c.S[AR_IDC] = idc + num_new; *c.ncreated = nc0 + num_new; }
+      AG_SERIAL { s.m[k] = nm; s.dl[k] = dl; }
+      SW(c, AR_IDC, idc + num_new); c.ncreated = nc0 + num_new;
     }
-    AG_SERIAL { int ne = c.S[AR_NEVV]; if (ne < AG_EVV_CAP) c.evv[ne] = vi; else c.S[AR_FLAGS] |= 8; c.S[AR_NEVV] = ne + 1; }
-    ag_fence();
+    int ne = SR(c, AR_NEVV);
+    if (ne < AG_EVV_CAP) { AG_SERIAL { L_I(c, L_EVV)[ne] = vi; } } else flag(c, 8u);
+    SW(c, AR_NEVV, ne + 1);
+    ag_lds_order();
     return true;
   }
   return false;
@@ -610,458 +796,561 @@ AG_DEV bool virus_collisions(AgCtx &c, int p, int n, int create_limit, bool can_
 // order, so whether pellet j is eaten can depend on pellets eaten before it.  Fast path: no pellet
 // inside the *current* radius => nothing is eaten.  Otherwise gather the candidate set that is closed
 // under the maximal possible growth, order it like the reference's scan, and replay it on lane 0.
-AG_DEV int pellets_eat(AgCtx &c, int p, int n) {
+template <int NS, bool AV> AG_DEV int pellets_eat(AgCtx<NS, AV> &c, const Cells &s, int n) {
   int np = SR(c, AR_NPEL);
   if (np == 0) return 0;
-  int l = p * c.d.CC, eaten_total = 0;
-  bool all_vis = c.g.pgw <= 2 && c.g.pgh <= 2;  // every bucket is within +-1 of every other
-  for (int ci = 0; ci < n; ci++) {
-    int k = l + ci;
-    unsigned m = ag_uniu(c.cm[k]);
-    float x = ag_unif(c.cx[k]), y = ag_unif(c.cy[k]);
+  int eaten_total = 0;
+  for (int k = 0; k < n; k++) {
+    unsigned m = ag_uniu(s.m[k]);
+    float x = ag_unif(s.x[k]), y = ag_unif(s.y[k]);
     int gx = f2i(x) / AG_PELLET_GRID, gy = f2i(y) / AG_PELLET_GRID;
-    float r0 = radius_of(c, m); float rr0 = r0 * r0;
-    auto hit = [&](int i, float rr) -> bool {
-      float qx = c.px[i], qy = c.py[i];
+    float r0 = ag_uniu(s.cmc[k]) == m ? ag_unif(s.crad[k]) : radius_of(c, m);
+    float rr0 = r0 * r0;
+    // sentinel-padded registers: pellets past n_pellets sit at 3e38 and can never be inside a radius
+    auto hit = [&](float qx, float qy, float rr) -> bool {
       bool ok = rr >= sqr_dist(x, y, qx, qy);
-      if (!all_vis) { int ddx = f2i(qx) / AG_PELLET_GRID - gx, ddy = f2i(qy) / AG_PELLET_GRID - gy; ok = ok && ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1; }
+      if constexpr (!AV) { int ddx = f2i(qx) / AG_PELLET_GRID - gx, ddy = f2i(qy) / AG_PELLET_GRID - gy; ok = ok && ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1; }
       return ok;
     };
-    int c0 = wave_sum(np, [&](int i) { return hit(i, rr0) ? 1 : 0; });
-    if (c0 == 0) continue;
+    if (!pel_any(c, [&](float qx, float qy, int) { return hit(qx, qy, rr0); })) continue;  // hot path: ~3.5 VALU per 64 pellets
+    pel_launder(c);
+    int c0 = pel_count(c, [&](float qx, float qy, int) { return hit(qx, qy, rr0); });
     // closure of the candidate set under growth
     int K = c0; float rrK = rr0;
     for (;;) {
       if (m + (unsigned)K >= (unsigned)AG_LUT_SIZE) { flag(c, 32u); }
       float rk = radius_of(c, m + (unsigned)K); rrK = rk * rk;
-      int cK = wave_sum(np, [&](int i) { return hit(i, rrK) ? 1 : 0; });
+      pel_launder(c);
+      int cK = pel_count(c, [&](float qx, float qy, int) { return hit(qx, qy, rrK); });
       if (cK == K) break;
       K = cK;
     }
-    if (K > AG_CAND_CAP) { flag(c, 8u); }
-    unsigned PC = (unsigned)c.d.PC;
-    int ncand = wave_compact(np, [&](int i) { return hit(i, rrK); }, [&](int i, int rank) {
-      if (rank < AG_CAND_CAP) {
-        int ddx = f2i(c.px[i]) / AG_PELLET_GRID - gx, ddy = f2i(c.py[i]) / AG_PELLET_GRID - gy;
-        c.cand[rank] = (unsigned)((ddx + 1) * 3 + (ddy + 1)) * PC + (unsigned)i;
+    if (K > AG_CAND_CAP / 4) { flag(c, 8u); }
+    // candidate records (key, index, x, y) in LDS, ascending index; key = (bucket visit rank, index)
+    unsigned PC = (unsigned)c.PC;
+    unsigned *cand = (unsigned *)L_I(c, L_CAND);
+    pel_launder(c);
+    int ncand = pel_compact(c, [&](float qx, float qy, int) { return hit(qx, qy, rrK); }, [&](float qx, float qy, int i, int rank) {
+      if (rank < AG_CAND_CAP / 4) {
+        int ddx = f2i(qx) / AG_PELLET_GRID - gx, ddy = f2i(qy) / AG_PELLET_GRID - gy;
+        cand[4 * rank] = (unsigned)((ddx + 1) * 3 + (ddy + 1)) * PC + (unsigned)i;
+        cand[4 * rank + 1] = (unsigned)i; cand[4 * rank + 2] = (unsigned)f2u(qx); cand[4 * rank + 3] = (unsigned)f2u(qy);
       }
     });
-    if (ncand > AG_CAND_CAP) ncand = AG_CAND_CAP;
-    ag_fence();
+    if (ncand > AG_CAND_CAP / 4) ncand = AG_CAND_CAP / 4;
+    ag_lds_order();
+    int ne0 = SR(c, AR_NEVP);
+    int *T = L_I(c, L_TMP); int *evp = L_I(c, L_EVP);
+    const float *lut_r = c.gs->lut_r;
     AG_SERIAL {
-      for (int a = 1; a < ncand; a++) { unsigned v = c.cand[a]; int b = a - 1; while (b >= 0 && c.cand[b] > v) { c.cand[b + 1] = c.cand[b]; b--; } c.cand[b + 1] = v; }
-      unsigned mc = m; int ne = c.S[AR_NEVP], e0 = ne;
+      for (int a = 1; a < ncand; a++) {  // insertion sort of the 4-word records by key
+        unsigned k0 = cand[4 * a], k1 = cand[4 * a + 1], k2 = cand[4 * a + 2], k3 = cand[4 * a + 3]; int b = a - 1;
+        while (b >= 0 && cand[4 * b] > k0) { cand[4 * b + 4] = cand[4 * b]; cand[4 * b + 5] = cand[4 * b + 1]; cand[4 * b + 6] = cand[4 * b + 2]; cand[4 * b + 7] = cand[4 * b + 3]; b--; }
+        cand[4 * b + 4] = k0; cand[4 * b + 5] = k1; cand[4 * b + 6] = k2; cand[4 * b + 7] = k3;
+      }
+      unsigned mc = m; int ne = ne0;
       for (int a = 0; a < ncand; a++) {
-        int i = (int)(c.cand[a] % PC);
-        float rc = radius_of(c, mc); float rrc = rc * rc;
-        if (rrc >= sqr_dist(x, y, c.px[i], c.py[i])) {
-          if (ne < AG_EV_CAP) c.evp[ne] = i; else c.S[AR_FLAGS] |= 8;
+        float rc = lut(lut_r, mc); float rrc = rc * rc;
+        if (rrc >= sqr_dist(x, y, u2f((int)cand[4 * a + 2]), u2f((int)cand[4 * a + 3]))) {
+          if (ne < AG_EV_CAP) evp[ne] = (int)cand[4 * a + 1];
           ne++; mc = clamp_mass(mc + AG_PELLET_MASS);
         }
       }
-      c.cm[k] = mc; c.S[AR_NEVP] = ne; c.tmp[0] = ne - e0;
+      s.m[k] = mc; T[0] = ne;
     }
-    ag_fence();
-    eaten_total += ag_uni(c.tmp[0]);
+    ag_lds_order();
+    int ne1 = ag_uni(T[0]);
+    if (ne1 > AG_EV_CAP) flag(c, 8u);
+    SW(c, AR_NEVP, ne1);
+    eaten_total += ne1 - ne0;
   }
   return eaten_total;
 }
 
 // ---- foods.  R: Engine.hpp:1011-1025 (eat), 1027-1054 (emit), 632-687 (move / feed virus) ------------------
-AG_DEV int eat_food(AgCtx &c, int k) {
+template <int NS, bool AV> AG_DEV int eat_food(AgCtx<NS, AV> &c, const Cells &s, int k) {
   int nf = SR(c, AR_NFOOD);
   if (nf == 0) return 0;
-  unsigned m = ag_uniu(c.cm[k]);
+  unsigned m = ag_uniu(s.m[k]);
   if (m < AG_FOOD_MASS) return 0;
-  float x = ag_unif(c.cx[k]), y = ag_unif(c.cy[k]);
+  float x = ag_unif(s.x[k]), y = ag_unif(s.y[k]);
   float r = radius_of(c, m), fr = radius_of(c, AG_FOOD_MASS);
-  auto eaten = [&](int i) -> bool { return can_eat_mass(m, AG_FOOD_MASS) && collides(x, y, r, c.fx[i], c.fy[i], fr); };
-  int cnt = wave_sum(nf, [&](int i) { return eaten(i) ? 1 : 0; });
+  float *fx = g_fx(c), *fy = g_fy(c), *fvx = g_fvx(c), *fvy = g_fvy(c); int32_t *fid = g_fid(c);
+  auto eaten = [&](int i) -> bool { return can_eat_mass(m, AG_FOOD_MASS) && collides(x, y, r, fx[i], fy[i], fr); };
+  int cnt = wave_count(nf, [&](int i) { return eaten(i); });
   if (cnt == 0) return 0;
-  // order-preserving erase(remove_if(...)) in place
+  // order-preserving erase(remove_if(...)) in place: rank <= i, chunks ascending, and within a 64-chunk
+  // all lanes load before any lane stores
   int kept = wave_compact(nf, [&](int i) { return !eaten(i); }, [&](int i, int rank) {
-    float a = c.fx[i], b = c.fy[i], e = c.fvx[i], f = c.fvy[i]; int id = c.fid[i];
-    c.fx[rank] = a; c.fy[rank] = b; c.fvx[rank] = e; c.fvy[rank] = f; c.fid[rank] = id;
+    float a = fx[i], b = fy[i], e = fvx[i], f = fvy[i]; int id = fid[i];
+    fx[rank] = a; fy[rank] = b; fvx[rank] = e; fvy[rank] = f; fid[rank] = id;
   });
-  // NOTE: the predicate of a later 64-chunk reads entries no earlier chunk has overwritten
-  // (rank <= i), and within a chunk all lanes load before any lane stores.
-  AG_SERIAL { c.S[AR_NFOOD] = kept; c.cm[k] = clamp_mass(m + (unsigned)(nf - kept) * AG_FOOD_MASS); }
-  ag_fence();
+  SW(c, AR_NFOOD, kept);
+  AG_SERIAL { s.m[k] = clamp_mass(m + (unsigned)(nf - kept) * AG_FOOD_MASS); }
+  ag_mem_fence();
   return nf - kept;
 }
-AG_DEV void maybe_emit_food(AgCtx &c, int p, int n) {
-  int cd = PR(c, p, PL_FEED_CD);
+template <int NS, bool AV> AG_DEV void maybe_emit_food(AgCtx<NS, AV> &c, const Cells &s, int n) {
+  int cd = PR(c, PL_FEED_CD);
   if (cd > 0) cd -= 1;
-  if (PR(c, p, PL_ACTION) == 1 && cd == 0) {
-    int l = p * c.d.CC; int nf = SR(c, AR_NFOOD), idc = SR(c, AR_IDC);
-    float tx = PRF(c, p, PL_TX), ty = PRF(c, p, PL_TY);
-    int FC = c.d.FC;
-    int made = wave_compact(n, [&](int i) { return c.cm[l + i] >= AG_CELL_MIN_SIZE + AG_FOOD_MASS; }, [&](int i, int rank) {
-      int k = l + i; float x = c.cx[k], y = c.cy[k];
+  if (PR(c, PL_ACTION) == 1 && cd == 0) {
+    int nf = SR(c, AR_NFOOD), idc = SR(c, AR_IDC);
+    float tx = PRF(c, PL_TX), ty = PRF(c, PL_TY);
+    int FC = c.gs->d.FC;
+    float *fx = g_fx(c), *fy = g_fy(c), *fvx = g_fvx(c), *fvy = g_fvy(c); int32_t *fid = g_fid(c);
+    int made = wave_compact(n, [&](int i) { return s.m[i] >= AG_CELL_MIN_SIZE + AG_FOOD_MASS; }, [&](int i, int rank) {
+      float x = s.x[i], y = s.y[i];
       float ddx = tx - x, ddy = ty - y;
       float ax = fabsf(ddx), ay = fabsf(ddy); float n2 = ax * ax, n2b = ay * ay; float nrm = ag_sqrtf(n2 + n2b);
       float dirx = ag_divf(ddx, nrm), diry = ag_divf(ddy, nrm);
-      float r = radius_of(c, c.cm[k]);
+      float r = radius_of(c, s.m[i]);
       float ox = dirx * r, oy = diry * r;
       int f = nf + rank;
-      if (f < FC) { c.fx[f] = x + ox; c.fy[f] = y + oy; c.fvx[f] = dirx * AG_FOOD_SPEED; c.fvy[f] = diry * AG_FOOD_SPEED; c.fid[f] = idc + 1 + rank; }
-      c.cm[k] = clamp_mass(c.cm[k] - AG_FOOD_MASS);
+      if (f < FC) { fx[f] = x + ox; fy[f] = y + oy; fvx[f] = dirx * AG_FOOD_SPEED; fvy[f] = diry * AG_FOOD_SPEED; fid[f] = idc + 1 + rank; }
+      s.m[i] = clamp_mass(s.m[i] - AG_FOOD_MASS);
     });
     int nf2 = nf + made;
     if (nf2 > FC) { flag(c, 2u); nf2 = FC; }
     SW(c, AR_NFOOD, nf2); SW(c, AR_IDC, idc + made);
     cd = 10;
+    ag_mem_fence();
   }
-  PW(c, p, PL_FEED_CD, cd);
-  ag_fence();
+  PW(c, PL_FEED_CD, cd);
 }
-AG_DEV void maybe_split(AgCtx &c, int p, int n, int create_limit) {  // R: Engine.hpp:1056-1064, 1095-1107
-  int cd = PR(c, p, PL_SPLIT_CD);
+template <int NS, bool AV> AG_DEV void maybe_split(AgCtx<NS, AV> &c, const Cells &s, int n, int create_limit) {  // R: Engine.hpp:1056-1064, 1095-1107
+  int cd = PR(c, PL_SPLIT_CD);
   if (cd > 0) cd -= 1;
-  if (PR(c, p, PL_ACTION) == 2 && cd == 0) {
+  if (PR(c, PL_ACTION) == 2 && cd == 0) {
     if (create_limit != 0) {
-      int l = p * c.d.CC; int idc = SR(c, AR_IDC), nc0 = ag_uni(*c.ncreated);
-      float tx = PRF(c, p, PL_TX), ty = PRF(c, p, PL_TY);
-      int made = wave_compact(n, [&](int i) { unsigned m = c.cm[l + i]; return m >= AG_CELL_SPLIT_MINIMUM && m >= 2u * AG_CELL_MIN_SIZE; },
-                              [&](int i, int rank) { if (create_limit < 0 || rank < create_limit) do_cell_split(c, l + i, nc0 + rank, idc + 1 + rank, tx, ty); });
+      int idc = SR(c, AR_IDC), nc0 = c.ncreated;
+      float tx = PRF(c, PL_TX), ty = PRF(c, PL_TY);
+      unsigned dl = (unsigned)SR(c, AR_CLOCK) + (unsigned)c.gs->g.recomb_ticks;
+      Cells nw = created_of(c);
+      int made = wave_compact(n, [&](int i) { unsigned m = s.m[i]; return m >= AG_CELL_SPLIT_MINIMUM && m >= 2u * AG_CELL_MIN_SIZE; },
+                              [&](int i, int rank) { if (create_limit < 0 || rank < create_limit) do_cell_split(c, s, nw, i, nc0 + rank, idc + 1 + rank, tx, ty, dl); });
       if (create_limit > 0 && made > create_limit) made = create_limit;
-      if (nc0 + made > c.d.CC) flag(c, 1u);
-      AG_SERIAL { c.S[AR_IDC] = idc + made; *c.ncreated = nc0 + made; }
+      if (nc0 + made > AG_CC) flag(c, 1u);
+      SW(c, AR_IDC, idc + made); c.ncreated = nc0 + made;
+      ag_lds_order();
     }
     cd = 30;
   }
-  PW(c, p, PL_SPLIT_CD, cd);
-  ag_fence();
+  PW(c, PL_SPLIT_CD, cd);
 }
-AG_DEV void move_foods(AgCtx &c) {
+template <int NS, bool AV> AG_DEV void move_foods(AgCtx<NS, AV> &c) {
   int nf = SR(c, AR_NFOOD);
   if (nf == 0) return;
-  float dt = c.g.dt; float fr = radius_of(c, AG_FOOD_MASS);
-  bool moving = wave_any(nf, [&](int i) { return !(vmag(c.fvx[i], c.fvy[i]) == 0); });
+  float dt = c.gs->g.dt, W = c.gs->g.W; float fr = radius_of(c, AG_FOOD_MASS);
+  float *fx = g_fx(c), *fy = g_fy(c), *fvx = g_fvx(c), *fvy = g_fvy(c); int32_t *fid = g_fid(c);
+  bool moving = wave_any(nf, [&](int i) { return !(vmag(fvx[i], fvy[i]) == 0); });
   if (!moving) return;
   int nv = SR(c, AR_NVIR);
-  auto advance = [&](int i, float &x, float &y, float &vx, float &vy) { v_decelerate(vx, vy, AG_FOOD_DECEL, dt); float t = vx * dt; x += t; t = vy * dt; y += t; boundary(c, x, y, fr); };
+  float *vx = g_vx(c), *vy = g_vy(c), *vvx = g_vvx(c), *vvy = g_vvy(c); int32_t *vm = g_vm(c), *vh = g_vh(c), *vid = g_vid(c);
+  auto advance = [&](float &x, float &y, float &ux, float &uy) { v_decelerate(ux, uy, AG_FOOD_DECEL, dt); float t = ux * dt; x += t; t = uy * dt; y += t; boundary(W, x, y, fr); };
   // does any moving food reach a virus after its move?  (virus radii only grow by being fed)
   bool hits = nv > 0 && wave_any(nf, [&](int i) {
-    float x = c.fx[i], y = c.fy[i], vx = c.fvx[i], vy = c.fvy[i];
-    if (vmag(vx, vy) == 0) return false;
-    advance(i, x, y, vx, vy);
+    float x = fx[i], y = fy[i], ux = fvx[i], uy = fvy[i];
+    if (vmag(ux, uy) == 0) return false;
+    advance(x, y, ux, uy);
     bool h = false;
-    for (int v = 0; v < nv; v++) h = h || collides(x, y, fr, c.vx[v], c.vy[v], radius_of(c, (unsigned)c.vm[v]));
+    for (int v = 0; v < nv; v++) h = h || collides(x, y, fr, vx[v], vy[v], radius_of(c, (unsigned)vm[v]));
     return h;
   });
   if (!hits) {
     AG_LANES(i, nf) {
-      float x = c.fx[i], y = c.fy[i], vx = c.fvx[i], vy = c.fvy[i];
-      if (!(vmag(vx, vy) == 0)) { advance(i, x, y, vx, vy); c.fx[i] = x; c.fy[i] = y; c.fvx[i] = vx; c.fvy[i] = vy; }
+      float x = fx[i], y = fy[i], ux = fvx[i], uy = fvy[i];
+      if (!(vmag(ux, uy) == 0)) { advance(x, y, ux, uy); fx[i] = x; fy[i] = y; fvx[i] = ux; fvy[i] = uy; }
     }
-    ag_fence();
+    ag_mem_fence();
     return;
   }
+  int idc0 = SR(c, AR_IDC), VC = c.gs->d.VC; float dt10 = c.gs->g.dt10;
+  int *T = L_I(c, L_TMP);
   AG_SERIAL {  // exact sequential replay incl. swap-pop and virus feeding.  R: Engine.hpp:632-687
-    int n = nf, nvir = nv, idc = c.S[AR_IDC];
+    int n = nf, nvir = nv, idc = idc0, fl = 0;
     for (int i = 0; i < n;) {
-      float x = c.fx[i], y = c.fy[i], vx = c.fvx[i], vy = c.fvy[i];
-      if (vmag(vx, vy) == 0) { i++; continue; }
-      float fvx = vx, fvy = vy;
-      advance(i, x, y, vx, vy);
-      c.fx[i] = x; c.fy[i] = y; c.fvx[i] = vx; c.fvy[i] = vy;
+      float x = fx[i], y = fy[i], ux = fvx[i], uy = fvy[i];
+      if (vmag(ux, uy) == 0) { i++; continue; }
+      float pvx = ux, pvy = uy;
+      advance(x, y, ux, uy);
+      fx[i] = x; fy[i] = y; fvx[i] = ux; fvy[i] = uy;
       bool hit = false;
       int nscan = nvir;
       for (int v = 0; v < nscan; v++) {
-        if (collides(x, y, fr, c.vx[v], c.vy[v], radius_of(c, (unsigned)c.vm[v]))) {
-          if (c.vh[v] >= AG_FOOD_HITS) {
-            c.vh[v] = 0; c.vm[v] = (int)AG_VIRUS_MASS;
-            float nx = c.vx[v], ny = c.vy[v];
-            float t = fvx * c.g.dt10; nx += t; t = fvy * c.g.dt10; ny += t;
-            boundary(c, nx, ny, radius_of(c, AG_VIRUS_MASS));
+        if (collides(x, y, fr, vx[v], vy[v], radius_of(c, (unsigned)vm[v]))) {
+          if (vh[v] >= AG_FOOD_HITS) {
+            vh[v] = 0; vm[v] = (int)AG_VIRUS_MASS;
+            float nx = vx[v], ny = vy[v];
+            float t = pvx * dt10; nx += t; t = pvy * dt10; ny += t;
+            boundary(W, nx, ny, radius_of(c, AG_VIRUS_MASS));
             idc++;
-            if (nvir < c.d.VC) { c.vx[nvir] = nx; c.vy[nvir] = ny; c.vvx[nvir] = fvx; c.vvy[nvir] = fvy; c.vm[nvir] = (int)AG_VIRUS_MASS; c.vh[nvir] = 0; c.vid[nvir] = idc; nvir++; }
-            else c.S[AR_FLAGS] |= 4;
-          } else { c.vh[v] += 1; c.vm[v] += (int)AG_FOOD_MASS; }
+            if (nvir < VC) { vx[nvir] = nx; vy[nvir] = ny; vvx[nvir] = pvx; vvy[nvir] = pvy; vm[nvir] = (int)AG_VIRUS_MASS; vh[nvir] = 0; vid[nvir] = idc; nvir++; }
+            else fl |= 4;
+          } else { vh[v] += 1; vm[v] += (int)AG_FOOD_MASS; }
           hit = true; break;
         }
       }
       if (hit) {
         if (n > 1) {
           int j = n - 1;
-          float a = c.fx[j], b = c.fy[j], e = c.fvx[j], f = c.fvy[j]; int id = c.fid[j];
-          c.fx[j] = c.fx[i]; c.fy[j] = c.fy[i]; c.fvx[j] = c.fvx[i]; c.fvy[j] = c.fvy[i]; c.fid[j] = c.fid[i];
-          c.fx[i] = a; c.fy[i] = b; c.fvx[i] = e; c.fvy[i] = f; c.fid[i] = id;
+          float a = fx[j], b = fy[j], e = fvx[j], f = fvy[j]; int id = fid[j];
+          fx[j] = fx[i]; fy[j] = fy[i]; fvx[j] = fvx[i]; fvy[j] = fvy[i]; fid[j] = fid[i];
+          fx[i] = a; fy[i] = b; fvx[i] = e; fvy[i] = f; fid[i] = id;
         }
         n--;
       } else i++;
     }
-    c.S[AR_NFOOD] = n; c.S[AR_NVIR] = nvir; c.S[AR_IDC] = idc;
+    T[0] = n; T[1] = nvir; T[2] = idc; T[3] = fl;
   }
-  ag_fence();
+  ag_mem_fence();
+  SW(c, AR_NFOOD, ag_uni(T[0])); SW(c, AR_NVIR, ag_uni(T[1])); SW(c, AR_IDC, ag_uni(T[2]));
+  int fl = ag_uni(T[3]); if (fl) flag(c, (unsigned)fl);
 }
 
 // ---- recombine / decay.  R: Engine.hpp:1160-1179, 550-584; Entities.hpp:183-203 -------------------------
-AG_DEV void recombine_cells(AgCtx &c, int p, int n) {
-  if (n < 2) return;
-  int l = p * c.d.CC; unsigned clock = (unsigned)SR(c, AR_CLOCK);
-  int nrec = wave_sum(n, [&](int i) { return clock >= c.cdl[l + i] ? 1 : 0; });
-  if (nrec < 2) return;
-  bool any = wave_any(n * n, [&](int k) { int a = k / n, b = k - a * n; return a < b && clock >= c.cdl[l + a] && clock >= c.cdl[l + b] && cells_touch(c, l + a, l + b); });
-  if (!any) return;  // masses (radii) only grow once a first merge has happened
+template <int NS, bool AV> AG_DEV int recombine_cells(AgCtx<NS, AV> &c, const Cells &s, int n) {
+  if (n < 2) return n;
+  unsigned clock = (unsigned)SR(c, AR_CLOCK);
+  int nrec = wave_count(n, [&](int i) { return clock >= s.dl[i]; });
+  if (nrec < 2) return n;
+  bool any = wave_any(n * n, [&](int k) { int a = k / n, b = k - a * n; return a < b && clock >= s.dl[a] && clock >= s.dl[b] && cells_touch(c, s, a, b); });
+  if (!any) return n;  // masses (radii) only grow once a first merge has happened
+  int *T = L_I(c, L_TMP);
   AG_SERIAL {
     int m = n;
     for (int i = 0; i < m; i++) {
-      if (!(clock >= c.cdl[l + i])) continue;
+      if (!(clock >= s.dl[i])) continue;
       for (int j = i + 1; j < m;) {
-        if (clock >= c.cdl[l + j] && cells_touch(c, l + i, l + j)) {
-          c.cm[l + i] = clamp_mass(c.cm[l + i] + c.cm[l + j]);
-          int e = l + m - 1, q = l + j;  // swap(*it2, back()); pop_back()
-          c.cx[q] = c.cx[e]; c.cy[q] = c.cy[e]; c.cvx[q] = c.cvx[e]; c.cvy[q] = c.cvy[e]; c.csx[q] = c.csx[e]; c.csy[q] = c.csy[e];
-          c.cm[q] = c.cm[e]; c.cid[q] = c.cid[e]; c.cdl[q] = c.cdl[e];
+        if (clock >= s.dl[j] && touches(s.x[i], s.y[i], radius_of(c, s.m[i]), s.x[j], s.y[j], radius_of(c, s.m[j]))) {
+          s.m[i] = clamp_mass(s.m[i] + s.m[j]);
+          int e = m - 1;  // swap(*it2, back()); pop_back()
+          s.x[j] = s.x[e]; s.y[j] = s.y[e]; s.vx[j] = s.vx[e]; s.vy[j] = s.vy[e]; s.sx[j] = s.sx[e]; s.sy[j] = s.sy[e];
+          s.m[j] = s.m[e]; s.id[j] = s.id[e]; s.dl[j] = s.dl[e]; s.cmc[j] = 0u;
           m--;
         } else j++;
       }
     }
-    c.PLS[p * PL_WORDS + PL_NCELLS] = m;
+    T[0] = m;
   }
-  ag_fence();
+  ag_lds_order();
+  return ag_uni(T[0]);
 }
-AG_DEV void decay(AgCtx &c, int p, int n) {
-  int elapsed = PR(c, p, PL_ELAPSED);
-  if (!(c.g.mass_decay && elapsed % 60 == 0)) return;
-  int nt = PR(c, p, PL_NVTICKS);
+template <int NS, bool AV> AG_DEV void decay(AgCtx<NS, AV> &c, const Cells &s, int p, int n) {
+  int elapsed = PR(c, PL_ELAPSED);
+  if (!(c.gs->g.mass_decay && elapsed % 60 == 0)) return;
+  int nt = PR(c, PL_NVTICKS);
   if (nt > 0) {
+    int *T = L_I(c, L_TMP); int32_t *vt = g_vt(c, p);
     AG_SERIAL {
-      int *vt = c.gvt + p * AG_VT_CAP; int fall = elapsed - AG_ANTI_TEAM_TICKS, w = 0;
+      int fall = elapsed - AG_ANTI_TEAM_TICKS, w = 0;
       for (int i = 0; i < nt; i++) if (!(vt[i] < fall)) vt[w++] = vt[i];
-      c.PLS[p * PL_WORDS + PL_NVTICKS] = w;
-      if (w != 0) c.PLS[p * PL_WORDS + PL_ANTI_TEAM] = f2u(c.lut_anti[w - 1 < AG_ANTI_LUT ? w - 1 : AG_ANTI_LUT - 1]);
+      T[0] = w;
     }
-    ag_fence();
+    ag_mem_fence();
+    int w = ag_uni(T[0]);
+    PW(c, PL_NVTICKS, w);
+    if (w != 0) PW(c, PL_ANTI_TEAM, f2u(c.gs->lut_anti[w - 1 < AG_ANTI_LUT ? w - 1 : AG_ANTI_LUT - 1]));
   }
-  if (elapsed - PR(c, p, PL_LAST_DECAY) >= 60) {
-    int l = p * c.d.CC; double rate = (double)PRF(c, p, PL_ANTI_TEAM);
+  if (elapsed - PR(c, PL_LAST_DECAY) >= 60) {
+    double rate = (double)PRF(c, PL_ANTI_TEAM);
     AG_LANES(i, n) {
-      double nm = (double)c.cm[l + i] * (1 - 0.002 * rate);
+      double nm = (double)s.m[i] * (1 - 0.002 * rate);
       unsigned um = (unsigned)nm;
-      c.cm[l + i] = um > AG_CELL_MIN_SIZE ? um : AG_CELL_MIN_SIZE;
+      s.m[i] = um > AG_CELL_MIN_SIZE ? um : AG_CELL_MIN_SIZE;
     }
-    PW(c, p, PL_LAST_DECAY, elapsed);
-    ag_fence();
+    PW(c, PL_LAST_DECAY, elapsed);
+    ag_lds_order();
   }
 }
 
 // ---- one player's tick.  R: Engine.hpp:495-542 --------------------------------------------------------------
-AG_DEV void tick_player(AgCtx &c, int p) {
-  int n = PR(c, p, PL_NCELLS);
-  int l = p * c.d.CC;
-  PW(c, p, PL_ELAPSED, PR(c, p, PL_ELAPSED) + 1);
+template <int NS, bool AV> AG_DEV void tick_player(AgCtx<NS, AV> &c, int p) {
+  ub_load(c.PB, PLS(c, p), PL_WORDS);
+  int n = PR(c, PL_NCELLS);
+  if (n == 0) return;  // dead players are skipped (Engine.hpp:216)
+  Cells s = cells_of(c, p);
+  PW(c, PL_ELAPSED, PR(c, PL_ELAPSED) + 1);
   // (bots' take_action every 10th tick: not on the HIP path yet -- agarcl_create rejects num_bots > 0)
-  ag_fence();
-  move_player(c, p, n);
-  AG_SERIAL { *c.ncreated = 0; }
-  ag_fence();
+  AG_T(c, 2);
+#ifndef AG_ABLATE_MOVE
+  move_player(c, s, n);
+#endif
+  AG_T(c, 3);
+  c.ncreated = 0;
   int create_limit = AG_PLAYER_CELL_LIMIT - n;
   bool can_eat_virus = n >= AG_PLAYER_CELL_LIMIT;
-  if (virus_collisions(c, p, n, create_limit, can_eat_virus)) {
-    AG_SERIAL {
-      int *P = c.PLS + p * PL_WORDS; int nt = P[PL_NVTICKS];
-      if (nt < AG_VT_CAP) { c.gvt[p * AG_VT_CAP + nt] = P[PL_ELAPSED]; P[PL_NVTICKS] = nt + 1; } else c.S[AR_FLAGS] |= 16;
-      P[PL_VIRUSES_EATEN] += 1;
-    }
-    ag_fence();
+  if (virus_collisions(c, s, n, create_limit, can_eat_virus)) {
+    int nt = PR(c, PL_NVTICKS), el = PR(c, PL_ELAPSED);
+    if (nt < AG_VT_CAP) { int32_t *vt = g_vt(c, p); AG_SERIAL { vt[nt] = el; } PW(c, PL_NVTICKS, nt + 1); ag_mem_fence(); } else flag(c, 16u);
+    PW(c, PL_VIRUSES_EATEN, PR(c, PL_VIRUSES_EATEN) + 1);
   }
-  int ate = pellets_eat(c, p, n);
-  unsigned total = (unsigned)wave_sum(n, [&](int i) { return (int)c.cm[l + i]; });
-  AG_SERIAL {
-    int *P = c.PLS + p * PL_WORDS;
-    P[PL_FOOD_EATEN] += ate;
-    if ((unsigned)P[PL_HIGHEST_MASS] < total) P[PL_HIGHEST_MASS] = (int)total;
-  }
+  AG_T(c, 4);
+#ifndef AG_ABLATE_PELLETS
+  int ate = pellets_eat(c, s, n);
+#else
+  int ate = 0;
+#endif
+  AG_T(c, 5);
+  unsigned total = n == 1 ? ag_uniu(s.m[0]) : (unsigned)wave_sum(n, [&](int i) { return (int)s.m[i]; });
+  if (ate) PW(c, PL_FOOD_EATEN, PR(c, PL_FOOD_EATEN) + ate);
+  if ((unsigned)PR(c, PL_HIGHEST_MASS) < total) PW(c, PL_HIGHEST_MASS, (int)total);
   // per-cell: auto split (mass >= 22500) then eat ejected food.  R: Engine.hpp:520-525, 592-601
-  bool big = wave_any(n, [&](int i) { return c.cm[l + i] >= AG_MAX_MASS; });
+  bool big = total >= AG_MAX_MASS && wave_any(n, [&](int i) { return s.m[i] >= AG_MAX_MASS; });
   if (big || SR(c, AR_NFOOD) > 0) {
-    float tx = PRF(c, p, PL_TX), ty = PRF(c, p, PL_TY);
-    for (int ci = 0; ci < n; ci++) {
-      int k = l + ci;
-      if (big && ag_uniu(c.cm[k]) >= AG_MAX_MASS) {
-        AG_SERIAL {
-          if (n < AG_PLAYER_CELL_LIMIT) {
-            if (c.cm[k] >= AG_CELL_SPLIT_MINIMUM) {
-              int nc0 = *c.ncreated, idc = c.S[AR_IDC] + 1;
-              if (nc0 >= c.d.CC) c.S[AR_FLAGS] |= 1;
-              do_cell_split(c, k, nc0, idc, tx, ty);
-              c.S[AR_IDC] = idc; *c.ncreated = nc0 + 1;
-            }
-          } else c.cm[k] = clamp_mass(AG_NEW_MASS_NO_SPLIT);
-        }
-        ag_fence();
+    float tx = PRF(c, PL_TX), ty = PRF(c, PL_TY);
+    int fe_total = 0;
+    for (int k = 0; k < n; k++) {
+      if (big && ag_uniu(s.m[k]) >= AG_MAX_MASS) {
+        if (n < AG_PLAYER_CELL_LIMIT) {
+          int nc0 = c.ncreated, idc = SR(c, AR_IDC) + 1;
+          unsigned dl = (unsigned)SR(c, AR_CLOCK) + (unsigned)c.gs->g.recomb_ticks;
+          if (nc0 >= AG_CC) flag(c, 1u);
+          Cells nw = created_of(c);
+          AG_SERIAL { do_cell_split(c, s, nw, k, nc0, idc, tx, ty, dl); }
+          SW(c, AR_IDC, idc); c.ncreated = nc0 + 1;
+        } else { AG_SERIAL { s.m[k] = clamp_mass(AG_NEW_MASS_NO_SPLIT); } }
+        ag_lds_order();
       }
-      int fe = eat_food(c, k);
-      if (fe) { AG_SERIAL { c.PLS[p * PL_WORDS + PL_FOOD_EATEN] += fe; } }
+      fe_total += eat_food(c, s, k);
     }
+    if (fe_total) PW(c, PL_FOOD_EATEN, PR(c, PL_FOOD_EATEN) + fe_total);
   }
-  ag_fence();
-  create_limit -= ag_uni(*c.ncreated);
-  maybe_emit_food(c, p, n);
-  maybe_split(c, p, n, create_limit);
+  AG_T(c, 6);
+  create_limit -= c.ncreated;
+  maybe_emit_food(c, s, n);
+  maybe_split(c, s, n, create_limit);
   // add created cells.  R: core/Player.hpp:195-201
-  int ncr = ag_uni(*c.ncreated);
+  int ncr = c.ncreated;
   if (ncr > 0) {
-    if (ncr > c.d.CC) ncr = c.d.CC;
-    int room = c.d.CC - n;
+    if (ncr > AG_CC) ncr = AG_CC;
+    int room = AG_CC - n;
     if (ncr > room) { flag(c, 1u); ncr = room; }
+    Cells nw = created_of(c);
     AG_LANES(j, ncr) {
-      int k = l + n + j;
-      c.cx[k] = c.nx[j]; c.cy[k] = c.ny[j]; c.cvx[k] = c.nvx[j]; c.cvy[k] = c.nvy[j]; c.csx[k] = c.nsx[j]; c.csy[k] = c.nsy[j];
-      c.cm[k] = c.nm[j]; c.cid[k] = c.nid[j]; c.cdl[k] = c.ndl[j];
+      int k = n + j;
+      s.x[k] = nw.x[j]; s.y[k] = nw.y[j]; s.vx[k] = nw.vx[j]; s.vy[k] = nw.vy[j]; s.sx[k] = nw.sx[j]; s.sy[k] = nw.sy[j];
+      s.m[k] = nw.m[j]; s.id[k] = nw.id[j]; s.dl[k] = nw.dl[j]; s.cmc[k] = 0u;
     }
     n += ncr;
-    PW(c, p, PL_NCELLS, n);
-    ag_fence();
+    ag_lds_order();
   }
-  recombine_cells(c, p, n);
-  n = PR(c, p, PL_NCELLS);
-  decay(c, p, n);
+  AG_T(c, 7);
+  n = recombine_cells(c, s, n);
+  PW(c, PL_NCELLS, n);
+  decay(c, s, p, n);
+  ub_store(c.PB, PLS(c, p), PL_WORDS);
+  ag_lds_order();
+  AG_T(c, 8);
 }
 
 // ---- end-of-tick bookkeeping.  R: Engine.hpp:1002-1009, 1253-1260, 150-200 ------------------------------------
-AG_DEV void remove_pellets(AgCtx &c) {
+template <int NS, bool AV> AG_DEV void remove_pellets(AgCtx<NS, AV> &c) {
   int ne = SR(c, AR_NEVP);
   if (ne == 0) return;
-  AG_SERIAL {
-    int n = c.S[AR_NPEL]; int lim = ne < AG_EV_CAP ? ne : AG_EV_CAP;
-    for (int e = 0; e < lim; e++) {
-      int idx = c.evp[e];
-      if (n > 1 && idx < n - 1) {  // std::swap(p[idx], p.back()): the stale value parked at the back is popped
-        int b = n - 1;
-        float tx = c.px[idx], ty = c.py[idx]; int tid = c.gpid[idx];
-        c.px[idx] = c.px[b]; c.py[idx] = c.py[b]; c.gpid[idx] = c.gpid[b];
-        c.px[b] = tx; c.py[b] = ty; c.gpid[b] = tid;
-      }
-      if (n >= 1) n--;
+  int n = SR(c, AR_NPEL);
+  const int *evp = L_I(c, L_EVP); int32_t *gid = g_pid(c);
+  int lim = ne < AG_EV_CAP ? ne : AG_EV_CAP;
+  for (int e = 0; e < lim; e++) {  // wave-level replay of the stale-index swap-pop
+    int idx = ag_uni(evp[e]);
+    if (n > 1 && idx < n - 1) {  // std::swap(p[idx], p.back()): the half parked at the back is popped and never read again
+      int b = n - 1;
+      pel_move(c, idx, b);
+      AG_SERIAL { gid[idx] = gid[b]; }
+      ag_mem_fence();
     }
-    c.S[AR_NPEL] = n;
+    if (n >= 1) n--;
   }
-  ag_fence();
+  // keep the padding invariant: everything at index >= n is a sentinel again
+  int n0 = SR(c, AR_NPEL);
+  AG_PEL_FOR(s, lane, i) { if (i >= n && i < n0) { PELX(c, s, lane) = AG_PEL_SENTINEL; PELY(c, s, lane) = AG_PEL_SENTINEL; } }
+  SW(c, AR_NPEL, n);
+  c.pel_dirty = true;
 }
-AG_DEV void remove_viruses(AgCtx &c) {
+template <int NS, bool AV> AG_DEV void remove_viruses(AgCtx<NS, AV> &c) {
   int ne = SR(c, AR_NEVV);
   if (ne == 0) return;
+  int n0 = SR(c, AR_NVIR);
+  int *T = L_I(c, L_TMP); const int *evv = L_I(c, L_EVV);
+  float *vx = g_vx(c), *vy = g_vy(c), *vvx = g_vvx(c), *vvy = g_vvy(c); int32_t *vm = g_vm(c), *vh = g_vh(c), *vid = g_vid(c);
   AG_SERIAL {
-    int n = c.S[AR_NVIR]; int lim = ne < AG_EVV_CAP ? ne : AG_EVV_CAP;
+    int n = n0; int lim = ne < AG_EVV_CAP ? ne : AG_EVV_CAP;
     for (int e = 0; e < lim; e++) {
-      int idx = c.evv[e];
+      int idx = evv[e];
       if (n > 1 && idx < n - 1) {
         int b = n - 1;
-        float a1 = c.vx[idx], a2 = c.vy[idx], a3 = c.vvx[idx], a4 = c.vvy[idx]; int a5 = c.vm[idx], a6 = c.vh[idx], a7 = c.vid[idx];
-        c.vx[idx] = c.vx[b]; c.vy[idx] = c.vy[b]; c.vvx[idx] = c.vvx[b]; c.vvy[idx] = c.vvy[b]; c.vm[idx] = c.vm[b]; c.vh[idx] = c.vh[b]; c.vid[idx] = c.vid[b];
-        c.vx[b] = a1; c.vy[b] = a2; c.vvx[b] = a3; c.vvy[b] = a4; c.vm[b] = a5; c.vh[b] = a6; c.vid[b] = a7;
+        float a1 = vx[idx], a2 = vy[idx], a3 = vvx[idx], a4 = vvy[idx]; int a5 = vm[idx], a6 = vh[idx], a7 = vid[idx];
+        vx[idx] = vx[b]; vy[idx] = vy[b]; vvx[idx] = vvx[b]; vvy[idx] = vvy[b]; vm[idx] = vm[b]; vh[idx] = vh[b]; vid[idx] = vid[b];
+        vx[b] = a1; vy[b] = a2; vvx[b] = a3; vvy[b] = a4; vm[b] = a5; vh[b] = a6; vid[b] = a7;
       }
       if (n >= 1) n--;
     }
-    c.S[AR_NVIR] = n;
+    T[0] = n;
   }
-  ag_fence();
+  ag_mem_fence();
+  SW(c, AR_NVIR, ag_uni(T[0]));
 }
 // sort(player.cells) by id (Engine.hpp:157); ids are unique so the result is the sorted order.
-AG_DEV void sort_cells_by_id(AgCtx &c, int p) {
-  int n = PR(c, p, PL_NCELLS);
+template <int NS, bool AV> AG_DEV void sort_cells_by_id(AgCtx<NS, AV> &c, int p) {
+  int n = ag_uni(PLS(c, p)[PL_NCELLS]);
   if (n < 2) return;
-  int l = p * c.d.CC;
-  bool unsorted = wave_any(n - 1, [&](int i) { return c.cid[l + i] > c.cid[l + i + 1]; });
+  Cells s = cells_of(c, p);
+  bool unsorted = wave_any(n - 1, [&](int i) { return s.id[i] > s.id[i + 1]; });
   if (!unsorted) return;
+  Cells t = created_of(c);
   AG_LANES(i, n) {  // rank sort through the created-cell buffer
-    int id = c.cid[l + i], r = 0;
-    for (int j = 0; j < n; j++) r += c.cid[l + j] < id ? 1 : 0;
-    c.nx[r] = c.cx[l + i]; c.ny[r] = c.cy[l + i]; c.nvx[r] = c.cvx[l + i]; c.nvy[r] = c.cvy[l + i]; c.nsx[r] = c.csx[l + i]; c.nsy[r] = c.csy[l + i];
-    c.nm[r] = c.cm[l + i]; c.nid[r] = id; c.ndl[r] = c.cdl[l + i];
+    int id = s.id[i], r = 0;
+    for (int j = 0; j < n; j++) r += s.id[j] < id ? 1 : 0;
+    t.x[r] = s.x[i]; t.y[r] = s.y[i]; t.vx[r] = s.vx[i]; t.vy[r] = s.vy[i]; t.sx[r] = s.sx[i]; t.sy[r] = s.sy[i];
+    t.m[r] = s.m[i]; t.id[r] = id; t.dl[r] = s.dl[i];
   }
-  ag_fence();
+  ag_lds_order();
   AG_LANES(i, n) {
-    c.cx[l + i] = c.nx[i]; c.cy[l + i] = c.ny[i]; c.cvx[l + i] = c.nvx[i]; c.cvy[l + i] = c.nvy[i]; c.csx[l + i] = c.nsx[i]; c.csy[l + i] = c.nsy[i];
-    c.cm[l + i] = c.nm[i]; c.cid[l + i] = c.nid[i]; c.cdl[l + i] = c.ndl[i];
+    s.x[i] = t.x[i]; s.y[i] = t.y[i]; s.vx[i] = t.vx[i]; s.vy[i] = t.vy[i]; s.sx[i] = t.sx[i]; s.sy[i] = t.sy[i];
+    s.m[i] = t.m[i]; s.id[i] = t.id[i]; s.dl[i] = t.dl[i]; s.cmc[i] = 0u;
   }
-  ag_fence();
+  ag_lds_order();
+}
+
+// ---- quiet run: the dominant case in RL rollouts ------------------------------------------------------------------
+// One player, one cell, no ejected food anywhere, no reachable virus, no decay / regen due and no pellet inside the
+// (moved) cell: then Engine::tick reduces to the cell's kinematics plus counters.  Everything is wave-uniform, so a
+// run of consecutive quiet ticks executes on registers only: state is read once, each tick is move_one + one pass
+// over the pellet registers + a few integer updates, and the result is committed once.  The run stops BEFORE the
+// first tick that needs anything else (nothing of that tick has been written) and the general path takes over.
+// Returns the number of ticks performed (0 .. max_ticks).
+template <int NS, bool AV> AG_DEV int quiet_run(AgCtx<NS, AV> &c, int max_ticks) {
+  if (c.P != 1 || SR(c, AR_NFOOD) != 0) return 0;
+  int *P = PLS(c, 0);
+  ub_load(c.PB, P, PL_WORDS);
+  if (PR(c, PL_NCELLS) != 1) return 0;
+  Cells s = cells_of(c, 0);
+  unsigned m = ag_uniu(s.m[0]);
+  int action = PR(c, PL_ACTION);
+  if (m >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && action != 0) return 0;  // eject needs >= 35, split >= 50
+  if (m >= 111u && SR(c, AR_NVIR) != 0) return 0;                      // virus contact needs >= 111
+  if (ag_uniu(s.cmc[0]) != m) return 0;                                // radius / speed cache must be valid
+  float x = ag_unif(s.x[0]), y = ag_unif(s.y[0]), svx = ag_unif(s.sx[0]), svy = ag_unif(s.sy[0]);
+  float vx = ag_unif(s.vx[0]), vy = ag_unif(s.vy[0]);
+  float r = ag_unif(s.crad[0]), hi = ag_unif(s.cms[0]), rr = r * r;
+  float tx = PRF(c, PL_TX), ty = PRF(c, PL_TY), dt = c.gs->g.dt, W = c.gs->g.W;
+  int ticks = SR(c, AR_TICKS), elapsed = PR(c, PL_ELAPSED), fcd = PR(c, PL_FEED_CD), scd = PR(c, PL_SPLIT_CD);
+  bool regen = c.gs->g.regen != 0, decay = c.gs->g.mass_decay != 0, have_pellets = SR(c, AR_NPEL) != 0;
+  int done = 0;
+  while (done < max_ticks) {
+    if (regen && ticks % 120 == 0) break;
+    if (decay && (elapsed + 1) % 60 == 0) break;
+    float nx = x, ny = y, nvx, nvy, nsx = svx, nsy = svy;
+    move_one(nx, ny, nvx, nvy, nsx, nsy, hi, r, tx, ty, dt, W);
+    if (have_pellets) {
+      int gx = f2i(nx) / AG_PELLET_GRID, gy = f2i(ny) / AG_PELLET_GRID;
+      bool hit = pel_any(c, [&](float qx, float qy, int) {
+        bool ok = rr >= sqr_dist(nx, ny, qx, qy);
+        if constexpr (!AV) { int ddx = f2i(qx) / AG_PELLET_GRID - gx, ddy = f2i(qy) / AG_PELLET_GRID - gy; ok = ok && ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1; }
+        return ok;
+      });
+      if (hit) break;
+    }
+    x = nx; y = ny; vx = nvx; vy = nvy; svx = nsx; svy = nsy;
+    elapsed += 1; ticks += 1; done += 1;
+    if (fcd > 0) fcd -= 1; if (action == 1 && fcd == 0) fcd = 10;   // Engine.hpp:1046-1054 (nothing can be ejected: mass < 35)
+    if (scd > 0) scd -= 1; if (action == 2 && scd == 0) scd = 30;   // Engine.hpp:1056-1064 (nothing can split: mass < 50)
+  }
+  if (done == 0) return 0;
+  int hm = PR(c, PL_HIGHEST_MASS); if ((unsigned)hm < m) hm = (int)m;
+  AG_SERIAL {
+    s.x[0] = x; s.y[0] = y; s.vx[0] = vx; s.vy[0] = vy; s.sx[0] = svx; s.sy[0] = svy;
+    P[PL_ELAPSED] = elapsed; P[PL_MIN_MASS] = (int)m; P[PL_HIGHEST_MASS] = hm; P[PL_FEED_CD] = fcd; P[PL_SPLIT_CD] = scd;
+  }
+  SW(c, AR_NEVP, 0); SW(c, AR_NEVV, 0);
+  SW(c, AR_TICKS, ticks); SW(c, AR_CLOCK, SR(c, AR_CLOCK) + done);
+  ag_lds_order();
+  return done;
 }
 
 // ---- Engine::tick.  R: Engine.hpp:208-240 --------------------------------------------------------------------
-AG_DEV void arena_tick(AgCtx &c) {
+template <int NS, bool AV> AG_DEV void arena_tick(AgCtx<NS, AV> &c) {
+
   SW(c, AR_NEVP, 0); SW(c, AR_NEVV, 0);
-  ag_fence();
-  for (int k = 0; k < c.d.P; k++) {
-    int p = SR(c, AR_ORDER0 + k);
-    if (PR(c, p, PL_NCELLS) > 0) tick_player(c, p);
-  }
+  AG_T(c, 1);
+  for (int k = 0; k < c.P; k++) tick_player(c, SR(c, AR_ORDER0 + k));
   remove_pellets(c);
   remove_viruses(c);
-  for (int k = 0; k < c.d.P; k++) sort_cells_by_id(c, SR(c, AR_ORDER0 + k));
+  for (int k = 0; k < c.P; k++) sort_cells_by_id(c, SR(c, AR_ORDER0 + k));
   // PrecisionCollisionDetection::solve: with one player every strip scan breaks on an own cell
   // (utils/collision_detection.hpp:51) => no eats.  P > 1 is rejected at create time for now.
   move_foods(c);
   int ticks = SR(c, AR_TICKS);
-  if (c.g.regen && ticks % 120 == 0) {
-    add_pellets(c, c.g.target_pellets - SR(c, AR_NPEL));
-    add_viruses(c, c.g.target_viruses - SR(c, AR_NVIR));
+  if (c.gs->g.regen && ticks % 120 == 0) {
+    add_pellets(c, c.gs->g.target_pellets - SR(c, AR_NPEL));
+    add_viruses(c, c.gs->g.target_viruses - SR(c, AR_NVIR));
   }
   SW(c, AR_TICKS, ticks + 1); SW(c, AR_CLOCK, SR(c, AR_CLOCK) + 1);
-  ag_fence();
+  AG_T(c, 9);
 }
 
 // ---- BaseEnvironment.  R: environment/envs/BaseEnvironment.hpp:89-204 -----------------------------------------
-AG_DEV unsigned player_mass(const AgCtx &c, int p) { int n = PR(c, p, PL_NCELLS), l = p * c.d.CC; unsigned t = 0; for (int i = 0; i < n; i++) t += ag_uniu(c.cm[l + i]); return t; }
-AG_DEV void take_action(AgCtx &c, int p, float dx, float dy, int action) {  // R: :162-176, Player.hpp:102-126
-  int n = PR(c, p, PL_NCELLS);
+template <int NS, bool AV> AG_DEV unsigned player_mass(const AgCtx<NS, AV> &c, int p) { int n = ag_uni(PLS(c, p)[PL_NCELLS]); Cells s = cells_of(c, p); unsigned t = 0; for (int i = 0; i < n; i++) t += ag_uniu(s.m[i]); return t; }
+template <int NS, bool AV> AG_DEV void take_action(AgCtx<NS, AV> &c, int p, float dx, float dy, int action) {  // R: :162-176, Player.hpp:102-126
+  int n = ag_uni(PLS(c, p)[PL_NCELLS]);
   if (n == 0) return;
-  int l = p * c.d.CC; float sx = 0.0f, sy = 0.0f; unsigned tm = 0;
-  for (int i = 0; i < n; i++) { unsigned m = ag_uniu(c.cm[l + i]); float fm = (float)m; float t = ag_unif(c.cx[l + i]) * fm; sx += t; t = ag_unif(c.cy[l + i]) * fm; sy += t; tm += m; }
+  Cells s = cells_of(c, p); float sx = 0.0f, sy = 0.0f; unsigned tm = 0;
+  for (int i = 0; i < n; i++) { unsigned m = ag_uniu(s.m[i]); float fm = (float)m; float t = ag_unif(s.x[i]) * fm; sx += t; t = ag_unif(s.y[i]) * fm; sy += t; tm += m; }
   float px = ag_divf(sx, (float)tm), py = ag_divf(sy, (float)tm);
   float ox = dx * 10.0f, oy = dy * 10.0f;
-  AG_SERIAL { int *P = c.PLS + p * PL_WORDS; P[PL_ACTION] = action; P[PL_TX] = f2u(px + ox); P[PL_TY] = f2u(py + oy); }
-  ag_fence();
+  int *P = PLS(c, p);
+  AG_SERIAL { P[PL_ACTION] = action; P[PL_TX] = f2u(px + ox); P[PL_TY] = f2u(py + oy); }
+  ag_lds_order();
 }
-AG_DEV void respawn_dead(AgCtx &c) { for (int k = 0; k < c.d.P; k++) { int p = SR(c, AR_ORDER0 + k); if (PR(c, p, PL_NCELLS) == 0) respawn(c, p); } }
+template <int NS, bool AV> AG_DEV void respawn_dead(AgCtx<NS, AV> &c) { for (int k = 0; k < c.P; k++) { int p = SR(c, AR_ORDER0 + k); if (ag_uni(PLS(c, p)[PL_NCELLS]) == 0) respawn(c, p); } }
 
-AG_DEV void env_step(AgCtx &c, const AgState &s, int ticks, bool with_env) {
-  int na = c.d.n_agents;
+template <int NS, bool AV> AG_DEV void env_step(AgCtx<NS, AV> &c, int ticks, bool with_env) {
+  int na = c.gs->d.n_agents, mode = c.gs->g.mode;
   unsigned before[AG_MAX_PLAYERS];
   if (with_env) {
     for (int i = 0; i < na; i++) {
       size_t o = (size_t)c.arena * na + i;
-      if (s.act) take_action(c, i, s.act_dxdy[2 * o], s.act_dxdy[2 * o + 1], s.act[o]);
+      if (c.act) take_action(c, i, c.act_dxdy[2 * o], c.act_dxdy[2 * o + 1], c.act[o]);
     }
     SW(c, AR_RESPAWNED, 0);
-    for (int i = 0; i < na; i++) { before[i] = player_mass(c, i); if (c.g.mode == 3 && before[i] >= 23000u) SW(c, AR_DONE, 1); }
+    for (int i = 0; i < na; i++) { before[i] = player_mass(c, i); if (mode == 3 && before[i] >= 23000u) SW(c, AR_DONE, 1); }
   }
-  for (int t = 0; t < ticks; t++) arena_tick(c);
+  for (int t = 0; t < ticks;) {
+#ifndef AG_NO_QUIET
+    t += quiet_run(c, ticks - t);
+    if (t >= ticks) break;
+#endif
+    arena_tick(c); t++;
+  }
   if (with_env) {
-    if (c.g.mode == 0) respawn_dead(c);
+    if (mode == 0) respawn_dead(c);
     for (int i = 0; i < na; i++) {
       unsigned m = player_mass(c, i);
-      if (c.g.mode == 3 && m >= 23000u) SW(c, AR_DONE, 1);
+      if (mode == 3 && m >= 23000u) SW(c, AR_DONE, 1);
       double r = (double)m;
-      if (c.g.reward_type) { float b = (float)before[i]; float sub = b - (float)(SR(c, AR_RESPAWNED) ? c.g.c_death : 0); r -= (double)sub; }
+      if (c.gs->g.reward_type) { float b = (float)before[i]; float sub = b - (float)(SR(c, AR_RESPAWNED) ? c.gs->g.c_death : 0); r -= (double)sub; }
       size_t o = (size_t)c.arena * na + i;
-      ag_fence();
       int done = SR(c, AR_DONE);
-      AG_SERIAL { s.rewards[o] = r; s.masses[o] = (int)m; s.dones[o] = (uint8_t)(i == 0 ? done : 0); }
+      double *rw = c.gs->rewards; int32_t *ms = c.gs->masses; uint8_t *dn = c.gs->dones;
+      AG_SERIAL { rw[o] = r; ms[o] = (int)m; dn[o] = (uint8_t)(i == 0 ? done : 0); }
     }
   }
 }
 
-AG_DEV void env_reset(AgCtx &c, int reset_ids) {  // R: BaseEnvironment.hpp:179-204, Engine.hpp:98-117
+template <int NS, bool AV> AG_DEV void env_reset(AgCtx<NS, AV> &c, int reset_ids) {  // R: BaseEnvironment.hpp:179-204, Engine.hpp:98-117
   if (reset_ids) SW(c, AR_IDC, 1);
   SW(c, AR_NPEL, 0); SW(c, AR_NVIR, 0); SW(c, AR_NFOOD, 0); SW(c, AR_TICKS, 0); SW(c, AR_FLAGS, 0);
   SW(c, AR_NEVP, 0); SW(c, AR_NEVV, 0); SW(c, AR_DONE, 0); SW(c, AR_RESPAWNED, 0);
-  ag_fence();
-  if (c.g.squared) create_squared_pellets(c); else add_pellets(c, c.g.target_pellets);
-  add_viruses(c, c.g.target_viruses);
-  for (int i = 0; i < c.d.P; i++) {  // add_player (Engine.hpp:70-83): slot i gets pid next_pid++
+  if (c.gs->g.squared) create_squared_pellets(c); else add_pellets(c, c.gs->g.target_pellets);
+  add_viruses(c, c.gs->g.target_viruses);
+  for (int i = 0; i < c.P; i++) {  // add_player (Engine.hpp:70-83): slot i gets pid next_pid++
+    int pid = SR(c, AR_NEXT_PID); SW(c, AR_NEXT_PID, (pid + 1) & 0xFFFF);
+    SW(c, AR_ORDER0 + i, i);
+    int *P = PLS(c, i);
     AG_SERIAL {
-      int *P = c.PLS + i * PL_WORDS;
-      int pid = c.S[AR_NEXT_PID]; c.S[AR_NEXT_PID] = (pid + 1) & 0xFFFF;
       P[PL_PID] = pid; P[PL_KIND] = 0; P[PL_ACTION] = 0; P[PL_TX] = 0; P[PL_TY] = 0;
       P[PL_FOOD_EATEN] = 0; P[PL_HIGHEST_MASS] = (int)AG_CELL_MIN_SIZE; P[PL_CELLS_EATEN] = 0; P[PL_VIRUSES_EATEN] = 0;
-      c.S[AR_ORDER0 + i] = i;
     }
-    ag_fence();
+    ag_lds_order();
     respawn(c, i);
   }
 }

@@ -38,7 +38,9 @@ static int dsync(ag_stream_t) { return 0; }
 #else
 typedef hipStream_t ag_stream_t;
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(AGARCL_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
-static void *dmalloc(size_t n) { void *p = nullptr; if (hipMalloc(&p, n ? n : 1) != hipSuccess) return nullptr; (void)hipMemset(p, 0, n ? n : 1); return p; }
+// zero-filled device memory; the fill is drained before returning: hipMemset runs on the NULL stream, which does
+// NOT order against the env's non-blocking stream (a late fill would wipe data uploaded through that stream)
+static void *dmalloc(size_t n) { void *p = nullptr; if (hipMalloc(&p, n ? n : 1) != hipSuccess) return nullptr; if (hipMemset(p, 0, n ? n : 1) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; } return p; }
 static void dfree(void *p) { if (p) (void)hipFree(p); }
 static int h2d(void *d, const void *h, size_t n, ag_stream_t s) { return hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
 static int d2h(void *h, const void *d, size_t n, ag_stream_t s) { return hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
@@ -47,47 +49,72 @@ static int dsync(ag_stream_t s) { return hipStreamSynchronize(s) == hipSuccess ?
 
 struct agarcl_env {
   agarcl_config cfg;
-  AgDims d; AgParams g; AgState s;
+  AgDims d; AgParams g; AgState s;   // host copy of the descriptor
+  AgState *d_state;                  // HBM-resident copy the kernels read (== &s in the test-only build)
+  const float *act_dxdy; const int32_t *act;
   int device;
   ag_stream_t stream; bool own_stream;
-  size_t lds_bytes;
+  size_t lds_bytes; int ns; bool all_vis;
   std::vector<void *> allocs;
   float *d_act_dxdy; int32_t *d_act;  // env-owned action buffers (host-copy path)
   float *lut_r, *lut_ms, *lut_ss, *lut_anti;
 };
 
 // ---- kernels ----------------------------------------------------------------------------------------
+// NS = pellet register slots per lane (64 pellets per slot): 4 / 8 / 16 / 32 <=> up to 256 / 512 / 1024 / 2048 pellets
+template <int NS, bool AV> AG_DEV void ag_ctx_init(AgCtx<NS, AV> &c, const AgState *gs, int arena, unsigned char *lds, const float *act_dxdy, const int32_t *act) {
+  c.gs = gs; c.arena = arena; c.lds = lds; c.act_dxdy = act_dxdy; c.act = act;
+  c.P = gs->d.P; c.PC = gs->d.PC;
+  ag_lds_layout(c.P, &c.cells_off);
+  c.ncreated = 0; c.pel_dirty = false;
+}
+#define AG_DISPATCH_NS(ns, CALL) do { if (e->all_vis) { switch (ns) { case 4: CALL(4, true); break; case 8: CALL(8, true); break; case 16: CALL(16, true); break; default: CALL(32, true); break; } } \
+  else { switch (ns) { case 4: CALL(4, false); break; case 8: CALL(8, false); break; case 16: CALL(16, false); break; default: CALL(32, false); break; } } } while (0)
 #ifdef AGAR_CPU_EMU
-template <class F> static void for_each_arena(agarcl_env *e, F f) {
+template <int NS, bool AV, class F> static void for_each_arena_ns(agarcl_env *e, F f) {
   std::vector<unsigned char> lds(e->lds_bytes + 64);
   for (int a = 0; a < e->d.A; a++) {
-    AgCtx c; c.d = e->d; c.g = e->g;
-    ag_bind_lds(c, lds.data()); ag_bind_arena(c, e->s, a);
-    f(c);
+    AgCtx<NS, AV> *c = new AgCtx<NS, AV>();
+    ag_ctx_init(*c, &e->s, a, lds.data(), e->act_dxdy, e->act);
+    f(*c);
+    delete c;
   }
 }
 #else
 extern __shared__ __align__(16) unsigned char ag_lds[];
-#define AG_KERNEL_PROLOGUE AgCtx c; c.d = d; c.g = g; ag_bind_lds(c, ag_lds); ag_bind_arena(c, s, (int)blockIdx.x);
+#define AG_KERNEL_PROLOGUE AgCtx<NS, AV> c; ag_ctx_init(c, gs, (int)blockIdx.x, ag_lds, act_dxdy, act);
 
-__global__ void __launch_bounds__(64) k_step(AgState s, AgDims d, AgParams g, int ticks, int with_env) {
+template <int NS, bool AV> __global__ void __launch_bounds__(64) k_step(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env) {
   AG_KERNEL_PROLOGUE
-  arena_load(c, s);
-  env_step(c, s, ticks, with_env != 0);
-  arena_store(c, s);
+#ifdef AGAR_PROFILE
+  for (int i = 0; i < AG_NPROF; i++) c.tacc[i] = 0;
+  c.tlast = (unsigned)__builtin_readcyclecounter();
+#endif
+  arena_load(c);
+  AG_T(c, 0);
+  env_step(c, ticks, with_env != 0);
+  AG_T(c, 10);
+  arena_store(c);
+  AG_T(c, 11);
+#ifdef AGAR_PROFILE
+  if (threadIdx.x == 0 && gs->prof) for (int i = 0; i < AG_NPROF; i++) gs->prof[(size_t)blockIdx.x * AG_NPROF + i] += c.tacc[i];
+#endif
 }
-__global__ void __launch_bounds__(64) k_reset(AgState s, AgDims d, AgParams g, const uint8_t *mask, int reset_ids) {
+template <int NS, bool AV> __global__ void __launch_bounds__(64) k_reset(const AgState *__restrict__ gs, const uint8_t *mask, int reset_ids) {
   if (mask && !mask[blockIdx.x]) return;
+  const float *act_dxdy = nullptr; const int32_t *act = nullptr;
   AG_KERNEL_PROLOGUE
-  arena_load(c, s);
+  arena_load(c);
   env_reset(c, reset_ids);
-  arena_store(c, s);
+  c.pel_dirty = true;
+  arena_store(c);
 }
-__global__ void __launch_bounds__(64) k_respawn(AgState s, AgDims d, AgParams g) {
+template <int NS, bool AV> __global__ void __launch_bounds__(64) k_respawn(const AgState *__restrict__ gs) {
+  const float *act_dxdy = nullptr; const int32_t *act = nullptr;
   AG_KERNEL_PROLOGUE
-  arena_load(c, s);
+  arena_load(c);
   respawn_dead(c);
-  arena_store(c, s);
+  arena_store(c);
 }
 __global__ void k_set_word(int32_t *base, int stride, int n, int value) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -97,9 +124,13 @@ __global__ void k_set_word(int32_t *base, int stride, int n, int value) {
 
 static int launch_step(agarcl_env *e, int ticks, int with_env) {
 #ifdef AGAR_CPU_EMU
-  for_each_arena(e, [&](AgCtx &c) { arena_load(c, e->s); env_step(c, e->s, ticks, with_env != 0); arena_store(c, e->s); });
+#define CALL(N, V) for_each_arena_ns<N, V>(e, [&](AgCtx<N, V> &c) { arena_load(c); env_step(c, ticks, with_env != 0); arena_store(c); })
+  AG_DISPATCH_NS(e->ns, CALL);
+#undef CALL
 #else
-  hipLaunchKernelGGL(k_step, dim3(e->d.A), dim3(64), e->lds_bytes, e->stream, e->s, e->d, e->g, ticks, with_env);
+#define CALL(N, V) hipLaunchKernelGGL((k_step<N, V>), dim3(e->d.A), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env)
+  AG_DISPATCH_NS(e->ns, CALL);
+#undef CALL
   HIPCHK(hipGetLastError());
 #endif
   return 0;
@@ -107,10 +138,27 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
 static int launch_reset(agarcl_env *e, const uint8_t *mask_dev, const uint8_t *mask_host, int reset_ids) {
 #ifdef AGAR_CPU_EMU
   (void)mask_dev;
-  for_each_arena(e, [&](AgCtx &c) { if (mask_host && !mask_host[c.arena]) return; arena_load(c, e->s); env_reset(c, reset_ids); arena_store(c, e->s); });
+#define CALL(N, V) for_each_arena_ns<N, V>(e, [&](AgCtx<N, V> &c) { if (mask_host && !mask_host[c.arena]) return; arena_load(c); env_reset(c, reset_ids); c.pel_dirty = true; arena_store(c); })
+  AG_DISPATCH_NS(e->ns, CALL);
+#undef CALL
 #else
   (void)mask_host;
-  hipLaunchKernelGGL(k_reset, dim3(e->d.A), dim3(64), e->lds_bytes, e->stream, e->s, e->d, e->g, mask_dev, reset_ids);
+#define CALL(N, V) hipLaunchKernelGGL((k_reset<N, V>), dim3(e->d.A), dim3(64), e->lds_bytes, e->stream, e->d_state, mask_dev, reset_ids)
+  AG_DISPATCH_NS(e->ns, CALL);
+#undef CALL
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+static int launch_respawn(agarcl_env *e) {
+#ifdef AGAR_CPU_EMU
+#define CALL(N, V) for_each_arena_ns<N, V>(e, [&](AgCtx<N, V> &c) { arena_load(c); respawn_dead(c); arena_store(c); })
+  AG_DISPATCH_NS(e->ns, CALL);
+#undef CALL
+#else
+#define CALL(N, V) hipLaunchKernelGGL((k_respawn<N, V>), dim3(e->d.A), dim3(64), e->lds_bytes, e->stream, e->d_state)
+  AG_DISPATCH_NS(e->ns, CALL);
+#undef CALL
   HIPCHK(hipGetLastError());
 #endif
   return 0;
@@ -176,6 +224,7 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
 #endif
   agarcl_env *e = new agarcl_env();
   e->cfg = *cfg; e->device = device; e->own_stream = true; e->d_act_dxdy = nullptr; e->d_act = nullptr;
+  e->d_state = nullptr; e->act_dxdy = nullptr; e->act = nullptr;
 #ifdef AGAR_CPU_EMU
   e->stream = nullptr;
 #else
@@ -192,35 +241,45 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   g.vgw = g.vgh = (int)((g.W + (float)AG_VIRUS_GRID - 1.0f) / (float)AG_VIRUS_GRID);
   AgDims d;
   d.A = num_arenas; d.n_agents = cfg->num_agents; d.P = cfg->num_agents + cfg->num_bots;
-  d.CC = cfg->cap_cells > 0 ? cfg->cap_cells : 32;
   int npel = cfg->num_pellets;
   if (g.squared) { int pps = (int)(g.W / 2.0f); npel = 4 * pps; }
   d.PC = ((npel > 0 ? npel : 1) + 63) / 64 * 64;
   d.VC = cfg->cap_viruses > 0 ? cfg->cap_viruses : cfg->num_viruses + 64;
   d.FC = cfg->cap_foods > 0 ? cfg->cap_foods : 256;
   if (d.P > AG_MAX_PLAYERS) { agarcl_destroy(e); return fail(AGARCL_E_UNSUPPORTED, "too many players per arena"); }
-  if (d.CC > 64 || d.CC < 16) { agarcl_destroy(e); return fail(AGARCL_E_INVALID, "cap_cells must be in [16, 64]"); }
+  if (cfg->cap_cells != 0 && cfg->cap_cells != AG_CC) { agarcl_destroy(e); return fail(AGARCL_E_INVALID, "cap_cells is fixed at 32 in this build"); }
   e->d = d; e->g = g;
-  e->lds_bytes = ag_lds_bytes(d);
+  e->lds_bytes = ag_lds_layout(d.P, nullptr);
+  e->all_vis = g.pgw <= 2 && g.pgh <= 2;
+  e->ns = d.PC <= 256 ? 4 : d.PC <= 512 ? 8 : d.PC <= 1024 ? 16 : 32;
+  if (d.PC > 2048) { agarcl_destroy(e); return fail(AGARCL_E_UNSUPPORTED, "more than 2048 pellets per arena do not fit the pellet register file layout"); }
   if (e->lds_bytes > 160 * 1024) { agarcl_destroy(e); return fail(AGARCL_E_UNSUPPORTED, "arena does not fit the 160 KiB LDS of a CU (too many pellets)"); }
   AgState &s = e->s; memset(&s, 0, sizeof(s));
+  s.d = d; s.g = g;
   size_t A = (size_t)d.A;
-  s.pel_x = alloc<float>(e, A * d.PC); s.pel_y = alloc<float>(e, A * d.PC); s.pel_id = alloc<int32_t>(e, A * d.PC);
+  s.pel_xy = alloc<float>(e, A * d.PC * 2); s.pel_id = alloc<int32_t>(e, A * d.PC);
   s.vir_x = alloc<float>(e, A * d.VC); s.vir_y = alloc<float>(e, A * d.VC); s.vir_vx = alloc<float>(e, A * d.VC); s.vir_vy = alloc<float>(e, A * d.VC);
   s.vir_mass = alloc<int32_t>(e, A * d.VC); s.vir_hits = alloc<int32_t>(e, A * d.VC); s.vir_id = alloc<int32_t>(e, A * d.VC);
   s.food_x = alloc<float>(e, A * d.FC); s.food_y = alloc<float>(e, A * d.FC); s.food_vx = alloc<float>(e, A * d.FC); s.food_vy = alloc<float>(e, A * d.FC); s.food_id = alloc<int32_t>(e, A * d.FC);
-  size_t NC = A * d.P * d.CC;
-  s.cell_x = alloc<float>(e, NC); s.cell_y = alloc<float>(e, NC); s.cell_vx = alloc<float>(e, NC); s.cell_vy = alloc<float>(e, NC); s.cell_sx = alloc<float>(e, NC); s.cell_sy = alloc<float>(e, NC);
-  s.cell_m = alloc<uint32_t>(e, NC); s.cell_id = alloc<int32_t>(e, NC); s.cell_dl = alloc<uint32_t>(e, NC);
+  s.cells = alloc<uint32_t>(e, A * d.P * CF_FIELDS * AG_CC);
   s.pl = alloc<int32_t>(e, A * d.P * PL_WORDS); s.vticks = alloc<int32_t>(e, A * d.P * AG_VT_CAP); s.ar = alloc<int32_t>(e, A * AR_WORDS);
-  s.mt = alloc<uint64_t>(e, A * 312); s.rnd = alloc<int32_t>(e, A * 35);
+  s.mt = alloc<uint64_t>(e, A * 312);
   s.rewards = alloc<double>(e, A * d.n_agents); s.dones = alloc<uint8_t>(e, A * d.n_agents); s.masses = alloc<int32_t>(e, A * d.n_agents);
   s.counts = alloc<int32_t>(e, A * 4); s.ev_p = alloc<int32_t>(e, A * AG_EV_CAP); s.ev_v = alloc<int32_t>(e, A * AG_EVV_CAP);
   e->d_act_dxdy = alloc<float>(e, A * d.n_agents * 2); e->d_act = alloc<int32_t>(e, A * d.n_agents);
   e->lut_r = alloc<float>(e, AG_LUT_SIZE); e->lut_ms = alloc<float>(e, AG_LUT_SIZE); e->lut_ss = alloc<float>(e, AG_LUT_SIZE); e->lut_anti = alloc<float>(e, AG_ANTI_LUT);
-  if (!e->lut_anti || !s.ev_v || !s.mt || !s.cell_dl) { agarcl_destroy(e); return fail(AGARCL_E_NOMEM, "device allocation failed"); }
+  if (!e->lut_anti || !s.ev_v || !s.mt || !s.cells || !s.pel_xy) { agarcl_destroy(e); return fail(AGARCL_E_NOMEM, "device allocation failed"); }
   s.lut_r = e->lut_r; s.lut_ms = e->lut_ms; s.lut_ss = e->lut_ss; s.lut_anti = e->lut_anti;
   s.act_dxdy = nullptr; s.act = nullptr;
+  s.prof = alloc<unsigned long long>(e, (size_t)d.A * 16);
+#ifdef AGAR_CPU_EMU
+  e->d_state = &e->s;
+#else
+  e->d_state = (AgState *)dmalloc(sizeof(AgState));
+  if (!e->d_state) { agarcl_destroy(e); return fail(AGARCL_E_NOMEM, "device allocation failed"); }
+  e->allocs.push_back(e->d_state);
+  if (h2d(e->d_state, &e->s, sizeof(AgState), e->stream)) { agarcl_destroy(e); return fail(AGARCL_E_HIP, "descriptor upload failed"); }
+#endif
   {  // mass -> fp32 tables: the reference's double-precision islands, evaluated with the host libm
      // (core/utils.hpp:8-11; Engine.hpp:1296-1302; Engine.hpp:567)
     std::vector<float> r(AG_LUT_SIZE), ms(AG_LUT_SIZE), ss(AG_LUT_SIZE), an(AG_ANTI_LUT);
@@ -302,9 +361,9 @@ extern "C" int agarcl_reset(agarcl_env *e, const uint8_t *mask_host, int32_t res
 extern "C" int agarcl_set_actions(agarcl_env *e, const float *dxdy, const int32_t *act, int32_t on_device) {
   if (!e || !dxdy || !act) return fail(AGARCL_E_INVALID, "agarcl_set_actions: null pointer");
   size_t n = (size_t)e->d.A * e->d.n_agents;
-  if (on_device) { e->s.act_dxdy = dxdy; e->s.act = act; return AGARCL_OK; }
+  if (on_device) { e->act_dxdy = dxdy; e->act = act; return AGARCL_OK; }
   if (h2d(e->d_act_dxdy, dxdy, n * 8, e->stream) || h2d(e->d_act, act, n * 4, e->stream)) return fail(AGARCL_E_HIP, "action upload failed");
-  e->s.act_dxdy = e->d_act_dxdy; e->s.act = e->d_act;
+  e->act_dxdy = e->d_act_dxdy; e->act = e->d_act;
   return AGARCL_OK;
 }
 
@@ -338,14 +397,10 @@ extern "C" int agarcl_set_targets(agarcl_env *e, const float *txy_host, const in
 
 extern "C" int agarcl_respawn_dead(agarcl_env *e) {
   if (!e) return fail(AGARCL_E_INVALID, "null env");
-#ifdef AGAR_CPU_EMU
-  for_each_arena(e, [&](AgCtx &c) { arena_load(c, e->s); respawn_dead(c); arena_store(c, e->s); });
-#else
+#ifndef AGAR_CPU_EMU
   HIPCHK(hipSetDevice(e->device));
-  hipLaunchKernelGGL(k_respawn, dim3(e->d.A), dim3(64), e->lds_bytes, e->stream, e->s, e->d, e->g);
-  HIPCHK(hipGetLastError());
 #endif
-  return AGARCL_OK;
+  return launch_respawn(e);
 }
 
 extern "C" const double *agarcl_rewards_dev(agarcl_env *e) { return e ? e->s.rewards : nullptr; }
@@ -385,6 +440,14 @@ extern "C" int agarcl_get_events(agarcl_env *e, int32_t *n_events_host, int32_t 
   return AGARCL_OK;
 }
 
+extern "C" int agarcl_debug_prof(agarcl_env *e, unsigned long long *out16, int reset) {
+  if (!e || !out16) return AGARCL_E_INVALID;
+  std::vector<unsigned long long> h((size_t)e->d.A * 16);
+  if (d2h(h.data(), e->s.prof, h.size() * 8, e->stream)) return AGARCL_E_HIP;
+  for (int i = 0; i < 16; i++) { out16[i] = 0; for (int a = 0; a < e->d.A; a++) out16[i] += h[(size_t)a * 16 + i]; }
+  if (reset) { std::fill(h.begin(), h.end(), 0ull); if (h2d(e->s.prof, h.data(), h.size() * 8, e->stream)) return AGARCL_E_HIP; }
+  return AGARCL_OK;
+}
 extern "C" int agarcl_num_arenas(agarcl_env *e) { return e ? e->d.A : 0; }
 extern "C" int agarcl_players_per_arena(agarcl_env *e) { return e ? e->d.P : 0; }
 
@@ -392,8 +455,8 @@ extern "C" int agarcl_players_per_arena(agarcl_env *e) { return e ? e->d.P : 0; 
 namespace {
 struct ArenaHost {
   std::vector<int32_t> ar, pl, vt;
-  std::vector<float> px, py, vx, vy, vvx, vvy, fx, fy, fvx, fvy, cx, cy, cvx, cvy, csx, csy;
-  std::vector<int32_t> pid, vm, vh, vid, fid, cid; std::vector<uint32_t> cm, cdl;
+  std::vector<float> pxy, vx, vy, vvx, vvy, fx, fy, fvx, fvy;
+  std::vector<int32_t> pid, vm, vh, vid, fid; std::vector<uint32_t> cells;
 };
 template <class T> int pull(agarcl_env *e, std::vector<T> &h, const T *dev, size_t off, size_t n) { h.resize(n); return n ? d2h(h.data(), dev + off, n * sizeof(T), e->stream) : 0; }
 template <class T> int push(agarcl_env *e, const std::vector<T> &h, T *dev, size_t off) { return h.empty() ? 0 : h2d(dev + off, h.data(), h.size() * sizeof(T), e->stream); }
@@ -405,19 +468,20 @@ extern "C" int agarcl_dump_arena(agarcl_env *e, int32_t arena, uint32_t *buf, in
   rc |= pull(e, h.ar, s.ar, a * AR_WORDS, AR_WORDS); rc |= pull(e, h.pl, s.pl, a * d.P * PL_WORDS, (size_t)d.P * PL_WORDS); rc |= pull(e, h.vt, s.vticks, a * d.P * AG_VT_CAP, (size_t)d.P * AG_VT_CAP);
   if (rc) return fail(AGARCL_E_HIP, "copy failed");
   size_t np = (size_t)h.ar[AR_NPEL], nv = (size_t)h.ar[AR_NVIR], nf = (size_t)h.ar[AR_NFOOD];
-  rc |= pull(e, h.px, s.pel_x, a * d.PC, np); rc |= pull(e, h.py, s.pel_y, a * d.PC, np); rc |= pull(e, h.pid, s.pel_id, a * d.PC, np);
+  rc |= pull(e, h.pxy, s.pel_xy, a * d.PC * 2, np * 2); rc |= pull(e, h.pid, s.pel_id, a * d.PC, np);
   rc |= pull(e, h.vx, s.vir_x, a * d.VC, nv); rc |= pull(e, h.vy, s.vir_y, a * d.VC, nv); rc |= pull(e, h.vvx, s.vir_vx, a * d.VC, nv); rc |= pull(e, h.vvy, s.vir_vy, a * d.VC, nv);
   rc |= pull(e, h.vm, s.vir_mass, a * d.VC, nv); rc |= pull(e, h.vh, s.vir_hits, a * d.VC, nv); rc |= pull(e, h.vid, s.vir_id, a * d.VC, nv);
   rc |= pull(e, h.fx, s.food_x, a * d.FC, nf); rc |= pull(e, h.fy, s.food_y, a * d.FC, nf); rc |= pull(e, h.fvx, s.food_vx, a * d.FC, nf); rc |= pull(e, h.fvy, s.food_vy, a * d.FC, nf); rc |= pull(e, h.fid, s.food_id, a * d.FC, nf);
-  size_t nc = (size_t)d.P * d.CC, co = a * nc;
-  rc |= pull(e, h.cx, s.cell_x, co, nc); rc |= pull(e, h.cy, s.cell_y, co, nc); rc |= pull(e, h.cvx, s.cell_vx, co, nc); rc |= pull(e, h.cvy, s.cell_vy, co, nc);
-  rc |= pull(e, h.csx, s.cell_sx, co, nc); rc |= pull(e, h.csy, s.cell_sy, co, nc); rc |= pull(e, h.cm, s.cell_m, co, nc); rc |= pull(e, h.cid, s.cell_id, co, nc); rc |= pull(e, h.cdl, s.cell_dl, co, nc);
+  size_t nc = (size_t)d.P * CF_FIELDS * AG_CC;
+  rc |= pull(e, h.cells, s.cells, a * nc, nc);
   if (rc) return fail(AGARCL_E_HIP, "copy failed");
   std::vector<uint32_t> o;
   auto F = [&](float f) { uint32_t u; memcpy(&u, &f, 4); o.push_back(u); };
   o.push_back(0x31524741u); o.push_back((uint32_t)h.ar[AR_TICKS]); o.push_back((uint32_t)h.ar[AR_IDC]); o.push_back((uint32_t)h.ar[AR_NEXT_PID]);
   o.push_back((uint32_t)np); o.push_back((uint32_t)nv); o.push_back((uint32_t)nf); o.push_back((uint32_t)d.P);
-  for (float v : h.px) F(v); for (float v : h.py) F(v); for (int32_t v : h.pid) o.push_back((uint32_t)v);
+  for (size_t i = 0; i < np; i++) F(h.pxy[2 * i]);
+  for (size_t i = 0; i < np; i++) F(h.pxy[2 * i + 1]);
+  for (int32_t v : h.pid) o.push_back((uint32_t)v);
   for (float v : h.vx) F(v); for (float v : h.vy) F(v); for (float v : h.vvx) F(v); for (float v : h.vvy) F(v);
   for (int32_t v : h.vm) o.push_back((uint32_t)v); for (int32_t v : h.vh) o.push_back((uint32_t)v); for (int32_t v : h.vid) o.push_back((uint32_t)v);
   for (float v : h.fx) F(v); for (float v : h.fy) F(v); for (float v : h.fvx) F(v); for (float v : h.fvy) F(v); for (int32_t v : h.fid) o.push_back((uint32_t)v);
@@ -430,11 +494,11 @@ extern "C" int agarcl_dump_arena(agarcl_env *e, int32_t arena, uint32_t *buf, in
     o.push_back((uint32_t)P[PL_FOOD_EATEN]); o.push_back((uint32_t)P[PL_HIGHEST_MASS]); o.push_back((uint32_t)P[PL_CELLS_EATEN]); o.push_back((uint32_t)P[PL_VIRUSES_EATEN]);
     o.push_back((uint32_t)P[PL_MIN_MASS]); o.push_back((uint32_t)P[PL_NVTICKS]);
     for (int i = 0; i < P[PL_NVTICKS]; i++) o.push_back((uint32_t)h.vt[(size_t)p * AG_VT_CAP + i]);
+    const uint32_t *C = &h.cells[(size_t)p * CF_FIELDS * AG_CC];
     for (int i = 0; i < P[PL_NCELLS]; i++) {
-      size_t q = (size_t)p * d.CC + i;
-      F(h.cx[q]); F(h.cy[q]); F(h.cvx[q]); F(h.cvy[q]); F(h.csx[q]); F(h.csy[q]);
-      o.push_back(h.cm[q]); o.push_back((uint32_t)h.cid[q]);
-      o.push_back(h.cdl[q] > clock ? h.cdl[q] - clock : 0u);
+      for (int f = CF_X; f <= CF_ID; f++) o.push_back(C[f * AG_CC + i]);
+      uint32_t dl = C[CF_DL * AG_CC + i];
+      o.push_back(dl > clock ? dl - clock : 0u);
     }
   }
   if ((int64_t)o.size() > cap) return -(int)o.size() - 1000;
@@ -454,21 +518,21 @@ extern "C" int agarcl_load_arena(agarcl_env *e, int32_t arena, const uint32_t *b
   const uint32_t *p = b + 8;
   h.ar[AR_TICKS] = (int32_t)b[1]; h.ar[AR_IDC] = (int32_t)b[2]; h.ar[AR_NEXT_PID] = (int32_t)b[3];
   h.ar[AR_NPEL] = (int32_t)np; h.ar[AR_NVIR] = (int32_t)nv; h.ar[AR_NFOOD] = (int32_t)nf;
-  for (uint32_t i = 0; i < np; i++) { h.px.push_back(U2F(p[i])); h.py.push_back(U2F(p[np + i])); h.pid.push_back((int32_t)p[2 * np + i]); }
+  for (uint32_t i = 0; i < np; i++) { h.pxy.push_back(U2F(p[i])); h.pxy.push_back(U2F(p[np + i])); h.pid.push_back((int32_t)p[2 * np + i]); }
   p += 3 * np;
   for (uint32_t i = 0; i < nv; i++) { h.vx.push_back(U2F(p[i])); h.vy.push_back(U2F(p[nv + i])); h.vvx.push_back(U2F(p[2 * nv + i])); h.vvy.push_back(U2F(p[3 * nv + i]));
     h.vm.push_back((int32_t)p[4 * nv + i]); h.vh.push_back((int32_t)p[5 * nv + i]); h.vid.push_back((int32_t)p[6 * nv + i]); }
   p += 7 * nv;
   for (uint32_t i = 0; i < nf; i++) { h.fx.push_back(U2F(p[i])); h.fy.push_back(U2F(p[nf + i])); h.fvx.push_back(U2F(p[2 * nf + i])); h.fvy.push_back(U2F(p[3 * nf + i])); h.fid.push_back((int32_t)p[4 * nf + i]); }
   p += 5 * nf;
-  size_t nc = (size_t)d.P * d.CC;
-  h.cx.assign(nc, 0); h.cy.assign(nc, 0); h.cvx.assign(nc, 0); h.cvy.assign(nc, 0); h.csx.assign(nc, 0); h.csy.assign(nc, 0); h.cm.assign(nc, 0); h.cid.assign(nc, 0); h.cdl.assign(nc, 0);
+  size_t nc = (size_t)d.P * CF_FIELDS * AG_CC;
+  h.cells.assign(nc, 0);
   uint32_t clock = (uint32_t)h.ar[AR_CLOCK];
   for (int k = 0; k < d.P; k++) {
     int slot = h.ar[AR_ORDER0 + k]; int32_t *P = &h.pl[(size_t)slot * PL_WORDS];
     if ((int32_t)p[0] != P[PL_PID]) return fail(AGARCL_E_INVALID, "agarcl_load_arena: pid / iteration order mismatch");
     uint32_t ncell = p[2];
-    if ((int)ncell > d.CC) return fail(AGARCL_E_CAPACITY, "agarcl_load_arena: too many cells");
+    if ((int)ncell > AG_CC) return fail(AGARCL_E_CAPACITY, "agarcl_load_arena: too many cells");
     P[PL_NCELLS] = (int32_t)ncell; P[PL_ACTION] = (int32_t)p[3]; P[PL_TX] = (int32_t)p[4]; P[PL_TY] = (int32_t)p[5]; P[PL_SPLIT_CD] = (int32_t)p[6]; P[PL_FEED_CD] = (int32_t)p[7];
     P[PL_ELAPSED] = (int32_t)p[8]; P[PL_LAST_DECAY] = (int32_t)p[9]; P[PL_ANTI_TEAM] = (int32_t)p[10]; P[PL_FOOD_EATEN] = (int32_t)p[11]; P[PL_HIGHEST_MASS] = (int32_t)p[12];
     P[PL_CELLS_EATEN] = (int32_t)p[13]; P[PL_VIRUSES_EATEN] = (int32_t)p[14]; P[PL_MIN_MASS] = (int32_t)p[15];
@@ -477,22 +541,20 @@ extern "C" int agarcl_load_arena(agarcl_env *e, int32_t arena, const uint32_t *b
     P[PL_NVTICKS] = (int32_t)nt;
     for (uint32_t i = 0; i < nt; i++) h.vt[(size_t)slot * AG_VT_CAP + i] = (int32_t)p[17 + i];
     p += 17 + nt;
+    uint32_t *C = &h.cells[(size_t)slot * CF_FIELDS * AG_CC];
     for (uint32_t i = 0; i < ncell; i++, p += 9) {
-      size_t q = (size_t)slot * d.CC + i;
-      h.cx[q] = U2F(p[0]); h.cy[q] = U2F(p[1]); h.cvx[q] = U2F(p[2]); h.cvy[q] = U2F(p[3]); h.csx[q] = U2F(p[4]); h.csy[q] = U2F(p[5]);
-      h.cm[q] = p[6] > AG_CELL_MIN_SIZE ? p[6] : AG_CELL_MIN_SIZE; h.cid[q] = (int32_t)p[7]; h.cdl[q] = clock + p[8];
+      for (int f = CF_X; f <= CF_SY; f++) C[f * AG_CC + i] = p[f];
+      C[CF_M * AG_CC + i] = p[6] > AG_CELL_MIN_SIZE ? p[6] : AG_CELL_MIN_SIZE; C[CF_ID * AG_CC + i] = p[7]; C[CF_DL * AG_CC + i] = clock + p[8];
     }
   }
   if (p - b != words) return fail(AGARCL_E_INVALID, "agarcl_load_arena: blob length mismatch");
   int rc = 0;
   rc |= push(e, h.ar, s.ar, a * AR_WORDS); rc |= push(e, h.pl, s.pl, a * d.P * PL_WORDS); rc |= push(e, h.vt, s.vticks, a * d.P * AG_VT_CAP);
-  rc |= push(e, h.px, s.pel_x, a * d.PC); rc |= push(e, h.py, s.pel_y, a * d.PC); rc |= push(e, h.pid, s.pel_id, a * d.PC);
+  rc |= push(e, h.pxy, s.pel_xy, a * d.PC * 2); rc |= push(e, h.pid, s.pel_id, a * d.PC);
   rc |= push(e, h.vx, s.vir_x, a * d.VC); rc |= push(e, h.vy, s.vir_y, a * d.VC); rc |= push(e, h.vvx, s.vir_vx, a * d.VC); rc |= push(e, h.vvy, s.vir_vy, a * d.VC);
   rc |= push(e, h.vm, s.vir_mass, a * d.VC); rc |= push(e, h.vh, s.vir_hits, a * d.VC); rc |= push(e, h.vid, s.vir_id, a * d.VC);
   rc |= push(e, h.fx, s.food_x, a * d.FC); rc |= push(e, h.fy, s.food_y, a * d.FC); rc |= push(e, h.fvx, s.food_vx, a * d.FC); rc |= push(e, h.fvy, s.food_vy, a * d.FC); rc |= push(e, h.fid, s.food_id, a * d.FC);
-  size_t co = a * nc;
-  rc |= push(e, h.cx, s.cell_x, co); rc |= push(e, h.cy, s.cell_y, co); rc |= push(e, h.cvx, s.cell_vx, co); rc |= push(e, h.cvy, s.cell_vy, co);
-  rc |= push(e, h.csx, s.cell_sx, co); rc |= push(e, h.csy, s.cell_sy, co); rc |= push(e, h.cm, s.cell_m, co); rc |= push(e, h.cid, s.cell_id, co); rc |= push(e, h.cdl, s.cell_dl, co);
+  rc |= push(e, h.cells, s.cells, a * nc);
   return rc ? fail(AGARCL_E_HIP, "upload failed") : AGARCL_OK;
 }
 

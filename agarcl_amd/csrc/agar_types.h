@@ -34,18 +34,21 @@ enum {
   AR_WORDS = 32
 };
 #define AG_MAX_PLAYERS (AR_WORDS - AR_ORDER0)
+#define AG_CC 32        // cell capacity per player (reference: unbounded vector, nominal limit 14)
 #define AG_EV_CAP 256   // pellet eat events per arena-tick
 #define AG_EVV_CAP 16   // virus eat events per arena-tick (<= players)
-#define AG_CAND_CAP 128 // pellet candidates per cell in the ordered slow path
+#define AG_CAND_CAP 1024 // words of the ordered-replay candidate list: 256 records of (key, index, x, y)
 #define AG_VT_CAP 32    // virus_eaten_ticks kept per player
 #define AG_LUT_SIZE (1 << 19)
 #define AG_ANTI_LUT 64
+
+// cell fields, player-major in LDS and HBM: [player][field][AG_CC]
+enum { CF_X = 0, CF_Y, CF_VX, CF_VY, CF_SX, CF_SY, CF_M, CF_ID, CF_DL, CF_FIELDS };
 
 struct AgDims {
   int A;         // arenas
   int P;         // player slots per arena (agents + bots)
   int n_agents;  // RL-controlled players per arena
-  int CC;        // cell capacity per player
   int PC;        // pellet capacity per arena (multiple of 64)
   int VC;        // virus capacity
   int FC;        // food capacity
@@ -61,21 +64,22 @@ struct AgParams {
   int pgw, pgh, vgw, vgh;  // pellet / virus grid dims (Engine.hpp:964-965,1210-1211)
 };
 
+// HBM-resident descriptor of one env; kernels take a pointer to it (scalar loads on demand keep the
+// SGPR budget for the hot path)
 struct AgState {
-  // pellets [A][PC]
-  float *pel_x, *pel_y; int32_t *pel_id;
+  AgDims d; AgParams g;
+  // pellets [A][PC] interleaved (x,y) pairs + ids
+  float *pel_xy; int32_t *pel_id;
   // viruses [A][VC]
   float *vir_x, *vir_y, *vir_vx, *vir_vy; int32_t *vir_mass, *vir_hits, *vir_id;
   // foods [A][FC]
   float *food_x, *food_y, *food_vx, *food_vy; int32_t *food_id;
-  // cells [A][P][CC]
-  float *cell_x, *cell_y, *cell_vx, *cell_vy, *cell_sx, *cell_sy;
-  uint32_t *cell_m; int32_t *cell_id; uint32_t *cell_dl;
+  // cells [A][P][CF_FIELDS][AG_CC] as 32-bit words
+  uint32_t *cells;
   int32_t *pl;      // [A][P][PL_WORDS]
   int32_t *vticks;  // [A][P][AG_VT_CAP]
   int32_t *ar;      // [A][AR_WORDS]
   uint64_t *mt;     // [A][312]
-  int32_t *rnd;     // [A][35] glibc rand() state (bots / colour draws)
   // inputs
   const float *act_dxdy;  // [A][n_agents][2]
   const int32_t *act;     // [A][n_agents]
@@ -88,4 +92,5 @@ struct AgState {
   int32_t *ev_v;          // [A][AG_EVV_CAP]
   // read-only tables (mass -> fp32), host generated (Engine.hpp:1296-1302, core/utils.hpp:8-11)
   const float *lut_r, *lut_ms, *lut_ss, *lut_anti;
+  unsigned long long *prof;  // [16] phase cycle sums (diagnostic builds only; may be null)
 };
