@@ -54,6 +54,14 @@ AG_DEV float ag_divf(float a, float b) { return a / b; }
 
 #include "agar_libm.inl"
 
+// Pointers fetched from the HBM-resident descriptor are generic to the compiler (flat_load/flat_store); every
+// accessor below casts them to the global address space so they become global_load / global_store.
+#ifdef AGAR_CPU_EMU
+#define AG_GLOBAL
+#else
+#define AG_GLOBAL __attribute__((address_space(1)))
+#endif
+
 // ---- collectives --------------------------------------------------------------------------------
 #ifdef AGAR_CPU_EMU
 // (no short-circuiting: functors may have side effects, exactly like on the device)
@@ -104,14 +112,14 @@ template <class P, class S> AG_DEV int wave_compact(int n, P pred, S sink) {
 struct UBlock { int w[32]; };
 AG_DEV int ub_get(const UBlock &b, int k) { return b.w[k]; }
 AG_DEV void ub_set(UBlock &b, int k, int v) { b.w[k] = v; }
-AG_DEV void ub_load(UBlock &b, const int *src, int n) { for (int i = 0; i < 32; i++) b.w[i] = i < n ? src[i] : 0; }
-AG_DEV void ub_store(const UBlock &b, int *dst, int n) { for (int i = 0; i < n; i++) dst[i] = b.w[i]; }
+template <class PT> AG_DEV void ub_load(UBlock &b, PT src, int n) { for (int i = 0; i < 32; i++) b.w[i] = i < n ? src[i] : 0; }
+template <class PT> AG_DEV void ub_store(const UBlock &b, PT dst, int n) { for (int i = 0; i < n; i++) dst[i] = b.w[i]; }
 #else
 struct UBlock { int v; };
 AG_DEV int ub_get(const UBlock &b, int k) { return __builtin_amdgcn_readlane(b.v, k); }
 AG_DEV void ub_set(UBlock &b, int k, int v) { b.v = ((int)threadIdx.x == k) ? v : b.v; }
-AG_DEV void ub_load(UBlock &b, const int *src, int n) { int l = (int)threadIdx.x; b.v = l < n ? src[l] : 0; }
-AG_DEV void ub_store(const UBlock &b, int *dst, int n) { int l = (int)threadIdx.x; if (l < n) dst[l] = b.v; }
+template <class PT> AG_DEV void ub_load(UBlock &b, PT src, int n) { int l = (int)threadIdx.x; b.v = l < n ? src[l] : 0; }
+template <class PT> AG_DEV void ub_store(const UBlock &b, PT dst, int n) { int l = (int)threadIdx.x; if (l < n) dst[l] = b.v; }
 #endif
 
 // ---- numerics: C++ std::min/max/clamp on floats with their NaN behaviour (R: core/utils.hpp:19-21)
@@ -190,7 +198,7 @@ template <int NS, bool AV> struct AgCtx {
   unsigned tacc[AG_NPROF]; unsigned tlast;
 #endif
   const AgState *gs;
-  const float *act_dxdy; const int32_t *act;
+  const AG_GLOBAL float *act_dxdy; const AG_GLOBAL int32_t *act;
   int arena, P, PC, cells_off;
   unsigned char *lds;
   UBlock S;    // arena words (AR_*): register-resident for the whole launch
@@ -218,16 +226,19 @@ template <int NS, bool AV> AG_DEV Cells created_of(const AgCtx<NS, AV> &c) {
   return k;
 }
 // HBM slices of this arena (pointer + capacity fetched with scalar loads when a rare path needs them)
-#define G_SLICE(name, type, field, cap) template <int NS, bool AV> AG_DEV type *name(const AgCtx<NS, AV> &c) { return c.gs->field + (size_t)c.arena * (size_t)(cap); }
+#define G_SLICE(name, type, field, cap) template <int NS, bool AV> AG_DEV AG_GLOBAL type *name(const AgCtx<NS, AV> &c) { return (AG_GLOBAL type *)(c.gs->field + (size_t)c.arena * (size_t)(cap)); }
 G_SLICE(g_pxy, float, pel_xy, 2 * c.PC) G_SLICE(g_pid, int32_t, pel_id, c.PC)
 G_SLICE(g_vx, float, vir_x, c.gs->d.VC) G_SLICE(g_vy, float, vir_y, c.gs->d.VC) G_SLICE(g_vvx, float, vir_vx, c.gs->d.VC) G_SLICE(g_vvy, float, vir_vy, c.gs->d.VC)
 G_SLICE(g_vm, int32_t, vir_mass, c.gs->d.VC) G_SLICE(g_vh, int32_t, vir_hits, c.gs->d.VC) G_SLICE(g_vid, int32_t, vir_id, c.gs->d.VC)
 G_SLICE(g_fx, float, food_x, c.gs->d.FC) G_SLICE(g_fy, float, food_y, c.gs->d.FC) G_SLICE(g_fvx, float, food_vx, c.gs->d.FC) G_SLICE(g_fvy, float, food_vy, c.gs->d.FC)
 G_SLICE(g_fid, int32_t, food_id, c.gs->d.FC)
 G_SLICE(g_mt, uint64_t, mt, 312) G_SLICE(g_ar, int32_t, ar, AR_WORDS)
-template <int NS, bool AV> AG_DEV int32_t *g_pl(const AgCtx<NS, AV> &c) { return c.gs->pl + (size_t)c.arena * c.P * PL_WORDS; }
-template <int NS, bool AV> AG_DEV int32_t *g_vt(const AgCtx<NS, AV> &c, int p) { return c.gs->vticks + ((size_t)c.arena * c.P + p) * AG_VT_CAP; }
-template <int NS, bool AV> AG_DEV uint32_t *g_cells(const AgCtx<NS, AV> &c, int p) { return c.gs->cells + ((size_t)c.arena * c.P + p) * (CF_FIELDS * AG_CC); }
+template <int NS, bool AV> AG_DEV AG_GLOBAL int32_t *g_pl(const AgCtx<NS, AV> &c) { return (AG_GLOBAL int32_t *)(c.gs->pl + (size_t)c.arena * c.P * PL_WORDS); }
+template <int NS, bool AV> AG_DEV AG_GLOBAL int32_t *g_vt(const AgCtx<NS, AV> &c, int p) { return (AG_GLOBAL int32_t *)(c.gs->vticks + ((size_t)c.arena * c.P + p) * AG_VT_CAP); }
+template <int NS, bool AV> AG_DEV AG_GLOBAL uint32_t *g_cells(const AgCtx<NS, AV> &c, int p) { return (AG_GLOBAL uint32_t *)(c.gs->cells + ((size_t)c.arena * c.P + p) * (CF_ALL * AG_CC)); }
+template <int NS, bool AV> AG_DEV const AG_GLOBAL float *g_lut_r(const AgCtx<NS, AV> &c) { return (const AG_GLOBAL float *)c.gs->lut_r; }
+template <int NS, bool AV> AG_DEV const AG_GLOBAL float *g_lut_ms(const AgCtx<NS, AV> &c) { return (const AG_GLOBAL float *)c.gs->lut_ms; }
+template <int NS, bool AV> AG_DEV const AG_GLOBAL float *g_lut_ss(const AgCtx<NS, AV> &c) { return (const AG_GLOBAL float *)c.gs->lut_ss; }
 
 template <int NS, bool AV> AG_DEV int SR(const AgCtx<NS, AV> &c, int k) { return ub_get(c.S, k); }
 template <int NS, bool AV> AG_DEV void SW(AgCtx<NS, AV> &c, int k, int v) { ub_set(c.S, k, v); }
@@ -235,8 +246,8 @@ template <int NS, bool AV> AG_DEV int PR(const AgCtx<NS, AV> &c, int k) { return
 template <int NS, bool AV> AG_DEV float PRF(const AgCtx<NS, AV> &c, int k) { return u2f(ub_get(c.PB, k)); }
 template <int NS, bool AV> AG_DEV void PW(AgCtx<NS, AV> &c, int k, int v) { ub_set(c.PB, k, v); }
 template <int NS, bool AV> AG_DEV void flag(AgCtx<NS, AV> &c, unsigned f) { SW(c, AR_FLAGS, SR(c, AR_FLAGS) | (int)f); }
-AG_DEV float lut(const float *t, unsigned m) { return t[m < (unsigned)AG_LUT_SIZE ? m : (unsigned)AG_LUT_SIZE - 1u]; }
-template <int NS, bool AV> AG_DEV float radius_of(const AgCtx<NS, AV> &c, unsigned m) { return lut(c.gs->lut_r, m); }
+template <class PT> AG_DEV float lut(PT t, unsigned m) { return t[m < (unsigned)AG_LUT_SIZE ? m : (unsigned)AG_LUT_SIZE - 1u]; }
+template <int NS, bool AV> AG_DEV float radius_of(const AgCtx<NS, AV> &c, unsigned m) { return lut(g_lut_r(c), m); }
 // lane-level radius of LDS cell k of `cs`, through the per-cell cache when it is valid
 template <int NS, bool AV> AG_DEV float cell_rad(const AgCtx<NS, AV> &c, const Cells &cs, int k) { unsigned m = cs.m[k]; return cs.cmc[k] == m ? cs.crad[k] : radius_of(c, m); }
 
@@ -306,28 +317,22 @@ template <int NS, bool AV> AG_DEV void pel_get(const AgCtx<NS, AV> &c, int i, fl
 
 // ---- load / store arena state between HBM and LDS / registers -------------------------------------
 template <int NS, bool AV> AG_DEV void arena_load(AgCtx<NS, AV> &c) {
+  // Every load below is independent of every other (no count is needed to form an address), so the whole arena
+  // arrives in ONE round trip to HBM: pellets (NS x 512 B per wave-instruction), arena words, player words, and all
+  // AG_CC cell slots of every player incl. the persisted radius / speed cache (slots >= n_cells are never read).
+  auto gxy = g_pxy(c);
+  AG_PEL_FOR(s, lane, i) { PELX(c, s, lane) = gxy[2 * i]; PELY(c, s, lane) = gxy[2 * i + 1]; }
   ub_load(c.S, g_ar(c), AR_WORDS);
-  const int32_t *gpl = g_pl(c);
+  auto gpl = g_pl(c);
   AG_LANES(i, c.P * PL_WORDS) PLS(c, 0)[i] = gpl[i];
-  int np = SR(c, AR_NPEL);
-  const float *gxy = g_pxy(c);
-  AG_PEL_FOR(s, lane, i) {  // 8 B per lane, 512 B per wave-instruction, all slots in flight together
-    float x = AG_PEL_SENTINEL, y = AG_PEL_SENTINEL;
-    if (i < np) { x = gxy[2 * i]; y = gxy[2 * i + 1]; }
-    PELX(c, s, lane) = x; PELY(c, s, lane) = y;
-  }
-  ag_lds_order();
   for (int p = 0; p < c.P; p++) {
-    int n = ag_uni(PLS(c, p)[PL_NCELLS]);
-    Cells cs = cells_of(c, p); const uint32_t *g = g_cells(c, p);
-    AG_LANES(i, n) {
-      cs.x[i] = u2f((int)g[CF_X * AG_CC + i]); cs.y[i] = u2f((int)g[CF_Y * AG_CC + i]); cs.vx[i] = u2f((int)g[CF_VX * AG_CC + i]); cs.vy[i] = u2f((int)g[CF_VY * AG_CC + i]);
-      cs.sx[i] = u2f((int)g[CF_SX * AG_CC + i]); cs.sy[i] = u2f((int)g[CF_SY * AG_CC + i]);
-      cs.m[i] = g[CF_M * AG_CC + i]; cs.id[i] = (int)g[CF_ID * AG_CC + i]; cs.dl[i] = g[CF_DL * AG_CC + i];
+    auto g = g_cells(c, p); uint32_t *l = (uint32_t *)(c.lds + c.cells_off + p * CELL_STRIDE);
+    AG_LANES(i, AG_CC) {
+#ifndef AGAR_CPU_EMU
+#pragma unroll
+#endif
+      for (int f = 0; f < CF_ALL; f++) l[f * AG_CC + i] = g[f * AG_CC + i];
     }
-    // radius / max-speed cache (valid for cell i iff cmc[i] == m[i]); slots past n start invalid (no cell has mass 0)
-    const float *lut_r = c.gs->lut_r, *lut_ms = c.gs->lut_ms;
-    AG_LANES(i, AG_CC) { if (i < n) { unsigned m = g[CF_M * AG_CC + i]; cs.cmc[i] = m; cs.crad[i] = lut(lut_r, m); cs.cms[i] = lut(lut_ms, m); } else cs.cmc[i] = 0u; }
   }
   c.pel_dirty = false; c.ncreated = 0;
   ag_lds_order();
@@ -335,29 +340,30 @@ template <int NS, bool AV> AG_DEV void arena_load(AgCtx<NS, AV> &c) {
 template <int NS, bool AV> AG_DEV void arena_store(AgCtx<NS, AV> &c) {
   ag_lds_order();
   int np = SR(c, AR_NPEL);
-  if (c.pel_dirty) {
-    float *gxy = g_pxy(c);
-    AG_PEL_FOR(s, lane, i) { if (i < np) { gxy[2 * i] = PELX(c, s, lane); gxy[2 * i + 1] = PELY(c, s, lane); } }
+  if (c.pel_dirty) {  // whole register file incl. sentinels
+    auto gxy = g_pxy(c);
+    AG_PEL_FOR(s, lane, i) { gxy[2 * i] = PELX(c, s, lane); gxy[2 * i + 1] = PELY(c, s, lane); }
   }
   int total_cells = 0;
   for (int p = 0; p < c.P; p++) {
     int n = ag_uni(PLS(c, p)[PL_NCELLS]);
     total_cells += n;
-    Cells cs = cells_of(c, p); uint32_t *g = g_cells(c, p);
+    auto g = g_cells(c, p); const uint32_t *l = (const uint32_t *)(c.lds + c.cells_off + p * CELL_STRIDE);
     AG_LANES(i, n) {
-      g[CF_X * AG_CC + i] = (uint32_t)f2u(cs.x[i]); g[CF_Y * AG_CC + i] = (uint32_t)f2u(cs.y[i]); g[CF_VX * AG_CC + i] = (uint32_t)f2u(cs.vx[i]); g[CF_VY * AG_CC + i] = (uint32_t)f2u(cs.vy[i]);
-      g[CF_SX * AG_CC + i] = (uint32_t)f2u(cs.sx[i]); g[CF_SY * AG_CC + i] = (uint32_t)f2u(cs.sy[i]);
-      g[CF_M * AG_CC + i] = cs.m[i]; g[CF_ID * AG_CC + i] = (uint32_t)cs.id[i]; g[CF_DL * AG_CC + i] = cs.dl[i];
+#ifndef AGAR_CPU_EMU
+#pragma unroll
+#endif
+      for (int f = 0; f < CF_ALL; f++) g[f * AG_CC + i] = l[f * AG_CC + i];
     }
   }
   ub_store(c.S, g_ar(c), AR_WORDS);
-  int32_t *gpl = g_pl(c);
+  auto gpl = g_pl(c);
   AG_LANES(i, c.P * PL_WORDS) gpl[i] = PLS(c, 0)[i];
   int nevp = SR(c, AR_NEVP), nevv = SR(c, AR_NEVV);
-  if (nevp > 0) { int32_t *ge = c.gs->ev_p + (size_t)c.arena * AG_EV_CAP; int lim = nevp < AG_EV_CAP ? nevp : AG_EV_CAP; AG_LANES(i, lim) ge[i] = L_I(c, L_EVP)[i]; }
-  if (nevv > 0) { int32_t *ge = c.gs->ev_v + (size_t)c.arena * AG_EVV_CAP; int lim = nevv < AG_EVV_CAP ? nevv : AG_EVV_CAP; AG_LANES(i, lim) ge[i] = L_I(c, L_EVV)[i]; }
+  if (nevp > 0) { auto ge = (AG_GLOBAL int32_t *)(c.gs->ev_p + (size_t)c.arena * AG_EV_CAP); int lim = nevp < AG_EV_CAP ? nevp : AG_EV_CAP; AG_LANES(i, lim) ge[i] = L_I(c, L_EVP)[i]; }
+  if (nevv > 0) { auto ge = (AG_GLOBAL int32_t *)(c.gs->ev_v + (size_t)c.arena * AG_EVV_CAP); int lim = nevv < AG_EVV_CAP ? nevv : AG_EVV_CAP; AG_LANES(i, lim) ge[i] = L_I(c, L_EVV)[i]; }
   int nv = SR(c, AR_NVIR), nf = SR(c, AR_NFOOD);
-  AG_SERIAL { int32_t *cn = c.gs->counts + (size_t)c.arena * 4; cn[0] = np; cn[1] = nv; cn[2] = nf; cn[3] = total_cells; }
+  AG_SERIAL { auto cn = (AG_GLOBAL int32_t *)(c.gs->counts + (size_t)c.arena * 4); cn[0] = np; cn[1] = nv; cn[2] = nf; cn[3] = total_cells; }
 }
 
 // ---- mt19937_64, one generator per arena, state in HBM.  R: GameState.hpp:51, Engine.hpp:1304-1311
@@ -370,7 +376,7 @@ AG_DEV uint64_t mt_mix(uint64_t a, uint64_t b, uint64_t far) {
   return far ^ (y >> 1) ^ ((y & 1ULL) ? 0xB5026F5AA96619E9ULL : 0ULL);
 }
 template <int NS, bool AV> AG_DEV void mt_twist(AgCtx<NS, AV> &c) {  // three dependency phases, each data-parallel across the wave
-  uint64_t *mt = g_mt(c);
+  auto mt = g_mt(c);
   ag_mem_fence();
   for (int base = 0; base < 156; base += 64) {  // phase 1: reads old values only
     int lim = base + 64 < 156 ? base + 64 : 156;
@@ -407,7 +413,7 @@ template <int NS, bool AV> AG_DEV void mt_fill(AgCtx<NS, AV> &c, int n) {
     int idx = SR(c, AR_MTIDX);
     if (idx >= 312) { mt_twist(c); idx = 0; }
     int take = 312 - idx < n - produced ? 312 - idx : n - produced;
-    const uint64_t *mt = g_mt(c);
+    auto mt = g_mt(c);
     AG_LANES(j, take) rb[produced + j] = mt_temper(mt[idx + j]);
     SW(c, AR_MTIDX, idx + take);
     produced += take;
@@ -444,7 +450,7 @@ template <int NS, bool AV> AG_DEV void add_pellets(AgCtx<NS, AV> &c, int n) {
   int np = SR(c, AR_NPEL), idc = SR(c, AR_IDC);
   if (np + n > c.PC) { flag(c, 64u); n = c.PC - np; if (n <= 0) return; }
   float r = radius_of(c, AG_PELLET_MASS);
-  int32_t *gid = g_pid(c);
+  auto gid = g_pid(c);
   float *stage = (float *)L_I(c, L_CAND);  // 64 (x,y) pairs; the candidate list is idle during regen
   float two_r = 2.0f * r; float span = c.gs->g.W - two_r;
   const uint64_t *rb = (const uint64_t *)(c.lds + L_NEW);
@@ -469,7 +475,7 @@ template <int NS, bool AV> AG_DEV void add_viruses(AgCtx<NS, AV> &c, int n) {
   int nv = SR(c, AR_NVIR), idc = SR(c, AR_IDC), VC = c.gs->d.VC;
   if (nv + n > VC) { flag(c, 4u); n = VC - nv; if (n <= 0) return; }
   float r = radius_of(c, AG_VIRUS_MASS);
-  float *vx = g_vx(c), *vy = g_vy(c), *vvx = g_vvx(c), *vvy = g_vvy(c); int32_t *vm = g_vm(c), *vh = g_vh(c), *vid = g_vid(c);
+  auto vx = g_vx(c); auto vy = g_vy(c); auto vvx = g_vvx(c); auto vvy = g_vvy(c); auto vm = g_vm(c); auto vh = g_vh(c); auto vid = g_vid(c);
   draw_locations(c, n, r, [&](int j, float x, float y) {
     int k = nv + j; vx[k] = x; vy[k] = y; vvx[k] = 0.0f; vvy[k] = 0.0f; vm[k] = (int)AG_VIRUS_MASS; vh[k] = 0; vid[k] = idc + 1 + j; });
   SW(c, AR_NVIR, nv + n); SW(c, AR_IDC, idc + n);
@@ -484,7 +490,7 @@ template <int NS, bool AV> AG_DEV void create_squared_pellets(AgCtx<NS, AV> &c) 
   // every generated point lies inside the arena (centre +- W/4), so all 4*pps are kept, in order
   int total = 4 * pps;
   if (total > c.PC) { flag(c, 64u); total = c.PC; }
-  int32_t *gid = g_pid(c);
+  auto gid = g_pid(c);
   AG_PEL_FOR(s, lane, k) {
     if (k < total) {
       int side = k / pps, i = k - side * pps; float t = (float)i * 1.0f; float x, y;
@@ -686,7 +692,7 @@ AG_DEV void move_one(float &x, float &y, float &vx, float &vy, float &svx, float
 }
 template <int NS, bool AV> AG_DEV void move_player(AgCtx<NS, AV> &c, const Cells &s, int n) {
   float tx = PRF(c, PL_TX), ty = PRF(c, PL_TY), dt = c.gs->g.dt, W = c.gs->g.W;
-  const float *lut_r = c.gs->lut_r, *lut_ms = c.gs->lut_ms;
+  auto lut_r = g_lut_r(c); auto lut_ms = g_lut_ms(c);
   AG_LANES(i, n) {
     float x = s.x[i], y = s.y[i], svx = s.sx[i], svy = s.sy[i]; unsigned m = s.m[i];
     if (s.cmc[i] != m) { s.cmc[i] = m; s.crad[i] = lut(lut_r, m); s.cms[i] = lut(lut_ms, m); }  // refresh the cache on mass change
@@ -721,7 +727,7 @@ template <int NS, bool AV> AG_DEV void do_cell_split(const AgCtx<NS, AV> &c, con
   float lx = x + ox, ly = y + oy;
   lx = smaxf(0.0f, clampf(lx, r, W - r));
   ly = smaxf(0.0f, clampf(ly, r, W - r));
-  float ss = lut(c.gs->lut_ss, split_mass);
+  float ss = lut(g_lut_ss(c), split_mass);
   float vx = dirx * ss, vy = diry * ss;
   put_created(nw, slot, lx, ly, vx, vy, vx, vy, split_mass, id, dl);
   s.dl[k] = dl;
@@ -733,7 +739,7 @@ template <int NS, bool AV> AG_DEV bool virus_collisions(AgCtx<NS, AV> &c, const 
   if (nv == 0) return false;
   unsigned maxm = n == 1 ? ag_uniu(s.m[0]) : wave_max(n, [&](int i) { return s.m[i]; });
   if (maxm < 111u) return false;  // virus mass >= 100 and can_eat needs mass > 1.1 * virus mass
-  const float *vx_ = g_vx(c), *vy_ = g_vy(c); const int32_t *vm_ = g_vm(c);
+  auto vx_ = g_vx(c); auto vy_ = g_vy(c); auto vm_ = g_vm(c);
   int vgw = c.gs->g.vgw, vgh = c.gs->g.vgh; unsigned VC = (unsigned)c.gs->d.VC;
   for (int k = 0; k < n; k++) {
     unsigned m = ag_uniu(s.m[k]);
@@ -764,7 +770,7 @@ template <int NS, bool AV> AG_DEV bool virus_collisions(AgCtx<NS, AV> &c, const 
       if (create_limit < num_new) num_new = create_limit;
       float cvx = ag_unif(s.vx[k]), cvy = ag_unif(s.vy[k]);
       float theta = v_direction(cvx, cvy);
-      float sp = lut(c.gs->lut_ms, AG_CELL_POP_SIZE);
+      float sp = lut(g_lut_ms(c), AG_CELL_POP_SIZE);
       float virx = ag_unif(vx_[vi]), viry = ag_unif(vy_[vi]);
       int idc = SR(c, AR_IDC), nc0 = c.ncreated;
       unsigned dl = (unsigned)SR(c, AR_CLOCK) + (unsigned)c.gs->g.recomb_ticks;
@@ -841,7 +847,7 @@ template <int NS, bool AV> AG_DEV int pellets_eat(AgCtx<NS, AV> &c, const Cells 
     ag_lds_order();
     int ne0 = SR(c, AR_NEVP);
     int *T = L_I(c, L_TMP); int *evp = L_I(c, L_EVP);
-    const float *lut_r = c.gs->lut_r;
+    auto lut_r = g_lut_r(c);
     AG_SERIAL {
       for (int a = 1; a < ncand; a++) {  // insertion sort of the 4-word records by key
         unsigned k0 = cand[4 * a], k1 = cand[4 * a + 1], k2 = cand[4 * a + 2], k3 = cand[4 * a + 3]; int b = a - 1;
@@ -875,7 +881,7 @@ template <int NS, bool AV> AG_DEV int eat_food(AgCtx<NS, AV> &c, const Cells &s,
   if (m < AG_FOOD_MASS) return 0;
   float x = ag_unif(s.x[k]), y = ag_unif(s.y[k]);
   float r = radius_of(c, m), fr = radius_of(c, AG_FOOD_MASS);
-  float *fx = g_fx(c), *fy = g_fy(c), *fvx = g_fvx(c), *fvy = g_fvy(c); int32_t *fid = g_fid(c);
+  auto fx = g_fx(c); auto fy = g_fy(c); auto fvx = g_fvx(c); auto fvy = g_fvy(c); auto fid = g_fid(c);
   auto eaten = [&](int i) -> bool { return can_eat_mass(m, AG_FOOD_MASS) && collides(x, y, r, fx[i], fy[i], fr); };
   int cnt = wave_count(nf, [&](int i) { return eaten(i); });
   if (cnt == 0) return 0;
@@ -897,7 +903,7 @@ template <int NS, bool AV> AG_DEV void maybe_emit_food(AgCtx<NS, AV> &c, const C
     int nf = SR(c, AR_NFOOD), idc = SR(c, AR_IDC);
     float tx = PRF(c, PL_TX), ty = PRF(c, PL_TY);
     int FC = c.gs->d.FC;
-    float *fx = g_fx(c), *fy = g_fy(c), *fvx = g_fvx(c), *fvy = g_fvy(c); int32_t *fid = g_fid(c);
+    auto fx = g_fx(c); auto fy = g_fy(c); auto fvx = g_fvx(c); auto fvy = g_fvy(c); auto fid = g_fid(c);
     int made = wave_compact(n, [&](int i) { return s.m[i] >= AG_CELL_MIN_SIZE + AG_FOOD_MASS; }, [&](int i, int rank) {
       float x = s.x[i], y = s.y[i];
       float ddx = tx - x, ddy = ty - y;
@@ -941,11 +947,11 @@ template <int NS, bool AV> AG_DEV void move_foods(AgCtx<NS, AV> &c) {
   int nf = SR(c, AR_NFOOD);
   if (nf == 0) return;
   float dt = c.gs->g.dt, W = c.gs->g.W; float fr = radius_of(c, AG_FOOD_MASS);
-  float *fx = g_fx(c), *fy = g_fy(c), *fvx = g_fvx(c), *fvy = g_fvy(c); int32_t *fid = g_fid(c);
+  auto fx = g_fx(c); auto fy = g_fy(c); auto fvx = g_fvx(c); auto fvy = g_fvy(c); auto fid = g_fid(c);
   bool moving = wave_any(nf, [&](int i) { return !(vmag(fvx[i], fvy[i]) == 0); });
   if (!moving) return;
   int nv = SR(c, AR_NVIR);
-  float *vx = g_vx(c), *vy = g_vy(c), *vvx = g_vvx(c), *vvy = g_vvy(c); int32_t *vm = g_vm(c), *vh = g_vh(c), *vid = g_vid(c);
+  auto vx = g_vx(c); auto vy = g_vy(c); auto vvx = g_vvx(c); auto vvy = g_vvy(c); auto vm = g_vm(c); auto vh = g_vh(c); auto vid = g_vid(c);
   auto advance = [&](float &x, float &y, float &ux, float &uy) { v_decelerate(ux, uy, AG_FOOD_DECEL, dt); float t = ux * dt; x += t; t = uy * dt; y += t; boundary(W, x, y, fr); };
   // does any moving food reach a virus after its move?  (virus radii only grow by being fed)
   bool hits = nv > 0 && wave_any(nf, [&](int i) {
@@ -1040,7 +1046,7 @@ template <int NS, bool AV> AG_DEV void decay(AgCtx<NS, AV> &c, const Cells &s, i
   if (!(c.gs->g.mass_decay && elapsed % 60 == 0)) return;
   int nt = PR(c, PL_NVTICKS);
   if (nt > 0) {
-    int *T = L_I(c, L_TMP); int32_t *vt = g_vt(c, p);
+    int *T = L_I(c, L_TMP); auto vt = g_vt(c, p);
     AG_SERIAL {
       int fall = elapsed - AG_ANTI_TEAM_TICKS, w = 0;
       for (int i = 0; i < nt; i++) if (!(vt[i] < fall)) vt[w++] = vt[i];
@@ -1081,7 +1087,7 @@ template <int NS, bool AV> AG_DEV void tick_player(AgCtx<NS, AV> &c, int p) {
   bool can_eat_virus = n >= AG_PLAYER_CELL_LIMIT;
   if (virus_collisions(c, s, n, create_limit, can_eat_virus)) {
     int nt = PR(c, PL_NVTICKS), el = PR(c, PL_ELAPSED);
-    if (nt < AG_VT_CAP) { int32_t *vt = g_vt(c, p); AG_SERIAL { vt[nt] = el; } PW(c, PL_NVTICKS, nt + 1); ag_mem_fence(); } else flag(c, 16u);
+    if (nt < AG_VT_CAP) { auto vt = g_vt(c, p); AG_SERIAL { vt[nt] = el; } PW(c, PL_NVTICKS, nt + 1); ag_mem_fence(); } else flag(c, 16u);
     PW(c, PL_VIRUSES_EATEN, PR(c, PL_VIRUSES_EATEN) + 1);
   }
   AG_T(c, 4);
@@ -1148,7 +1154,7 @@ template <int NS, bool AV> AG_DEV void remove_pellets(AgCtx<NS, AV> &c) {
   int ne = SR(c, AR_NEVP);
   if (ne == 0) return;
   int n = SR(c, AR_NPEL);
-  const int *evp = L_I(c, L_EVP); int32_t *gid = g_pid(c);
+  const int *evp = L_I(c, L_EVP); auto gid = g_pid(c);
   int lim = ne < AG_EV_CAP ? ne : AG_EV_CAP;
   for (int e = 0; e < lim; e++) {  // wave-level replay of the stale-index swap-pop
     int idx = ag_uni(evp[e]);
@@ -1171,7 +1177,7 @@ template <int NS, bool AV> AG_DEV void remove_viruses(AgCtx<NS, AV> &c) {
   if (ne == 0) return;
   int n0 = SR(c, AR_NVIR);
   int *T = L_I(c, L_TMP); const int *evv = L_I(c, L_EVV);
-  float *vx = g_vx(c), *vy = g_vy(c), *vvx = g_vvx(c), *vvy = g_vvy(c); int32_t *vm = g_vm(c), *vh = g_vh(c), *vid = g_vid(c);
+  auto vx = g_vx(c); auto vy = g_vy(c); auto vvx = g_vvx(c); auto vvy = g_vvy(c); auto vm = g_vm(c); auto vh = g_vh(c); auto vid = g_vid(c);
   AG_SERIAL {
     int n = n0; int lim = ne < AG_EVV_CAP ? ne : AG_EVV_CAP;
     for (int e = 0; e < lim; e++) {
@@ -1330,7 +1336,7 @@ template <int NS, bool AV> AG_DEV void env_step(AgCtx<NS, AV> &c, int ticks, boo
       if (c.gs->g.reward_type) { float b = (float)before[i]; float sub = b - (float)(SR(c, AR_RESPAWNED) ? c.gs->g.c_death : 0); r -= (double)sub; }
       size_t o = (size_t)c.arena * na + i;
       int done = SR(c, AR_DONE);
-      double *rw = c.gs->rewards; int32_t *ms = c.gs->masses; uint8_t *dn = c.gs->dones;
+      auto rw = (AG_GLOBAL double *)c.gs->rewards; auto ms = (AG_GLOBAL int32_t *)c.gs->masses; auto dn = (AG_GLOBAL uint8_t *)c.gs->dones;
       AG_SERIAL { rw[o] = r; ms[o] = (int)m; dn[o] = (uint8_t)(i == 0 ? done : 0); }
     }
   }
@@ -1340,6 +1346,7 @@ template <int NS, bool AV> AG_DEV void env_reset(AgCtx<NS, AV> &c, int reset_ids
   if (reset_ids) SW(c, AR_IDC, 1);
   SW(c, AR_NPEL, 0); SW(c, AR_NVIR, 0); SW(c, AR_NFOOD, 0); SW(c, AR_TICKS, 0); SW(c, AR_FLAGS, 0);
   SW(c, AR_NEVP, 0); SW(c, AR_NEVV, 0); SW(c, AR_DONE, 0); SW(c, AR_RESPAWNED, 0);
+  AG_PEL_FOR(s, lane, i) { PELX(c, s, lane) = AG_PEL_SENTINEL; PELY(c, s, lane) = AG_PEL_SENTINEL; }
   if (c.gs->g.squared) create_squared_pellets(c); else add_pellets(c, c.gs->g.target_pellets);
   add_viruses(c, c.gs->g.target_viruses);
   for (int i = 0; i < c.P; i++) {  // add_player (Engine.hpp:70-83): slot i gets pid next_pid++

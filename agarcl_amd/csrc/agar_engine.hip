@@ -63,7 +63,7 @@ struct agarcl_env {
 // ---- kernels ----------------------------------------------------------------------------------------
 // NS = pellet register slots per lane (64 pellets per slot): 4 / 8 / 16 / 32 <=> up to 256 / 512 / 1024 / 2048 pellets
 template <int NS, bool AV> AG_DEV void ag_ctx_init(AgCtx<NS, AV> &c, const AgState *gs, int arena, unsigned char *lds, const float *act_dxdy, const int32_t *act) {
-  c.gs = gs; c.arena = arena; c.lds = lds; c.act_dxdy = act_dxdy; c.act = act;
+  c.gs = gs; c.arena = arena; c.lds = lds; c.act_dxdy = (const AG_GLOBAL float *)act_dxdy; c.act = (const AG_GLOBAL int32_t *)act;
   c.P = gs->d.P; c.PC = gs->d.PC;
   ag_lds_layout(c.P, &c.cells_off);
   c.ncreated = 0; c.pel_dirty = false;
@@ -252,7 +252,9 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   e->lds_bytes = ag_lds_layout(d.P, nullptr);
   e->all_vis = g.pgw <= 2 && g.pgh <= 2;
   e->ns = d.PC <= 256 ? 4 : d.PC <= 512 ? 8 : d.PC <= 1024 ? 16 : 32;
-  if (d.PC > 2048) { agarcl_destroy(e); return fail(AGARCL_E_UNSUPPORTED, "more than 2048 pellets per arena do not fit the pellet register file layout"); }
+  int pc_needed = d.PC;
+  d.PC = e->ns * 64; e->d = d;  // pellet capacity == register file size: loads / stores need no bounds test
+  if (pc_needed > 2048) { agarcl_destroy(e); return fail(AGARCL_E_UNSUPPORTED, "more than 2048 pellets per arena do not fit the pellet register file layout"); }
   if (e->lds_bytes > 160 * 1024) { agarcl_destroy(e); return fail(AGARCL_E_UNSUPPORTED, "arena does not fit the 160 KiB LDS of a CU (too many pellets)"); }
   AgState &s = e->s; memset(&s, 0, sizeof(s));
   s.d = d; s.g = g;
@@ -261,7 +263,7 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   s.vir_x = alloc<float>(e, A * d.VC); s.vir_y = alloc<float>(e, A * d.VC); s.vir_vx = alloc<float>(e, A * d.VC); s.vir_vy = alloc<float>(e, A * d.VC);
   s.vir_mass = alloc<int32_t>(e, A * d.VC); s.vir_hits = alloc<int32_t>(e, A * d.VC); s.vir_id = alloc<int32_t>(e, A * d.VC);
   s.food_x = alloc<float>(e, A * d.FC); s.food_y = alloc<float>(e, A * d.FC); s.food_vx = alloc<float>(e, A * d.FC); s.food_vy = alloc<float>(e, A * d.FC); s.food_id = alloc<int32_t>(e, A * d.FC);
-  s.cells = alloc<uint32_t>(e, A * d.P * CF_FIELDS * AG_CC);
+  s.cells = alloc<uint32_t>(e, A * d.P * CF_ALL * AG_CC);
   s.pl = alloc<int32_t>(e, A * d.P * PL_WORDS); s.vticks = alloc<int32_t>(e, A * d.P * AG_VT_CAP); s.ar = alloc<int32_t>(e, A * AR_WORDS);
   s.mt = alloc<uint64_t>(e, A * 312);
   s.rewards = alloc<double>(e, A * d.n_agents); s.dones = alloc<uint8_t>(e, A * d.n_agents); s.masses = alloc<int32_t>(e, A * d.n_agents);
@@ -472,7 +474,7 @@ extern "C" int agarcl_dump_arena(agarcl_env *e, int32_t arena, uint32_t *buf, in
   rc |= pull(e, h.vx, s.vir_x, a * d.VC, nv); rc |= pull(e, h.vy, s.vir_y, a * d.VC, nv); rc |= pull(e, h.vvx, s.vir_vx, a * d.VC, nv); rc |= pull(e, h.vvy, s.vir_vy, a * d.VC, nv);
   rc |= pull(e, h.vm, s.vir_mass, a * d.VC, nv); rc |= pull(e, h.vh, s.vir_hits, a * d.VC, nv); rc |= pull(e, h.vid, s.vir_id, a * d.VC, nv);
   rc |= pull(e, h.fx, s.food_x, a * d.FC, nf); rc |= pull(e, h.fy, s.food_y, a * d.FC, nf); rc |= pull(e, h.fvx, s.food_vx, a * d.FC, nf); rc |= pull(e, h.fvy, s.food_vy, a * d.FC, nf); rc |= pull(e, h.fid, s.food_id, a * d.FC, nf);
-  size_t nc = (size_t)d.P * CF_FIELDS * AG_CC;
+  size_t nc = (size_t)d.P * CF_ALL * AG_CC;
   rc |= pull(e, h.cells, s.cells, a * nc, nc);
   if (rc) return fail(AGARCL_E_HIP, "copy failed");
   std::vector<uint32_t> o;
@@ -494,7 +496,7 @@ extern "C" int agarcl_dump_arena(agarcl_env *e, int32_t arena, uint32_t *buf, in
     o.push_back((uint32_t)P[PL_FOOD_EATEN]); o.push_back((uint32_t)P[PL_HIGHEST_MASS]); o.push_back((uint32_t)P[PL_CELLS_EATEN]); o.push_back((uint32_t)P[PL_VIRUSES_EATEN]);
     o.push_back((uint32_t)P[PL_MIN_MASS]); o.push_back((uint32_t)P[PL_NVTICKS]);
     for (int i = 0; i < P[PL_NVTICKS]; i++) o.push_back((uint32_t)h.vt[(size_t)p * AG_VT_CAP + i]);
-    const uint32_t *C = &h.cells[(size_t)p * CF_FIELDS * AG_CC];
+    const uint32_t *C = &h.cells[(size_t)p * CF_ALL * AG_CC];
     for (int i = 0; i < P[PL_NCELLS]; i++) {
       for (int f = CF_X; f <= CF_ID; f++) o.push_back(C[f * AG_CC + i]);
       uint32_t dl = C[CF_DL * AG_CC + i];
@@ -519,14 +521,15 @@ extern "C" int agarcl_load_arena(agarcl_env *e, int32_t arena, const uint32_t *b
   h.ar[AR_TICKS] = (int32_t)b[1]; h.ar[AR_IDC] = (int32_t)b[2]; h.ar[AR_NEXT_PID] = (int32_t)b[3];
   h.ar[AR_NPEL] = (int32_t)np; h.ar[AR_NVIR] = (int32_t)nv; h.ar[AR_NFOOD] = (int32_t)nf;
   for (uint32_t i = 0; i < np; i++) { h.pxy.push_back(U2F(p[i])); h.pxy.push_back(U2F(p[np + i])); h.pid.push_back((int32_t)p[2 * np + i]); }
+  h.pxy.resize((size_t)d.PC * 2, AG_PEL_SENTINEL);  // HBM invariant: sentinel at every index >= n_pellets
   p += 3 * np;
   for (uint32_t i = 0; i < nv; i++) { h.vx.push_back(U2F(p[i])); h.vy.push_back(U2F(p[nv + i])); h.vvx.push_back(U2F(p[2 * nv + i])); h.vvy.push_back(U2F(p[3 * nv + i]));
     h.vm.push_back((int32_t)p[4 * nv + i]); h.vh.push_back((int32_t)p[5 * nv + i]); h.vid.push_back((int32_t)p[6 * nv + i]); }
   p += 7 * nv;
   for (uint32_t i = 0; i < nf; i++) { h.fx.push_back(U2F(p[i])); h.fy.push_back(U2F(p[nf + i])); h.fvx.push_back(U2F(p[2 * nf + i])); h.fvy.push_back(U2F(p[3 * nf + i])); h.fid.push_back((int32_t)p[4 * nf + i]); }
   p += 5 * nf;
-  size_t nc = (size_t)d.P * CF_FIELDS * AG_CC;
-  h.cells.assign(nc, 0);
+  size_t nc = (size_t)d.P * CF_ALL * AG_CC;
+  h.cells.assign(nc, 0);  // cache words 0 => invalid (no cell has mass 0): the first tick refreshes it
   uint32_t clock = (uint32_t)h.ar[AR_CLOCK];
   for (int k = 0; k < d.P; k++) {
     int slot = h.ar[AR_ORDER0 + k]; int32_t *P = &h.pl[(size_t)slot * PL_WORDS];
@@ -541,7 +544,7 @@ extern "C" int agarcl_load_arena(agarcl_env *e, int32_t arena, const uint32_t *b
     P[PL_NVTICKS] = (int32_t)nt;
     for (uint32_t i = 0; i < nt; i++) h.vt[(size_t)slot * AG_VT_CAP + i] = (int32_t)p[17 + i];
     p += 17 + nt;
-    uint32_t *C = &h.cells[(size_t)slot * CF_FIELDS * AG_CC];
+    uint32_t *C = &h.cells[(size_t)slot * CF_ALL * AG_CC];
     for (uint32_t i = 0; i < ncell; i++, p += 9) {
       for (int f = CF_X; f <= CF_SY; f++) C[f * AG_CC + i] = p[f];
       C[CF_M * AG_CC + i] = p[6] > AG_CELL_MIN_SIZE ? p[6] : AG_CELL_MIN_SIZE; C[CF_ID * AG_CC + i] = p[7]; C[CF_DL * AG_CC + i] = clock + p[8];

@@ -43,7 +43,10 @@ enum {
 #define AG_ANTI_LUT 64
 
 // cell fields, player-major in LDS and HBM: [player][field][AG_CC]
-enum { CF_X = 0, CF_Y, CF_VX, CF_VY, CF_SX, CF_SY, CF_M, CF_ID, CF_DL, CF_FIELDS };
+enum { CF_X = 0, CF_Y, CF_VX, CF_VY, CF_SX, CF_SY, CF_M, CF_ID, CF_DL, CF_FIELDS,
+       // derived, persisted so a launch needs no dependent table lookups: radius / max-speed cache of the cell,
+       // valid iff CF_CMC == CF_M (agar_core.inl: Cells::cmc/crad/cms)
+       CF_CMC = CF_FIELDS, CF_CRAD, CF_CMS, CF_ALL };
 
 struct AgDims {
   int A;         // arenas
@@ -74,7 +77,7 @@ struct AgState {
   float *vir_x, *vir_y, *vir_vx, *vir_vy; int32_t *vir_mass, *vir_hits, *vir_id;
   // foods [A][FC]
   float *food_x, *food_y, *food_vx, *food_vy; int32_t *food_id;
-  // cells [A][P][CF_FIELDS][AG_CC] as 32-bit words
+  // cells [A][P][CF_ALL][AG_CC] as 32-bit words
   uint32_t *cells;
   int32_t *pl;      // [A][P][PL_WORDS]
   int32_t *vticks;  // [A][P][AG_VT_CAP]
