@@ -64,12 +64,15 @@ def cpu_baseline(seconds_budget=12.0):
     rate1 = 4000 / dt1
     chunk = 2000
     done = [0] * cores
+    mk_lock = threading.Lock()
     deadline = time.perf_counter() + seconds_budget
 
     def worker(w):  # one engine per thread at a time (the reference's BotEvaluator pattern), time-bounded
         j = 0
         while time.perf_counter() < deadline:
-            env = mk(); env.seed(10000 + w * 64 + j); env.reset(True)
+            with mk_lock:
+                env = mk()
+            env.seed(10000 + w * 64 + j); env.reset(True)
             for _ in range(10):
                 done[w] += env.run_random(chunk, policy_seed=w * 64 + j + 1, allow_actions=False)
                 if time.perf_counter() >= deadline:

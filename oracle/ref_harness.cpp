@@ -21,6 +21,7 @@
 #include <cstdint>
 #include <cstring>
 #include <iostream>
+#include <mutex>
 #include <sstream>
 #include <vector>
 
@@ -100,6 +101,8 @@ extern "C" {
 void *ref_env_create(int num_agents, int ticks_per_step, int arena_size, int pellet_regen,
                      int num_pellets, int num_viruses, int num_bots, int reward_type, int c_death,
                      int mode, int recomb_ticks) {
+  static std::mutex ctor_mutex;  // the std::cout redirection below is process-global
+  std::lock_guard<std::mutex> lock(ctor_mutex);
   Silence s;
   try {
     VClock tmp; tmp.recomb = recomb_ticks; VClock *prev = g_clock; g_clock = &tmp;
