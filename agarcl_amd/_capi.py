@@ -58,7 +58,7 @@ SYMBOLS = [
     ("agarcl_get_flags", C.c_int, [C.c_void_p, C.c_void_p]),
     ("agarcl_get_counts", C.c_int, [C.c_void_p, C.c_void_p]),
     ("agarcl_get_events", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
-    ("agarcl_grid_obs", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]),
+    ("agarcl_grid_obs", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     ("agarcl_dump_arena", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     ("agarcl_load_arena", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     ("agarcl_num_arenas", C.c_int, [C.c_void_p]),
@@ -207,6 +207,17 @@ class BatchedEngine:
         ve = np.full((self.num_arenas, cap_v), -1, dtype=np.int32)
         self._chk(self.L.agarcl_get_events(self.h, _ptr(n), _ptr(pe), cap, _ptr(ve), cap_v))
         return n, pe, ve
+
+    def grid_obs(self, grid_size=128, cells=True, others=True, viruses=True, pellets=True, out_ptr=None):
+        """int32 [A, n_agents, C, G, G] (host copy), or written to the HBM pointer `out_ptr` (returns C)."""
+        ch = C.c_int32(0)
+        self._chk(self.L.agarcl_grid_obs(self.h, grid_size, int(cells), int(others), int(viruses), int(pellets), None, 0, C.byref(ch)))
+        if out_ptr is not None:
+            self._chk(self.L.agarcl_grid_obs(self.h, grid_size, int(cells), int(others), int(viruses), int(pellets), C.c_void_p(out_ptr), 1, C.byref(ch)))
+            return ch.value
+        out = np.zeros((self.num_arenas, self.num_agents, ch.value, grid_size, grid_size), dtype=np.int32)
+        self._chk(self.L.agarcl_grid_obs(self.h, grid_size, int(cells), int(others), int(viruses), int(pellets), _ptr(out), 0, C.byref(ch)))
+        return out
 
     def device_ptrs(self):
         return {"rewards": self.L.agarcl_rewards_dev(self.h), "dones": self.L.agarcl_dones_dev(self.h),

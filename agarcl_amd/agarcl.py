@@ -12,6 +12,10 @@ from . import _capi
 # the OpenGL ScreenEnvironment is outside the hot path
 has_screen_env = False
 
+# Test seam only: CPU tests point this at the test-only wave-emulation build of the kernel source.  The default
+# (None) is the HIP library, and there is no automatic fallback: without libagarcl_hip.so / a GPU construction raises.
+_LIB = None
+
 
 class _Environment:
     def __init__(self, num_agents, ticks_per_step, arena_size, pellet_regen, num_pellets, num_viruses, num_bots,
@@ -19,7 +23,7 @@ class _Environment:
         self._num_agents = int(num_agents)
         self._engine = _capi.BatchedEngine(1, int(num_agents), int(ticks_per_step), int(arena_size), bool(pellet_regen),
                                            int(num_pellets), int(num_viruses), int(num_bots), int(bool(reward_type)) if isinstance(reward_type, bool) else int(reward_type),
-                                           int(c_death), int(mode_number), device=device)
+                                           int(c_death), int(mode_number), device=device, lib=_LIB)
 
     def seed(self, s):                       # bindings.cpp:103
         self._engine.seed(np.asarray([int(s) & 0xFFFFFFFF], dtype=np.uint32))

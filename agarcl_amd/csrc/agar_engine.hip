@@ -21,6 +21,7 @@
 
 #include "../../include/agarcl_batch.h"
 #include "agar_core.inl"
+#include "agar_obs.inl"
 
 // ---- thread-local error string -------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -58,6 +59,7 @@ struct agarcl_env {
   std::vector<void *> allocs;
   float *d_act_dxdy; int32_t *d_act;  // env-owned action buffers (host-copy path)
   float *lut_r, *lut_ms, *lut_ss, *lut_anti;
+  int32_t *obs_buf; size_t obs_cap;  // staging for host-side grid observations
 };
 
 // ---- kernels ----------------------------------------------------------------------------------------
@@ -201,6 +203,9 @@ extern "C" int agarcl_destroy(agarcl_env *e) {
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
 #endif
   for (void *p : e->allocs) dfree(p);
+#ifndef AGAR_CPU_EMU
+  if (e->obs_buf) (void)hipFree(e->obs_buf);
+#endif
   delete e;
   return AGARCL_OK;
 }
@@ -224,7 +229,7 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
 #endif
   agarcl_env *e = new agarcl_env();
   e->cfg = *cfg; e->device = device; e->own_stream = true; e->d_act_dxdy = nullptr; e->d_act = nullptr;
-  e->d_state = nullptr; e->act_dxdy = nullptr; e->act = nullptr;
+  e->d_state = nullptr; e->act_dxdy = nullptr; e->act = nullptr; e->obs_buf = nullptr; e->obs_cap = 0;
 #ifdef AGAR_CPU_EMU
   e->stream = nullptr;
 #else
@@ -567,7 +572,40 @@ extern "C" int64_t agarcl_state_bytes(agarcl_env *e) {
   return 8LL * e->cfg.num_pellets + 12LL * e->cfg.num_viruses + 72LL * 1 + 112LL * e->d.P + 24LL * e->d.n_agents;
 }
 
-extern "C" int agarcl_grid_obs(agarcl_env *e, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t *, int32_t *) {
+#ifndef AGAR_CPU_EMU
+__global__ void __launch_bounds__(256) k_grid_obs(const AgState *__restrict__ gs, AgObsCfg o, int32_t *out) {
+  int b = (int)blockIdx.x, na = gs->d.n_agents;
+  grid_obs_agent(gs, b / na, b % na, o, out + (size_t)b * obs_channels(o) * o.G * o.G);
+}
+#endif
+
+extern "C" int agarcl_grid_obs(agarcl_env *e, int32_t G, int32_t cells, int32_t others, int32_t viruses, int32_t pellets,
+                               int32_t *out, int32_t on_device, int32_t *channels) {
   if (!e) return fail(AGARCL_E_INVALID, "null env");
-  return fail(AGARCL_E_UNSUPPORTED, "agarcl_grid_obs: not implemented yet");
+  if (G < 1 || G > 1024) return fail(AGARCL_E_INVALID, "agarcl_grid_obs: grid_size must be in [1, 1024]");
+  AgObsCfg o; o.G = G; o.cells = cells != 0; o.others = others != 0; o.viruses = viruses != 0; o.pellets = pellets != 0;
+  int C = 1 + o.cells + 2 * o.others + 2 * o.viruses + 2 * o.pellets;
+  if (channels) *channels = C;
+  if (!out) return AGARCL_OK;
+  size_t n = (size_t)e->d.A * e->d.n_agents, words = n * C * G * G;
+#ifdef AGAR_CPU_EMU
+  (void)on_device;
+  for (size_t b = 0; b < n; b++) grid_obs_agent(&e->s, (int)(b / e->d.n_agents), (int)(b % e->d.n_agents), o, out + b * C * G * G);
+  return AGARCL_OK;
+#else
+  HIPCHK(hipSetDevice(e->device));
+  int32_t *dst = out;
+  if (!on_device) {
+    if (e->obs_cap < words) {
+      if (e->obs_buf) { HIPCHK(hipStreamSynchronize(e->stream)); (void)hipFree(e->obs_buf); e->obs_buf = nullptr; e->obs_cap = 0; }
+      if (hipMalloc((void **)&e->obs_buf, words * 4) != hipSuccess) return fail(AGARCL_E_NOMEM, "agarcl_grid_obs: staging allocation failed");
+      e->obs_cap = words;
+    }
+    dst = e->obs_buf;
+  }
+  hipLaunchKernelGGL(k_grid_obs, dim3((unsigned)n), dim3(256), 0, e->stream, e->d_state, o, dst);
+  HIPCHK(hipGetLastError());
+  if (!on_device && d2h(out, dst, words * 4, e->stream)) return fail(AGARCL_E_HIP, "agarcl_grid_obs: copy failed");
+  return AGARCL_OK;
+#endif
 }

@@ -1,0 +1,116 @@
+// Grid observation kernel: GridObservation::add_frame of the reference
+// (/root/reference/environment/envs/GridEnvironment.hpp:91-123, helpers :188-296) for every (arena, agent):
+// an egocentric int32 tensor [C][G][G], C = 1 (out-of-bounds) + 2 pellets + 2 viruses + 1 own cells + 2 others.
+//
+// One 256-thread workgroup per (arena, agent).  Phase 1 streams the whole tensor out once (coalesced 4-byte
+// stores: channel 0 = out-of-bounds mask computed per grid cell, the rest zero); phase 2 scatters the entities
+// (a few hundred 4-byte writes / integer atomics per agent).  The tensor (512 KiB per agent at G = 128) is the
+// HBM traffic of this kernel; entity state is read straight from the engine's SoA arrays.
+//
+// Order-dependent channel ops of the reference ("at least one": last writer in vector order wins) are kept exact:
+// pellets all carry mass 1 (order-free), viruses / cells are few and are replayed in order by one thread.
+#pragma once
+#include "agar_types.h"
+#include <limits.h>
+
+#ifdef AGAR_CPU_EMU
+#define OBS_DEV static inline
+#define OBS_FOR(k, n) for (int k = 0; k < (n); ++k)
+#define OBS_BARRIER()
+#define OBS_THREAD0 true
+#define OBS_ATOMIC_ADD(p, v) (*(p) += (v))
+#else
+#define OBS_DEV __device__ __forceinline__
+#define OBS_FOR(k, n) for (int k = (int)threadIdx.x; k < (n); k += (int)blockDim.x)
+#define OBS_BARRIER() __syncthreads()
+#define OBS_THREAD0 (threadIdx.x == 0)
+#define OBS_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#endif
+
+struct AgObsCfg { int G, cells, others, viruses, pellets; };
+
+OBS_DEV int obs_channels(const AgObsCfg &o) { return 1 + o.cells + 2 * o.others + 2 * o.viruses + 2 * o.pellets; }
+
+OBS_DEV float obs_smaxf(float a, float b) { return (a < b) ? b : a; }
+OBS_DEV float obs_sminf(float a, float b) { return (b < a) ? b : a; }
+OBS_DEV int obs_f2i(float f) { if (!(f > -2147483904.0f && f < 2147483648.0f)) return INT_MIN; return (int)f; }
+
+// mass-weighted centroid and total mass of player `p` (Player::x/y/mass, core/Player.hpp:102-126): sequential fp32
+// sums in cell order, evaluated redundantly by every thread
+OBS_DEV void obs_player(const AgState *gs, int arena, int p, float &px, float &py, unsigned &mass) {
+  const int32_t *pl = gs->pl + ((size_t)arena * gs->d.P + p) * PL_WORDS;
+  const uint32_t *C = gs->cells + ((size_t)arena * gs->d.P + p) * (CF_ALL * AG_CC);
+  int n = pl[PL_NCELLS]; float sx = 0.0f, sy = 0.0f; unsigned tm = 0;
+  for (int i = 0; i < n; i++) {
+    union { uint32_t u; float f; } x, y; x.u = C[CF_X * AG_CC + i]; y.u = C[CF_Y * AG_CC + i];
+    unsigned m = C[CF_M * AG_CC + i]; float fm = (float)m;
+    float t = x.f * fm; sx += t; t = y.f * fm; sy += t; tm += m;
+  }
+  px = sx / (float)tm; py = sy / (float)tm; mass = tm;
+}
+
+OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o, int32_t *out) {
+  const int G = o.G, GG = G * G, C = obs_channels(o);
+  float px, py; unsigned mass;
+  obs_player(gs, arena, agent, px, py, mass);
+  float view = obs_smaxf(obs_sminf((float)(2u * mass), 300.0f), 100.0f);  // clamp<float>(2*mass, 100, 300), :251-254
+  float centering = (float)(G / 2.0);
+  float W = gs->g.W;
+  // phase 1: channel 0 = out-of-bounds mask (:235-248), all other channels 0
+  OBS_FOR(k, GG) {
+    int i = k / G, j = k - i * G;
+    float xd = (float)i - centering, yd = (float)j - centering;
+    float dx = xd * view; dx = dx / (float)G;
+    float dy = yd * view; dy = dy / (float)G;
+    float lx = px + dx, ly = py + dy;
+    bool inb = 0 <= lx && lx < W && 0 <= ly && ly < W;
+    out[k] = inb ? 0 : -1;
+  }
+  OBS_FOR(k, (C - 1) * GG) out[GG + k] = 0;
+  OBS_BARRIER();
+  // world -> grid (:258-268)
+  auto w2g = [&](float ex, float ey, int &gx, int &gy) {
+    float ddx = ex - px, ddy = ey - py;
+    float t1 = (float)G * ddx; t1 = t1 / view; gx = obs_f2i(t1 + centering);
+    float t2 = (float)G * ddy; t2 = t2 / view; gy = obs_f2i(t2 + centering);
+    return 0 <= gx && gx < G && 0 <= gy && gy < G;
+  };
+  int ch = 0;
+  if (o.pellets) {  // ch+1: "at least one" (= mass 1), ch+2: count
+    const float *pxy = gs->pel_xy + (size_t)arena * gs->d.PC * 2; int np = gs->ar[(size_t)arena * AR_WORDS + AR_NPEL];
+    int32_t *a1 = out + (size_t)(ch + 1) * GG, *a2 = out + (size_t)(ch + 2) * GG;
+    OBS_FOR(k, np) { int gx, gy; if (w2g(pxy[2 * k], pxy[2 * k + 1], gx, gy)) { a1[gx * G + gy] = 1; OBS_ATOMIC_ADD(&a2[gx * G + gy], 1); } }
+    ch += 2;
+  }
+  if (OBS_THREAD0) {
+    int c2 = o.pellets ? 2 : 0;
+    if (o.viruses) {  // in vector order: "at least one" keeps the LAST virus' mass, the second channel sums
+      size_t vo = (size_t)arena * gs->d.VC; int nv = gs->ar[(size_t)arena * AR_WORDS + AR_NVIR];
+      int32_t *a1 = out + (size_t)(c2 + 1) * GG, *a2 = out + (size_t)(c2 + 2) * GG;
+      for (int k = 0; k < nv; k++) { int gx, gy; if (w2g(gs->vir_x[vo + k], gs->vir_y[vo + k], gx, gy)) { a1[gx * G + gy] = gs->vir_mass[vo + k]; a2[gx * G + gy] += gs->vir_mass[vo + k]; } }
+      c2 += 2;
+    }
+    auto cells_into = [&](int p, int32_t *dst, int mode) {  // mode 0: += mass, 1: min (0 = empty), 2: max
+      const int32_t *pl = gs->pl + ((size_t)arena * gs->d.P + p) * PL_WORDS;
+      const uint32_t *Cc = gs->cells + ((size_t)arena * gs->d.P + p) * (CF_ALL * AG_CC);
+      int n = pl[PL_NCELLS];
+      for (int i = 0; i < n; i++) {
+        union { uint32_t u; float f; } x, y; x.u = Cc[CF_X * AG_CC + i]; y.u = Cc[CF_Y * AG_CC + i];
+        int m = (int)Cc[CF_M * AG_CC + i], gx, gy;
+        if (!w2g(x.f, y.f, gx, gy)) continue;
+        int32_t *d = &dst[gx * G + gy];
+        if (mode == 0) *d += m; else if (mode == 1) *d = (*d == 0) ? m : (*d < m ? *d : m); else *d = (*d > m ? *d : m);
+      }
+    };
+    if (o.cells) { cells_into(agent, out + (size_t)(c2 + 1) * GG, 0); c2 += 1; }
+    if (o.others) {
+      const int32_t *ar = gs->ar + (size_t)arena * AR_WORDS;
+      for (int k = 0; k < gs->d.P; k++) {  // players in the engine's iteration order (:113-121)
+        int p = ar[AR_ORDER0 + k];
+        if (p == agent) continue;
+        cells_into(p, out + (size_t)(c2 + 1) * GG, 1);
+        cells_into(p, out + (size_t)(c2 + 2) * GG, 2);
+      }
+    }
+  }
+}

@@ -1,0 +1,150 @@
+"""gym-style wrapper with the surface of the reference's gym_agario.AgarioEnv
+(/root/reference/gym_agario/AgarioEnv.py:46-404) on top of agarcl_amd.agarcl.
+
+Same constructor keywords ("difficulty" presets + overrides, AgarioEnv.py:298-363), same return shapes:
+reset() -> (obs, {}), step(a) -> (obs, reward, done, truncated=False, {'steps', 'untransformed_rewards'}),
+single-agent unwrapping (AgarioEnv.py:114-118), episodic cut-off after `number_steps` (AgarioEnv.py:111-112).
+gymnasium is optional: when it is importable the class derives from gymnasium.Env and exposes real spaces.
+Video recording (cv2) and OpenGL rendering are outside the hot path and not provided.
+"""
+import numpy as np
+
+from . import agarcl
+
+try:  # optional
+    import gymnasium as _gym
+    from gymnasium import spaces as _spaces
+    _Base = _gym.Env
+except Exception:  # pragma: no cover - gymnasium is not installed in the build image
+    _gym = None
+    _spaces = None
+    _Base = object
+
+
+class AgarioEnv(_Base):
+    metadata = {"render_modes": ["human", "rgb_array"], "render_fps": 60}
+
+    def __init__(self, obs_type="grid", render_mode=None, **kwargs):
+        if _gym is not None:
+            super().__init__()
+        if obs_type not in ("ram", "screen", "grid", "gobigger"):
+            raise ValueError(obs_type)
+        self._env, self.observation_shape = self._make_environment(obs_type, kwargs)
+        self.steps = None
+        self.obs_type = obs_type
+        self.render_mode = render_mode
+        self.agent_view = kwargs.get("agent_view", False)
+        self.add_noise = kwargs.get("add_noise", True)
+        self.number_of_steps = kwargs.get("number_steps", 500)
+        self.mode = kwargs.get("mode", 0)
+        self.env_type = kwargs.get("env_type", 0)  # 0 episodic, 1 continuing
+        self._seed = None
+        if _spaces is not None:
+            self.action_space = _spaces.Tuple((_spaces.Box(low=-1, high=1, shape=(2,)), _spaces.Discrete(3)))
+            self.observation_space = _spaces.Box(-1, np.iinfo(np.int32).max, self.observation_shape, dtype=np.int32)
+
+    # -- AgarioEnv.py:298-363 -------------------------------------------------------------------------
+    def _get_env_args(self, kwargs):
+        difficulty = kwargs.get("difficulty", "normal").lower()
+        if difficulty not in ["normal", "empty", "trivial"]:
+            raise ValueError("Unrecognized difficulty: %s" % difficulty)
+        d = dict(ticks_per_step=4, num_frames=1, arena_size=1000, num_pellets=1000, num_viruses=0, num_bots=0,
+                 pellet_regen=True, allow_respawn=True, reward_type=1)
+        if difficulty == "trivial":
+            d.update(arena_size=50, num_pellets=200, num_viruses=0, num_bots=0)
+        self.grid_size = kwargs.get("grid_size", 128)
+        self.multi_agent = kwargs.get("multi_agent", False)
+        self.num_agents = kwargs.get("num_agents", 1)
+        for k in ("ticks_per_step", "num_frames", "arena_size", "num_pellets", "num_viruses", "num_bots", "pellet_regen",
+                  "allow_respawn", "reward_type"):
+            setattr(self, k, kwargs.get(k, d[k]))
+        self.c_death = kwargs.get("c_death", 0)
+        self.mode = kwargs.get("mode", 0)
+        self.load_env_snapshot = kwargs.get("load_env_snapshot", False)
+        self.multi_agent = self.multi_agent or self.num_agents > 1
+        if type(self.ticks_per_step) is not int or self.ticks_per_step <= 0:
+            raise ValueError("ticks_per_step must be a positive integer")
+        return (self.num_agents, self.ticks_per_step, self.arena_size, self.pellet_regen, self.num_pellets,
+                self.num_viruses, self.num_bots, self.reward_type, self.c_death, self.mode)
+
+    def _make_environment(self, obs_type, kwargs):
+        args = self._get_env_args(kwargs)
+        if obs_type == "grid":
+            env = agarcl.GridEnvironment(*args)
+            cfg = dict(num_frames=1, grid_size=128, observe_cells=True, observe_others=True, observe_viruses=True, observe_pellets=True)
+            cfg.update({k: kwargs[k] for k in cfg if k in kwargs})
+            env.configure_observation(cfg)
+            channels, width, height = env.observation_shape()
+            return env, (width, height, channels)
+        if obs_type == "screen":
+            raise ValueError("agarcl was not compiled to include ScreenEnvironment")  # AgarioEnv.py:232-233
+        raise ValueError("obs_type %r is not provided by the HIP engine" % obs_type)
+
+    # -- AgarioEnv.py:270-296 (validation; the reference samples noise and then discards it) --------------
+    def _sanitize_actions(self, actions):
+        if not self.multi_agent and type(actions) is not list:
+            actions = [actions]
+        if type(actions) is not list:
+            raise ValueError("Action list must be a list of two-element tuples")
+        if len(actions) != self.num_agents:
+            raise ValueError("Number of actions %d does not match number of agents %d" % (len(actions), self.num_agents))
+        out = []
+        for tgt, a in actions:
+            tx, ty = float(tgt[0]), float(tgt[1])
+            if not (-1.0 <= tx <= 1.0 and -1.0 <= ty <= 1.0 and int(a) in (0, 1, 2)):
+                raise ValueError("action %r not in action space" % ((tgt, a),))
+            out.append((tx, ty, int(a)))
+        return out
+
+    def _make_observations(self):
+        states = self._env.get_state()
+        assert len(states) == self.num_agents
+        return [np.transpose(s, [1, 2, 0]) for s in states]  # NCHW -> NHWC, AgarioEnv.py:192-194
+
+    def step(self, actions):
+        assert self.steps is not None, "Cannot call step() before calling reset()"
+        self._env.take_actions(self._sanitize_actions(actions))
+        rewards = self._env.step()
+        assert len(rewards) == self.num_agents
+        self.observations = self._make_observations()
+        dones = self._env.dones()
+        truncations = [False] * len(dones)
+        if self.steps >= self.number_of_steps and self.env_type == 0:
+            dones = [True] * len(dones)
+        if not self.multi_agent:
+            self.observations, rewards, dones, truncations = self.observations[0], rewards[0], dones[0], truncations[0]
+        self.steps += 1
+        return self.observations, rewards, dones, truncations, {"steps": self.steps, "untransformed_rewards": rewards}
+
+    def reset(self, **kwargs):
+        self.steps = 0
+        self._env.reset()
+        obs = self._make_observations()
+        return (obs if self.multi_agent else obs[0]), {}
+
+    def seed(self, seed=None):
+        if seed is not None:
+            self._seed = seed
+            self._env.seed(seed)
+            return [self._seed]
+
+    def render(self):
+        return None
+
+    def close(self):
+        self._env.close()
+
+    def save_env_state(self, filename):
+        self._env.save_env_state(filename)
+
+    def load_env_state(self, filename):
+        self._env.load_env_state(filename)
+
+
+def register():
+    """gymnasium ids of the reference (gym_agario/__init__.py:9-23); no-op without gymnasium."""
+    if _gym is None:
+        return False
+    from gymnasium.envs.registration import register as _reg
+    _reg(id="agario-grid-v0", entry_point="agarcl_amd.gym_agario:AgarioEnv", kwargs={"obs_type": "grid"})
+    return True

@@ -119,10 +119,13 @@ int agarcl_get_events(agarcl_env *env, int32_t *n_events_host, int32_t *pellet_i
                       int32_t *virus_idx_host, int32_t cap_v);
 
 /* replaces: configure_observation(dict) + observation_shape() + get_state() of GridEnvironment,
- * bindings.cpp:104-116,133 -> GridObservation::add_frame, GridEnvironment.hpp:91-123.
- * Writes i32[num_arenas][num_agents][C][G][G] into out_dev (HBM); returns C through *channels. */
+ * bindings.cpp:104-116,133 -> GridObservation::add_frame, GridEnvironment.hpp:91-123 (one frame: the state
+ * after the last step).  Writes i32[num_arenas][num_agents][C][G][G], C = 1 + cells + 2*others + 2*viruses +
+ * 2*pellets, into `out` (HBM pointer if on_device != 0, else a host buffer); returns C through *channels.
+ * out == NULL only queries C. */
 int agarcl_grid_obs(agarcl_env *env, int32_t grid_size, int32_t observe_cells, int32_t observe_others,
-                    int32_t observe_viruses, int32_t observe_pellets, int32_t *out_dev, int32_t *channels);
+                    int32_t observe_viruses, int32_t observe_pellets, int32_t *out, int32_t on_device,
+                    int32_t *channels);
 
 /* full-state exchange for parity tests and snapshots (layout: oracle/BLOB_FORMAT.md); synchronising */
 int agarcl_dump_arena(agarcl_env *env, int32_t arena, uint32_t *buf_host, int32_t cap_words);

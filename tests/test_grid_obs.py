@@ -1,0 +1,68 @@
+"""Grid observation (GridObservation::add_frame, GridEnvironment.hpp:91-123): engine vs the oracle's restatement,
+int-exact.  NOTE: the oracle side of O1 is *unpinned* against the real reference (GridEnvironment.hpp is not
+buildable here without OpenGL stand-ins)."""
+import numpy as np
+import pytest
+
+from lockstep import policy
+
+CFGS = [
+    dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode=6),
+    dict(arena_size=250, num_pellets=500, num_viruses=10, mode=6),
+    dict(arena_size=60, num_pellets=200, num_viruses=0, mode=0),   # tiny arena: large out-of-bounds band
+]
+
+
+def _run(engine_cls, oracle_lib, lib, cfg, steps=60, A=3):
+    kw = dict(lib=lib) if lib is not None else {}
+    eng = engine_cls(A, **kw, **cfg)
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    seeds = np.arange(31, 31 + A).astype(np.uint32)
+    eng.seed(seeds); eng.reset(reset_ids=True)
+    for o, s in zip(oras, seeds):
+        o.seed(int(s)); o.reset(True)
+    for t in range(steps):
+        dxdy = np.zeros((A, 1, 2), np.float32); act = np.zeros((A, 1), np.int32)
+        for a in range(A):
+            dd, aa = policy(5 + a, t, 1, True, 8); dxdy[a, 0] = dd[0]; act[a, 0] = aa[0]
+        eng.set_actions(dxdy, act); eng.step()
+        for a in range(A):
+            oras[a].take_actions(dxdy[a], act[a]); oras[a].step()
+        if t % 20 == 19:
+            for G, flags in ((128, (True, True, True, True)), (32, (True, False, True, True)), (64, (False, True, False, True))):
+                got = eng.grid_obs(G, *flags)
+                for a in range(A):
+                    want = oras[a].grid_obs(0, G, *flags)
+                    assert got.shape[2:] == want.shape
+                    assert np.array_equal(got[a, 0], want), (cfg, t, a, G, flags)
+                assert (got[:, 0, 0] == -1).any() or cfg["arena_size"] > 300
+    eng.close()
+
+
+@pytest.mark.parametrize("cfg", CFGS)
+def test_grid_obs_kernel_source_emulation(emu_lib, oracle_lib, cfg):
+    from agarcl_amd import _capi
+    _run(_capi.BatchedEngine, oracle_lib, emu_lib, cfg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", CFGS)
+def test_grid_obs_hip(hip_engine_cls, oracle_lib, cfg):
+    _run(hip_engine_cls, oracle_lib, None, cfg)
+
+
+@pytest.mark.gpu
+def test_grid_obs_device_buffer_4096(hip_engine_cls):
+    """BASELINE config 5 shape: int32 [4096][1][8][128][128] written straight into a torch HBM tensor."""
+    import torch
+    A = 4096
+    eng = hip_engine_cls(A, arena_size=1000, num_pellets=1000, num_viruses=25, mode=0)
+    eng.seed(None, 10000); eng.reset(reset_ids=True)
+    out = torch.empty((A, 1, 8, 128, 128), dtype=torch.int32, device="cuda")
+    c = eng.grid_obs(128, out_ptr=out.data_ptr())
+    eng.sync()
+    assert c == 8
+    host = eng.grid_obs(128)
+    assert np.array_equal(out[:8].cpu().numpy(), host[:8])
+    assert int(out[:, 0, 5].sum().item()) == 25 * A   # own-cell channel: one cell of mass 25 per agent
+    eng.close()
