@@ -142,8 +142,8 @@ AG_DEV unsigned clamp_mass(unsigned m) { return m > AG_CELL_MIN_SIZE ? m : AG_CE
 #define L_EVP 0                                   // int[AG_EV_CAP]   pellet eat events of the tick
 #define L_EVV (L_EVP + 4 * AG_EV_CAP)             // int[AG_EVV_CAP]
 #define L_CAND (L_EVV + 4 * AG_EVV_CAP)           // unsigned[AG_CAND_CAP] ordered-replay keys
-#define L_TMP (L_CAND + 4 * AG_CAND_CAP)          // int[64] mailbox / scratch
-#define L_NEW (L_TMP + 4 * 64)                    // created cells [CF_FIELDS][AG_CC]; also the RNG draw buffer (128 x u64)
+#define L_TMP (L_CAND + 4 * AG_CAND_CAP)          // int[128] mailbox / scratch
+#define L_NEW (L_TMP + 4 * 128)                    // created cells [CF_FIELDS][AG_CC]; also the RNG draw buffer (128 x u64)
 #define L_PLS (L_NEW + 4 * CF_FIELDS * AG_CC)     // int[P][PL_WORDS]
 #define CELL_STRIDE (4 * (CF_FIELDS + 3) * AG_CC) // per player: 9 fields + (cached-for mass, radius, max speed)
 #ifdef AGAR_CPU_EMU
@@ -1069,6 +1069,8 @@ template <int NS, bool AV> AG_DEV void decay(AgCtx<NS, AV> &c, const Cells &s, i
   }
 }
 
+#include "agar_multi.inl"
+
 // ---- one player's tick.  R: Engine.hpp:495-542 --------------------------------------------------------------
 template <int NS, bool AV> AG_DEV void tick_player(AgCtx<NS, AV> &c, int p) {
   ub_load(c.PB, PLS(c, p), PL_WORDS);
@@ -1076,7 +1078,7 @@ template <int NS, bool AV> AG_DEV void tick_player(AgCtx<NS, AV> &c, int p) {
   if (n == 0) return;  // dead players are skipped (Engine.hpp:216)
   Cells s = cells_of(c, p);
   PW(c, PL_ELAPSED, PR(c, PL_ELAPSED) + 1);
-  // (bots' take_action every 10th tick: not on the HIP path yet -- agarcl_create rejects num_bots > 0)
+  if (c.P > 1 && SR(c, AR_TICKS) % 10 == 0) bot_take_action(c, p);  // Engine.hpp:498-499
   AG_T(c, 2);
 #ifndef AG_ABLATE_MOVE
   move_player(c, s, n);
@@ -1283,7 +1285,8 @@ template <int NS, bool AV> AG_DEV void arena_tick(AgCtx<NS, AV> &c) {
   remove_viruses(c);
   for (int k = 0; k < c.P; k++) sort_cells_by_id(c, SR(c, AR_ORDER0 + k));
   // PrecisionCollisionDetection::solve: with one player every strip scan breaks on an own cell
-  // (utils/collision_detection.hpp:51) => no eats.  P > 1 is rejected at create time for now.
+  // (utils/collision_detection.hpp:51) => no eats.
+  players_collision(c);
   move_foods(c);
   int ticks = SR(c, AR_TICKS);
   if (c.gs->g.regen && ticks % 120 == 0) {
@@ -1309,16 +1312,27 @@ template <int NS, bool AV> AG_DEV void take_action(AgCtx<NS, AV> &c, int p, floa
 }
 template <int NS, bool AV> AG_DEV void respawn_dead(AgCtx<NS, AV> &c) { for (int k = 0; k < c.P; k++) { int p = SR(c, AR_ORDER0 + k); if (ag_uni(PLS(c, p)[PL_NCELLS]) == 0) respawn(c, p); } }
 
+// k-th RL-controlled (non-bot) player in the engine's iteration order -- the order of BaseEnvironment::masses()
+// (BaseEnvironment.hpp:125-138), i.e. of the rewards list; -1 if there are fewer.
+template <int NS, bool AV> AG_DEV int agent_in_order(const AgCtx<NS, AV> &c, int k) {
+  for (int j = 0; j < c.P; j++) { int p = SR(c, AR_ORDER0 + j); if (ag_uni(PLS(c, p)[PL_KIND]) != 0) continue; if (k == 0) return p; k--; }
+  return -1;
+}
 template <int NS, bool AV> AG_DEV void env_step(AgCtx<NS, AV> &c, int ticks, bool with_env) {
   int na = c.gs->d.n_agents, mode = c.gs->g.mode;
-  unsigned before[AG_MAX_PLAYERS];
+  int *before = L_I(c, L_TMP) + 20;  // [n_agents] masses before the ticks, in rewards order (LDS, not private memory)
   if (with_env) {
-    for (int i = 0; i < na; i++) {
+    for (int i = 0; i < na; i++) {  // take_actions: agent i == player slot i (pids_[i]), BaseEnvironment.hpp:141-176
       size_t o = (size_t)c.arena * na + i;
       if (c.act) take_action(c, i, c.act_dxdy[2 * o], c.act_dxdy[2 * o + 1], c.act[o]);
     }
     SW(c, AR_RESPAWNED, 0);
-    for (int i = 0; i < na; i++) { before[i] = player_mass(c, i); if (mode == 3 && before[i] >= 23000u) SW(c, AR_DONE, 1); }
+    for (int i = 0; i < na; i++) {
+      int p = agent_in_order(c, i); unsigned m = p >= 0 ? player_mass(c, p) : 0u;
+      AG_SERIAL { before[i] = (int)m; }
+      if (mode == 3 && m >= 23000u) SW(c, AR_DONE, 1);
+    }
+    ag_lds_order();
   }
   for (int t = 0; t < ticks;) {
 #ifndef AG_NO_QUIET
@@ -1329,11 +1343,20 @@ template <int NS, bool AV> AG_DEV void env_step(AgCtx<NS, AV> &c, int ticks, boo
   }
   if (with_env) {
     if (mode == 0) respawn_dead(c);
+    else if (mode > 6) {  // BaseEnvironment.hpp:103-114
+      int done = SR(c, AR_DONE);
+      for (int k = 0; k < c.P; k++) {
+        bool dead = ag_uni(PLS(c, SR(c, AR_ORDER0 + k))[PL_NCELLS]) == 0;
+        done = (dead || SR(c, AR_RESPAWNED)) ? 1 : 0;
+        if (dead) { done = 1; break; }
+      }
+      SW(c, AR_DONE, done);
+    }
     for (int i = 0; i < na; i++) {
-      unsigned m = player_mass(c, i);
+      int p = agent_in_order(c, i); unsigned m = p >= 0 ? player_mass(c, p) : 0u;
       if (mode == 3 && m >= 23000u) SW(c, AR_DONE, 1);
       double r = (double)m;
-      if (c.gs->g.reward_type) { float b = (float)before[i]; float sub = b - (float)(SR(c, AR_RESPAWNED) ? c.gs->g.c_death : 0); r -= (double)sub; }
+      if (c.gs->g.reward_type) { float b = (float)(unsigned)ag_uni(before[i]); float sub = b - (float)(SR(c, AR_RESPAWNED) ? c.gs->g.c_death : 0); r -= (double)sub; }
       size_t o = (size_t)c.arena * na + i;
       int done = SR(c, AR_DONE);
       auto rw = (AG_GLOBAL double *)c.gs->rewards; auto ms = (AG_GLOBAL int32_t *)c.gs->masses; auto dn = (AG_GLOBAL uint8_t *)c.gs->dones;
@@ -1349,15 +1372,23 @@ template <int NS, bool AV> AG_DEV void env_reset(AgCtx<NS, AV> &c, int reset_ids
   AG_PEL_FOR(s, lane, i) { PELX(c, s, lane) = AG_PEL_SENTINEL; PELY(c, s, lane) = AG_PEL_SENTINEL; }
   if (c.gs->g.squared) create_squared_pellets(c); else add_pellets(c, c.gs->g.target_pellets);
   add_viruses(c, c.gs->g.target_viruses);
-  for (int i = 0; i < c.P; i++) {  // add_player (Engine.hpp:70-83): slot i gets pid next_pid++
+  int na = c.gs->d.n_agents, mode = c.gs->g.mode, nb = c.P - na;
+  auto rnd = g_rnd(c);
+  for (int i = 0; i < c.P; i++) {  // add_player (Engine.hpp:70-83): slot i gets pid next_pid++; agents first, then bots
     int pid = SR(c, AR_NEXT_PID); SW(c, AR_NEXT_PID, (pid + 1) & 0xFFFF);
-    SW(c, AR_ORDER0 + i, i);
+    // BaseEnvironment::add_bots (mode 0, :374-399): Hungry, HungryShy, Aggressive, AggressiveShy by i % num_bots;
+    // custom_add_bot (mode > 6, :401-425): one bot of type mode - 7
+    int kind = 0;
+    if (i >= na) { int b = mode > 6 ? mode - 7 : (i - na) % nb; kind = b == 0 ? AG_KIND_HUNGRY : b == 1 ? AG_KIND_HUNGRY_SHY : b == 2 ? AG_KIND_AGGRESSIVE : b == 3 ? AG_KIND_AGGRESSIVE_SHY : AG_KIND_HUNGRY; }
     int *P = PLS(c, i);
     AG_SERIAL {
-      P[PL_PID] = pid; P[PL_KIND] = 0; P[PL_ACTION] = 0; P[PL_TX] = 0; P[PL_TY] = 0;
+      P[PL_PID] = pid; P[PL_KIND] = kind; P[PL_ACTION] = 0; P[PL_TX] = 0; P[PL_TY] = 0;
       P[PL_FOOD_EATEN] = 0; P[PL_HIGHEST_MASS] = (int)AG_CELL_MIN_SIZE; P[PL_CELLS_EATEN] = 0; P[PL_VIRUSES_EATEN] = 0;
+      if (kind == 0) (void)ag_rand_next(rnd);  // Player(pid, name) draws random_color(): core/Player.hpp:53, color.hpp:14-16
     }
     ag_lds_order();
     respawn(c, i);
   }
+  ag_mem_fence();
+  compute_player_order(c);
 }

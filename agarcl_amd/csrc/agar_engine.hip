@@ -169,6 +169,18 @@ static int launch_respawn(agarcl_env *e) {
 // ---- host helpers -------------------------------------------------------------------------------------
 template <class T> static T *alloc(agarcl_env *e, size_t n) { T *p = (T *)dmalloc(n * sizeof(T)); if (p) e->allocs.push_back(p); return p; }
 
+// glibc srand(): TYPE_3 additive-feedback state after the 310 discarded outputs, as the 34-word ring the device
+// continues (agar_multi.inl: ag_rand_next).  Engine::seed calls std::srand(s) (Engine.hpp:242-245).
+static void glibc_srand_host(int32_t *st, unsigned seed) {
+  int32_t r[344];
+  if (seed == 0) seed = 1;
+  r[0] = (int32_t)seed;
+  for (int i = 1; i < 31; i++) { long long hi = r[i - 1] / 127773, lo = r[i - 1] % 127773; long long w = 16807 * lo - 2836 * hi; if (w < 0) w += 2147483647; r[i] = (int32_t)w; }
+  for (int i = 31; i < 34; i++) r[i] = r[i - 31];
+  for (int i = 34; i < 344; i++) r[i] = (int32_t)((uint32_t)r[i - 31] + (uint32_t)r[i - 3]);
+  for (int i = 0; i < 34; i++) st[i] = r[310 + i];
+  st[34] = 0;
+}
 static void mt_seed_host(uint64_t *mt, uint64_t seed) {  // std::mt19937_64::seed
   mt[0] = seed;
   for (int i = 1; i < 312; i++) mt[i] = 6364136223846793005ULL * (mt[i - 1] ^ (mt[i - 1] >> 62)) + (uint64_t)i;
@@ -216,11 +228,6 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
     return fail(AGARCL_E_INVALID, "agarcl_create: invalid environment arguments");
   AgParams g; memset(&g, 0, sizeof(g));
   if (set_mode(g, cfg->mode_number) != 0) return fail(AGARCL_E_MODE, "Invalid mode number");
-  // Scope of the HIP path this round: one RL agent per arena, no scripted bots.
-  if (cfg->num_bots > 0 && (cfg->mode_number == 0 || cfg->mode_number > 6))
-    return fail(AGARCL_E_UNSUPPORTED, "agarcl_create: scripted bots are not implemented on the HIP path yet (num_bots must be 0; modes 7-10 need a bot)");
-  if (cfg->mode_number > 6) return fail(AGARCL_E_UNSUPPORTED, "agarcl_create: modes 7-10 add a scripted bot, not implemented on the HIP path yet");
-  if (cfg->num_agents != 1) return fail(AGARCL_E_UNSUPPORTED, "agarcl_create: multi-agent arenas (cell-eats-cell) are not implemented on the HIP path yet");
 #ifndef AGAR_CPU_EMU
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(AGARCL_E_HIP, "agarcl_create: no HIP device available (the HIP engine has no CPU fallback)");
@@ -245,7 +252,9 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   g.pgw = g.pgh = (int)((g.W + (float)AG_PELLET_GRID - 1.0f) / (float)AG_PELLET_GRID);
   g.vgw = g.vgh = (int)((g.W + (float)AG_VIRUS_GRID - 1.0f) / (float)AG_VIRUS_GRID);
   AgDims d;
-  d.A = num_arenas; d.n_agents = cfg->num_agents; d.P = cfg->num_agents + cfg->num_bots;
+  // bots exist only in mode 0 (num_bots of them, BaseEnvironment.hpp:374-399) and modes 7-10 (exactly one, :401-425)
+  int nbots = cfg->mode_number == 0 ? cfg->num_bots : (cfg->mode_number > 6 ? 1 : 0);
+  d.A = num_arenas; d.n_agents = cfg->num_agents; d.P = cfg->num_agents + nbots;
   int npel = cfg->num_pellets;
   if (g.squared) { int pps = (int)(g.W / 2.0f); npel = 4 * pps; }
   d.PC = ((npel > 0 ? npel : 1) + 63) / 64 * 64;
@@ -270,7 +279,9 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   s.food_x = alloc<float>(e, A * d.FC); s.food_y = alloc<float>(e, A * d.FC); s.food_vx = alloc<float>(e, A * d.FC); s.food_vy = alloc<float>(e, A * d.FC); s.food_id = alloc<int32_t>(e, A * d.FC);
   s.cells = alloc<uint32_t>(e, A * d.P * CF_ALL * AG_CC);
   s.pl = alloc<int32_t>(e, A * d.P * PL_WORDS); s.vticks = alloc<int32_t>(e, A * d.P * AG_VT_CAP); s.ar = alloc<int32_t>(e, A * AR_WORDS);
-  s.mt = alloc<uint64_t>(e, A * 312);
+  s.mt = alloc<uint64_t>(e, A * 312); s.rnd = alloc<int32_t>(e, A * 35);
+  s.scratch = d.P > 1 ? alloc<int32_t>(e, A * (size_t)AGM_WORDS) : nullptr;
+  if (d.P > 1 && !s.scratch) { agarcl_destroy(e); return fail(AGARCL_E_NOMEM, "device allocation failed"); }
   s.rewards = alloc<double>(e, A * d.n_agents); s.dones = alloc<uint8_t>(e, A * d.n_agents); s.masses = alloc<int32_t>(e, A * d.n_agents);
   s.counts = alloc<int32_t>(e, A * 4); s.ev_p = alloc<int32_t>(e, A * AG_EV_CAP); s.ev_v = alloc<int32_t>(e, A * AG_EVV_CAP);
   e->d_act_dxdy = alloc<float>(e, A * d.n_agents * 2); e->d_act = alloc<int32_t>(e, A * d.n_agents);
@@ -339,6 +350,9 @@ extern "C" int agarcl_seed(agarcl_env *e, const uint32_t *seeds_host, uint32_t b
   std::vector<uint64_t> mt(A * 312);
   for (size_t a = 0; a < A; a++) mt_seed_host(&mt[a * 312], (uint64_t)(seeds_host ? seeds_host[a] : base_seed + (uint32_t)a));
   if (h2d(e->s.mt, mt.data(), mt.size() * 8, e->stream)) return fail(AGARCL_E_HIP, "seed upload failed");
+  std::vector<int32_t> rnd(A * 35);
+  for (size_t a = 0; a < A; a++) glibc_srand_host(&rnd[a * 35], seeds_host ? seeds_host[a] : base_seed + (uint32_t)a);
+  if (h2d(e->s.rnd, rnd.data(), rnd.size() * 4, e->stream)) return fail(AGARCL_E_HIP, "seed upload failed");
 #ifdef AGAR_CPU_EMU
   for (size_t a = 0; a < A; a++) e->s.ar[a * AR_WORDS + AR_MTIDX] = 312;
 #else

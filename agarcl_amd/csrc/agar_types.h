@@ -30,10 +30,11 @@ enum {
 // per-arena int32 words ([A][AR_WORDS])
 enum {
   AR_TICKS = 0, AR_CLOCK, AR_IDC, AR_NEXT_PID, AR_NPEL, AR_NVIR, AR_NFOOD, AR_FLAGS, AR_MTIDX,
-  AR_NEVP, AR_NEVV, AR_DONE, AR_RESPAWNED, AR_ORDER0 /* P slots of player order follow */,
+  AR_NEVP, AR_NEVV, AR_DONE, AR_RESPAWNED, AR_ORDER0 /* AG_MAX_PLAYERS slots: player slots in the engine's iteration order */,
+  AR_HM_BUCKETS = AR_ORDER0 + 16, AR_HM_RESIZE,  // rehash-policy state of the players map (survives reset, GameState.hpp:61-67)
   AR_WORDS = 32
 };
-#define AG_MAX_PLAYERS (AR_WORDS - AR_ORDER0)
+#define AG_MAX_PLAYERS 16
 #define AG_CC 32        // cell capacity per player (reference: unbounded vector, nominal limit 14)
 #define AG_EV_CAP 256   // pellet eat events per arena-tick
 #define AG_EVV_CAP 16   // virus eat events per arena-tick (<= players)
@@ -83,6 +84,8 @@ struct AgState {
   int32_t *vticks;  // [A][P][AG_VT_CAP]
   int32_t *ar;      // [A][AR_WORDS]
   uint64_t *mt;     // [A][312]
+  int32_t *rnd;     // [A][35] glibc rand() ring + position (Player colours, bots' fallbacks)
+  int32_t *scratch; // [A][AGM_WORDS] multi-player working memory (null when P == 1)
   // inputs
   const float *act_dxdy;  // [A][n_agents][2]
   const int32_t *act;     // [A][n_agents]

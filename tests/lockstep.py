@@ -62,12 +62,13 @@ def run_batched_lockstep(engine, oracles, steps, seeds, policy_seed=1, allow_act
         d = blob.diff(oracles[a].dump(), engine.dump(a), rtol)
         if d:
             return False, "after reset: arena %d: %s" % (a, d)
+    n = engine.num_agents
     for t in range(steps):
-        dxdy = np.zeros((A, 1, 2), np.float32)
-        act = np.zeros((A, 1), np.int32)
+        dxdy = np.zeros((A, n, 2), np.float32)
+        act = np.zeros((A, n), np.int32)
         for a in range(A):
-            dd, aa = policy(policy_seed + 7919 * a, t, 1, allow_actions, sticky)
-            dxdy[a, 0] = dd[0]; act[a, 0] = aa[0]
+            dd, aa = policy(policy_seed + 7919 * a, t, n, allow_actions, sticky)
+            dxdy[a] = dd; act[a] = aa
         engine.set_actions(dxdy, act)
         engine.step(ticks_per_step)
         rw = []
@@ -178,7 +179,7 @@ def golden_files(gpu_capable_only=False):
     for p in sorted(glob.glob(os.path.join(here, "*.npz"))):
         if gpu_capable_only:
             cfg = json.loads(str(np.load(p)["cfg"]))
-            if cfg.get("num_agents", 1) != 1 or cfg.get("num_bots", 0) != 0 or cfg.get("mode", 0) > 6:
+            if cfg.get("num_agents", 1) + cfg.get("num_bots", 0) > 16:
                 continue
         out.append(p)
     return out

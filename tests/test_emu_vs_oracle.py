@@ -12,6 +12,15 @@ CASES = [
     (dict(arena_size=300, num_pellets=300, num_viruses=5, mode=1), 200, 8),
     (dict(arena_size=1200, num_pellets=800, num_viruses=15, mode=3), 200, 8),
     (dict(arena_size=60, num_pellets=200, num_viruses=0, mode=0), 200, 8),
+    # several players per arena: bots (mode 0, modes 7-10) and multi-agent (cell-eats-cell, map order)
+    (dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0), 600, 4),
+    (dict(num_agents=3, arena_size=250, num_pellets=500, num_viruses=10, mode=6), 500, 8),
+    (dict(num_agents=1, arena_size=200, num_pellets=500, num_viruses=5, num_bots=1, mode=7), 300, 8),
+    (dict(num_agents=1, arena_size=200, num_pellets=500, num_viruses=5, num_bots=1, mode=8), 300, 8),
+    (dict(num_agents=1, arena_size=200, num_pellets=500, num_viruses=5, num_bots=1, mode=9), 300, 8),
+    (dict(num_agents=1, arena_size=200, num_pellets=500, num_viruses=5, num_bots=1, mode=10), 300, 8),
+    (dict(num_agents=14, arena_size=300, num_pellets=300, num_viruses=5, mode=0), 60, 8),   # 14th insert rehashes the player map
+    (dict(num_agents=2, arena_size=150, num_pellets=300, num_viruses=3, num_bots=3, mode=0, reward_type=0), 400, 8),
 ]
 
 

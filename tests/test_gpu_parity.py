@@ -30,6 +30,15 @@ def test_hip_matches_reference_golden(hip_engine_cls, path):
     (dict(arena_size=1200, num_pellets=800, num_viruses=15, mode=3), 300, 8),
     (dict(arena_size=60, num_pellets=200, num_viruses=0, mode=0), 300, 8),   # "trivial" difficulty-like tiny arena
     (dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode=6, reward_type=0), 200, 8),
+    # several players per arena: bots, multi-agent, map-order rehash
+    (dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0), 600, 4),
+    (dict(num_agents=3, arena_size=250, num_pellets=500, num_viruses=10, mode=6), 500, 8),
+    (dict(num_agents=1, arena_size=200, num_pellets=500, num_viruses=5, num_bots=1, mode=7), 300, 8),
+    (dict(num_agents=1, arena_size=200, num_pellets=500, num_viruses=5, num_bots=1, mode=8), 300, 8),
+    (dict(num_agents=1, arena_size=200, num_pellets=500, num_viruses=5, num_bots=1, mode=9), 300, 8),
+    (dict(num_agents=1, arena_size=200, num_pellets=500, num_viruses=5, num_bots=1, mode=10), 300, 8),
+    (dict(num_agents=14, arena_size=300, num_pellets=300, num_viruses=5, mode=0), 60, 8),
+    (dict(num_agents=2, arena_size=150, num_pellets=300, num_viruses=3, num_bots=3, mode=0, reward_type=0), 400, 8),
 ])
 def test_hip_vs_oracle_lockstep(hip_engine_cls, oracle_lib, cfg, steps, sticky):
     A = 16
@@ -159,7 +168,9 @@ def test_error_paths(hip_engine_cls):
     with pytest.raises(AgarclError):
         hip_engine_cls(1, mode=11)                      # Engine.hpp:413-414 "Invalid mode number"
     with pytest.raises(AgarclError):
-        hip_engine_cls(1, num_bots=2, mode=0)           # loud, not a silent fallback
+        hip_engine_cls(1, num_agents=12, num_bots=8, mode=0)   # more than 16 players per arena: loud, not a silent fallback
+    with pytest.raises(AgarclError):
+        hip_engine_cls(1, num_pellets=5000)             # beyond the pellet register file
     e = hip_engine_cls(2, **C2)
     with pytest.raises(Exception):
         e.set_actions(np.zeros((3, 1, 2), np.float32), np.zeros((3, 1), np.int32))
