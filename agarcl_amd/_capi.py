@@ -52,6 +52,8 @@ SYMBOLS = [
     ("agarcl_dones_dev", C.c_void_p, [C.c_void_p]),
     ("agarcl_masses_dev", C.c_void_p, [C.c_void_p]),
     ("agarcl_flags_dev", C.c_void_p, [C.c_void_p]),
+    ("agarcl_packed_dev", C.c_void_p, [C.c_void_p, C.c_int32]),
+    ("agarcl_last_slot", C.c_int, [C.c_void_p]),
     ("agarcl_get_rewards", C.c_int, [C.c_void_p, C.c_void_p]),
     ("agarcl_get_dones", C.c_int, [C.c_void_p, C.c_void_p]),
     ("agarcl_get_masses", C.c_int, [C.c_void_p, C.c_void_p]),
@@ -221,7 +223,11 @@ class BatchedEngine:
 
     def device_ptrs(self):
         return {"rewards": self.L.agarcl_rewards_dev(self.h), "dones": self.L.agarcl_dones_dev(self.h),
-                "masses": self.L.agarcl_masses_dev(self.h), "flags": self.L.agarcl_flags_dev(self.h)}
+                "masses": self.L.agarcl_masses_dev(self.h), "flags": self.L.agarcl_flags_dev(self.h),
+                "packed0": self.L.agarcl_packed_dev(self.h, 0), "packed1": self.L.agarcl_packed_dev(self.h, 1)}
+
+    def last_slot(self):
+        return int(self.L.agarcl_last_slot(self.h))
 
     def state_bytes(self):
         return int(self.L.agarcl_state_bytes(self.h))

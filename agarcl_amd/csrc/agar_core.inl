@@ -199,7 +199,7 @@ template <int NS, bool AV> struct AgCtx {
 #endif
   const AgState *gs;
   const AG_GLOBAL float *act_dxdy; const AG_GLOBAL int32_t *act;
-  int arena, P, PC, cells_off;
+  int arena, P, PC, cells_off, slot;
   unsigned char *lds;
   UBlock S;    // arena words (AR_*): register-resident for the whole launch
   UBlock PB;   // current player's words (PL_*): valid inside tick_player only; LDS PLS is its home
@@ -1360,7 +1360,8 @@ template <int NS, bool AV> AG_DEV void env_step(AgCtx<NS, AV> &c, int ticks, boo
       size_t o = (size_t)c.arena * na + i;
       int done = SR(c, AR_DONE);
       auto rw = (AG_GLOBAL double *)c.gs->rewards; auto ms = (AG_GLOBAL int32_t *)c.gs->masses; auto dn = (AG_GLOBAL uint8_t *)c.gs->dones;
-      AG_SERIAL { rw[o] = r; ms[o] = (int)m; dn[o] = (uint8_t)(i == 0 ? done : 0); }
+      auto pk = (AG_GLOBAL float *)(c.gs->packed + ((size_t)c.slot * c.gs->d.A * na + o) * 2);
+      AG_SERIAL { rw[o] = r; ms[o] = (int)m; dn[o] = (uint8_t)(i == 0 ? done : 0); pk[0] = (float)r; pk[1] = (i == 0 && done) ? 1.0f : 0.0f; }
     }
   }
 }

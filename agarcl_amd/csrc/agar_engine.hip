@@ -56,6 +56,7 @@ struct agarcl_env {
   int device;
   ag_stream_t stream; bool own_stream;
   size_t lds_bytes; int ns; bool all_vis;
+  int slot;  // ping-pong index of the packed result buffer written by the NEXT step
   std::vector<void *> allocs;
   float *d_act_dxdy; int32_t *d_act;  // env-owned action buffers (host-copy path)
   float *lut_r, *lut_ms, *lut_ss, *lut_anti;
@@ -64,7 +65,8 @@ struct agarcl_env {
 
 // ---- kernels ----------------------------------------------------------------------------------------
 // NS = pellet register slots per lane (64 pellets per slot): 4 / 8 / 16 / 32 <=> up to 256 / 512 / 1024 / 2048 pellets
-template <int NS, bool AV> AG_DEV void ag_ctx_init(AgCtx<NS, AV> &c, const AgState *gs, int arena, unsigned char *lds, const float *act_dxdy, const int32_t *act) {
+template <int NS, bool AV> AG_DEV void ag_ctx_init(AgCtx<NS, AV> &c, const AgState *gs, int arena, unsigned char *lds, const float *act_dxdy, const int32_t *act, int slot = 0) {
+  c.slot = slot;
   c.gs = gs; c.arena = arena; c.lds = lds; c.act_dxdy = (const AG_GLOBAL float *)act_dxdy; c.act = (const AG_GLOBAL int32_t *)act;
   c.P = gs->d.P; c.PC = gs->d.PC;
   ag_lds_layout(c.P, &c.cells_off);
@@ -77,7 +79,7 @@ template <int NS, bool AV, class F> static void for_each_arena_ns(agarcl_env *e,
   std::vector<unsigned char> lds(e->lds_bytes + 64);
   for (int a = 0; a < e->d.A; a++) {
     AgCtx<NS, AV> *c = new AgCtx<NS, AV>();
-    ag_ctx_init(*c, &e->s, a, lds.data(), e->act_dxdy, e->act);
+    ag_ctx_init(*c, &e->s, a, lds.data(), e->act_dxdy, e->act, e->slot);
     f(*c);
     delete c;
   }
@@ -86,8 +88,9 @@ template <int NS, bool AV, class F> static void for_each_arena_ns(agarcl_env *e,
 extern __shared__ __align__(16) unsigned char ag_lds[];
 #define AG_KERNEL_PROLOGUE AgCtx<NS, AV> c; ag_ctx_init(c, gs, (int)blockIdx.x, ag_lds, act_dxdy, act);
 
-template <int NS, bool AV> __global__ void __launch_bounds__(64) k_step(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env) {
+template <int NS, bool AV> __global__ void __launch_bounds__(64) k_step(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot) {
   AG_KERNEL_PROLOGUE
+  c.slot = slot;
 #ifdef AGAR_PROFILE
   for (int i = 0; i < AG_NPROF; i++) c.tacc[i] = 0;
   c.tlast = (unsigned)__builtin_readcyclecounter();
@@ -130,7 +133,7 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
   AG_DISPATCH_NS(e->ns, CALL);
 #undef CALL
 #else
-#define CALL(N, V) hipLaunchKernelGGL((k_step<N, V>), dim3(e->d.A), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env)
+#define CALL(N, V) hipLaunchKernelGGL((k_step<N, V>), dim3(e->d.A), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot)
   AG_DISPATCH_NS(e->ns, CALL);
 #undef CALL
   HIPCHK(hipGetLastError());
@@ -236,7 +239,7 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
 #endif
   agarcl_env *e = new agarcl_env();
   e->cfg = *cfg; e->device = device; e->own_stream = true; e->d_act_dxdy = nullptr; e->d_act = nullptr;
-  e->d_state = nullptr; e->act_dxdy = nullptr; e->act = nullptr; e->obs_buf = nullptr; e->obs_cap = 0;
+  e->slot = 0; e->d_state = nullptr; e->act_dxdy = nullptr; e->act = nullptr; e->obs_buf = nullptr; e->obs_cap = 0;
 #ifdef AGAR_CPU_EMU
   e->stream = nullptr;
 #else
@@ -283,6 +286,7 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   s.scratch = d.P > 1 ? alloc<int32_t>(e, A * (size_t)AGM_WORDS) : nullptr;
   if (d.P > 1 && !s.scratch) { agarcl_destroy(e); return fail(AGARCL_E_NOMEM, "device allocation failed"); }
   s.rewards = alloc<double>(e, A * d.n_agents); s.dones = alloc<uint8_t>(e, A * d.n_agents); s.masses = alloc<int32_t>(e, A * d.n_agents);
+  s.packed = alloc<float>(e, 2 * A * d.n_agents * 2);
   s.counts = alloc<int32_t>(e, A * 4); s.ev_p = alloc<int32_t>(e, A * AG_EV_CAP); s.ev_v = alloc<int32_t>(e, A * AG_EVV_CAP);
   e->d_act_dxdy = alloc<float>(e, A * d.n_agents * 2); e->d_act = alloc<int32_t>(e, A * d.n_agents);
   e->lut_r = alloc<float>(e, AG_LUT_SIZE); e->lut_ms = alloc<float>(e, AG_LUT_SIZE); e->lut_ss = alloc<float>(e, AG_LUT_SIZE); e->lut_anti = alloc<float>(e, AG_ANTI_LUT);
@@ -393,8 +397,12 @@ extern "C" int agarcl_step(agarcl_env *e, int32_t ticks) {
 #ifndef AGAR_CPU_EMU
   HIPCHK(hipSetDevice(e->device));
 #endif
-  return launch_step(e, ticks > 0 ? ticks : e->cfg.ticks_per_step, 1);
+  int rc = launch_step(e, ticks > 0 ? ticks : e->cfg.ticks_per_step, 1);
+  e->slot ^= 1;
+  return rc;
 }
+extern "C" const float *agarcl_packed_dev(agarcl_env *e, int32_t slot) { return e ? e->s.packed + (size_t)(slot & 1) * e->d.A * e->d.n_agents * 2 : nullptr; }
+extern "C" int agarcl_last_slot(agarcl_env *e) { return e ? (e->slot ^ 1) : 0; }
 extern "C" int agarcl_tick(agarcl_env *e, int32_t ticks) {
   if (!e) return fail(AGARCL_E_INVALID, "null env");
 #ifndef AGAR_CPU_EMU

@@ -93,6 +93,7 @@ struct AgState {
   double *rewards;        // [A][n_agents]
   uint8_t *dones;         // [A][n_agents]
   int32_t *masses;        // [A][n_agents]
+  float *packed;          // [2][A][n_agents][2] (reward, done) as f32, ping-pong by step parity: what gets gathered across GPUs
   int32_t *counts;        // [A][4]
   int32_t *ev_p;          // [A][AG_EV_CAP]
   int32_t *ev_v;          // [A][AG_EVV_CAP]

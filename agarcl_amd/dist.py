@@ -54,6 +54,17 @@ class ResultGatherer:
                                         async_op=True)
         return s
 
+    def gather_packed(self, slot, packed):
+        """Zero-copy variant: `packed` is the engine's own ping-pong buffer of step parity `slot` ([A_local, 2] f32,
+        agarcl_packed_dev).  wait_slot(slot) must be called before the engine overwrites that parity again."""
+        self.work[slot] = self.dist.gather(packed, self.recv[slot] if self.rank == 0 else None, dst=0, group=self.group,
+                                           async_op=True)
+
+    def wait_slot(self, slot):
+        if self.work[slot] is not None:
+            self.work[slot].wait()
+            self.work[slot] = None
+
     def wait_all(self):
         for i, w in enumerate(self.work):
             if w is not None:

@@ -38,6 +38,8 @@ class VecEnvironment:
         self.rewards = torch.as_tensor(_DevArray(p["rewards"], (A, n), "<f8"), device=self.device)
         self.dones_u8 = torch.as_tensor(_DevArray(p["dones"], (A, n), "|u1"), device=self.device)
         self.masses = torch.as_tensor(_DevArray(p["masses"], (A, n), "<i4"), device=self.device)
+        # (reward, done) f32 pairs, double-buffered by step parity: packed[engine.last_slot()] belongs to the last step
+        self.packed = [torch.as_tensor(_DevArray(p["packed%d" % k], (A * n, 2), "<f4"), device=self.device) for k in (0, 1)]
         self._act_keep = None
 
     def seed(self, seeds=None, base_seed=0):

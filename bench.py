@@ -111,17 +111,24 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU.  (AGAR_BENCH_BACKEND=gloo + fewer GPUs than ranks is only for exercising the
+    # multi-rank code path on a single-GPU box; the driver's runs use nccl == RCCL over xGMI.)
+    backend = os.environ.get("AGAR_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     A = args.arenas
     K, Wm = args.steps, args.warmup
     lo, hi = rank * A, (rank + 1) * A  # weak scaling: every GPU owns `A` arenas
-    env = VecEnvironment(A, device=local_rank, **CFG)
+    env = VecEnvironment(A, device=dev_index, **CFG)
     env.seed(agdist.arena_seeds(10000, lo, hi))
     env.reset(reset_ids=True)
 
@@ -134,9 +141,11 @@ def main():
 
     def one_step(k):
         eng.set_actions_device(dxdy[k].data_ptr(), act[k].data_ptr())
-        eng.step(CFG["ticks_per_step"])
         if gather is not None:
-            gather.pack(k, env.rewards, env.dones_u8)
+            gather.wait_slot(k & 1)             # the engine is about to overwrite this parity's packed results
+        eng.step(CFG["ticks_per_step"])
+        if gather is not None:                  # RCCL gather of (reward, done) straight from engine memory; overlaps step k+1
+            gather.gather_packed(k & 1, env.packed[eng.last_slot()])
 
     for k in range(Wm):
         one_step(k)

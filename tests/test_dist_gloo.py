@@ -44,6 +44,21 @@ def _worker(rank, world, port, q):
             exp_r = torch.arange(0, world * n_local, dtype=torch.float32) + 100.0 * k
             exp_d = ((torch.arange(0, world * n_local) + k) % 3 == 0).to(torch.float32)
             ok = ok and torch.equal(got[:, 0], exp_r) and torch.equal(got[:, 1], exp_d)
+    # zero-copy variant used by bench.py: gather straight from the (engine's) ping-pong buffers
+    packed = [torch.zeros((n_local, 2), dtype=torch.float32) for _ in range(2)]
+    for k in range(6):
+        g.wait_slot(k & 1)
+        lo = rank * n_local
+        packed[k & 1][:, 0] = torch.arange(lo, lo + n_local, dtype=torch.float32) * 2 + k
+        packed[k & 1][:, 1] = float(k % 2)
+        g.gather_packed(k & 1, packed[k & 1])
+        if k >= 1:
+            g.wait_slot((k - 1) & 1)
+            if rank == 0:
+                got = g.gathered((k - 1) & 1)
+                ok = ok and torch.equal(got[:, 0], torch.arange(0, world * n_local, dtype=torch.float32) * 2 + (k - 1))
+                ok = ok and bool((got[:, 1] == float((k - 1) % 2)).all())
+    g.wait_all()
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
