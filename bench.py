@@ -183,6 +183,13 @@ def main():
         b_tick = 8 * counts[0] + 12 * counts[1] + 72 * counts[3] + 40 * counts[2] + 112 * 1 + 24 * 1
         bytes_per_launch = b_tick * A * ticks
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from the PMC counters (collected separately: profiles/r01_pmc_traffic.json)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if A == 4096 and ticks == 4:
+                traffic = tj["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "env-steps/sec (arenas x ticks/s)", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -192,7 +199,8 @@ def main():
                        "arenas_total": world * A, "ticks_per_step": ticks,
                        "parallelism": "arena-sharded x%d, per-step reward/done gather to rank 0" % world if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
                          "kernel": "k_step", "kernel_ms": kernel_ms, "algorithmic_bytes_per_arena_tick": b_tick},
             "capacity_flags_raised": int((flags != 0).sum()),
         }
