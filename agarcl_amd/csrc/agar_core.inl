@@ -204,7 +204,7 @@ template <int NS, bool AV> struct AgCtx {
   UBlock S;    // arena words (AR_*): register-resident for the whole launch
   UBlock PB;   // current player's words (PL_*): valid inside tick_player only; LDS PLS is its home
   int ncreated;
-  bool pel_dirty;
+  bool pel_dirty, pel_loaded;
 };
 
 template <int NS, bool AV> AG_DEV int *L_I(const AgCtx<NS, AV> &c, int off) { return (int *)(c.lds + off); }
@@ -272,6 +272,16 @@ template <int NS, bool AV, class F> AG_DEV int pel_count(const AgCtx<NS, AV> &c,
   return n;
 #endif
 }
+// minimum over all pellets of a non-negative float (as its bit pattern, which orders like the value)
+template <int NS, bool AV, class F> AG_DEV unsigned pel_min_bits(const AgCtx<NS, AV> &c, F f) {
+  unsigned b = 0x7f800000u;
+  AG_PEL_FOR(s, lane, i) { unsigned v = (unsigned)f2u(f(PELX(c, s, lane), PELY(c, s, lane), i)); b = v < b ? v : b; }
+#ifdef AGAR_CPU_EMU
+  return b;
+#else
+  return wred_min(b);
+#endif
+}
 // ordered compaction in ascending pellet index: sink(x, y, i, rank)
 template <int NS, bool AV, class F, class S> AG_DEV int pel_compact(const AgCtx<NS, AV> &c, F pred, S sink) {
   int count = 0;
@@ -317,11 +327,11 @@ template <int NS, bool AV> AG_DEV void pel_get(const AgCtx<NS, AV> &c, int i, fl
 
 // ---- load / store arena state between HBM and LDS / registers -------------------------------------
 template <int NS, bool AV> AG_DEV void arena_load(AgCtx<NS, AV> &c) {
-  // Every load below is independent of every other (no count is needed to form an address), so the whole arena
-  // arrives in ONE round trip to HBM: pellets (NS x 512 B per wave-instruction), arena words, player words, and all
-  // AG_CC cell slots of every player incl. the persisted radius / speed cache (slots >= n_cells are never read).
-  auto gxy = g_pxy(c);
-  AG_PEL_FOR(s, lane, i) { PELX(c, s, lane) = gxy[2 * i]; PELY(c, s, lane) = gxy[2 * i + 1]; }
+  // Every load below is independent of every other (no count is needed to form an address), so the arena arrives in
+  // ONE round trip to HBM: arena words, player words, and all AG_CC cell slots of every player incl. the persisted
+  // radius / speed cache (slots >= n_cells are never read).
+  // (pellets are NOT loaded here: ensure_pellets() fetches them on first use, and a launch whose cell provably stays
+  // out of reach of every pellet -- AR_SAFE budget -- never touches them)
   ub_load(c.S, g_ar(c), AR_WORDS);
   auto gpl = g_pl(c);
   AG_LANES(i, c.P * PL_WORDS) PLS(c, 0)[i] = gpl[i];
@@ -334,8 +344,16 @@ template <int NS, bool AV> AG_DEV void arena_load(AgCtx<NS, AV> &c) {
       for (int f = 0; f < CF_ALL; f++) l[f * AG_CC + i] = g[f * AG_CC + i];
     }
   }
-  c.pel_dirty = false; c.ncreated = 0;
+  c.pel_dirty = false; c.pel_loaded = false; c.ncreated = 0;
   ag_lds_order();
+}
+// Pellet capacity is exactly NS*64 and HBM keeps the sentinel at every index >= n_pellets, so the load is NS
+// unconditional 8-byte-per-lane loads (512 B per wave-instruction), all in flight together.
+template <int NS, bool AV> AG_DEV void ensure_pellets(AgCtx<NS, AV> &c) {
+  if (c.pel_loaded) return;
+  auto gxy = g_pxy(c);
+  AG_PEL_FOR(s, lane, i) { PELX(c, s, lane) = gxy[2 * i]; PELY(c, s, lane) = gxy[2 * i + 1]; }
+  c.pel_loaded = true;
 }
 template <int NS, bool AV> AG_DEV void arena_store(AgCtx<NS, AV> &c) {
   ag_lds_order();
@@ -516,6 +534,7 @@ template <int NS, bool AV> AG_DEV void respawn(AgCtx<NS, AV> &c, int p) {
   float r25 = radius_of(c, AG_CELL_MIN_SIZE), W = c.gs->g.W;
   Cells cs = cells_of(c, p);
   if (SR(c, AR_NPEL) > 0 && c.gs->g.squared) {
+    ensure_pellets(c);
     float x, y; pel_get(c, 0, x, y);
     float t = 2.0f * r25; x += t; y += t;
     x = sminf(x, W - r25); y = sminf(y, W - r25);
@@ -1220,12 +1239,18 @@ template <int NS, bool AV> AG_DEV void sort_cells_by_id(AgCtx<NS, AV> &c, int p)
 }
 
 // ---- quiet run: the dominant case in RL rollouts ------------------------------------------------------------------
-// One player, one cell, no ejected food anywhere, no reachable virus, no decay / regen due and no pellet inside the
-// (moved) cell: then Engine::tick reduces to the cell's kinematics plus counters.  Everything is wave-uniform, so a
-// run of consecutive quiet ticks executes on registers only: state is read once, each tick is move_one + one pass
-// over the pellet registers + a few integer updates, and the result is committed once.  The run stops BEFORE the
-// first tick that needs anything else (nothing of that tick has been written) and the general path takes over.
-// Returns the number of ticks performed (0 .. max_ticks).
+// One player, one cell, no ejected food anywhere, no reachable virus, nothing to regenerate: then Engine::tick
+// reduces to the cell's kinematics, counters, the periodic decay and -- now and then -- eating ONE pellet.
+// Everything is wave-uniform, so a run of consecutive quiet ticks executes on registers only: state is read once,
+// each tick is move_one + integer updates, and the result is committed once.
+//   * Out-of-reach budget (AR_SAFE): after a pellet scan the cell knows slack = (distance to its nearest pellet) -
+//     radius.  Pellets are static, so while the path length walked since (bounded by |dx| + |dy| per tick) stays
+//     below the slack no pellet can be inside the radius: no scan, and if the whole launch stays inside the budget
+//     the pellets are never even loaded from HBM.  (Only with AV: otherwise buckets change visibility as the cell moves.)
+//   * A plain eat (exactly one pellet inside the radius, still exactly one inside the grown radius, not a regen
+//     tick) is performed inline: mass + 1, swap-pop removal, event record -- identical to the general path's result.
+// The run stops BEFORE the first tick that needs anything else (nothing of that tick has been written) and the
+// general path takes over.  Returns the number of ticks performed (0 .. max_ticks).
 template <int NS, bool AV> AG_DEV int quiet_run(AgCtx<NS, AV> &c, int max_ticks) {
   if (c.P != 1 || SR(c, AR_NFOOD) != 0) return 0;
   int *P = PLS(c, 0);
@@ -1233,51 +1258,104 @@ template <int NS, bool AV> AG_DEV int quiet_run(AgCtx<NS, AV> &c, int max_ticks)
   if (PR(c, PL_NCELLS) != 1) return 0;
   Cells s = cells_of(c, 0);
   unsigned m = ag_uniu(s.m[0]);
-  int action = PR(c, PL_ACTION);
-  if (m >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && action != 0) return 0;  // eject needs >= 35, split >= 50
-  if (m >= 111u && SR(c, AR_NVIR) != 0) return 0;                      // virus contact needs >= 111
-  if (ag_uniu(s.cmc[0]) != m) return 0;                                // radius / speed cache must be valid
+  if (ag_uniu(s.cmc[0]) != m) return 0;  // radius / speed cache must be valid
+  int action = PR(c, PL_ACTION), nv = SR(c, AR_NVIR), np = SR(c, AR_NPEL);
   float x = ag_unif(s.x[0]), y = ag_unif(s.y[0]), svx = ag_unif(s.sx[0]), svy = ag_unif(s.sy[0]);
   float vx = ag_unif(s.vx[0]), vy = ag_unif(s.vy[0]);
   float r = ag_unif(s.crad[0]), hi = ag_unif(s.cms[0]), rr = r * r;
   float tx = PRF(c, PL_TX), ty = PRF(c, PL_TY), dt = c.gs->g.dt, W = c.gs->g.W;
   int ticks = SR(c, AR_TICKS), elapsed = PR(c, PL_ELAPSED), fcd = PR(c, PL_FEED_CD), scd = PR(c, PL_SPLIT_CD);
-  bool regen = c.gs->g.regen != 0, decay = c.gs->g.mass_decay != 0, have_pellets = SR(c, AR_NPEL) != 0;
-  int done = 0;
+  int last_decay = PR(c, PL_LAST_DECAY), nvt = PR(c, PL_NVTICKS), food_eaten = PR(c, PL_FOOD_EATEN), hm = PR(c, PL_HIGHEST_MASS);
+  double rate = (double)PRF(c, PL_ANTI_TEAM);
+  bool regen = c.gs->g.regen != 0, decay = c.gs->g.mass_decay != 0;
+  int tgt_p = c.gs->g.target_pellets, tgt_v = c.gs->g.target_viruses;
+  float slack = AV ? u2f(SR(c, AR_SAFE)) : 0.0f;
+  unsigned m_move = m; int last_ev = -1, done = 0;
+  auto lut_r = g_lut_r(c); auto lut_ms = g_lut_ms(c);
   while (done < max_ticks) {
-    if (regen && ticks % 120 == 0) break;
-    if (decay && (elapsed + 1) % 60 == 0) break;
+    if (m >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && action != 0) break;  // eject needs >= 35, split >= 50
+    if (m >= 111u && nv != 0) break;                                  // virus contact needs >= 111
+    bool regen_tick = regen && ticks % 120 == 0;
+    if (regen_tick && (tgt_p - np > 0 || tgt_v - nv > 0)) break;      // something to spawn: needs the RNG
+    bool decay_tick = decay && (elapsed + 1) % 60 == 0;
+    if (decay_tick && nvt != 0) break;                                // anti-team bookkeeping
     float nx = x, ny = y, nvx, nvy, nsx = svx, nsy = svy;
     move_one(nx, ny, nvx, nvy, nsx, nsy, hi, r, tx, ty, dt, W);
-    if (have_pellets) {
-      int gx = f2i(nx) / AG_PELLET_GRID, gy = f2i(ny) / AG_PELLET_GRID;
-      bool hit = pel_any(c, [&](float qx, float qy, int) {
-        bool ok = rr >= sqr_dist(nx, ny, qx, qy);
-        if constexpr (!AV) { int ddx = f2i(qx) / AG_PELLET_GRID - gx, ddy = f2i(qy) / AG_PELLET_GRID - gy; ok = ok && ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1; }
-        return ok;
-      });
-      if (hit) break;
+    unsigned nm = m; int ev = -1; float nslack = 0.0f;
+    if (np != 0) {
+      float adv = fabsf(nx - x) + fabsf(ny - y) + 2.5e-4f;  // >= Euclidean step (+ rounding head-room)
+      if (AV && slack > adv) nslack = slack - adv;          // provably out of reach of every pellet
+      else {
+        ensure_pellets(c);
+        int gx = f2i(nx) / AG_PELLET_GRID, gy = f2i(ny) / AG_PELLET_GRID;
+        auto vis = [&](float qx, float qy) -> bool {
+          if constexpr (AV) return true;
+          else { int ddx = f2i(qx) / AG_PELLET_GRID - gx, ddy = f2i(qy) / AG_PELLET_GRID - gy; return ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1; }
+        };
+        float dmin2 = u2f((int)pel_min_bits(c, [&](float qx, float qy, int) { return vis(qx, qy) ? sqr_dist(nx, ny, qx, qy) : 3.0e38f; }));
+        if (rr >= dmin2) {  // somebody is inside the radius
+          if (regen_tick) break;
+          pel_launder(c);
+          if (pel_count(c, [&](float qx, float qy, int) { return vis(qx, qy) && rr >= sqr_dist(nx, ny, qx, qy); }) != 1) break;
+          nm = clamp_mass(m + AG_PELLET_MASS);
+          if (nm >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && action != 0) break;  // eject / split run after the eat, on the grown mass
+          float r1 = lut(lut_r, nm); float rr1 = r1 * r1;
+          pel_launder(c);
+          if (pel_count(c, [&](float qx, float qy, int) { return vis(qx, qy) && rr1 >= sqr_dist(nx, ny, qx, qy); }) != 1) break;  // growth would reach a second one
+          int *T = L_I(c, L_TMP);
+          pel_launder(c);
+          pel_compact(c, [&](float qx, float qy, int) { return vis(qx, qy) && rr >= sqr_dist(nx, ny, qx, qy); }, [&](float, float, int i, int) { T[0] = i; });
+          ag_lds_order();
+          ev = ag_uni(T[0]);
+        } else {
+          float sl = ag_sqrtf(dmin2) - r; sl = sl - 0.01f;
+          nslack = sl > 0.0f ? sl : 0.0f;
+        }
+      }
     }
-    x = nx; y = ny; vx = nvx; vy = nvy; svx = nsx; svy = nsy;
-    elapsed += 1; ticks += 1; done += 1;
+    // ---- the tick is quiet: commit it to the register state ----
+    m_move = m;
+    x = nx; y = ny; vx = nvx; vy = nvy; svx = nsx; svy = nsy; slack = nslack;
+    elapsed += 1; done += 1; last_ev = ev;
+    if (ev >= 0) {  // Engine.hpp:991-994 (eat), :1002-1009 (swap-pop)
+      m = nm; food_eaten += 1;
+      r = lut(lut_r, m); hi = lut(lut_ms, m); rr = r * r;
+      if (np > 1 && ev < np - 1) { pel_move(c, ev, np - 1); auto gid = g_pid(c); AG_SERIAL { gid[ev] = gid[np - 1]; } }
+      int lastp = np - 1;
+      AG_PEL_FOR(sl_, lane, i) { if (i == lastp) { PELX(c, sl_, lane) = AG_PEL_SENTINEL; PELY(c, sl_, lane) = AG_PEL_SENTINEL; } }
+      np -= 1; c.pel_dirty = true; slack = 0.0f;
+    }
+    if ((unsigned)hm < m) hm = (int)m;
     if (fcd > 0) fcd -= 1; if (action == 1 && fcd == 0) fcd = 10;   // Engine.hpp:1046-1054 (nothing can be ejected: mass < 35)
     if (scd > 0) scd -= 1; if (action == 2 && scd == 0) scd = 30;   // Engine.hpp:1056-1064 (nothing can split: mass < 50)
+    if (decay_tick && elapsed - last_decay >= 60) {                 // Engine.hpp:575-584, Entities.hpp:199-203
+      double dm = (double)m * (1 - 0.002 * rate); unsigned um = (unsigned)dm;
+      um = um > AG_CELL_MIN_SIZE ? um : AG_CELL_MIN_SIZE;
+      last_decay = elapsed;
+      if (um != m) { m = um; r = lut(lut_r, m); hi = lut(lut_ms, m); rr = r * r; }  // a smaller radius keeps the budget valid
+    }
+    ticks += 1;
   }
   if (done == 0) return 0;
-  int hm = PR(c, PL_HIGHEST_MASS); if ((unsigned)hm < m) hm = (int)m;
+  int *evp = L_I(c, L_EVP);
   AG_SERIAL {
     s.x[0] = x; s.y[0] = y; s.vx[0] = vx; s.vy[0] = vy; s.sx[0] = svx; s.sy[0] = svy;
-    P[PL_ELAPSED] = elapsed; P[PL_MIN_MASS] = (int)m; P[PL_HIGHEST_MASS] = hm; P[PL_FEED_CD] = fcd; P[PL_SPLIT_CD] = scd;
+    s.m[0] = m; s.cmc[0] = m; s.crad[0] = r; s.cms[0] = hi;
+    P[PL_ELAPSED] = elapsed; P[PL_MIN_MASS] = (int)m_move; P[PL_HIGHEST_MASS] = hm; P[PL_FEED_CD] = fcd; P[PL_SPLIT_CD] = scd;
+    P[PL_FOOD_EATEN] = food_eaten; P[PL_LAST_DECAY] = last_decay;
+    if (last_ev >= 0) evp[0] = last_ev;
   }
-  SW(c, AR_NEVP, 0); SW(c, AR_NEVV, 0);
-  SW(c, AR_TICKS, ticks); SW(c, AR_CLOCK, SR(c, AR_CLOCK) + done);
+  SW(c, AR_NEVP, last_ev >= 0 ? 1 : 0); SW(c, AR_NEVV, 0); SW(c, AR_NPEL, np);
+  SW(c, AR_TICKS, ticks); SW(c, AR_CLOCK, SR(c, AR_CLOCK) + done); SW(c, AR_SAFE, f2u(slack));
   ag_lds_order();
+  if (c.pel_dirty) ag_mem_fence();
   return done;
 }
 
 // ---- Engine::tick.  R: Engine.hpp:208-240 --------------------------------------------------------------------
 template <int NS, bool AV> AG_DEV void arena_tick(AgCtx<NS, AV> &c) {
-
+  ensure_pellets(c);
+  SW(c, AR_SAFE, 0);  // the out-of-reach budget is only maintained by quiet_run
   SW(c, AR_NEVP, 0); SW(c, AR_NEVV, 0);
   AG_T(c, 1);
   for (int k = 0; k < c.P; k++) tick_player(c, SR(c, AR_ORDER0 + k));
@@ -1371,6 +1449,7 @@ template <int NS, bool AV> AG_DEV void env_reset(AgCtx<NS, AV> &c, int reset_ids
   SW(c, AR_NPEL, 0); SW(c, AR_NVIR, 0); SW(c, AR_NFOOD, 0); SW(c, AR_TICKS, 0); SW(c, AR_FLAGS, 0);
   SW(c, AR_NEVP, 0); SW(c, AR_NEVV, 0); SW(c, AR_DONE, 0); SW(c, AR_RESPAWNED, 0);
   AG_PEL_FOR(s, lane, i) { PELX(c, s, lane) = AG_PEL_SENTINEL; PELY(c, s, lane) = AG_PEL_SENTINEL; }
+  c.pel_loaded = true; SW(c, AR_SAFE, 0);
   if (c.gs->g.squared) create_squared_pellets(c); else add_pellets(c, c.gs->g.target_pellets);
   add_viruses(c, c.gs->g.target_viruses);
   int na = c.gs->d.n_agents, mode = c.gs->g.mode, nb = c.P - na;

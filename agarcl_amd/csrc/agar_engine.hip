@@ -70,7 +70,7 @@ template <int NS, bool AV> AG_DEV void ag_ctx_init(AgCtx<NS, AV> &c, const AgSta
   c.gs = gs; c.arena = arena; c.lds = lds; c.act_dxdy = (const AG_GLOBAL float *)act_dxdy; c.act = (const AG_GLOBAL int32_t *)act;
   c.P = gs->d.P; c.PC = gs->d.PC;
   ag_lds_layout(c.P, &c.cells_off);
-  c.ncreated = 0; c.pel_dirty = false;
+  c.ncreated = 0; c.pel_dirty = false; c.pel_loaded = false;
 }
 #define AG_DISPATCH_NS(ns, CALL) do { if (e->all_vis) { switch (ns) { case 4: CALL(4, true); break; case 8: CALL(8, true); break; case 16: CALL(16, true); break; default: CALL(32, true); break; } } \
   else { switch (ns) { case 4: CALL(4, false); break; case 8: CALL(8, false); break; case 16: CALL(16, false); break; default: CALL(32, false); break; } } } while (0)
@@ -546,7 +546,7 @@ extern "C" int agarcl_load_arena(agarcl_env *e, int32_t arena, const uint32_t *b
   auto U2F = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
   const uint32_t *p = b + 8;
   h.ar[AR_TICKS] = (int32_t)b[1]; h.ar[AR_IDC] = (int32_t)b[2]; h.ar[AR_NEXT_PID] = (int32_t)b[3];
-  h.ar[AR_NPEL] = (int32_t)np; h.ar[AR_NVIR] = (int32_t)nv; h.ar[AR_NFOOD] = (int32_t)nf;
+  h.ar[AR_NPEL] = (int32_t)np; h.ar[AR_NVIR] = (int32_t)nv; h.ar[AR_NFOOD] = (int32_t)nf; h.ar[AR_SAFE] = 0;
   for (uint32_t i = 0; i < np; i++) { h.pxy.push_back(U2F(p[i])); h.pxy.push_back(U2F(p[np + i])); h.pid.push_back((int32_t)p[2 * np + i]); }
   h.pxy.resize((size_t)d.PC * 2, AG_PEL_SENTINEL);  // HBM invariant: sentinel at every index >= n_pellets
   p += 3 * np;

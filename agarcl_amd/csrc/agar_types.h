@@ -32,6 +32,7 @@ enum {
   AR_TICKS = 0, AR_CLOCK, AR_IDC, AR_NEXT_PID, AR_NPEL, AR_NVIR, AR_NFOOD, AR_FLAGS, AR_MTIDX,
   AR_NEVP, AR_NEVV, AR_DONE, AR_RESPAWNED, AR_ORDER0 /* AG_MAX_PLAYERS slots: player slots in the engine's iteration order */,
   AR_HM_BUCKETS = AR_ORDER0 + 16, AR_HM_RESIZE,  // rehash-policy state of the players map (survives reset, GameState.hpp:61-67)
+  AR_SAFE,  // f32 bits: proven lower bound on (distance from the single cell to its nearest pellet) - radius; 0 = unknown
   AR_WORDS = 32
 };
 #define AG_MAX_PLAYERS 16
