@@ -6,8 +6,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "agar_engine.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "agar_core.inl"), os.path.join(HERE, "csrc", "agar_libm.inl"), os.path.join(HERE, "csrc", "agar_types.h"),
-        os.path.join(HERE, "..", "include", "agarcl_batch.h")]
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("agar_core.inl", "agar_quiet.inl", "agar_multi.inl", "agar_obs.inl", "agar_libm.inl", "agar_types.h")] + \
+       [os.path.join(HERE, "..", "include", "agarcl_batch.h")]
 OUT = os.path.join(HERE, "libagarcl_hip.so")
 
 FLAGS = [
@@ -31,10 +31,11 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, extra=(), out=OUT):
+    """extra/out: diagnostic variants only (e.g. -DAGAR_PROFILE -> libagarcl_hip_prof.so, used by scripts/)."""
+    if not force and not needs_build() and out == OUT:
         return OUT
-    cmd = [hipcc()] + FLAGS + ["-o", OUT, SRC]
+    cmd = [hipcc()] + FLAGS + list(extra) + ["-o", out, SRC]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)
@@ -42,4 +43,7 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    if "--profile" in sys.argv:
+        print(build(True, "-v" in sys.argv, ["-DAGAR_PROFILE"], os.path.join(HERE, "libagarcl_hip_prof.so")))
+    else:
+        print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

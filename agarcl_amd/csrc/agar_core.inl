@@ -25,6 +25,7 @@
 
 #ifdef AGAR_CPU_EMU
 #define AG_DEV static inline
+#define AG_MEM inline
 #define AG_LANES(i, n) for (int i = 0; i < (n); ++i)
 #define AG_SERIAL if (true)
 AG_DEV int ag_uni(int v) { return v; }
@@ -36,6 +37,7 @@ AG_DEV float ag_sqrtf(float x) { return sqrtf(x); }
 AG_DEV float ag_divf(float a, float b) { return a / b; }
 #else
 #define AG_DEV __device__ __forceinline__
+#define AG_MEM __device__ __forceinline__
 #define AG_LANES(i, n) for (int i = (int)threadIdx.x; i < (n); i += 64)
 #define AG_SERIAL if (threadIdx.x == 0)
 AG_DEV int ag_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -722,6 +724,7 @@ template <int NS, bool AV> AG_DEV void move_player(AgCtx<NS, AV> &c, const Cells
   ag_lds_order();
   unsigned mn = n == 1 ? ag_uniu(s.m[0]) : wave_min(n, [&](int i) { return s.m[i]; });
   PW(c, PL_MIN_MASS, (int)mn);
+  AG_T(c, 12);
 #ifndef AG_ABL_SELFCOL
   if (n >= 2) self_collisions(c, s, n, tx, ty);
 #endif
@@ -1246,110 +1249,166 @@ template <int NS, bool AV> AG_DEV void sort_cells_by_id(AgCtx<NS, AV> &c, int p)
 //   * Out-of-reach budget (AR_SAFE): after a pellet scan the cell knows slack = (distance to its nearest pellet) -
 //     radius.  Pellets are static, so while the path length walked since (bounded by |dx| + |dy| per tick) stays
 //     below the slack no pellet can be inside the radius: no scan, and if the whole launch stays inside the budget
-//     the pellets are never even loaded from HBM.  (Only with AV: otherwise buckets change visibility as the cell moves.)
+//     the pellets are never even read from HBM.  (Only with AV: otherwise buckets change visibility as the cell moves.)
 //   * A plain eat (exactly one pellet inside the radius, still exactly one inside the grown radius, not a regen
 //     tick) is performed inline: mass + 1, swap-pop removal, event record -- identical to the general path's result.
 // The run stops BEFORE the first tick that needs anything else (nothing of that tick has been written) and the
-// general path takes over.  Returns the number of ticks performed (0 .. max_ticks).
+// general path takes over.
+// quiet_ticks() is shared by two callers that differ only in where the pellets live (the `Pel` accessor):
+// k_step's quiet_run (pellets in the wave's registers) and the lean kernel k_quiet (pellets streamed from HBM/L2).
+struct QState {  // all wave-uniform
+  unsigned m, m_move;  // mass; mass at the last tick's move (Player::min_mass bookkeeping)
+  int action, nv, np, ticks, elapsed, fcd, scd, last_decay, nvt, food_eaten, hm, last_ev, done;
+  float x, y, svx, svy, vx, vy, r, hi, tx, ty, slack;
+  double rate;
+  bool pel_changed;
+};
+template <bool AV, class PelT, class LutT> AG_DEV void quiet_ticks(QState &q, const AgParams &g, LutT lut_r, LutT lut_ms, PelT &pel, int max_ticks) {
+  const float dt = g.dt, W = g.W;
+  const bool regen = g.regen != 0, decay = g.mass_decay != 0;
+  const int tgt_p = g.target_pellets, tgt_v = g.target_viruses;
+  float rr = q.r * q.r;
+  if (!AV) q.slack = 0.0f;
+  q.done = 0; q.last_ev = -1; q.m_move = q.m; q.pel_changed = false;
+  while (q.done < max_ticks) {
+    if (q.m >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0) break;  // eject needs >= 35, split >= 50
+    if (q.m >= 111u && q.nv != 0) break;                                  // virus contact needs >= 111
+    bool regen_tick = regen && q.ticks % 120 == 0;
+    if (regen_tick && (tgt_p - q.np > 0 || tgt_v - q.nv > 0)) break;      // something to spawn: needs the RNG
+    bool decay_tick = decay && (q.elapsed + 1) % 60 == 0;
+    if (decay_tick && q.nvt != 0) break;                                  // anti-team bookkeeping
+    float nx = q.x, ny = q.y, nvx, nvy, nsx = q.svx, nsy = q.svy;
+    move_one(nx, ny, nvx, nvy, nsx, nsy, q.hi, q.r, q.tx, q.ty, dt, W);
+    unsigned nm = q.m; int ev = -1; float nslack = 0.0f;
+    if (q.np != 0) {
+      float adv = fabsf(nx - q.x) + fabsf(ny - q.y) + 2.5e-4f;  // >= Euclidean step (+ rounding head-room)
+      if (AV && q.slack > adv) nslack = q.slack - adv;          // provably out of reach of every pellet
+      else {
+        int gx = f2i(nx) / AG_PELLET_GRID, gy = f2i(ny) / AG_PELLET_GRID;
+        auto vis = [&](float qx, float qy) -> bool {
+          if constexpr (AV) return true;
+          else { int ddx = f2i(qx) / AG_PELLET_GRID - gx, ddy = f2i(qy) / AG_PELLET_GRID - gy; return ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1; }
+        };
+        float dmin2 = u2f((int)pel.min_bits([&](float qx, float qy) { return vis(qx, qy) ? sqr_dist(nx, ny, qx, qy) : 3.0e38f; }));
+        if (rr >= dmin2) {  // somebody is inside the radius
+          if (regen_tick) break;
+          if (pel.count([&](float qx, float qy) { return vis(qx, qy) && rr >= sqr_dist(nx, ny, qx, qy); }) != 1) break;
+          nm = clamp_mass(q.m + AG_PELLET_MASS);
+          if (nm >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0) break;  // eject / split run after the eat, on the grown mass
+          float r1 = lut(lut_r, nm); float rr1 = r1 * r1;
+          if (pel.count([&](float qx, float qy) { return vis(qx, qy) && rr1 >= sqr_dist(nx, ny, qx, qy); }) != 1) break;  // growth would reach a second one
+          ev = pel.first([&](float qx, float qy) { return vis(qx, qy) && rr >= sqr_dist(nx, ny, qx, qy); });
+        } else {
+          float sl = ag_sqrtf(dmin2) - q.r; sl = sl - 0.01f;
+          nslack = sl > 0.0f ? sl : 0.0f;
+        }
+      }
+    }
+    // ---- the tick is quiet: commit it to the register state ----
+    q.m_move = q.m;
+    q.x = nx; q.y = ny; q.vx = nvx; q.vy = nvy; q.svx = nsx; q.svy = nsy; q.slack = nslack;
+    q.elapsed += 1; q.done += 1; q.last_ev = ev;
+    if (ev >= 0) {  // Engine.hpp:991-994 (eat), :1002-1009 (swap-pop)
+      q.m = nm; q.food_eaten += 1;
+      q.r = lut(lut_r, q.m); q.hi = lut(lut_ms, q.m); rr = q.r * q.r;
+      pel.swap_pop(ev, q.np);
+      q.np -= 1; q.pel_changed = true; q.slack = 0.0f;
+    }
+    if ((unsigned)q.hm < q.m) q.hm = (int)q.m;
+    if (q.fcd > 0) q.fcd -= 1; if (q.action == 1 && q.fcd == 0) q.fcd = 10;   // Engine.hpp:1046-1054 (nothing can be ejected: mass < 35)
+    if (q.scd > 0) q.scd -= 1; if (q.action == 2 && q.scd == 0) q.scd = 30;   // Engine.hpp:1056-1064 (nothing can split: mass < 50)
+    if (decay_tick && q.elapsed - q.last_decay >= 60) {                       // Engine.hpp:575-584, Entities.hpp:199-203
+      double dm = (double)q.m * (1 - 0.002 * q.rate); unsigned um = (unsigned)dm;
+      um = um > AG_CELL_MIN_SIZE ? um : AG_CELL_MIN_SIZE;
+      q.last_decay = q.elapsed;
+      if (um != q.m) { q.m = um; q.r = lut(lut_r, q.m); q.hi = lut(lut_ms, q.m); rr = q.r * q.r; }  // a smaller radius keeps the budget valid
+    }
+    q.ticks += 1;
+  }
+}
+// first lane / index for which a wave-wide predicate holds (callers know exactly one does)
+#ifndef AGAR_CPU_EMU
+AG_DEV int ag_first_lane(unsigned long long m) { return (int)__builtin_ctzll(m); }
+#endif
+
+// pellets in the wave's registers (k_step)
+template <int NS, bool AV> struct RegPel {
+  AgCtx<NS, AV> &c;
+  template <class F> AG_MEM unsigned min_bits(F f) { ensure_pellets(c); pel_launder(c); return pel_min_bits(c, [&](float x, float y, int) { return f(x, y); }); }
+  template <class F> AG_MEM int count(F f) { pel_launder(c); return pel_count(c, [&](float x, float y, int) { return f(x, y); }); }
+  template <class F> AG_MEM int first(F f) {
+    pel_launder(c);
+    int r = -1;
+#ifdef AGAR_CPU_EMU
+    AG_PEL_FOR(s, lane, i) { if (r < 0 && f(PELX(c, s, lane), PELY(c, s, lane))) r = i; }
+#else
+    AG_PEL_FOR(s, lane, i) { unsigned long long m = __ballot((bool)f(PELX(c, s, lane), PELY(c, s, lane))); if (r < 0 && m) r = s * 64 + ag_first_lane(m); }
+#endif
+    return r;
+  }
+  AG_MEM void swap_pop(int ev, int np) {
+    if (np > 1 && ev < np - 1) { pel_move(c, ev, np - 1); auto gid = g_pid(c); AG_SERIAL { gid[ev] = gid[np - 1]; } }
+    int lastp = np - 1;
+    AG_PEL_FOR(sl_, lane, i) { if (i == lastp) { PELX(c, sl_, lane) = AG_PEL_SENTINEL; PELY(c, sl_, lane) = AG_PEL_SENTINEL; } }
+    c.pel_dirty = true;
+  }
+};
+// pellets streamed from HBM / L2 (k_quiet): nothing is kept in registers between scans
+template <int NS> struct MemPel {
+  AG_GLOBAL float *xy; AG_GLOBAL int32_t *id;
+#ifdef AGAR_CPU_EMU
+  template <class F> AG_MEM unsigned min_bits(F f) { unsigned b = 0x7f800000u; for (int i = 0; i < NS * 64; i++) { unsigned v = (unsigned)f2u(f(xy[2 * i], xy[2 * i + 1])); b = v < b ? v : b; } return b; }
+  template <class F> AG_MEM int count(F f) { int n = 0; for (int i = 0; i < NS * 64; i++) n += f(xy[2 * i], xy[2 * i + 1]) ? 1 : 0; return n; }
+  template <class F> AG_MEM int first(F f) { for (int i = 0; i < NS * 64; i++) if (f(xy[2 * i], xy[2 * i + 1])) return i; return -1; }
+#else
+  typedef float XY __attribute__((ext_vector_type(2)));
+  AG_MEM void fetch(XY (&p)[NS]) { auto g = (const AG_GLOBAL XY *)xy; _Pragma("unroll") for (int s = 0; s < NS; s++) p[s] = g[s * 64 + (int)threadIdx.x]; }  // NS x 512 B per wave, all in flight
+  template <class F> AG_MEM unsigned min_bits(F f) { XY p[NS]; fetch(p); unsigned b = 0x7f800000u; _Pragma("unroll") for (int s = 0; s < NS; s++) { unsigned v = (unsigned)f2u(f(p[s].x, p[s].y)); b = v < b ? v : b; } return wred_min(b); }
+  template <class F> AG_MEM int count(F f) { XY p[NS]; fetch(p); int n = 0; _Pragma("unroll") for (int s = 0; s < NS; s++) n += __popcll(__ballot((bool)f(p[s].x, p[s].y))); return n; }
+  template <class F> AG_MEM int first(F f) { XY p[NS]; fetch(p); int r = -1; _Pragma("unroll") for (int s = 0; s < NS; s++) { unsigned long long m = __ballot((bool)f(p[s].x, p[s].y)); if (r < 0 && m) r = s * 64 + ag_first_lane(m); } return r; }
+#endif
+  AG_MEM void swap_pop(int ev, int np) {
+    AG_SERIAL {
+      if (np > 1 && ev < np - 1) { xy[2 * ev] = xy[2 * (np - 1)]; xy[2 * ev + 1] = xy[2 * (np - 1) + 1]; id[ev] = id[np - 1]; }
+      xy[2 * (np - 1)] = AG_PEL_SENTINEL; xy[2 * (np - 1) + 1] = AG_PEL_SENTINEL;
+    }
+    ag_mem_fence();
+  }
+};
+
+// Returns the number of ticks performed (0 .. max_ticks).
 template <int NS, bool AV> AG_DEV int quiet_run(AgCtx<NS, AV> &c, int max_ticks) {
   if (c.P != 1 || SR(c, AR_NFOOD) != 0) return 0;
   int *P = PLS(c, 0);
   ub_load(c.PB, P, PL_WORDS);
   if (PR(c, PL_NCELLS) != 1) return 0;
   Cells s = cells_of(c, 0);
-  unsigned m = ag_uniu(s.m[0]);
-  if (ag_uniu(s.cmc[0]) != m) return 0;  // radius / speed cache must be valid
-  int action = PR(c, PL_ACTION), nv = SR(c, AR_NVIR), np = SR(c, AR_NPEL);
-  float x = ag_unif(s.x[0]), y = ag_unif(s.y[0]), svx = ag_unif(s.sx[0]), svy = ag_unif(s.sy[0]);
-  float vx = ag_unif(s.vx[0]), vy = ag_unif(s.vy[0]);
-  float r = ag_unif(s.crad[0]), hi = ag_unif(s.cms[0]), rr = r * r;
-  float tx = PRF(c, PL_TX), ty = PRF(c, PL_TY), dt = c.gs->g.dt, W = c.gs->g.W;
-  int ticks = SR(c, AR_TICKS), elapsed = PR(c, PL_ELAPSED), fcd = PR(c, PL_FEED_CD), scd = PR(c, PL_SPLIT_CD);
-  int last_decay = PR(c, PL_LAST_DECAY), nvt = PR(c, PL_NVTICKS), food_eaten = PR(c, PL_FOOD_EATEN), hm = PR(c, PL_HIGHEST_MASS);
-  double rate = (double)PRF(c, PL_ANTI_TEAM);
-  bool regen = c.gs->g.regen != 0, decay = c.gs->g.mass_decay != 0;
-  int tgt_p = c.gs->g.target_pellets, tgt_v = c.gs->g.target_viruses;
-  float slack = AV ? u2f(SR(c, AR_SAFE)) : 0.0f;
-  unsigned m_move = m; int last_ev = -1, done = 0;
-  auto lut_r = g_lut_r(c); auto lut_ms = g_lut_ms(c);
-  while (done < max_ticks) {
-    if (m >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && action != 0) break;  // eject needs >= 35, split >= 50
-    if (m >= 111u && nv != 0) break;                                  // virus contact needs >= 111
-    bool regen_tick = regen && ticks % 120 == 0;
-    if (regen_tick && (tgt_p - np > 0 || tgt_v - nv > 0)) break;      // something to spawn: needs the RNG
-    bool decay_tick = decay && (elapsed + 1) % 60 == 0;
-    if (decay_tick && nvt != 0) break;                                // anti-team bookkeeping
-    float nx = x, ny = y, nvx, nvy, nsx = svx, nsy = svy;
-    move_one(nx, ny, nvx, nvy, nsx, nsy, hi, r, tx, ty, dt, W);
-    unsigned nm = m; int ev = -1; float nslack = 0.0f;
-    if (np != 0) {
-      float adv = fabsf(nx - x) + fabsf(ny - y) + 2.5e-4f;  // >= Euclidean step (+ rounding head-room)
-      if (AV && slack > adv) nslack = slack - adv;          // provably out of reach of every pellet
-      else {
-        ensure_pellets(c);
-        int gx = f2i(nx) / AG_PELLET_GRID, gy = f2i(ny) / AG_PELLET_GRID;
-        auto vis = [&](float qx, float qy) -> bool {
-          if constexpr (AV) return true;
-          else { int ddx = f2i(qx) / AG_PELLET_GRID - gx, ddy = f2i(qy) / AG_PELLET_GRID - gy; return ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1; }
-        };
-        float dmin2 = u2f((int)pel_min_bits(c, [&](float qx, float qy, int) { return vis(qx, qy) ? sqr_dist(nx, ny, qx, qy) : 3.0e38f; }));
-        if (rr >= dmin2) {  // somebody is inside the radius
-          if (regen_tick) break;
-          pel_launder(c);
-          if (pel_count(c, [&](float qx, float qy, int) { return vis(qx, qy) && rr >= sqr_dist(nx, ny, qx, qy); }) != 1) break;
-          nm = clamp_mass(m + AG_PELLET_MASS);
-          if (nm >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && action != 0) break;  // eject / split run after the eat, on the grown mass
-          float r1 = lut(lut_r, nm); float rr1 = r1 * r1;
-          pel_launder(c);
-          if (pel_count(c, [&](float qx, float qy, int) { return vis(qx, qy) && rr1 >= sqr_dist(nx, ny, qx, qy); }) != 1) break;  // growth would reach a second one
-          int *T = L_I(c, L_TMP);
-          pel_launder(c);
-          pel_compact(c, [&](float qx, float qy, int) { return vis(qx, qy) && rr >= sqr_dist(nx, ny, qx, qy); }, [&](float, float, int i, int) { T[0] = i; });
-          ag_lds_order();
-          ev = ag_uni(T[0]);
-        } else {
-          float sl = ag_sqrtf(dmin2) - r; sl = sl - 0.01f;
-          nslack = sl > 0.0f ? sl : 0.0f;
-        }
-      }
-    }
-    // ---- the tick is quiet: commit it to the register state ----
-    m_move = m;
-    x = nx; y = ny; vx = nvx; vy = nvy; svx = nsx; svy = nsy; slack = nslack;
-    elapsed += 1; done += 1; last_ev = ev;
-    if (ev >= 0) {  // Engine.hpp:991-994 (eat), :1002-1009 (swap-pop)
-      m = nm; food_eaten += 1;
-      r = lut(lut_r, m); hi = lut(lut_ms, m); rr = r * r;
-      if (np > 1 && ev < np - 1) { pel_move(c, ev, np - 1); auto gid = g_pid(c); AG_SERIAL { gid[ev] = gid[np - 1]; } }
-      int lastp = np - 1;
-      AG_PEL_FOR(sl_, lane, i) { if (i == lastp) { PELX(c, sl_, lane) = AG_PEL_SENTINEL; PELY(c, sl_, lane) = AG_PEL_SENTINEL; } }
-      np -= 1; c.pel_dirty = true; slack = 0.0f;
-    }
-    if ((unsigned)hm < m) hm = (int)m;
-    if (fcd > 0) fcd -= 1; if (action == 1 && fcd == 0) fcd = 10;   // Engine.hpp:1046-1054 (nothing can be ejected: mass < 35)
-    if (scd > 0) scd -= 1; if (action == 2 && scd == 0) scd = 30;   // Engine.hpp:1056-1064 (nothing can split: mass < 50)
-    if (decay_tick && elapsed - last_decay >= 60) {                 // Engine.hpp:575-584, Entities.hpp:199-203
-      double dm = (double)m * (1 - 0.002 * rate); unsigned um = (unsigned)dm;
-      um = um > AG_CELL_MIN_SIZE ? um : AG_CELL_MIN_SIZE;
-      last_decay = elapsed;
-      if (um != m) { m = um; r = lut(lut_r, m); hi = lut(lut_ms, m); rr = r * r; }  // a smaller radius keeps the budget valid
-    }
-    ticks += 1;
-  }
-  if (done == 0) return 0;
+  QState q;
+  q.m = ag_uniu(s.m[0]);
+  if (ag_uniu(s.cmc[0]) != q.m) return 0;  // radius / speed cache must be valid
+  q.action = PR(c, PL_ACTION); q.nv = SR(c, AR_NVIR); q.np = SR(c, AR_NPEL);
+  q.x = ag_unif(s.x[0]); q.y = ag_unif(s.y[0]); q.svx = ag_unif(s.sx[0]); q.svy = ag_unif(s.sy[0]);
+  q.vx = ag_unif(s.vx[0]); q.vy = ag_unif(s.vy[0]); q.r = ag_unif(s.crad[0]); q.hi = ag_unif(s.cms[0]);
+  q.tx = PRF(c, PL_TX); q.ty = PRF(c, PL_TY);
+  q.ticks = SR(c, AR_TICKS); q.elapsed = PR(c, PL_ELAPSED); q.fcd = PR(c, PL_FEED_CD); q.scd = PR(c, PL_SPLIT_CD);
+  q.last_decay = PR(c, PL_LAST_DECAY); q.nvt = PR(c, PL_NVTICKS); q.food_eaten = PR(c, PL_FOOD_EATEN); q.hm = PR(c, PL_HIGHEST_MASS);
+  q.rate = (double)PRF(c, PL_ANTI_TEAM); q.slack = u2f(SR(c, AR_SAFE));
+  RegPel<NS, AV> pel{c};
+  quiet_ticks<AV>(q, c.gs->g, g_lut_r(c), g_lut_ms(c), pel, max_ticks);
+  if (q.done == 0) return 0;
   int *evp = L_I(c, L_EVP);
   AG_SERIAL {
-    s.x[0] = x; s.y[0] = y; s.vx[0] = vx; s.vy[0] = vy; s.sx[0] = svx; s.sy[0] = svy;
-    s.m[0] = m; s.cmc[0] = m; s.crad[0] = r; s.cms[0] = hi;
-    P[PL_ELAPSED] = elapsed; P[PL_MIN_MASS] = (int)m_move; P[PL_HIGHEST_MASS] = hm; P[PL_FEED_CD] = fcd; P[PL_SPLIT_CD] = scd;
-    P[PL_FOOD_EATEN] = food_eaten; P[PL_LAST_DECAY] = last_decay;
-    if (last_ev >= 0) evp[0] = last_ev;
+    s.x[0] = q.x; s.y[0] = q.y; s.vx[0] = q.vx; s.vy[0] = q.vy; s.sx[0] = q.svx; s.sy[0] = q.svy;
+    s.m[0] = q.m; s.cmc[0] = q.m; s.crad[0] = q.r; s.cms[0] = q.hi;
+    P[PL_ELAPSED] = q.elapsed; P[PL_MIN_MASS] = (int)q.m_move; P[PL_HIGHEST_MASS] = q.hm; P[PL_FEED_CD] = q.fcd; P[PL_SPLIT_CD] = q.scd;
+    P[PL_FOOD_EATEN] = q.food_eaten; P[PL_LAST_DECAY] = q.last_decay;
+    if (q.last_ev >= 0) evp[0] = q.last_ev;
   }
-  SW(c, AR_NEVP, last_ev >= 0 ? 1 : 0); SW(c, AR_NEVV, 0); SW(c, AR_NPEL, np);
-  SW(c, AR_TICKS, ticks); SW(c, AR_CLOCK, SR(c, AR_CLOCK) + done); SW(c, AR_SAFE, f2u(slack));
+  SW(c, AR_NEVP, q.last_ev >= 0 ? 1 : 0); SW(c, AR_NEVV, 0); SW(c, AR_NPEL, q.np);
+  SW(c, AR_TICKS, q.ticks); SW(c, AR_CLOCK, SR(c, AR_CLOCK) + q.done); SW(c, AR_SAFE, f2u(q.slack));
   ag_lds_order();
-  if (c.pel_dirty) ag_mem_fence();
-  return done;
+  if (q.pel_changed) ag_mem_fence();
+  return q.done;
 }
 
 // ---- Engine::tick.  R: Engine.hpp:208-240 --------------------------------------------------------------------
@@ -1361,11 +1420,14 @@ template <int NS, bool AV> AG_DEV void arena_tick(AgCtx<NS, AV> &c) {
   for (int k = 0; k < c.P; k++) tick_player(c, SR(c, AR_ORDER0 + k));
   remove_pellets(c);
   remove_viruses(c);
+  AG_T(c, 13);
   for (int k = 0; k < c.P; k++) sort_cells_by_id(c, SR(c, AR_ORDER0 + k));
+  AG_T(c, 14);
   // PrecisionCollisionDetection::solve: with one player every strip scan breaks on an own cell
   // (utils/collision_detection.hpp:51) => no eats.
   players_collision(c);
   move_foods(c);
+  AG_T(c, 15);
   int ticks = SR(c, AR_TICKS);
   if (c.gs->g.regen && ticks % 120 == 0) {
     add_pellets(c, c.gs->g.target_pellets - SR(c, AR_NPEL));
@@ -1396,10 +1458,24 @@ template <int NS, bool AV> AG_DEV int agent_in_order(const AgCtx<NS, AV> &c, int
   for (int j = 0; j < c.P; j++) { int p = SR(c, AR_ORDER0 + j); if (ag_uni(PLS(c, p)[PL_KIND]) != 0) continue; if (k == 0) return p; k--; }
   return -1;
 }
-template <int NS, bool AV> AG_DEV void env_step(AgCtx<NS, AV> &c, int ticks, bool with_env) {
+// BaseEnvironment::step's result for agent i (BaseEnvironment.hpp:116-121): reward = mass or mass delta (+ c_death
+// when respawned), done flag on agent 0; written as f64 / u8 / i32 and as the packed (reward, done) f32 pair.
+AG_DEV void emit_agent_result(const AgState *gs, int slot, int arena, int na, int i, unsigned m, unsigned before, int respawned, int done) {
+  double r = (double)m;
+  if (gs->g.reward_type) { float b = (float)before; float sub = b - (float)(respawned ? gs->g.c_death : 0); r -= (double)sub; }
+  size_t o = (size_t)arena * na + i;
+  auto rw = (AG_GLOBAL double *)gs->rewards; auto ms = (AG_GLOBAL int32_t *)gs->masses; auto dn = (AG_GLOBAL uint8_t *)gs->dones;
+  auto pk = (AG_GLOBAL float *)(gs->packed + ((size_t)slot * gs->d.A * na + o) * 2);
+  AG_SERIAL { rw[o] = r; ms[o] = (int)m; dn[o] = (uint8_t)(i == 0 ? done : 0); pk[0] = (float)r; pk[1] = (i == 0 && done) ? 1.0f : 0.0f; }
+}
+
+// q_done >= 0: the lean kernel (agar_quiet.inl) already did the prologue and the first q_done ticks of this step
+// (single player; q_before = the agent's mass before the step).
+template <int NS, bool AV> AG_DEV void env_step(AgCtx<NS, AV> &c, int ticks, bool with_env, int q_done = -1, int q_before = 0) {
   int na = c.gs->d.n_agents, mode = c.gs->g.mode;
   int *before = L_I(c, L_TMP) + 20;  // [n_agents] masses before the ticks, in rewards order (LDS, not private memory)
-  if (with_env) {
+  if (with_env && q_done >= 0) { AG_SERIAL { before[0] = q_before; } ag_lds_order(); }
+  else if (with_env) {
     for (int i = 0; i < na; i++) {  // take_actions: agent i == player slot i (pids_[i]), BaseEnvironment.hpp:141-176
       size_t o = (size_t)c.arena * na + i;
       if (c.act) take_action(c, i, c.act_dxdy[2 * o], c.act_dxdy[2 * o + 1], c.act[o]);
@@ -1412,7 +1488,7 @@ template <int NS, bool AV> AG_DEV void env_step(AgCtx<NS, AV> &c, int ticks, boo
     }
     ag_lds_order();
   }
-  for (int t = 0; t < ticks;) {
+  for (int t = q_done > 0 ? q_done : 0; t < ticks;) {
 #ifndef AG_NO_QUIET
     t += quiet_run(c, ticks - t);
     if (t >= ticks) break;
@@ -1433,13 +1509,7 @@ template <int NS, bool AV> AG_DEV void env_step(AgCtx<NS, AV> &c, int ticks, boo
     for (int i = 0; i < na; i++) {
       int p = agent_in_order(c, i); unsigned m = p >= 0 ? player_mass(c, p) : 0u;
       if (mode == 3 && m >= 23000u) SW(c, AR_DONE, 1);
-      double r = (double)m;
-      if (c.gs->g.reward_type) { float b = (float)(unsigned)ag_uni(before[i]); float sub = b - (float)(SR(c, AR_RESPAWNED) ? c.gs->g.c_death : 0); r -= (double)sub; }
-      size_t o = (size_t)c.arena * na + i;
-      int done = SR(c, AR_DONE);
-      auto rw = (AG_GLOBAL double *)c.gs->rewards; auto ms = (AG_GLOBAL int32_t *)c.gs->masses; auto dn = (AG_GLOBAL uint8_t *)c.gs->dones;
-      auto pk = (AG_GLOBAL float *)(c.gs->packed + ((size_t)c.slot * c.gs->d.A * na + o) * 2);
-      AG_SERIAL { rw[o] = r; ms[o] = (int)m; dn[o] = (uint8_t)(i == 0 ? done : 0); pk[0] = (float)r; pk[1] = (i == 0 && done) ? 1.0f : 0.0f; }
+      emit_agent_result(c.gs, c.slot, c.arena, na, i, m, (unsigned)ag_uni(before[i]), SR(c, AR_RESPAWNED), SR(c, AR_DONE));
     }
   }
 }

@@ -21,6 +21,7 @@
 
 #include "../../include/agarcl_batch.h"
 #include "agar_core.inl"
+#include "agar_quiet.inl"
 #include "agar_obs.inl"
 
 // ---- thread-local error string -------------------------------------------------------------------
@@ -61,6 +62,7 @@ struct agarcl_env {
   float *d_act_dxdy; int32_t *d_act;  // env-owned action buffers (host-copy path)
   float *lut_r, *lut_ms, *lut_ss, *lut_anti;
   int32_t *obs_buf; size_t obs_cap;  // staging for host-side grid observations
+  bool no_front;  // AGARCL_NO_FRONT=1 in the environment: skip k_quiet (diagnostics / A-B timing only)
 };
 
 // ---- kernels ----------------------------------------------------------------------------------------
@@ -88,7 +90,14 @@ template <int NS, bool AV, class F> static void for_each_arena_ns(agarcl_env *e,
 extern __shared__ __align__(16) unsigned char ag_lds[];
 #define AG_KERNEL_PROLOGUE AgCtx<NS, AV> c; ag_ctx_init(c, gs, (int)blockIdx.x, ag_lds, act_dxdy, act);
 
-template <int NS, bool AV> __global__ void __launch_bounds__(64) k_step(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot) {
+// use_q: k_quiet ran in front of this launch; arenas it finished exit on their first load, the others resume.
+template <int NS, bool AV> __global__ void __launch_bounds__(64) k_step(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int use_q) {
+  int q_done = -1, q_before = 0;
+  if (use_q) {
+    auto qi = (const AG_GLOBAL int32_t *)(gs->qinfo + (size_t)blockIdx.x * 2);
+    q_done = qi[0]; q_before = qi[1];
+    if (q_done == ticks) return;
+  }
   AG_KERNEL_PROLOGUE
   c.slot = slot;
 #ifdef AGAR_PROFILE
@@ -97,13 +106,16 @@ template <int NS, bool AV> __global__ void __launch_bounds__(64) k_step(const Ag
 #endif
   arena_load(c);
   AG_T(c, 0);
-  env_step(c, ticks, with_env != 0);
+  env_step(c, ticks, with_env != 0, q_done, q_before);
   AG_T(c, 10);
   arena_store(c);
   AG_T(c, 11);
 #ifdef AGAR_PROFILE
   if (threadIdx.x == 0 && gs->prof) for (int i = 0; i < AG_NPROF; i++) gs->prof[(size_t)blockIdx.x * AG_NPROF + i] += c.tacc[i];
 #endif
+}
+template <int NS, bool AV> __global__ void __launch_bounds__(64) k_quiet(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot) {
+  quiet_arena<NS, AV>(gs, (int)blockIdx.x, (const AG_GLOBAL float *)act_dxdy, (const AG_GLOBAL int32_t *)act, ticks, with_env != 0, slot);
 }
 template <int NS, bool AV> __global__ void __launch_bounds__(64) k_reset(const AgState *__restrict__ gs, const uint8_t *mask, int reset_ids) {
   if (mask && !mask[blockIdx.x]) return;
@@ -129,11 +141,21 @@ __global__ void k_set_word(int32_t *base, int stride, int n, int value) {
 
 static int launch_step(agarcl_env *e, int ticks, int with_env) {
 #ifdef AGAR_CPU_EMU
-#define CALL(N, V) for_each_arena_ns<N, V>(e, [&](AgCtx<N, V> &c) { arena_load(c); env_step(c, ticks, with_env != 0); arena_store(c); })
+  const int use_q = e->d.P == 1 && !e->no_front;  // the lean front kernel handles single-player arenas' quiet steps
+#define CALL(N, V) for_each_arena_ns<N, V>(e, [&](AgCtx<N, V> &c) { \
+    int qd = -1, qb = 0; \
+    if (use_q) { quiet_arena<N, V>(c.gs, c.arena, c.act_dxdy, c.act, ticks, with_env != 0, c.slot); qd = c.gs->qinfo[2 * c.arena]; qb = c.gs->qinfo[2 * c.arena + 1]; if (qd == ticks) return; } \
+    arena_load(c); env_step(c, ticks, with_env != 0, qd, qb); arena_store(c); })
   AG_DISPATCH_NS(e->ns, CALL);
 #undef CALL
 #else
-#define CALL(N, V) hipLaunchKernelGGL((k_step<N, V>), dim3(e->d.A), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot)
+  const int use_q = e->d.P == 1 && !e->no_front;
+  if (use_q) {
+#define CALL(N, V) hipLaunchKernelGGL((k_quiet<N, V>), dim3(e->d.A), dim3(64), 0, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot)
+    AG_DISPATCH_NS(e->ns, CALL);
+#undef CALL
+  }
+#define CALL(N, V) hipLaunchKernelGGL((k_step<N, V>), dim3(e->d.A), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, use_q)
   AG_DISPATCH_NS(e->ns, CALL);
 #undef CALL
   HIPCHK(hipGetLastError());
@@ -294,6 +316,8 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   s.lut_r = e->lut_r; s.lut_ms = e->lut_ms; s.lut_ss = e->lut_ss; s.lut_anti = e->lut_anti;
   s.act_dxdy = nullptr; s.act = nullptr;
   s.prof = alloc<unsigned long long>(e, (size_t)d.A * 16);
+  s.qinfo = alloc<int32_t>(e, (size_t)d.A * 2);
+  { const char *nf = getenv("AGARCL_NO_FRONT"); e->no_front = nf && nf[0] == '1'; }
 #ifdef AGAR_CPU_EMU
   e->d_state = &e->s;
 #else

@@ -100,5 +100,6 @@ struct AgState {
   int32_t *ev_v;          // [A][AG_EVV_CAP]
   // read-only tables (mass -> fp32), host generated (Engine.hpp:1296-1302, core/utils.hpp:8-11)
   const float *lut_r, *lut_ms, *lut_ss, *lut_anti;
+  int32_t *qinfo;         // [A][2] hand-over from k_quiet to k_step: ticks done (-1: nothing), agent mass before the step
   unsigned long long *prof;  // [16] phase cycle sums (diagnostic builds only; may be null)
 };

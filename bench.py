@@ -24,6 +24,16 @@ sys.path.insert(0, ROOT)
 ARENAS_PER_GPU = 4096
 CFG = dict(num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True, num_pellets=1000, num_viruses=0,
            num_bots=0, reward_type=1, c_death=0, mode_number=0)
+# The headline line is C2.  The other SURVEY 8(d) workloads are selectable for DESIGN.md's measurement table only.
+WORKLOADS = {
+    "C2": dict(desc="C2: %d arenas/GPU x 1 agent, 1000x1000 arena, 1000 pellets, 0 viruses, mode 0, 4 ticks/step, random (dx,dy), action none"),
+    "C3m0": dict(num_viruses=25, rand_act=True,
+                 desc="C3/mode 0: %d arenas/GPU x 1 agent, 1000x1000, 1000 pellets, 25 viruses, mode 0, 4 ticks/step, random (dx,dy), action ~ U{0,1,2}"),
+    "C3m6": dict(num_viruses=25, mode_number=6, rand_act=True,
+                 desc="C3/mode 6: %d arenas/GPU x 1 agent (mass 1000), 1000x1000, 1000 pellets, 25 viruses, mode 6, 4 ticks/step, random (dx,dy), action ~ U{0,1,2}"),
+    "C5": dict(num_viruses=25, mode_number=6, rand_act=True, grid_obs=True,
+               desc="C5: C3/mode 6 + int32 grid observation [%d][8][128][128] written once per step"),
+}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
 
 
@@ -97,7 +107,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--arenas", type=int, default=ARENAS_PER_GPU, help="arenas per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS), help="C2 = the headline metric's configuration")
     args = ap.parse_args()
+    wl = dict(WORKLOADS[args.workload])
+    desc, rand_act, with_obs = wl.pop("desc"), wl.pop("rand_act", False), wl.pop("grid_obs", False)
+    CFG.update(wl)
 
     import torch
     import numpy as np
@@ -136,6 +150,9 @@ def main():
     g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
     dxdy = (torch.rand((K + Wm, A, 1, 2), generator=g, device=dev, dtype=torch.float32) * 2.0 - 1.0).contiguous()
     act = torch.zeros((K + Wm, A, 1), dtype=torch.int32, device=dev)
+    if rand_act:
+        act = torch.randint(0, 3, (K + Wm, A, 1), generator=g, device=dev, dtype=torch.int32)
+    obs = torch.empty((A, 8, 128, 128), dtype=torch.int32, device=dev) if with_obs else None
     gather = agdist.ResultGatherer(A, dev) if world > 1 else None
     eng = env.engine
 
@@ -144,6 +161,8 @@ def main():
         if gather is not None:
             gather.wait_slot(k & 1)             # the engine is about to overwrite this parity's packed results
         eng.step(CFG["ticks_per_step"])
+        if obs is not None:
+            eng.grid_obs(128, True, True, True, True, out_ptr=obs.data_ptr())
         if gather is not None:                  # RCCL gather of (reward, done) straight from engine memory; overlaps step k+1
             gather.gather_packed(k & 1, env.packed[eng.last_slot()])
 
@@ -186,7 +205,7 @@ def main():
         traffic = None  # HBM bytes per launch from the PMC counters (collected separately: profiles/r01_pmc_traffic.json)
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if A == 4096 and ticks == 4:
+            if A == 4096 and ticks == 4 and args.workload == "C2":
                 traffic = tj["traffic_bytes_per_launch"]
         except Exception:
             pass
@@ -194,8 +213,7 @@ def main():
             "metric": "env-steps/sec (arenas x ticks/s)", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: %d arenas/GPU x 1 agent, 1000x1000 arena, 1000 pellets, 0 viruses, mode 0, "
-                                   "4 ticks/step, random (dx,dy), action none" % A,
+            "config": {"workload": desc % A,
                        "arenas_total": world * A, "ticks_per_step": ticks,
                        "parallelism": "arena-sharded x%d, per-step reward/done gather to rank 0" % world if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -204,7 +222,12 @@ def main():
                          "kernel": "k_step", "kernel_ms": kernel_ms, "algorithmic_bytes_per_arena_tick": b_tick},
             "capacity_flags_raised": int((flags != 0).sum()),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if with_obs:
+            out["roofline"]["algorithmic_bytes_per_launch"] = bytes_per_launch + A * 8 * 128 * 128 * 4
+            out["roofline"]["achieved"] = out["roofline"]["algorithmic_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
+            out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
+            out["roofline"]["kernel"] = "k_step + k_grid_obs"
+        if world == 1 and not args.no_cpu_baseline and args.workload == "C2":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     env.close()
