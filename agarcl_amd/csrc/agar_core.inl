@@ -328,12 +328,16 @@ template <int NS, bool AV> AG_DEV void pel_get(const AgCtx<NS, AV> &c, int i, fl
 }
 
 // ---- load / store arena state between HBM and LDS / registers -------------------------------------
-template <int NS, bool AV> AG_DEV void arena_load(AgCtx<NS, AV> &c) {
+template <int NS, bool AV> AG_DEV void arena_load(AgCtx<NS, AV> &c, bool want_pellets = false) {
   // Every load below is independent of every other (no count is needed to form an address), so the arena arrives in
   // ONE round trip to HBM: arena words, player words, and all AG_CC cell slots of every player incl. the persisted
   // radius / speed cache (slots >= n_cells are never read).
   // (pellets are NOT loaded here: ensure_pellets() fetches them on first use, and a launch whose cell provably stays
   // out of reach of every pellet -- AR_SAFE budget -- never touches them)
+  // (want_pellets: the caller knows a general tick is coming -- k_step resuming after k_quiet -- so the pellet loads
+  // join the same round trip)
+  c.pel_loaded = false;
+  if (want_pellets) { auto gxy = g_pxy(c); AG_PEL_FOR(s, lane, i) { PELX(c, s, lane) = gxy[2 * i]; PELY(c, s, lane) = gxy[2 * i + 1]; } c.pel_loaded = true; }
   ub_load(c.S, g_ar(c), AR_WORDS);
   auto gpl = g_pl(c);
   AG_LANES(i, c.P * PL_WORDS) PLS(c, 0)[i] = gpl[i];
@@ -346,7 +350,7 @@ template <int NS, bool AV> AG_DEV void arena_load(AgCtx<NS, AV> &c) {
       for (int f = 0; f < CF_ALL; f++) l[f * AG_CC + i] = g[f * AG_CC + i];
     }
   }
-  c.pel_dirty = false; c.pel_loaded = false; c.ncreated = 0;
+  c.pel_dirty = false; c.ncreated = 0;
   ag_lds_order();
 }
 // Pellet capacity is exactly NS*64 and HBM keeps the sentinel at every index >= n_pellets, so the load is NS
@@ -1246,133 +1250,140 @@ template <int NS, bool AV> AG_DEV void sort_cells_by_id(AgCtx<NS, AV> &c, int p)
 // reduces to the cell's kinematics, counters, the periodic decay and -- now and then -- eating ONE pellet.
 // Everything is wave-uniform, so a run of consecutive quiet ticks executes on registers only: state is read once,
 // each tick is move_one + integer updates, and the result is committed once.
-//   * Out-of-reach budget (AR_SAFE): after a pellet scan the cell knows slack = (distance to its nearest pellet) -
-//     radius.  Pellets are static, so while the path length walked since (bounded by |dx| + |dy| per tick) stays
-//     below the slack no pellet can be inside the radius: no scan, and if the whole launch stays inside the budget
-//     the pellets are never even read from HBM.  (Only with AV: otherwise buckets change visibility as the cell moves.)
+//   * Pellet-free disc (AR_SAFE, PL_SAFE_X/Y): a pellet scan at position p0 yields the distance dmin to the nearest
+//     pellet, i.e. a disc around p0 with no pellet in it.  Pellets are static, so while the cell's centre stays within
+//     S = dmin - radius - 0.01 of p0 nothing can be inside its radius: no scan, and a launch that stays in the disc
+//     never reads the pellets from HBM at all.  (A random walk leaves the disc far later than its path length would
+//     suggest.  Only with AV: otherwise buckets change visibility as the cell moves.)
 //   * A plain eat (exactly one pellet inside the radius, still exactly one inside the grown radius, not a regen
 //     tick) is performed inline: mass + 1, swap-pop removal, event record -- identical to the general path's result.
 // The run stops BEFORE the first tick that needs anything else (nothing of that tick has been written) and the
 // general path takes over.
 // quiet_ticks() is shared by two callers that differ only in where the pellets live (the `Pel` accessor):
 // k_step's quiet_run (pellets in the wave's registers) and the lean kernel k_quiet (pellets streamed from HBM/L2).
-struct QState {  // all wave-uniform
+struct QState {  // per arena: wave-uniform in k_step, uniform over the arena's lane group in k_quiet
   unsigned m, m_move;  // mass; mass at the last tick's move (Player::min_mass bookkeeping)
   int action, nv, np, ticks, elapsed, fcd, scd, last_decay, nvt, food_eaten, hm, last_ev, done;
-  float x, y, svx, svy, vx, vy, r, hi, tx, ty, slack;
+  float x, y, svx, svy, vx, vy, r, hi, tx, ty, slack, sx0, sy0;  // slack = S, (sx0, sy0) = centre of the pellet-free disc
   double rate;
   bool pel_changed;
 };
-template <bool AV, class PelT, class LutT> AG_DEV void quiet_ticks(QState &q, const AgParams &g, LutT lut_r, LutT lut_ms, PelT &pel, int max_ticks) {
+// One fused pass over an arena's pellets as seen from (x, y): squared distance to the nearest one, how many lie
+// within rr and within rr1 (the radius after eating one), and the index of the first one within rr.
+struct PelScan { float dmin2; int cnt, cnt1, first; };
+struct PelQuery { float x, y, rr, rr1; int gx, gy; };  // gx, gy: the cell's pellet bucket (used only without AV)
+template <bool AV> AG_DEV bool pel_visible(const PelQuery &k, float qx, float qy) {  // R: Engine.hpp:976-990 (3x3 bucket walk)
+  if constexpr (AV) return true;
+  else { int ddx = f2i(qx) / AG_PELLET_GRID - k.gx, ddy = f2i(qy) / AG_PELLET_GRID - k.gy; return ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1; }
+}
+// lane-level accumulation of one pellet into the partial results (dmin as float bits: orders like the value for d2 >= 0)
+template <bool AV> AG_DEV void pel_accumulate(const PelQuery &k, float qx, float qy, unsigned idx, unsigned &dmin, int &c0, int &c1, unsigned &first) {
+  if (!pel_visible<AV>(k, qx, qy)) return;
+  float d2 = sqr_dist(k.x, k.y, qx, qy);
+  unsigned b = (unsigned)f2u(d2); dmin = b < dmin ? b : dmin;
+  if (k.rr >= d2) { c0 += 1; first = idx < first ? idx : first; }
+  if (k.rr1 >= d2) c1 += 1;
+}
+
+// The tick loop is written in phases so that the pellet pass sits at a point every lane of the wave reaches together
+// (`pel.any`, `pel.scan`, `pel.swap_pop` are wave-level calls; everything inside `if (active)` is per-arena code):
+// k_quiet advances several arenas per wavefront and lets the whole wave scan for whichever of them needs it.
+template <bool AV, class PelT, class LutT> AG_DEV void quiet_ticks(QState &q, const AgParams &g, LutT lut_r, LutT lut_ms, PelT &pel, int max_ticks, bool active = true) {
   const float dt = g.dt, W = g.W;
   const bool regen = g.regen != 0, decay = g.mass_decay != 0;
   const int tgt_p = g.target_pellets, tgt_v = g.target_viruses;
   float rr = q.r * q.r;
   if (!AV) q.slack = 0.0f;
+  float s2 = q.slack * q.slack;
   q.done = 0; q.last_ev = -1; q.m_move = q.m; q.pel_changed = false;
-  while (q.done < max_ticks) {
-    if (q.m >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0) break;  // eject needs >= 35, split >= 50
-    if (q.m >= 111u && q.nv != 0) break;                                  // virus contact needs >= 111
-    bool regen_tick = regen && q.ticks % 120 == 0;
-    if (regen_tick && (tgt_p - q.np > 0 || tgt_v - q.nv > 0)) break;      // something to spawn: needs the RNG
-    bool decay_tick = decay && (q.elapsed + 1) % 60 == 0;
-    if (decay_tick && q.nvt != 0) break;                                  // anti-team bookkeeping
-    float nx = q.x, ny = q.y, nvx, nvy, nsx = q.svx, nsy = q.svy;
-    move_one(nx, ny, nvx, nvy, nsx, nsy, q.hi, q.r, q.tx, q.ty, dt, W);
-    unsigned nm = q.m; int ev = -1; float nslack = 0.0f;
-    if (q.np != 0) {
-      float adv = fabsf(nx - q.x) + fabsf(ny - q.y) + 2.5e-4f;  // >= Euclidean step (+ rounding head-room)
-      if (AV && q.slack > adv) nslack = q.slack - adv;          // provably out of reach of every pellet
-      else {
-        int gx = f2i(nx) / AG_PELLET_GRID, gy = f2i(ny) / AG_PELLET_GRID;
-        auto vis = [&](float qx, float qy) -> bool {
-          if constexpr (AV) return true;
-          else { int ddx = f2i(qx) / AG_PELLET_GRID - gx, ddy = f2i(qy) / AG_PELLET_GRID - gy; return ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1; }
-        };
-        float dmin2 = u2f((int)pel.min_bits([&](float qx, float qy) { return vis(qx, qy) ? sqr_dist(nx, ny, qx, qy) : 3.0e38f; }));
-        if (rr >= dmin2) {  // somebody is inside the radius
-          if (regen_tick) break;
-          if (pel.count([&](float qx, float qy) { return vis(qx, qy) && rr >= sqr_dist(nx, ny, qx, qy); }) != 1) break;
-          nm = clamp_mass(q.m + AG_PELLET_MASS);
-          if (nm >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0) break;  // eject / split run after the eat, on the grown mass
-          float r1 = lut(lut_r, nm); float rr1 = r1 * r1;
-          if (pel.count([&](float qx, float qy) { return vis(qx, qy) && rr1 >= sqr_dist(nx, ny, qx, qy); }) != 1) break;  // growth would reach a second one
-          ev = pel.first([&](float qx, float qy) { return vis(qx, qy) && rr >= sqr_dist(nx, ny, qx, qy); });
-        } else {
-          float sl = ag_sqrtf(dmin2) - q.r; sl = sl - 0.01f;
-          nslack = sl > 0.0f ? sl : 0.0f;
+  while (pel.any(active)) {
+    bool need = false, regen_tick = false, decay_tick = false;
+    float nx = q.x, ny = q.y, nvx = 0.0f, nvy = 0.0f, nsx = q.svx, nsy = q.svy;
+    unsigned nm = q.m; PelQuery k{0.0f, 0.0f, 0.0f, 0.0f, 0, 0};
+    if (active) {
+      regen_tick = regen && q.ticks % 120 == 0;
+      decay_tick = decay && (q.elapsed + 1) % 60 == 0;
+      if (q.done >= max_ticks) active = false;
+      else if (q.m >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0) active = false;  // eject needs >= 35, split >= 50
+      else if (q.m >= 111u && q.nv != 0) active = false;                                  // virus contact needs >= 111
+      else if (regen_tick && (tgt_p - q.np > 0 || tgt_v - q.nv > 0)) active = false;      // something to spawn: needs the RNG
+      else if (decay_tick && q.nvt != 0) active = false;                                  // anti-team bookkeeping
+      if (active) {
+        move_one(nx, ny, nvx, nvy, nsx, nsy, q.hi, q.r, q.tx, q.ty, dt, W);
+        if (q.np != 0) {
+          float ox = nx - q.sx0, oy = ny - q.sy0; float o2 = ox * ox, o2b = oy * oy; o2 = o2 + o2b;
+          if (!(AV && o2 < s2)) {  // left the pellet-free disc (or none known): look at the pellets
+            need = true;
+            nm = clamp_mass(q.m + AG_PELLET_MASS);
+            float r1 = lut(lut_r, nm);
+            k.x = nx; k.y = ny; k.rr = rr; k.rr1 = r1 * r1; k.gx = f2i(nx) / AG_PELLET_GRID; k.gy = f2i(ny) / AG_PELLET_GRID;
+          }
         }
       }
     }
-    // ---- the tick is quiet: commit it to the register state ----
-    q.m_move = q.m;
-    q.x = nx; q.y = ny; q.vx = nvx; q.vy = nvy; q.svx = nsx; q.svy = nsy; q.slack = nslack;
-    q.elapsed += 1; q.done += 1; q.last_ev = ev;
-    if (ev >= 0) {  // Engine.hpp:991-994 (eat), :1002-1009 (swap-pop)
-      q.m = nm; q.food_eaten += 1;
-      q.r = lut(lut_r, q.m); q.hi = lut(lut_ms, q.m); rr = q.r * q.r;
-      pel.swap_pop(ev, q.np);
-      q.np -= 1; q.pel_changed = true; q.slack = 0.0f;
+    PelScan sc = pel.template scan<AV>(need, k);
+    int ev = -1; bool pop = false; int np_before = q.np;
+    if (active) {
+      float nslack = 0.0f;
+      if (need) {
+        if (rr >= sc.dmin2) {  // somebody is inside the radius: a plain single eat, or the general path's business
+          if (regen_tick || sc.cnt != 1 || sc.cnt1 != 1 || (nm >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0)) active = false;
+          else ev = sc.first;
+        } else {
+          float sl = ag_sqrtf(sc.dmin2) - q.r; sl = sl - 0.01f;
+          nslack = sl > 0.0f ? sl : 0.0f;
+        }
+      }
+      if (active) {  // ---- the tick is quiet: commit it ----
+        q.m_move = q.m;
+        q.x = nx; q.y = ny; q.vx = nvx; q.vy = nvy; q.svx = nsx; q.svy = nsy;
+        if (need) { q.slack = nslack; q.sx0 = nx; q.sy0 = ny; s2 = nslack * nslack; }
+        q.elapsed += 1; q.done += 1; q.last_ev = ev;
+        if (ev >= 0) {  // Engine.hpp:991-994 (eat), :1002-1009 (swap-pop, below)
+          q.m = nm; q.food_eaten += 1;
+          q.r = lut(lut_r, q.m); q.hi = lut(lut_ms, q.m); rr = q.r * q.r;
+          pop = true;
+          q.np -= 1; q.pel_changed = true; q.slack = 0.0f; s2 = 0.0f;
+        }
+        if ((unsigned)q.hm < q.m) q.hm = (int)q.m;
+        if (q.fcd > 0) q.fcd -= 1; if (q.action == 1 && q.fcd == 0) q.fcd = 10;   // Engine.hpp:1046-1054 (nothing can be ejected: mass < 35)
+        if (q.scd > 0) q.scd -= 1; if (q.action == 2 && q.scd == 0) q.scd = 30;   // Engine.hpp:1056-1064 (nothing can split: mass < 50)
+        if (decay_tick && q.elapsed - q.last_decay >= 60) {                       // Engine.hpp:575-584, Entities.hpp:199-203
+          double dm = (double)q.m * (1 - 0.002 * q.rate); unsigned um = (unsigned)dm;
+          um = um > AG_CELL_MIN_SIZE ? um : AG_CELL_MIN_SIZE;
+          q.last_decay = q.elapsed;
+          if (um != q.m) { q.m = um; q.r = lut(lut_r, q.m); q.hi = lut(lut_ms, q.m); rr = q.r * q.r; }  // a smaller radius keeps the disc valid
+        }
+        q.ticks += 1;
+      }
     }
-    if ((unsigned)q.hm < q.m) q.hm = (int)q.m;
-    if (q.fcd > 0) q.fcd -= 1; if (q.action == 1 && q.fcd == 0) q.fcd = 10;   // Engine.hpp:1046-1054 (nothing can be ejected: mass < 35)
-    if (q.scd > 0) q.scd -= 1; if (q.action == 2 && q.scd == 0) q.scd = 30;   // Engine.hpp:1056-1064 (nothing can split: mass < 50)
-    if (decay_tick && q.elapsed - q.last_decay >= 60) {                       // Engine.hpp:575-584, Entities.hpp:199-203
-      double dm = (double)q.m * (1 - 0.002 * q.rate); unsigned um = (unsigned)dm;
-      um = um > AG_CELL_MIN_SIZE ? um : AG_CELL_MIN_SIZE;
-      q.last_decay = q.elapsed;
-      if (um != q.m) { q.m = um; q.r = lut(lut_r, q.m); q.hi = lut(lut_ms, q.m); rr = q.r * q.r; }  // a smaller radius keeps the budget valid
-    }
-    q.ticks += 1;
+    pel.swap_pop(pop, ev, np_before);
   }
 }
-// first lane / index for which a wave-wide predicate holds (callers know exactly one does)
-#ifndef AGAR_CPU_EMU
-AG_DEV int ag_first_lane(unsigned long long m) { return (int)__builtin_ctzll(m); }
-#endif
 
-// pellets in the wave's registers (k_step)
+// pellets in the wave's registers (k_step): one arena per wave, so every argument is wave-uniform
 template <int NS, bool AV> struct RegPel {
   AgCtx<NS, AV> &c;
-  template <class F> AG_MEM unsigned min_bits(F f) { ensure_pellets(c); pel_launder(c); return pel_min_bits(c, [&](float x, float y, int) { return f(x, y); }); }
-  template <class F> AG_MEM int count(F f) { pel_launder(c); return pel_count(c, [&](float x, float y, int) { return f(x, y); }); }
-  template <class F> AG_MEM int first(F f) {
-    pel_launder(c);
-    int r = -1;
-#ifdef AGAR_CPU_EMU
-    AG_PEL_FOR(s, lane, i) { if (r < 0 && f(PELX(c, s, lane), PELY(c, s, lane))) r = i; }
-#else
-    AG_PEL_FOR(s, lane, i) { unsigned long long m = __ballot((bool)f(PELX(c, s, lane), PELY(c, s, lane))); if (r < 0 && m) r = s * 64 + ag_first_lane(m); }
+  AG_MEM bool any(bool p) const { return p; }
+  template <bool AV2> AG_MEM PelScan scan(bool need, const PelQuery &k) {
+    PelScan out{3.0e38f, 0, 0, -1};
+    if (!need) return out;
+    ensure_pellets(c); pel_launder(c);
+    unsigned dmin = 0x7f800000u, first = 0xffffffffu; int c0 = 0, c1 = 0;
+    AG_PEL_FOR(s, lane, i) { pel_accumulate<AV>(k, PELX(c, s, lane), PELY(c, s, lane), (unsigned)i, dmin, c0, c1, first); }
+#ifndef AGAR_CPU_EMU
+    dmin = wred_min(dmin);
+    if (k.rr >= u2f((int)dmin)) { c0 = wred_add(c0); c1 = wred_add(c1); first = wred_min(first); }  // (uniform branch) only when somebody is in reach
 #endif
-    return r;
+    out.dmin2 = u2f((int)dmin); out.cnt = c0; out.cnt1 = c1; out.first = (int)first;
+    return out;
   }
-  AG_MEM void swap_pop(int ev, int np) {
+  AG_MEM void swap_pop(bool doit, int ev, int np) {
+    if (!doit) return;
     if (np > 1 && ev < np - 1) { pel_move(c, ev, np - 1); auto gid = g_pid(c); AG_SERIAL { gid[ev] = gid[np - 1]; } }
     int lastp = np - 1;
     AG_PEL_FOR(sl_, lane, i) { if (i == lastp) { PELX(c, sl_, lane) = AG_PEL_SENTINEL; PELY(c, sl_, lane) = AG_PEL_SENTINEL; } }
     c.pel_dirty = true;
-  }
-};
-// pellets streamed from HBM / L2 (k_quiet): nothing is kept in registers between scans
-template <int NS> struct MemPel {
-  AG_GLOBAL float *xy; AG_GLOBAL int32_t *id;
-#ifdef AGAR_CPU_EMU
-  template <class F> AG_MEM unsigned min_bits(F f) { unsigned b = 0x7f800000u; for (int i = 0; i < NS * 64; i++) { unsigned v = (unsigned)f2u(f(xy[2 * i], xy[2 * i + 1])); b = v < b ? v : b; } return b; }
-  template <class F> AG_MEM int count(F f) { int n = 0; for (int i = 0; i < NS * 64; i++) n += f(xy[2 * i], xy[2 * i + 1]) ? 1 : 0; return n; }
-  template <class F> AG_MEM int first(F f) { for (int i = 0; i < NS * 64; i++) if (f(xy[2 * i], xy[2 * i + 1])) return i; return -1; }
-#else
-  typedef float XY __attribute__((ext_vector_type(2)));
-  AG_MEM void fetch(XY (&p)[NS]) { auto g = (const AG_GLOBAL XY *)xy; _Pragma("unroll") for (int s = 0; s < NS; s++) p[s] = g[s * 64 + (int)threadIdx.x]; }  // NS x 512 B per wave, all in flight
-  template <class F> AG_MEM unsigned min_bits(F f) { XY p[NS]; fetch(p); unsigned b = 0x7f800000u; _Pragma("unroll") for (int s = 0; s < NS; s++) { unsigned v = (unsigned)f2u(f(p[s].x, p[s].y)); b = v < b ? v : b; } return wred_min(b); }
-  template <class F> AG_MEM int count(F f) { XY p[NS]; fetch(p); int n = 0; _Pragma("unroll") for (int s = 0; s < NS; s++) n += __popcll(__ballot((bool)f(p[s].x, p[s].y))); return n; }
-  template <class F> AG_MEM int first(F f) { XY p[NS]; fetch(p); int r = -1; _Pragma("unroll") for (int s = 0; s < NS; s++) { unsigned long long m = __ballot((bool)f(p[s].x, p[s].y)); if (r < 0 && m) r = s * 64 + ag_first_lane(m); } return r; }
-#endif
-  AG_MEM void swap_pop(int ev, int np) {
-    AG_SERIAL {
-      if (np > 1 && ev < np - 1) { xy[2 * ev] = xy[2 * (np - 1)]; xy[2 * ev + 1] = xy[2 * (np - 1) + 1]; id[ev] = id[np - 1]; }
-      xy[2 * (np - 1)] = AG_PEL_SENTINEL; xy[2 * (np - 1) + 1] = AG_PEL_SENTINEL;
-    }
-    ag_mem_fence();
   }
 };
 
@@ -1392,7 +1403,7 @@ template <int NS, bool AV> AG_DEV int quiet_run(AgCtx<NS, AV> &c, int max_ticks)
   q.tx = PRF(c, PL_TX); q.ty = PRF(c, PL_TY);
   q.ticks = SR(c, AR_TICKS); q.elapsed = PR(c, PL_ELAPSED); q.fcd = PR(c, PL_FEED_CD); q.scd = PR(c, PL_SPLIT_CD);
   q.last_decay = PR(c, PL_LAST_DECAY); q.nvt = PR(c, PL_NVTICKS); q.food_eaten = PR(c, PL_FOOD_EATEN); q.hm = PR(c, PL_HIGHEST_MASS);
-  q.rate = (double)PRF(c, PL_ANTI_TEAM); q.slack = u2f(SR(c, AR_SAFE));
+  q.rate = (double)PRF(c, PL_ANTI_TEAM); q.slack = u2f(SR(c, AR_SAFE)); q.sx0 = PRF(c, PL_SAFE_X); q.sy0 = PRF(c, PL_SAFE_Y);
   RegPel<NS, AV> pel{c};
   quiet_ticks<AV>(q, c.gs->g, g_lut_r(c), g_lut_ms(c), pel, max_ticks);
   if (q.done == 0) return 0;
@@ -1401,7 +1412,7 @@ template <int NS, bool AV> AG_DEV int quiet_run(AgCtx<NS, AV> &c, int max_ticks)
     s.x[0] = q.x; s.y[0] = q.y; s.vx[0] = q.vx; s.vy[0] = q.vy; s.sx[0] = q.svx; s.sy[0] = q.svy;
     s.m[0] = q.m; s.cmc[0] = q.m; s.crad[0] = q.r; s.cms[0] = q.hi;
     P[PL_ELAPSED] = q.elapsed; P[PL_MIN_MASS] = (int)q.m_move; P[PL_HIGHEST_MASS] = q.hm; P[PL_FEED_CD] = q.fcd; P[PL_SPLIT_CD] = q.scd;
-    P[PL_FOOD_EATEN] = q.food_eaten; P[PL_LAST_DECAY] = q.last_decay;
+    P[PL_FOOD_EATEN] = q.food_eaten; P[PL_LAST_DECAY] = q.last_decay; P[PL_SAFE_X] = f2u(q.sx0); P[PL_SAFE_Y] = f2u(q.sy0);
     if (q.last_ev >= 0) evp[0] = q.last_ev;
   }
   SW(c, AR_NEVP, q.last_ev >= 0 ? 1 : 0); SW(c, AR_NEVV, 0); SW(c, AR_NPEL, q.np);
@@ -1460,13 +1471,14 @@ template <int NS, bool AV> AG_DEV int agent_in_order(const AgCtx<NS, AV> &c, int
 }
 // BaseEnvironment::step's result for agent i (BaseEnvironment.hpp:116-121): reward = mass or mass delta (+ c_death
 // when respawned), done flag on agent 0; written as f64 / u8 / i32 and as the packed (reward, done) f32 pair.
+// Lane-level: the caller selects the ONE lane that writes.
 AG_DEV void emit_agent_result(const AgState *gs, int slot, int arena, int na, int i, unsigned m, unsigned before, int respawned, int done) {
   double r = (double)m;
   if (gs->g.reward_type) { float b = (float)before; float sub = b - (float)(respawned ? gs->g.c_death : 0); r -= (double)sub; }
   size_t o = (size_t)arena * na + i;
   auto rw = (AG_GLOBAL double *)gs->rewards; auto ms = (AG_GLOBAL int32_t *)gs->masses; auto dn = (AG_GLOBAL uint8_t *)gs->dones;
   auto pk = (AG_GLOBAL float *)(gs->packed + ((size_t)slot * gs->d.A * na + o) * 2);
-  AG_SERIAL { rw[o] = r; ms[o] = (int)m; dn[o] = (uint8_t)(i == 0 ? done : 0); pk[0] = (float)r; pk[1] = (i == 0 && done) ? 1.0f : 0.0f; }
+  rw[o] = r; ms[o] = (int)m; dn[o] = (uint8_t)(i == 0 ? done : 0); pk[0] = (float)r; pk[1] = (i == 0 && done) ? 1.0f : 0.0f;
 }
 
 // q_done >= 0: the lean kernel (agar_quiet.inl) already did the prologue and the first q_done ticks of this step
@@ -1509,7 +1521,7 @@ template <int NS, bool AV> AG_DEV void env_step(AgCtx<NS, AV> &c, int ticks, boo
     for (int i = 0; i < na; i++) {
       int p = agent_in_order(c, i); unsigned m = p >= 0 ? player_mass(c, p) : 0u;
       if (mode == 3 && m >= 23000u) SW(c, AR_DONE, 1);
-      emit_agent_result(c.gs, c.slot, c.arena, na, i, m, (unsigned)ag_uni(before[i]), SR(c, AR_RESPAWNED), SR(c, AR_DONE));
+      { unsigned b4 = (unsigned)ag_uni(before[i]); int rsp = SR(c, AR_RESPAWNED), dn = SR(c, AR_DONE); AG_SERIAL { emit_agent_result(c.gs, c.slot, c.arena, na, i, m, b4, rsp, dn); } }
     }
   }
 }

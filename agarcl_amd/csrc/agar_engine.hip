@@ -104,7 +104,7 @@ template <int NS, bool AV> __global__ void __launch_bounds__(64) k_step(const Ag
   for (int i = 0; i < AG_NPROF; i++) c.tacc[i] = 0;
   c.tlast = (unsigned)__builtin_readcyclecounter();
 #endif
-  arena_load(c);
+  arena_load(c, use_q != 0);
   AG_T(c, 0);
   env_step(c, ticks, with_env != 0, q_done, q_before);
   AG_T(c, 10);
@@ -114,8 +114,12 @@ template <int NS, bool AV> __global__ void __launch_bounds__(64) k_step(const Ag
   if (threadIdx.x == 0 && gs->prof) for (int i = 0; i < AG_NPROF; i++) gs->prof[(size_t)blockIdx.x * AG_NPROF + i] += c.tacc[i];
 #endif
 }
-template <int NS, bool AV> __global__ void __launch_bounds__(64) k_quiet(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot) {
-  quiet_arena<NS, AV>(gs, (int)blockIdx.x, (const AG_GLOBAL float *)act_dxdy, (const AG_GLOBAL int32_t *)act, ticks, with_env != 0, slot);
+// 256 threads = 16 arenas per workgroup, AG_QG lanes each (agar_quiet.inl)
+template <int NS, bool AV> __global__ void __launch_bounds__(256) k_quiet(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot) {
+  int arena = (int)blockIdx.x * (256 / AG_QG) + (int)threadIdx.x / AG_QG;
+  const int A = gs->d.A; const bool valid = arena < A;
+  if (!valid) arena = A - 1;
+  quiet_arena<NS, AV>(gs, arena, (int)threadIdx.x % AG_QG, valid, (const AG_GLOBAL float *)act_dxdy, (const AG_GLOBAL int32_t *)act, ticks, with_env != 0, slot);
 }
 template <int NS, bool AV> __global__ void __launch_bounds__(64) k_reset(const AgState *__restrict__ gs, const uint8_t *mask, int reset_ids) {
   if (mask && !mask[blockIdx.x]) return;
@@ -144,14 +148,14 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
   const int use_q = e->d.P == 1 && !e->no_front;  // the lean front kernel handles single-player arenas' quiet steps
 #define CALL(N, V) for_each_arena_ns<N, V>(e, [&](AgCtx<N, V> &c) { \
     int qd = -1, qb = 0; \
-    if (use_q) { quiet_arena<N, V>(c.gs, c.arena, c.act_dxdy, c.act, ticks, with_env != 0, c.slot); qd = c.gs->qinfo[2 * c.arena]; qb = c.gs->qinfo[2 * c.arena + 1]; if (qd == ticks) return; } \
+    if (use_q) { quiet_arena<N, V>(c.gs, c.arena, 0, true, c.act_dxdy, c.act, ticks, with_env != 0, c.slot); qd = c.gs->qinfo[2 * c.arena]; qb = c.gs->qinfo[2 * c.arena + 1]; if (qd == ticks) return; } \
     arena_load(c); env_step(c, ticks, with_env != 0, qd, qb); arena_store(c); })
   AG_DISPATCH_NS(e->ns, CALL);
 #undef CALL
 #else
   const int use_q = e->d.P == 1 && !e->no_front;
   if (use_q) {
-#define CALL(N, V) hipLaunchKernelGGL((k_quiet<N, V>), dim3(e->d.A), dim3(64), 0, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot)
+#define CALL(N, V) hipLaunchKernelGGL((k_quiet<N, V>), dim3((e->d.A + 256 / AG_QG - 1) / (256 / AG_QG)), dim3(256), 0, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot)
     AG_DISPATCH_NS(e->ns, CALL);
 #undef CALL
   }
@@ -499,6 +503,11 @@ extern "C" int agarcl_debug_prof(agarcl_env *e, unsigned long long *out16, int r
   if (d2h(h.data(), e->s.prof, h.size() * 8, e->stream)) return AGARCL_E_HIP;
   for (int i = 0; i < 16; i++) { out16[i] = 0; for (int a = 0; a < e->d.A; a++) out16[i] += h[(size_t)a * 16 + i]; }
   if (reset) { std::fill(h.begin(), h.end(), 0ull); if (h2d(e->s.prof, h.data(), h.size() * 8, e->stream)) return AGARCL_E_HIP; }
+  return AGARCL_OK;
+}
+extern "C" int agarcl_debug_prof_raw(agarcl_env *e, unsigned long long *out) {  // [A][16], diagnostic builds
+  if (!e || !out) return AGARCL_E_INVALID;
+  if (d2h(out, e->s.prof, (size_t)e->d.A * 16 * 8, e->stream)) return AGARCL_E_HIP;
   return AGARCL_OK;
 }
 extern "C" int agarcl_num_arenas(agarcl_env *e) { return e ? e->d.A : 0; }

@@ -1,80 +1,142 @@
-// Lean front kernel body: ONE wave per arena, no LDS, no pellet registers -> high occupancy.
+// Lean front kernel body: SIMT style, AG_QG lanes per arena, no LDS, nothing resident -> tiny
+// register footprint, 4 arenas per wavefront.
 //
 // In RL rollouts almost every env step of a single-player arena is "quiet" (see quiet_ticks in agar_core.inl):
-// the whole step touches ~300 bytes of state and now and then scans the pellets.  k_quiet runs first and does
-// the env prologue (take_actions), as many quiet ticks as it can and -- if that was the whole step -- the env
-// epilogue (rewards / dones / packed results).  What it could not finish is left to the general kernel k_step,
-// which runs right after it on the same stream: qinfo[arena] = { ticks already done (or -1: nothing, not even the
-// prologue), agent mass before the step }.  Arenas that are finished make k_step's wave exit on its first load.
-// Single-player envs only (P == 1); with several players k_quiet is never launched.
+// the whole step touches ~300 bytes of state and now and then scans the pellets.  The quiet tick itself is scalar
+// work per arena; on a machine whose scalar unit has no fp32 it has to run on the vector ALU, where a wave-uniform
+// formulation wastes 63 of 64 lanes and -- at 4096 arenas, 4 waves per SIMD -- is bound by VALU issue.  Here every
+// lane of a 16-lane group carries its arena's scalars redundantly (plain per-lane code, identical fp32 sequence),
+// the group's lanes split the pellet scan 16 ways and combine with a 4-step DPP row all-reduce, and only the
+// group's first lane stores.  4096 arenas = 1024 wavefronts = one per SIMD: latency-, not issue-bound.
+//
+// k_quiet runs first and does the env prologue (take_actions), as many quiet ticks as it can and -- if that was
+// the whole step -- the env epilogue (rewards / dones / packed results).  What it could not finish is left to the
+// general kernel k_step, which runs right after it on the same stream: qinfo[arena] = { ticks already done (or
+// -1: nothing, not even the prologue), agent mass before the step }.  Arenas that are finished make k_step's wave
+// exit on its first load.  Single-player envs only (P == 1); with several players k_quiet is never launched.
 #pragma once
-
-// lane k <- src[k * stride] (k < n): one gather load
-#ifdef AGAR_CPU_EMU
-template <class PT> AG_DEV void ub_load_strided(UBlock &b, PT src, int n, int stride) { for (int i = 0; i < 32; i++) b.w[i] = i < n ? (int)src[(size_t)i * stride] : 0; }
-template <class PT> AG_DEV void ub_store_strided(const UBlock &b, PT dst, int n, int stride) { for (int i = 0; i < n; i++) dst[(size_t)i * stride] = (uint32_t)b.w[i]; }
-#else
-template <class PT> AG_DEV void ub_load_strided(UBlock &b, PT src, int n, int stride) { int l = (int)threadIdx.x; b.v = l < n ? (int)src[(size_t)l * stride] : 0; }
-template <class PT> AG_DEV void ub_store_strided(const UBlock &b, PT dst, int n, int stride) { int l = (int)threadIdx.x; if (l < n) dst[(size_t)l * stride] = (uint32_t)b.v; }
+#ifndef AG_QG
+#define AG_QG 16   // lanes per arena (4 arenas per wavefront)
 #endif
 
-template <int NS, bool AV> AG_DEV void quiet_arena(const AgState *gs, int arena, const AG_GLOBAL float *act_dxdy, const AG_GLOBAL int32_t *act, int ticks, bool with_env, int slot) {
-  auto gar = (AG_GLOBAL int32_t *)(gs->ar + (size_t)arena * AR_WORDS);
-  auto gpl = (AG_GLOBAL int32_t *)(gs->pl + (size_t)arena * PL_WORDS);
-  auto gcell = (AG_GLOBAL uint32_t *)(gs->cells + (size_t)arena * (CF_ALL * AG_CC));
-  auto qi = (AG_GLOBAL int32_t *)(gs->qinfo + (size_t)arena * 2);
-  UBlock S, PB, CB;  // arena words, player words, the 12 words of cell 0: three independent loads, one round trip
-  ub_load(S, gar, AR_WORDS);
-  ub_load(PB, gpl, PL_WORDS);
-  ub_load_strided(CB, gcell, CF_ALL, AG_CC);
-  float dx = 0.0f, dy = 0.0f; int action = 0;
-  if (with_env && act) { dx = act_dxdy[2 * (size_t)arena]; dy = act_dxdy[2 * (size_t)arena + 1]; action = act[arena]; }
-  QState q;
-  q.m = (unsigned)ub_get(CB, CF_M);
-  if (ub_get(PB, PL_NCELLS) != 1 || ub_get(S, AR_NFOOD) != 0 || (unsigned)ub_get(CB, CF_CMC) != q.m) { AG_SERIAL { qi[0] = -1; qi[1] = 0; } return; }
-  q.x = u2f(ub_get(CB, CF_X)); q.y = u2f(ub_get(CB, CF_Y));
-  q.action = ub_get(PB, PL_ACTION); q.tx = u2f(ub_get(PB, PL_TX)); q.ty = u2f(ub_get(PB, PL_TY));
-  int done_flag = ub_get(S, AR_DONE), mode = gs->g.mode;
-  unsigned before = q.m;
-  if (with_env) {
-    if (act) {  // take_action with one cell (BaseEnvironment.hpp:162-176, Player.hpp:102-126): mass-weighted centroid in fp32
-      float fm = (float)q.m; float sx = 0.0f, sy = 0.0f; float t = q.x * fm; sx += t; t = q.y * fm; sy += t;
-      float px = ag_divf(sx, fm), py = ag_divf(sy, fm);
-      float ox = dx * 10.0f, oy = dy * 10.0f;
-      q.action = action; q.tx = px + ox; q.ty = py + oy;
-      ub_set(PB, PL_ACTION, action); ub_set(PB, PL_TX, f2u(q.tx)); ub_set(PB, PL_TY, f2u(q.ty));
+// Pellets streamed from HBM / L2.  A pass is a wave-level operation: for every lane group that asks for one, ALL 64
+// lanes read that arena's pellets (NS x 512 B per wave-instruction, every load issued before the first use: one
+// round trip per pass), accumulate lane-private partial results and combine them with DPP reductions.
+template <int NS> struct GrpPel {
+  AG_GLOBAL float *xy; AG_GLOBAL int32_t *id; int sub;
+#ifdef AGAR_CPU_EMU
+  AG_MEM bool lead() const { return true; }
+  AG_MEM bool any(bool p) const { return p; }
+  template <bool AV> AG_MEM PelScan scan(bool need, const PelQuery &k) {
+    PelScan out{3.0e38f, 0, 0, -1};
+    if (!need) return out;
+    unsigned dmin = 0x7f800000u, first = 0xffffffffu; int c0 = 0, c1 = 0;
+    for (int i = 0; i < NS * 64; i++) pel_accumulate<AV>(k, xy[2 * i], xy[2 * i + 1], (unsigned)i, dmin, c0, c1, first);
+    out.dmin2 = u2f((int)dmin); out.cnt = c0; out.cnt1 = c1; out.first = (int)first;
+    return out;
+  }
+#else
+  typedef float XY __attribute__((ext_vector_type(2)));
+  AG_MEM bool lead() const { return sub == 0; }
+  AG_MEM bool any(bool p) const { return __ballot(p) != 0ull; }
+  template <bool AV> AG_MEM PelScan scan(bool need, const PelQuery &k) {
+    PelScan out{3.0e38f, 0, 0, -1};
+    unsigned long long todo = __ballot(need);
+    const int lane = (int)threadIdx.x & 63;
+    while (todo) {
+      const int src = (int)__builtin_ctzll(todo);  // first lane of the first group that still waits
+      todo &= ~((AG_QG == 64 ? ~0ull : ((1ull << (AG_QG & 63)) - 1ull)) << src);
+      PelQuery b;  // that group's query, broadcast to the wave
+      b.x = u2f(__builtin_amdgcn_readlane(f2u(k.x), src)); b.y = u2f(__builtin_amdgcn_readlane(f2u(k.y), src));
+      b.rr = u2f(__builtin_amdgcn_readlane(f2u(k.rr), src)); b.rr1 = u2f(__builtin_amdgcn_readlane(f2u(k.rr1), src));
+      b.gx = __builtin_amdgcn_readlane(k.gx, src); b.gy = __builtin_amdgcn_readlane(k.gy, src);
+      unsigned long long pa = (unsigned long long)(AG_GLOBAL void *)xy;
+      unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)pa, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(pa >> 32), src);
+      auto gp = (const AG_GLOBAL XY *)(((unsigned long long)hi << 32) | lo) + lane;
+      XY p[NS];
+      _Pragma("unroll") for (int s = 0; s < NS; s++) p[s] = gp[s * 64];
+      unsigned dmin = 0x7f800000u, first = 0xffffffffu; int c0 = 0, c1 = 0;
+      _Pragma("unroll") for (int s = 0; s < NS; s++) pel_accumulate<AV>(b, p[s].x, p[s].y, (unsigned)(s * 64 + lane), dmin, c0, c1, first);
+      dmin = wred_min(dmin);
+      if (b.rr >= u2f((int)dmin)) { c0 = wred_add(c0); c1 = wred_add(c1); first = wred_min(first); }  // (uniform branch) only when somebody is in reach
+      if ((lane & ~(AG_QG - 1)) == src) { out.dmin2 = u2f((int)dmin); out.cnt = c0; out.cnt1 = c1; out.first = (int)first; }
     }
-    ub_set(S, AR_RESPAWNED, 0);
-    if (mode == 3 && q.m >= 23000u) { done_flag = 1; ub_set(S, AR_DONE, 1); }
+    return out;
   }
-  q.nv = ub_get(S, AR_NVIR); q.np = ub_get(S, AR_NPEL);
-  q.vx = u2f(ub_get(CB, CF_VX)); q.vy = u2f(ub_get(CB, CF_VY)); q.svx = u2f(ub_get(CB, CF_SX)); q.svy = u2f(ub_get(CB, CF_SY));
-  q.r = u2f(ub_get(CB, CF_CRAD)); q.hi = u2f(ub_get(CB, CF_CMS));
-  q.ticks = ub_get(S, AR_TICKS); q.elapsed = ub_get(PB, PL_ELAPSED); q.fcd = ub_get(PB, PL_FEED_CD); q.scd = ub_get(PB, PL_SPLIT_CD);
-  q.last_decay = ub_get(PB, PL_LAST_DECAY); q.nvt = ub_get(PB, PL_NVTICKS); q.food_eaten = ub_get(PB, PL_FOOD_EATEN); q.hm = ub_get(PB, PL_HIGHEST_MASS);
-  q.rate = (double)u2f(ub_get(PB, PL_ANTI_TEAM)); q.slack = u2f(ub_get(S, AR_SAFE));
-  MemPel<NS> pel{(AG_GLOBAL float *)(gs->pel_xy + (size_t)arena * 2 * (NS * 64)), (AG_GLOBAL int32_t *)(gs->pel_id + (size_t)arena * (NS * 64))};
-  quiet_ticks<AV>(q, gs->g, (const AG_GLOBAL float *)gs->lut_r, (const AG_GLOBAL float *)gs->lut_ms, pel, ticks);
-  if (q.done > 0) {
-    ub_set(CB, CF_X, f2u(q.x)); ub_set(CB, CF_Y, f2u(q.y)); ub_set(CB, CF_VX, f2u(q.vx)); ub_set(CB, CF_VY, f2u(q.vy));
-    ub_set(CB, CF_SX, f2u(q.svx)); ub_set(CB, CF_SY, f2u(q.svy)); ub_set(CB, CF_M, (int)q.m);
-    ub_set(CB, CF_CMC, (int)q.m); ub_set(CB, CF_CRAD, f2u(q.r)); ub_set(CB, CF_CMS, f2u(q.hi));
-    ub_store_strided(CB, gcell, CF_ALL, AG_CC);
-    ub_set(PB, PL_ELAPSED, q.elapsed); ub_set(PB, PL_MIN_MASS, (int)q.m_move); ub_set(PB, PL_HIGHEST_MASS, q.hm);
-    ub_set(PB, PL_FEED_CD, q.fcd); ub_set(PB, PL_SPLIT_CD, q.scd); ub_set(PB, PL_FOOD_EATEN, q.food_eaten); ub_set(PB, PL_LAST_DECAY, q.last_decay);
-    ub_set(S, AR_NEVP, q.last_ev >= 0 ? 1 : 0); ub_set(S, AR_NEVV, 0); ub_set(S, AR_NPEL, q.np);
-    ub_set(S, AR_TICKS, q.ticks); ub_set(S, AR_CLOCK, ub_get(S, AR_CLOCK) + q.done); ub_set(S, AR_SAFE, f2u(q.slack));
-    if (q.last_ev >= 0) { auto ge = (AG_GLOBAL int32_t *)(gs->ev_p + (size_t)arena * AG_EV_CAP); AG_SERIAL { ge[0] = q.last_ev; } }
-    auto cn = (AG_GLOBAL int32_t *)(gs->counts + (size_t)arena * 4);
-    int nv = q.nv, np = q.np;
-    AG_SERIAL { cn[0] = np; cn[1] = nv; cn[2] = 0; cn[3] = 1; }
+#endif
+  AG_MEM void swap_pop(bool doit, int ev, int np) {  // Engine.hpp:1002-1009 for one event
+    if (doit && lead()) {
+      if (np > 1 && ev < np - 1) { xy[2 * ev] = xy[2 * (np - 1)]; xy[2 * ev + 1] = xy[2 * (np - 1) + 1]; id[ev] = id[np - 1]; }
+      xy[2 * (np - 1)] = AG_PEL_SENTINEL; xy[2 * (np - 1) + 1] = AG_PEL_SENTINEL;
+    }
+    if (any(doit)) ag_mem_fence();
   }
-  bool finished = q.done == ticks;
-  if (finished && with_env) {  // epilogue of BaseEnvironment::step for a live single player: no respawn in any mode
-    if (mode == 3 && q.m >= 23000u) { done_flag = 1; ub_set(S, AR_DONE, 1); }
-    emit_agent_result(gs, slot, arena, 1, 0, q.m, before, 0, done_flag);
+};
+
+// `sub` = this lane's index within its arena's lane group (0 in the host emulation, which runs the same text as
+// scalar code); `valid` = false for the padding groups of the last wavefront (they run along but never store).
+template <int NS, bool AV> AG_DEV void quiet_arena(const AgState *gs, int arena, int sub, bool valid, const AG_GLOBAL float *act_dxdy, const AG_GLOBAL int32_t *act, int ticks, bool with_env, int slot) {
+  auto S = (AG_GLOBAL int32_t *)(gs->ar + (size_t)arena * AR_WORDS);
+  auto P = (AG_GLOBAL int32_t *)(gs->pl + (size_t)arena * PL_WORDS);
+  auto C = (AG_GLOBAL uint32_t *)(gs->cells + (size_t)arena * (CF_ALL * AG_CC));   // field f of cell 0 = C[f * AG_CC]
+  auto qi = (AG_GLOBAL int32_t *)(gs->qinfo + (size_t)arena * 2);
+  GrpPel<NS> pel{(AG_GLOBAL float *)(gs->pel_xy + (size_t)arena * 2 * (NS * 64)), (AG_GLOBAL int32_t *)(gs->pel_id + (size_t)arena * (NS * 64)), sub};
+  const bool lead = pel.lead() && valid;
+#if defined(AGAR_PROFILE) && !defined(AGAR_CPU_EMU)
+  unsigned t0_ = (unsigned)__builtin_readcyclecounter(); unsigned long long w0_ = wall_clock64();
+#endif
+  QState q;
+  q.m = C[CF_M * AG_CC];
+  int ncells = P[PL_NCELLS], nfood = S[AR_NFOOD]; unsigned cmc = C[CF_CMC * AG_CC];
+  // everything the step needs, requested up front: one round trip
+  q.x = u2f((int)C[CF_X * AG_CC]); q.y = u2f((int)C[CF_Y * AG_CC]); q.vx = u2f((int)C[CF_VX * AG_CC]); q.vy = u2f((int)C[CF_VY * AG_CC]);
+  q.svx = u2f((int)C[CF_SX * AG_CC]); q.svy = u2f((int)C[CF_SY * AG_CC]); q.r = u2f((int)C[CF_CRAD * AG_CC]); q.hi = u2f((int)C[CF_CMS * AG_CC]);
+  q.action = P[PL_ACTION]; q.tx = u2f(P[PL_TX]); q.ty = u2f(P[PL_TY]);
+  q.elapsed = P[PL_ELAPSED]; q.fcd = P[PL_FEED_CD]; q.scd = P[PL_SPLIT_CD]; q.last_decay = P[PL_LAST_DECAY]; q.nvt = P[PL_NVTICKS];
+  q.food_eaten = P[PL_FOOD_EATEN]; q.hm = P[PL_HIGHEST_MASS]; q.rate = (double)u2f(P[PL_ANTI_TEAM]); q.sx0 = u2f(P[PL_SAFE_X]); q.sy0 = u2f(P[PL_SAFE_Y]);
+  q.nv = S[AR_NVIR]; q.np = S[AR_NPEL]; q.ticks = S[AR_TICKS]; q.slack = u2f(S[AR_SAFE]);
+  int clock = S[AR_CLOCK], done_flag = S[AR_DONE];
+  float dx = 0.0f, dy = 0.0f; int action = 0;
+  const bool acting = with_env && act;
+  if (acting) { dx = act_dxdy[2 * (size_t)arena]; dy = act_dxdy[2 * (size_t)arena + 1]; action = act[arena]; }
+  const bool ok = valid && ncells == 1 && nfood == 0 && cmc == q.m;  // (no early return: the tick loop below is wave-synchronous)
+  const int mode = gs->g.mode;
+  const unsigned before = q.m;
+  if (acting) {  // take_action with one cell (BaseEnvironment.hpp:162-176, Player.hpp:102-126): mass-weighted centroid in fp32
+    float fm = (float)q.m; float sx = 0.0f, sy = 0.0f; float t = q.x * fm; sx += t; t = q.y * fm; sy += t;
+    float px = ag_divf(sx, fm), py = ag_divf(sy, fm);
+    float ox = dx * 10.0f, oy = dy * 10.0f;
+    q.action = action; q.tx = px + ox; q.ty = py + oy;
   }
-  if (q.done > 0 || with_env) { ub_store(PB, gpl, PL_WORDS); ub_store(S, gar, AR_WORDS); }
-  int qd = q.done;
-  AG_SERIAL { qi[0] = qd; qi[1] = (int)before; }
+  if (with_env && mode == 3 && q.m >= 23000u) done_flag = 1;
+#if defined(AGAR_PROFILE) && !defined(AGAR_CPU_EMU)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  unsigned t1_ = (unsigned)__builtin_readcyclecounter();
+#endif
+  quiet_ticks<AV>(q, gs->g, (const AG_GLOBAL float *)gs->lut_r, (const AG_GLOBAL float *)gs->lut_ms, pel, ticks, ok);
+#if defined(AGAR_PROFILE) && !defined(AGAR_CPU_EMU)
+  unsigned t2_ = (unsigned)__builtin_readcyclecounter();
+  if (lead && gs->prof) { gs->prof[(size_t)arena * 16 + 4] = w0_; gs->prof[(size_t)arena * 16 + 5] = wall_clock64(); gs->prof[(size_t)arena * 16 + 0] += t1_ - t0_; gs->prof[(size_t)arena * 16 + 1] += t2_ - t1_; gs->prof[(size_t)arena * 16 + 2] += (unsigned long long)q.done; }
+#endif
+  const bool finished = q.done == ticks;
+  if (finished && with_env && mode == 3 && q.m >= 23000u) done_flag = 1;
+  if (lead && !ok) { qi[0] = -1; qi[1] = 0; }
+  if (lead && ok) {
+    if (q.done > 0) {
+      C[CF_X * AG_CC] = (uint32_t)f2u(q.x); C[CF_Y * AG_CC] = (uint32_t)f2u(q.y); C[CF_VX * AG_CC] = (uint32_t)f2u(q.vx); C[CF_VY * AG_CC] = (uint32_t)f2u(q.vy);
+      C[CF_SX * AG_CC] = (uint32_t)f2u(q.svx); C[CF_SY * AG_CC] = (uint32_t)f2u(q.svy); C[CF_M * AG_CC] = q.m;
+      C[CF_CMC * AG_CC] = q.m; C[CF_CRAD * AG_CC] = (uint32_t)f2u(q.r); C[CF_CMS * AG_CC] = (uint32_t)f2u(q.hi);
+      P[PL_ELAPSED] = q.elapsed; P[PL_MIN_MASS] = (int)q.m_move; P[PL_HIGHEST_MASS] = q.hm; P[PL_FEED_CD] = q.fcd; P[PL_SPLIT_CD] = q.scd;
+      P[PL_FOOD_EATEN] = q.food_eaten; P[PL_LAST_DECAY] = q.last_decay; P[PL_SAFE_X] = f2u(q.sx0); P[PL_SAFE_Y] = f2u(q.sy0);
+      S[AR_NEVP] = q.last_ev >= 0 ? 1 : 0; S[AR_NEVV] = 0; S[AR_NPEL] = q.np; S[AR_TICKS] = q.ticks; S[AR_CLOCK] = clock + q.done; S[AR_SAFE] = f2u(q.slack);
+      if (q.last_ev >= 0) { auto ge = (AG_GLOBAL int32_t *)(gs->ev_p + (size_t)arena * AG_EV_CAP); ge[0] = q.last_ev; }
+      auto cn = (AG_GLOBAL int32_t *)(gs->counts + (size_t)arena * 4);
+      cn[0] = q.np; cn[1] = q.nv; cn[2] = 0; cn[3] = 1;
+    }
+    if (acting) { P[PL_ACTION] = q.action; P[PL_TX] = f2u(q.tx); P[PL_TY] = f2u(q.ty); }
+    if (with_env) { S[AR_RESPAWNED] = 0; S[AR_DONE] = done_flag; }
+    // epilogue of BaseEnvironment::step for a live single player: no respawn in any mode
+    if (finished && with_env) emit_agent_result(gs, slot, arena, 1, 0, q.m, before, 0, done_flag);
+    qi[0] = q.done; qi[1] = (int)before;
+  }
 }

@@ -25,6 +25,7 @@
 enum {
   PL_NCELLS = 0, PL_ACTION, PL_TX, PL_TY, PL_SPLIT_CD, PL_FEED_CD, PL_ELAPSED, PL_LAST_DECAY, PL_ANTI_TEAM,
   PL_FOOD_EATEN, PL_HIGHEST_MASS, PL_CELLS_EATEN, PL_VIRUSES_EATEN, PL_MIN_MASS, PL_NVTICKS, PL_PID, PL_KIND,
+  PL_SAFE_X, PL_SAFE_Y,  // single-player arenas: where the pellet-free disc of radius AR_SAFE was measured (agar_core.inl quiet_ticks)
   PL_WORDS = 20
 };
 // per-arena int32 words ([A][AR_WORDS])
@@ -32,7 +33,7 @@ enum {
   AR_TICKS = 0, AR_CLOCK, AR_IDC, AR_NEXT_PID, AR_NPEL, AR_NVIR, AR_NFOOD, AR_FLAGS, AR_MTIDX,
   AR_NEVP, AR_NEVV, AR_DONE, AR_RESPAWNED, AR_ORDER0 /* AG_MAX_PLAYERS slots: player slots in the engine's iteration order */,
   AR_HM_BUCKETS = AR_ORDER0 + 16, AR_HM_RESIZE,  // rehash-policy state of the players map (survives reset, GameState.hpp:61-67)
-  AR_SAFE,  // f32 bits: proven lower bound on (distance from the single cell to its nearest pellet) - radius; 0 = unknown
+  AR_SAFE,  // f32 bits S: no pellet within S + radius of (PL_SAFE_X, PL_SAFE_Y) of player 0; 0 = unknown
   AR_WORDS = 32
 };
 #define AG_MAX_PLAYERS 16
