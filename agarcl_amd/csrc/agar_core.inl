@@ -576,103 +576,103 @@ AG_DEV float v_direction(float dx, float dy) {  // R: types.hpp:167-174
   return angle;
 }
 
-// pair-level pieces of the self-collision relaxation (lane-level code on LDS cells a, b of `s`)
-AG_DEV void cell_move1(const Cells &s, int k, float dt) {
-  float sx = s.vx[k] + s.sx[k]; float tx = sx * dt; s.x[k] += tx;
-  float sy = s.vy[k] + s.sy[k]; float ty = sy * dt; s.y[k] += ty;
+// pair-level pieces of the self-collision relaxation.  A visit of pair (a, b) reads both cells from LDS ONCE into
+// lane-private registers (CellR), runs the reference's sequence of fp32 operations on them and writes back only what
+// can change (position and velocity): LDS sees 16 reads + 8 writes per visit instead of a round trip per operand.
+struct CellR { float x, y, vx, vy, sx, sy, r; unsigned m; };
+AG_DEV CellR cellr_load(const Cells &s, int k) { CellR c; c.x = s.x[k]; c.y = s.y[k]; c.vx = s.vx[k]; c.vy = s.vy[k]; c.sx = s.sx[k]; c.sy = s.sy[k]; c.r = s.crad[k]; c.m = s.m[k]; return c; }
+AG_DEV void cellr_store(const Cells &s, int k, const CellR &c) { s.x[k] = c.x; s.y[k] = c.y; s.vx[k] = c.vx; s.vy[k] = c.vy; }
+AG_DEV void cell_move1(CellR &c, float dt) {
+  float sx = c.vx + c.sx; float tx = sx * dt; c.x += tx;
+  float sy = c.vy + c.sy; float ty = sy * dt; c.y += ty;
 }
-template <int NS, bool AV> AG_DEV void avoid_static_overlap(const AgCtx<NS, AV> &c, const Cells &s, int a, int b, float W) {  // R: Engine.hpp:701-749
-  float dx = s.x[b] - s.x[a], dy = s.y[b] - s.y[a];
+AG_DEV void avoid_static_overlap(CellR &A, CellR &B, float W) {  // R: Engine.hpp:701-749
+  float dx = B.x - A.x, dy = B.y - A.y;
   float dist = vmag(dx, dy);
-  float ra = cell_rad(c, s, a), rb = cell_rad(c, s, b);
+  float ra = A.r, rb = B.r;
   float target = ra + rb;
   if (dist > target) return;
   float den = fabsf(dx) + fabsf(dy);
   float xr = ag_divf(dx, den), yr = ag_divf(dy, den);
   float depth = target - dist;
   float a1 = 0.5f, a2 = 0.5f, b1 = 0.5f, b2 = 0.5f;
-  if (s.x[a] == ra || s.x[a] == W - ra) { a1 = 1.0f; s.vx[a] = 0; }
-  if (s.y[a] == ra || s.y[a] == W - ra) { a2 = 1.0f; s.vy[a] = 0; }
-  if (s.x[b] == rb || s.x[b] == W - rb) { b1 = 1.0f; s.vx[b] = 0; }
-  if (s.y[b] == rb || s.y[b] == W - rb) { b2 = 1.0f; s.vy[b] = 0; }
+  if (A.x == ra || A.x == W - ra) { a1 = 1.0f; A.vx = 0; }
+  if (A.y == ra || A.y == W - ra) { a2 = 1.0f; A.vy = 0; }
+  if (B.x == rb || B.x == W - rb) { b1 = 1.0f; B.vx = 0; }
+  if (B.y == rb || B.y == W - rb) { b2 = 1.0f; B.vy = 0; }
   float t;
-  t = xr * depth; t = t * a1; s.x[a] -= t;
-  t = yr * depth; t = t * a2; s.y[a] -= t;
-  t = xr * depth; t = t * b1; s.x[b] += t;
-  t = yr * depth; t = t * b2; s.y[b] += t;
-  boundary(W, s.x[a], s.y[a], ra);
-  boundary(W, s.x[b], s.y[b], rb);
+  t = xr * depth; t = t * a1; A.x -= t;
+  t = yr * depth; t = t * a2; A.y -= t;
+  t = xr * depth; t = t * b1; B.x += t;
+  t = yr * depth; t = t * b2; B.y += t;
+  boundary(W, A.x, A.y, ra);
+  boundary(W, B.x, B.y, rb);
 }
-template <int NS, bool AV> AG_DEV void separate_cells(const AgCtx<NS, AV> &c, const Cells &s, int a, int b, float tx, float ty) {  // R: Engine.hpp:803-848
-  float dx = s.x[b] - s.x[a], dy = s.y[b] - s.y[a];
+AG_DEV void separate_cells(CellR &A, CellR &B, float tx, float ty) {  // R: Engine.hpp:803-848
+  float dx = B.x - A.x, dy = B.y - A.y;
   float dist = vmag(dx, dy);
-  float target = cell_rad(c, s, a) + cell_rad(c, s, b);
+  float target = A.r + B.r;
   if (dist > target) return;
   float den = fabsf(dx) + fabsf(dy);
   float xr = ag_divf(dx, den), yr = ag_divf(dy, den);
-  float diff_a = sqr_dist(tx, ty, s.x[a], s.y[a]);
-  float diff_b = sqr_dist(tx, ty, s.x[b], s.y[b]);
+  float diff_a = sqr_dist(tx, ty, A.x, A.y);
+  float diff_b = sqr_dist(tx, ty, B.x, B.y);
   float depth = target - dist;
-  int s1 = s.m[a] < s.m[b] ? 1 : -1;
+  int s1 = A.m < B.m ? 1 : -1;
   int s2 = diff_a >= diff_b ? 1 : -1;
   int sg = (s1 == s2) ? s2 : 0;
-  int tc = s.m[a] < s.m[b] ? a : b;
-  float fs = (float)sg, t;
+  const bool ta = A.m < B.m;  // the lighter cell gives way
+  float fs = (float)sg, t, px = ta ? A.x : B.x, py = ta ? A.y : B.y;
   if (dx >= 0) {
-    t = xr * depth; t = t * fs; s.x[tc] -= t;
-    if (dy >= 0) { t = yr * depth; t = t * fs; s.y[tc] -= t; } else { t = yr * depth; t = t * fs; s.y[tc] += t; }
+    t = xr * depth; t = t * fs; px -= t;
+    if (dy >= 0) { t = yr * depth; t = t * fs; py -= t; } else { t = yr * depth; t = t * fs; py += t; }
   } else {
-    t = xr * depth; t = t * fs; s.x[tc] += t;
-    if (dy >= 0) { t = yr * depth; t = t * fs; s.y[tc] -= t; } else { t = yr * depth; t = t * fs; s.y[tc] += t; }
+    t = xr * depth; t = t * fs; px += t;
+    if (dy >= 0) { t = yr * depth; t = t * fs; py -= t; } else { t = yr * depth; t = t * fs; py += t; }
   }
+  if (ta) { A.x = px; A.y = py; } else { B.x = px; B.y = py; }
 }
-AG_DEV void elastic(const Cells &s, int a, int b, float dx, float dy, float dist) {  // R: Engine.hpp:893-938
+AG_DEV void elastic(CellR &A, CellR &B, float dx, float dy, float dist) {  // R: Engine.hpp:893-938
   float nx = ag_divf(dx, dist), ny = ag_divf(dy, dist);
   float tx = -ny, ty = nx;
-  float p1 = s.vx[a] * nx, p2 = s.vy[a] * ny; float dpN1 = p1 + p2;
-  p1 = s.vx[b] * nx; p2 = s.vy[b] * ny; float dpN2 = p1 + p2;
-  p1 = s.vx[a] * tx; p2 = s.vy[a] * ty; float dpT1 = p1 + p2;
-  p1 = s.vx[b] * tx; p2 = s.vy[b] * ty; float dpT2 = p1 + p2;
-  int m1 = (int)s.m[a], m2 = (int)s.m[b];
+  float p1 = A.vx * nx, p2 = A.vy * ny; float dpN1 = p1 + p2;
+  p1 = B.vx * nx; p2 = B.vy * ny; float dpN2 = p1 + p2;
+  p1 = A.vx * tx; p2 = A.vy * ty; float dpT1 = p1 + p2;
+  p1 = B.vx * tx; p2 = B.vy * ty; float dpT2 = p1 + p2;
+  int m1 = (int)A.m, m2 = (int)B.m;
   float q1 = dpN1 * (float)(m1 - m2);
   float q2 = 2.0f * (float)m2; q2 = q2 * dpN2;
   float v1 = ag_divf(q1 + q2, (float)(m1 + m2));
   q1 = dpN2 * (float)(m2 - m1);
   q2 = 2.0f * (float)m1; q2 = q2 * dpN1;
   float v2 = ag_divf(q1 + q2, (float)(m1 + m2));
-  if (s.m[a] < s.m[b]) {
-    float u = tx * dpT1, w = nx * v1; s.vx[a] = u + w; u = ty * dpT1; w = ny * v1; s.vy[a] = u + w;
-  } else if (s.m[a] > s.m[b]) {
-    float u = tx * dpT2, w = nx * v2; s.vx[b] = u + w; u = ty * dpT2; w = ny * v2; s.vy[b] = u + w;
-  } else {
-    float u = tx * dpT1, w = nx * v1; s.vx[a] = u + w; u = ty * dpT1; w = ny * v1; s.vy[a] = u + w;
-    u = tx * dpT2; w = nx * v2; s.vx[b] = u + w; u = ty * dpT2; w = ny * v2; s.vy[b] = u + w;
-  }
+  if (A.m <= B.m) { float u = tx * dpT1, w = nx * v1; A.vx = u + w; u = ty * dpT1; w = ny * v1; A.vy = u + w; }
+  if (A.m >= B.m) { float u = tx * dpT2, w = nx * v2; B.vx = u + w; u = ty * dpT2; w = ny * v2; B.vy = u + w; }
 }
 template <int NS, bool AV> AG_DEV bool cells_touch(const AgCtx<NS, AV> &c, const Cells &s, int a, int b) {
   return touches(s.x[a], s.y[a], cell_rad(c, s, a), s.x[b], s.y[b], cell_rad(c, s, b));
 }
-template <int NS, bool AV> AG_DEV void prevent_overlap(const AgCtx<NS, AV> &c, const Cells &s, int a, int b, float dt, float tx, float ty, float W) {  // R: Engine.hpp:857-888
-  float dx = s.x[b] - s.x[a], dy = s.y[b] - s.y[a];
+AG_DEV void prevent_overlap(CellR &A, CellR &B, float dt, float tx, float ty, float W) {  // R: Engine.hpp:857-888
+  float dx = B.x - A.x, dy = B.y - A.y;
   float dist = vmag(dx, dy);
-  float ra = cell_rad(c, s, a), rb = cell_rad(c, s, b);
+  float ra = A.r, rb = B.r;
   float target = ra + rb;
   if (dist > target) return;
   float u, t;
-  u = s.vx[a] + s.sx[a]; t = u * dt; s.x[a] -= t;
-  u = s.vy[a] + s.sy[a]; t = u * dt; s.y[a] -= t;
-  u = s.vx[b] + s.sx[b]; t = u * dt; s.x[b] -= t;
-  u = s.vy[b] + s.sy[b]; t = u * dt; s.y[b] -= t;
-  elastic(s, a, b, dx, dy, dist);
-  cell_move1(s, a, dt);
-  cell_move1(s, b, dt);
-  if (touches(s.x[a], s.y[a], ra, s.x[b], s.y[b], rb)) {
-    int d = (int)(s.m[a] - s.m[b]);
-    if ((d < 0 ? -d : d) <= 10) avoid_static_overlap(c, s, a, b, W);
-    else separate_cells(c, s, a, b, tx, ty);
+  u = A.vx + A.sx; t = u * dt; A.x -= t;
+  u = A.vy + A.sy; t = u * dt; A.y -= t;
+  u = B.vx + B.sx; t = u * dt; B.x -= t;
+  u = B.vy + B.sy; t = u * dt; B.y -= t;
+  elastic(A, B, dx, dy, dist);
+  cell_move1(A, dt);
+  cell_move1(B, dt);
+  if (touches(A.x, A.y, ra, B.x, B.y, rb)) {
+    int d = (int)(A.m - B.m);
+    if ((d < 0 ? -d : d) <= 10) avoid_static_overlap(A, B, W);
+    else separate_cells(A, B, tx, ty);
   }
-  boundary(W, s.x[a], s.y[a], ra);
-  boundary(W, s.x[b], s.y[b], rb);
+  boundary(W, A.x, A.y, ra);
+  boundary(W, B.x, B.y, rb);
 }
 // R: Engine.hpp:763-794.  The reference visits pairs (a,b), a<b, in lexicographic order and every visit
 // touches only cells a and b.  Two visits commute unless they share a cell, and every earlier visit
@@ -689,16 +689,29 @@ template <class F> AG_DEV bool pair_levels(int n, F f) {
   return any;
 }
 template <int NS, bool AV> AG_DEV void self_collisions(AgCtx<NS, AV> &c, const Cells &s, int n, float tx, float ty) {
+  // (move_player has just refreshed every cell's radius cache, so s.crad[] is valid for all n cells)
   // wave-parallel any-touch test; when no pair touches the reference's first pass is a no-op
-  bool any = wave_any(n * n, [&](int k) { int a = k / n, b = k - a * n; return a < b && cells_touch(c, s, a, b); });
+  bool any = wave_any(n * n, [&](int k) { int a = k / n, b = k - a * n; return a < b && touches(s.x[a], s.y[a], s.crad[a], s.x[b], s.y[b], s.crad[b]); });
   if (!any) return;
   float dt = c.gs->g.dt, W = c.gs->g.W;
   bool overlap = false;
   for (int iter = 0; iter < 5; iter++) {
-    overlap = pair_levels(n, [&](int a, int b) { if (!cells_touch(c, s, a, b)) return false; prevent_overlap(c, s, a, b, dt, tx, ty, W); return true; });
+    overlap = pair_levels(n, [&](int a, int b) {
+      CellR A = cellr_load(s, a), B = cellr_load(s, b);
+      if (!touches(A.x, A.y, A.r, B.x, B.y, B.r)) return false;
+      prevent_overlap(A, B, dt, tx, ty, W);
+      cellr_store(s, a, A); cellr_store(s, b, B);
+      return true;
+    });
     if (!overlap) break;
   }
-  if (overlap) pair_levels(n, [&](int a, int b) { if (!cells_touch(c, s, a, b)) return false; avoid_static_overlap(c, s, a, b, W); return true; });
+  if (overlap) pair_levels(n, [&](int a, int b) {
+    CellR A = cellr_load(s, a), B = cellr_load(s, b);
+    if (!touches(A.x, A.y, A.r, B.x, B.y, B.r)) return false;
+    avoid_static_overlap(A, B, W);
+    cellr_store(s, a, A); cellr_store(s, b, B);
+    return true;
+  });
 }
 // Kinematics of ONE cell for one tick (Engine::move_player's loop body, Engine.hpp:616-626).  Shared by the
 // lane-parallel general path and the uniform-register quiet path so both execute the same fp32 sequence.

@@ -183,3 +183,32 @@ def golden_files(gpu_capable_only=False):
                 continue
         out.append(p)
     return out
+
+
+def run_quiet_rollout(eng, oras, steps, seeds, rng_seed, check_every=100):
+    """BASELINE C2's policy (action none, a fresh random direction every step) in batched lock-step: per-step
+    rewards and periodic full-state blobs must be identical.  Returns (ok, message or gain count)."""
+    A = len(oras)
+    seeds = np.asarray(seeds, dtype=np.uint32)
+    eng.seed(seeds); eng.reset(reset_ids=True)
+    for o, sd in zip(oras, seeds):
+        o.seed(int(sd)); o.reset(True)
+    rng = np.random.RandomState(rng_seed)
+    act = np.zeros((A, 1), np.int32)
+    gains = 0
+    for t in range(steps):
+        dxdy = rng.uniform(-1, 1, size=(A, 1, 2)).astype(np.float32)
+        eng.set_actions(dxdy, act); eng.step()
+        r = eng.rewards()
+        gains += int((r > 0).sum())
+        for a in range(A):
+            oras[a].take_actions(dxdy[a], act[a])
+            ro = oras[a].step()
+            if r[a, 0] != ro[0]:
+                return False, "step %d arena %d: reward %r vs %r" % (t, a, r[a, 0], ro[0])
+        if t % check_every == check_every - 1 or t == steps - 1:
+            for a in range(A):
+                d = blob.diff(oras[a].dump(), eng.dump(a))
+                if d:
+                    return False, "step %d arena %d: %s" % (t, a, d)
+    return True, gains   # on success: the number of (arena, step) pairs with a mass gain (evidence that pellets were eaten)

@@ -2,7 +2,7 @@
 (tests/emu, test-only) against the oracle in batched lock-step.  The GPU tests repeat this on hardware."""
 import numpy as np
 import pytest
-from lockstep import run_batched_lockstep
+from lockstep import run_batched_lockstep, run_quiet_rollout
 
 CASES = [
     (dict(arena_size=1000, num_pellets=1000, num_viruses=0, mode=0), 300, 4),
@@ -33,3 +33,21 @@ def test_emulated_kernel_logic_matches_oracle(emu_lib, oracle_lib, case):
     oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
     ok, msg = run_batched_lockstep(eng, oras, steps, seeds=np.arange(11, 11 + A), sticky=sticky, every=2)
     assert ok, "%s: %s" % (cfg, msg)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(arena_size=1000, num_pellets=1000, num_viruses=0, mode=0),     # BASELINE C2
+    dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode=0),    # C3 / mode 0
+    dict(arena_size=1400, num_pellets=1500, num_viruses=0, mode=0),     # 3x3 pellet grid: bucket visibility matters (no AV)
+    dict(arena_size=300, num_pellets=400, num_viruses=0, mode=1),       # squared pellets, no regen, no decay
+])
+def test_emulated_quiet_path_long_rollout(emu_lib, oracle_lib, cfg):
+    """The front kernel's logic (agar_quiet.inl + quiet_ticks: pellet-free disc, inline eat / decay, hand-over to the
+    general path) under the C2 policy for 1500 steps."""
+    from agarcl_amd import _capi
+    A = 3
+    eng = _capi.BatchedEngine(A, lib=emu_lib, **cfg)
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    ok, msg = run_quiet_rollout(eng, oras, 1500, 31000 + np.arange(A), rng_seed=17)
+    assert ok, "%s: %s" % (cfg, msg)
+    assert msg > 0    # somebody ate

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from lockstep import EngineAsEnv, golden_files, replay_golden, run_batched_lockstep, policy
+from lockstep import EngineAsEnv, golden_files, replay_golden, run_batched_lockstep, run_quiet_rollout, policy
 
 pytestmark = pytest.mark.gpu
 
@@ -47,6 +47,39 @@ def test_hip_vs_oracle_lockstep(hip_engine_cls, oracle_lib, cfg, steps, sticky):
     ok, msg = run_batched_lockstep(eng, oras, steps, seeds=np.arange(500, 500 + A), sticky=sticky, every=5)
     eng.close()
     assert ok, "%s: %s" % (cfg, msg)
+
+
+@pytest.mark.parametrize("A", [1, 5, 7, 67])
+def test_front_kernel_odd_arena_counts_long_quiet_rollout(hip_engine_cls, oracle_lib, A):
+    """The lean front kernel (agar_quiet.inl) packs 4 arenas per wavefront: arena counts that are not a multiple of
+    4 exercise its padding groups; 1200 steps of the C2 policy (action none, fresh direction every step) exercise
+    the pellet-free-disc rule, inline eats, decay and the hand-over to k_step on regen ticks -- all bit-exact."""
+    eng = hip_engine_cls(A, **C2)
+    oras = [oracle_lib.OraEnv(**C2) for _ in range(A)]
+    ok, msg = run_quiet_rollout(eng, oras, 1200, 20000 + np.arange(A), rng_seed=A)
+    assert ok, msg
+    assert msg > 0      # somebody ate
+    eng.close()
+
+
+def test_front_kernel_on_off_equivalence(hip_engine_cls, monkeypatch):
+    """AGARCL_NO_FRONT=1 (diagnostic switch) runs everything through k_step; results must not depend on it."""
+    A, steps = 64, 300
+    outs = []
+    for nf in ("0", "1"):
+        monkeypatch.setenv("AGARCL_NO_FRONT", nf)
+        eng = hip_engine_cls(A, **C3)
+        eng.seed(None, 4242); eng.reset(reset_ids=True)
+        rng = np.random.RandomState(5)
+        rs = []
+        for t in range(steps):
+            eng.set_actions(rng.uniform(-1, 1, size=(A, 1, 2)).astype(np.float32), rng.randint(0, 3, size=(A, 1)).astype(np.int32))
+            eng.step(); rs.append(eng.rewards().copy())
+        outs.append((np.array(rs), [eng.dump(a) for a in range(A)], eng.dones().copy()))
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][2], outs[1][2])
+    for b0, b1 in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(b0, b1)
 
 
 def test_masked_reset_and_reseed(hip_engine_cls, oracle_lib):
