@@ -608,30 +608,6 @@ AG_DEV void avoid_static_overlap(CellR &A, CellR &B, float W) {  // R: Engine.hp
   boundary(W, A.x, A.y, ra);
   boundary(W, B.x, B.y, rb);
 }
-AG_DEV void separate_cells(CellR &A, CellR &B, float tx, float ty) {  // R: Engine.hpp:803-848
-  float dx = B.x - A.x, dy = B.y - A.y;
-  float dist = vmag(dx, dy);
-  float target = A.r + B.r;
-  if (dist > target) return;
-  float den = fabsf(dx) + fabsf(dy);
-  float xr = ag_divf(dx, den), yr = ag_divf(dy, den);
-  float diff_a = sqr_dist(tx, ty, A.x, A.y);
-  float diff_b = sqr_dist(tx, ty, B.x, B.y);
-  float depth = target - dist;
-  int s1 = A.m < B.m ? 1 : -1;
-  int s2 = diff_a >= diff_b ? 1 : -1;
-  int sg = (s1 == s2) ? s2 : 0;
-  const bool ta = A.m < B.m;  // the lighter cell gives way
-  float fs = (float)sg, t, px = ta ? A.x : B.x, py = ta ? A.y : B.y;
-  if (dx >= 0) {
-    t = xr * depth; t = t * fs; px -= t;
-    if (dy >= 0) { t = yr * depth; t = t * fs; py -= t; } else { t = yr * depth; t = t * fs; py += t; }
-  } else {
-    t = xr * depth; t = t * fs; px += t;
-    if (dy >= 0) { t = yr * depth; t = t * fs; py -= t; } else { t = yr * depth; t = t * fs; py += t; }
-  }
-  if (ta) { A.x = px; A.y = py; } else { B.x = px; B.y = py; }
-}
 AG_DEV void elastic(CellR &A, CellR &B, float dx, float dy, float dist) {  // R: Engine.hpp:893-938
   float nx = ag_divf(dx, dist), ny = ag_divf(dy, dist);
   float tx = -ny, ty = nx;
@@ -652,6 +628,46 @@ AG_DEV void elastic(CellR &A, CellR &B, float dx, float dy, float dist) {  // R:
 template <int NS, bool AV> AG_DEV bool cells_touch(const AgCtx<NS, AV> &c, const Cells &s, int a, int b) {
   return touches(s.x[a], s.y[a], cell_rad(c, s, a), s.x[b], s.y[b], cell_rad(c, s, b));
 }
+// avoid_static_overlap (small == true) or separate_cells (small == false) in one body: both start with the same
+// distance / direction / depth computation (one sqrt, two divides), which lanes taking different branches would
+// otherwise execute twice.  Same operations in the same order as the two functions above.
+AG_DEV void resolve_overlap(CellR &A, CellR &B, bool small, float tx, float ty, float W) {
+  float dx = B.x - A.x, dy = B.y - A.y;
+  float dist = vmag(dx, dy);
+  float ra = A.r, rb = B.r;
+  float target = ra + rb;
+  if (dist > target) return;
+  float den = fabsf(dx) + fabsf(dy);
+  float xr = ag_divf(dx, den), yr = ag_divf(dy, den);
+  float depth = target - dist;
+  float xd = xr * depth, yd = yr * depth;
+  if (small) {  // R: Engine.hpp:701-749
+    float a1 = 0.5f, a2 = 0.5f, b1 = 0.5f, b2 = 0.5f;
+    if (A.x == ra || A.x == W - ra) { a1 = 1.0f; A.vx = 0; }
+    if (A.y == ra || A.y == W - ra) { a2 = 1.0f; A.vy = 0; }
+    if (B.x == rb || B.x == W - rb) { b1 = 1.0f; B.vx = 0; }
+    if (B.y == rb || B.y == W - rb) { b2 = 1.0f; B.vy = 0; }
+    float t;
+    t = xd * a1; A.x -= t;
+    t = yd * a2; A.y -= t;
+    t = xd * b1; B.x += t;
+    t = yd * b2; B.y += t;
+    boundary(W, A.x, A.y, ra);
+    boundary(W, B.x, B.y, rb);
+  } else {      // R: Engine.hpp:803-848
+    float diff_a = sqr_dist(tx, ty, A.x, A.y);
+    float diff_b = sqr_dist(tx, ty, B.x, B.y);
+    int s1 = A.m < B.m ? 1 : -1;
+    int s2 = diff_a >= diff_b ? 1 : -1;
+    int sg = (s1 == s2) ? s2 : 0;
+    const bool ta = A.m < B.m;  // the lighter cell gives way
+    float fs = (float)sg, px = ta ? A.x : B.x, py = ta ? A.y : B.y;
+    float tx_ = xd * fs, ty_ = yd * fs;
+    if (dx >= 0) px -= tx_; else px += tx_;
+    if (dy >= 0) py -= ty_; else py += ty_;
+    if (ta) { A.x = px; A.y = py; } else { B.x = px; B.y = py; }
+  }
+}
 AG_DEV void prevent_overlap(CellR &A, CellR &B, float dt, float tx, float ty, float W) {  // R: Engine.hpp:857-888
   float dx = B.x - A.x, dy = B.y - A.y;
   float dist = vmag(dx, dy);
@@ -668,50 +684,40 @@ AG_DEV void prevent_overlap(CellR &A, CellR &B, float dt, float tx, float ty, fl
   cell_move1(B, dt);
   if (touches(A.x, A.y, ra, B.x, B.y, rb)) {
     int d = (int)(A.m - B.m);
-    if ((d < 0 ? -d : d) <= 10) avoid_static_overlap(A, B, W);
-    else separate_cells(A, B, tx, ty);
+    resolve_overlap(A, B, (d < 0 ? -d : d) <= 10, tx, ty, W);
   }
   boundary(W, A.x, A.y, ra);
   boundary(W, B.x, B.y, rb);
 }
-// R: Engine.hpp:763-794.  The reference visits pairs (a,b), a<b, in lexicographic order and every visit
-// touches only cells a and b.  Two visits commute unless they share a cell, and every earlier visit
-// sharing a cell with (a,b) has a smaller a+b; so all pairs with equal a+b are independent and the
-// passes run as 2n-3 "anti-diagonal" levels, one pair per lane -- same result as the sequential sweep.
-template <class F> AG_DEV bool pair_levels(int n, F f) {
-  bool any = false;
-  for (int L = 1; L <= 2 * n - 3; L++) {
-    int a0 = L - (n - 1) > 0 ? L - (n - 1) : 0;
-    int a1 = (L - 1) / 2;  // a < b = L - a  <=>  a <= (L-1)/2
-    any = wave_any(a1 - a0 + 1, [&](int j) { int a = a0 + j; return f(a, L - a); }) || any;
-    ag_lds_order();
-  }
-  return any;
-}
+// R: Engine.hpp:763-794.  The reference makes up to 5 sweeps over the pairs (a,b), a<b, in lexicographic order
+// (prevent_overlap on touching pairs; stop after a sweep in which nothing touched) and, if the 5th still found an
+// overlap, a 6th sweep of avoid_static_overlap.  Every visit touches only cells a and b.  Two visits commute unless
+// they share a cell, and every earlier visit sharing a cell with (a,b) has a smaller a+b; so all pairs with equal
+// a+b are independent and a sweep runs as 2n-3 "anti-diagonal" levels, one pair per lane -- same result as the
+// sequential sweep.  (Overlapping consecutive sweeps, n levels apart, is also valid and was measured: fewer, fatter
+// steps, but slower on this kernel.)
 template <int NS, bool AV> AG_DEV void self_collisions(AgCtx<NS, AV> &c, const Cells &s, int n, float tx, float ty) {
   // (move_player has just refreshed every cell's radius cache, so s.crad[] is valid for all n cells)
-  // wave-parallel any-touch test; when no pair touches the reference's first pass is a no-op
+  // wave-parallel any-touch test; when no pair touches the reference's first sweep is a no-op
   bool any = wave_any(n * n, [&](int k) { int a = k / n, b = k - a * n; return a < b && touches(s.x[a], s.y[a], s.crad[a], s.x[b], s.y[b], s.crad[b]); });
   if (!any) return;
-  float dt = c.gs->g.dt, W = c.gs->g.W;
-  bool overlap = false;
-  for (int iter = 0; iter < 5; iter++) {
-    overlap = pair_levels(n, [&](int a, int b) {
-      CellR A = cellr_load(s, a), B = cellr_load(s, b);
-      if (!touches(A.x, A.y, A.r, B.x, B.y, B.r)) return false;
-      prevent_overlap(A, B, dt, tx, ty, W);
-      cellr_store(s, a, A); cellr_store(s, b, B);
-      return true;
-    });
+  const float dt = c.gs->g.dt, W = c.gs->g.W;
+  for (int iter = 0; iter < 6; iter++) {  // sweeps 0-4: prevent_overlap; sweep 5: avoid_static_overlap
+    bool overlap = false;
+    for (int L = 1; L <= 2 * n - 3; L++) {
+      const int a0 = L - (n - 1) > 0 ? L - (n - 1) : 0, a1 = (L - 1) / 2;  // a < b = L - a  <=>  a <= (L-1)/2
+      overlap = wave_any(a1 - a0 + 1, [&](int j) {
+        const int a = a0 + j, b = L - a;
+        CellR A = cellr_load(s, a), B = cellr_load(s, b);
+        if (!touches(A.x, A.y, A.r, B.x, B.y, B.r)) return false;
+        if (iter < 5) prevent_overlap(A, B, dt, tx, ty, W); else avoid_static_overlap(A, B, W);
+        cellr_store(s, a, A); cellr_store(s, b, B);
+        return true;
+      }) || overlap;
+      ag_lds_order();
+    }
     if (!overlap) break;
   }
-  if (overlap) pair_levels(n, [&](int a, int b) {
-    CellR A = cellr_load(s, a), B = cellr_load(s, b);
-    if (!touches(A.x, A.y, A.r, B.x, B.y, B.r)) return false;
-    avoid_static_overlap(A, B, W);
-    cellr_store(s, a, A); cellr_store(s, b, B);
-    return true;
-  });
 }
 // Kinematics of ONE cell for one tick (Engine::move_player's loop body, Engine.hpp:616-626).  Shared by the
 // lane-parallel general path and the uniform-register quiet path so both execute the same fp32 sequence.
