@@ -63,6 +63,10 @@ SYMBOLS = [
     ("agarcl_grid_obs", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     ("agarcl_dump_arena", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     ("agarcl_load_arena", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
+    ("agarcl_adopt_arena", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
+    ("agarcl_seed_arena", C.c_int, [C.c_void_p, C.c_int32, C.c_uint32]),
+    ("agarcl_get_seeds", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("agarcl_get_arena_words", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     ("agarcl_num_arenas", C.c_int, [C.c_void_p]),
     ("agarcl_players_per_arena", C.c_int, [C.c_void_p]),
     ("agarcl_state_bytes", C.c_int64, [C.c_void_p]),
@@ -228,6 +232,26 @@ class BatchedEngine:
 
     def last_slot(self):
         return int(self.L.agarcl_last_slot(self.h))
+
+    # -- snapshots (agarcl_amd/snapshot.py builds / parses the reference's JSON) -----------------
+    def adopt(self, arena, blob, kinds, hm_buckets, hm_next_resize):
+        blob = np.ascontiguousarray(blob, dtype=np.uint32); kinds = np.ascontiguousarray(kinds, dtype=np.int32)
+        self._chk(self.L.agarcl_adopt_arena(self.h, arena, _ptr(blob), len(blob), _ptr(kinds), hm_buckets, hm_next_resize))
+
+    def seed_arena(self, arena, seed):
+        self._chk(self.L.agarcl_seed_arena(self.h, arena, int(seed) & 0xFFFFFFFF))
+
+    def seeds(self):
+        out = np.zeros(self.num_arenas, dtype=np.uint32)
+        self._chk(self.L.agarcl_get_seeds(self.h, _ptr(out)))
+        return out
+
+    def arena_words(self, arena):
+        """(ar i32[32], pl i32[players][20]) raw words of one arena (agar_types.h AR_* / PL_*)."""
+        P = int(self.L.agarcl_players_per_arena(self.h))
+        ar = np.zeros(32, dtype=np.int32); pl = np.zeros((P, 20), dtype=np.int32)
+        self._chk(self.L.agarcl_get_arena_words(self.h, arena, _ptr(ar), _ptr(pl)))
+        return ar, pl
 
     def state_bytes(self):
         return int(self.L.agarcl_state_bytes(self.h))

@@ -7,7 +7,7 @@ Errors follow the reference: every failure is a RuntimeError (AgarclError subcla
 """
 import numpy as np
 
-from . import _capi
+from . import _capi, snapshot
 
 # the OpenGL ScreenEnvironment is outside the hot path
 has_screen_env = False
@@ -21,6 +21,11 @@ class _Environment:
     def __init__(self, num_agents, ticks_per_step, arena_size, pellet_regen, num_pellets, num_viruses, num_bots,
                  reward_type, c_death=0, mode_number=0, device=0):
         self._num_agents = int(num_agents)
+        self._cfg = dict(num_agents=int(num_agents), ticks_per_step=int(ticks_per_step), arena_size=int(arena_size), num_bots=int(num_bots),
+                         reward_type=bool(reward_type), c_death=int(c_death), pellet_regen=bool(pellet_regen),
+                         mode_number=0)   # Engine::mode_number as the reference's writer sees it: see snapshot.blob_to_json
+        self._loaded = False             # BaseEnvironment::is_loading_env_state
+        self._names = None               # player names in iteration order once a snapshot has been loaded
         self._engine = _capi.BatchedEngine(1, int(num_agents), int(ticks_per_step), int(arena_size), bool(pellet_regen),
                                            int(num_pellets), int(num_viruses), int(num_bots), int(bool(reward_type)) if isinstance(reward_type, bool) else int(reward_type),
                                            int(c_death), int(mode_number), device=device, lib=_LIB)
@@ -29,6 +34,8 @@ class _Environment:
         self._engine.seed(np.asarray([int(s) & 0xFFFFFFFF], dtype=np.uint32))
 
     def reset(self):                         # bindings.cpp:130
+        if self._loaded:                     # BaseEnvironment.hpp:180-181: reset() is a no-op once a snapshot was loaded
+            return
         self._engine.reset(reset_ids=False)
 
     def take_actions(self, actions):         # bindings.cpp:50-64,117-119
@@ -52,12 +59,25 @@ class _Environment:
     def close(self):
         self._engine.close()
 
-    def save_env_state(self, path):
-        """Binary state blob (oracle/BLOB_FORMAT.md) instead of the reference's JSON."""
-        np.save(path, self._engine.dump(0))
+    def save_env_state(self, path):          # bindings.cpp:131 -> BaseEnvironment.hpp:213-310: the reference's JSON
+        snap = snapshot.save_arena(self._engine, 0, self._cfg, names=self._names)
+        try:
+            with open(path, "w") as f:
+                f.write(snapshot.dumps(snap))
+        except OSError:
+            raise RuntimeError("Failed to open %s for writing" % path)   # BaseEnvironment.hpp:304-306
 
-    def load_env_state(self, path):
-        self._engine.load(np.load(path), 0)
+    def load_env_state(self, path):          # bindings.cpp:170,372 -> BaseEnvironment.hpp:312-343, Engine.hpp:247-348
+        import json
+        try:
+            with open(path) as f:
+                snap = json.load(f)
+        except OSError:
+            raise RuntimeError("Failed to open %s for reading" % path)   # Engine.hpp:255-257
+        # ids continue from the arena's counter, like the reference's process-global counter does
+        self._names = snapshot.load_arena(self._engine, 0, snap, reset_ids=False)
+        self._cfg["mode_number"] = int(snap["mode_number"])              # Engine.hpp:263
+        self._loaded = True
 
 
 class GridEnvironment(_Environment):

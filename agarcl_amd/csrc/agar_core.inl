@@ -1250,9 +1250,12 @@ template <int NS, bool AV> AG_DEV void sort_cells_by_id(AgCtx<NS, AV> &c, int p)
   bool unsorted = wave_any(n - 1, [&](int i) { return s.id[i] > s.id[i + 1]; });
   if (!unsorted) return;
   Cells t = created_of(c);
-  AG_LANES(i, n) {  // rank sort through the created-cell buffer
+  // Rank sort through the created-cell buffer.  Ids are unique in a game that started with reset(); after a snapshot
+  // load cells keep their saved ids while the counter restarts (Engine.hpp:304-311), so new cells can DUPLICATE an id:
+  // ties keep their order, as libstdc++'s std::sort does for the <= 16 cells a player can have (pure insertion sort).
+  AG_LANES(i, n) {
     int id = s.id[i], r = 0;
-    for (int j = 0; j < n; j++) r += s.id[j] < id ? 1 : 0;
+    for (int j = 0; j < n; j++) r += (s.id[j] < id || (s.id[j] == id && j < i)) ? 1 : 0;
     t.x[r] = s.x[i]; t.y[r] = s.y[i]; t.vx[r] = s.vx[i]; t.vy[r] = s.vy[i]; t.sx[r] = s.sx[i]; t.sy[r] = s.sy[i];
     t.m[r] = s.m[i]; t.id[r] = id; t.dl[r] = s.dl[i];
   }

@@ -62,6 +62,7 @@ struct agarcl_env {
   float *d_act_dxdy; int32_t *d_act;  // env-owned action buffers (host-copy path)
   float *lut_r, *lut_ms, *lut_ss, *lut_anti;
   int32_t *obs_buf; size_t obs_cap;  // staging for host-side grid observations
+  std::vector<uint32_t> seeds;  // last seed of every arena (BaseEnvironment::seed_, written into JSON snapshots)
   bool no_front;  // AGARCL_NO_FRONT=1 in the environment: skip k_quiet (diagnostics / A-B timing only)
 };
 
@@ -379,6 +380,8 @@ extern "C" int agarcl_sync(agarcl_env *e) {
 extern "C" int agarcl_seed(agarcl_env *e, const uint32_t *seeds_host, uint32_t base_seed) {
   if (!e) return fail(AGARCL_E_INVALID, "null env");
   size_t A = (size_t)e->d.A;
+  e->seeds.resize(A);
+  for (size_t a = 0; a < A; a++) e->seeds[a] = seeds_host ? seeds_host[a] : base_seed + (uint32_t)a;
   std::vector<uint64_t> mt(A * 312);
   for (size_t a = 0; a < A; a++) mt_seed_host(&mt[a * 312], (uint64_t)(seeds_host ? seeds_host[a] : base_seed + (uint32_t)a));
   if (h2d(e->s.mt, mt.data(), mt.size() * 8, e->stream)) return fail(AGARCL_E_HIP, "seed upload failed");
@@ -392,6 +395,31 @@ extern "C" int agarcl_seed(agarcl_env *e, const uint32_t *seeds_host, uint32_t b
   hipLaunchKernelGGL(k_set_word, dim3((e->d.A + 255) / 256), dim3(256), 0, e->stream, e->s.ar + AR_MTIDX, AR_WORDS, e->d.A, 312);
   HIPCHK(hipGetLastError());
 #endif
+  return AGARCL_OK;
+}
+
+// Engine::seed for ONE arena (Engine.hpp:242-245): used by snapshot loading, which ends with seed(json["seed"]).
+extern "C" int agarcl_seed_arena(agarcl_env *e, int32_t arena, uint32_t seed) {
+  if (!e || arena < 0 || arena >= e->d.A) return fail(AGARCL_E_INVALID, "agarcl_seed_arena: bad arguments");
+  std::vector<uint64_t> mt(312); mt_seed_host(mt.data(), (uint64_t)seed);
+  std::vector<int32_t> rnd(35); glibc_srand_host(rnd.data(), seed);
+  int32_t idx = 312;
+  if (h2d(e->s.mt + (size_t)arena * 312, mt.data(), 312 * 8, e->stream) || h2d(e->s.rnd + (size_t)arena * 35, rnd.data(), 35 * 4, e->stream) ||
+      h2d(e->s.ar + (size_t)arena * AR_WORDS + AR_MTIDX, &idx, 4, e->stream)) return fail(AGARCL_E_HIP, "seed upload failed");
+  // (BaseEnvironment::seed_ -- what a later save writes as "seed" -- is NOT touched by a load: Engine::seed is called
+  // directly, Engine.hpp:347; e->seeds therefore keeps the last agarcl_seed value)
+  return AGARCL_OK;
+}
+extern "C" int agarcl_get_seeds(agarcl_env *e, uint32_t *out) {
+  if (!e || !out) return fail(AGARCL_E_INVALID, "agarcl_get_seeds: null pointer");
+  for (int a = 0; a < e->d.A; a++) out[a] = (size_t)a < e->seeds.size() ? e->seeds[(size_t)a] : 0u;
+  return AGARCL_OK;
+}
+// Raw per-arena words (AR_*) and per-player words (PL_*, slot-major): introspection for the snapshot code and tests.
+extern "C" int agarcl_get_arena_words(agarcl_env *e, int32_t arena, int32_t *ar_out, int32_t *pl_out) {
+  if (!e || arena < 0 || arena >= e->d.A) return fail(AGARCL_E_INVALID, "agarcl_get_arena_words: bad arguments");
+  if (ar_out && d2h(ar_out, e->s.ar + (size_t)arena * AR_WORDS, AR_WORDS * 4, e->stream)) return fail(AGARCL_E_HIP, "copy failed");
+  if (pl_out && d2h(pl_out, e->s.pl + (size_t)arena * e->d.P * PL_WORDS, (size_t)e->d.P * PL_WORDS * 4, e->stream)) return fail(AGARCL_E_HIP, "copy failed");
   return AGARCL_OK;
 }
 
@@ -568,7 +596,11 @@ extern "C" int agarcl_dump_arena(agarcl_env *e, int32_t arena, uint32_t *buf, in
   return (int)o.size();
 }
 
-extern "C" int agarcl_load_arena(agarcl_env *e, int32_t arena, const uint32_t *b, int32_t words) {
+// kinds == nullptr: the blob's players must be the arena's players (same pids, same iteration order).
+// kinds != nullptr ("adopt"): the blob brings a NEW player set, as Engine::load_env_state creates one -- players in the
+// map's iteration order with fresh pids; kinds[k] = AG_KIND_* of the k-th blob player.  Non-bots take slots 0.. in that
+// order (BaseEnvironment::load_env_state rebuilds pids_ from the map, BaseEnvironment.hpp:324-335), bots follow.
+static int load_arena_impl(agarcl_env *e, int32_t arena, const uint32_t *b, int32_t words, const int32_t *kinds, int hm_buckets, int hm_next_resize) {
   if (!e || !b || arena < 0 || arena >= e->d.A || words < 8 || b[0] != 0x31524741u) return fail(AGARCL_E_INVALID, "agarcl_load_arena: bad arguments");
   const AgDims &d = e->d; const AgState &s = e->s; size_t a = (size_t)arena; ArenaHost h;
   uint32_t np = b[4], nv = b[5], nf = b[6], npl = b[7];
@@ -591,9 +623,18 @@ extern "C" int agarcl_load_arena(agarcl_env *e, int32_t arena, const uint32_t *b
   size_t nc = (size_t)d.P * CF_ALL * AG_CC;
   h.cells.assign(nc, 0);  // cache words 0 => invalid (no cell has mass 0): the first tick refreshes it
   uint32_t clock = (uint32_t)h.ar[AR_CLOCK];
+  if (kinds) {
+    int nonbots = 0; for (int k = 0; k < d.P; k++) nonbots += kinds[k] == 0;
+    if (nonbots != d.n_agents) return fail(AGARCL_E_INVALID, "agarcl_adopt_arena: number of non-bot players differs from num_agents");
+    int next_agent = 0, next_bot = d.n_agents;
+    for (int k = 0; k < d.P; k++) h.ar[AR_ORDER0 + k] = kinds[k] == 0 ? next_agent++ : next_bot++;
+    h.ar[AR_HM_BUCKETS] = hm_buckets; h.ar[AR_HM_RESIZE] = hm_next_resize;
+    h.ar[AR_DONE] = 0; h.ar[AR_RESPAWNED] = 0; h.ar[AR_FLAGS] = 0; h.ar[AR_NEVP] = 0; h.ar[AR_NEVV] = 0;
+  }
   for (int k = 0; k < d.P; k++) {
     int slot = h.ar[AR_ORDER0 + k]; int32_t *P = &h.pl[(size_t)slot * PL_WORDS];
-    if ((int32_t)p[0] != P[PL_PID]) return fail(AGARCL_E_INVALID, "agarcl_load_arena: pid / iteration order mismatch");
+    if (kinds) { for (int w = 0; w < PL_WORDS; w++) P[w] = 0; P[PL_PID] = (int32_t)p[0]; P[PL_KIND] = kinds[k]; }
+    else if ((int32_t)p[0] != P[PL_PID]) return fail(AGARCL_E_INVALID, "agarcl_load_arena: pid / iteration order mismatch");
     uint32_t ncell = p[2];
     if ((int)ncell > AG_CC) return fail(AGARCL_E_CAPACITY, "agarcl_load_arena: too many cells");
     P[PL_NCELLS] = (int32_t)ncell; P[PL_ACTION] = (int32_t)p[3]; P[PL_TX] = (int32_t)p[4]; P[PL_TY] = (int32_t)p[5]; P[PL_SPLIT_CD] = (int32_t)p[6]; P[PL_FEED_CD] = (int32_t)p[7];
@@ -619,6 +660,11 @@ extern "C" int agarcl_load_arena(agarcl_env *e, int32_t arena, const uint32_t *b
   rc |= push(e, h.fx, s.food_x, a * d.FC); rc |= push(e, h.fy, s.food_y, a * d.FC); rc |= push(e, h.fvx, s.food_vx, a * d.FC); rc |= push(e, h.fvy, s.food_vy, a * d.FC); rc |= push(e, h.fid, s.food_id, a * d.FC);
   rc |= push(e, h.cells, s.cells, a * nc);
   return rc ? fail(AGARCL_E_HIP, "upload failed") : AGARCL_OK;
+}
+extern "C" int agarcl_load_arena(agarcl_env *e, int32_t arena, const uint32_t *b, int32_t words) { return load_arena_impl(e, arena, b, words, nullptr, 0, 0); }
+extern "C" int agarcl_adopt_arena(agarcl_env *e, int32_t arena, const uint32_t *b, int32_t words, const int32_t *kinds, int32_t hm_buckets, int32_t hm_next_resize) {
+  if (!kinds) return fail(AGARCL_E_INVALID, "agarcl_adopt_arena: kinds is null");
+  return load_arena_impl(e, arena, b, words, kinds, hm_buckets, hm_next_resize);
 }
 
 extern "C" int64_t agarcl_state_bytes(agarcl_env *e) {

@@ -135,6 +135,24 @@ int agarcl_grid_obs(agarcl_env *env, int32_t grid_size, int32_t observe_cells, i
 int agarcl_dump_arena(agarcl_env *env, int32_t arena, uint32_t *buf_host, int32_t cap_words);
 int agarcl_load_arena(agarcl_env *env, int32_t arena, const uint32_t *blob_host, int32_t words);
 
+/* ---- snapshots.  The reference's wire format is JSON written by BaseEnvironment::save_env_state
+ * (environment/envs/BaseEnvironment.hpp:213-310) and read by Engine::load_env_state (agario/engine/Engine.hpp:247-348)
+ * + BaseEnvironment::load_env_state (:312-343).  The JSON text is produced / parsed on the host side above this ABI
+ * (agarcl_amd/snapshot.py); these entry points move the state in and out of HBM. ----------------------------------- */
+/* Loading a snapshot replaces the arena's player set (fresh pids 0..P-1 in file order, Engine.hpp:266-283): the blob
+ * lists the players in the NEW map iteration order; kinds[k] (0 agent, 1 Hungry, 2 HungryShy, 3 Aggressive,
+ * 4 AggressiveShy: the bot classes of agario/bots) describes the k-th of them; hm_* is the state of the players map
+ * after the inserts (libstdc++ bucket count / next resize, kept across clear()).  Non-bot players become agents
+ * 0,1,.. in map order (BaseEnvironment.hpp:324-335). */
+int agarcl_adopt_arena(agarcl_env *env, int32_t arena, const uint32_t *blob_host, int32_t words, const int32_t *kinds,
+                       int32_t hm_buckets, int32_t hm_next_resize);
+/* Engine::seed(s) for one arena (Engine.hpp:242-245): load_env_state ends with seed(json["seed"]) (:347) */
+int agarcl_seed_arena(agarcl_env *env, int32_t arena, uint32_t seed);
+/* last seed of every arena, u32[num_arenas] (BaseEnvironment::seed_, the "seed" field of a snapshot, :225) */
+int agarcl_get_seeds(agarcl_env *env, uint32_t *out_host);
+/* raw words of one arena: ar_out i32[32] (agar_types.h AR_*), pl_out i32[players][20] (PL_*, slot-major); either may be NULL */
+int agarcl_get_arena_words(agarcl_env *env, int32_t arena, int32_t *ar_out, int32_t *pl_out);
+
 /* introspection */
 int agarcl_num_arenas(agarcl_env *env);
 int agarcl_players_per_arena(agarcl_env *env);

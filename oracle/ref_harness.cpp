@@ -333,6 +333,26 @@ int ref_load(void *h, const uint32_t *b, int words) {
   return 0;
 }
 
+// ---- JSON snapshots: the reference's own save_env_state / load_env_state ---------
+// (environment/envs/BaseEnvironment.hpp:213-343, agario/engine/Engine.hpp:247-348)
+int ref_env_save_json(void *h, const char *path) {
+  auto *e = (RefEnv *)h; Use u(e);
+  try { e->save_env_state(path); return 0; } catch (const std::exception &ex) { std::cerr << "ref_env_save_json: " << ex.what() << std::endl; return -1; }
+}
+// reset_ids != 0: the entity id counter restarts at 1 before the load (fresh-process behaviour).  Note that the
+// reference's reset() is a no-op ever after (is_loading_env_state stays set, BaseEnvironment.hpp:180-181).
+int ref_env_load_json(void *h, const char *path, int reset_ids) {
+  auto *e = (RefEnv *)h; Use u(e);
+  static std::mutex m; std::lock_guard<std::mutex> lock(m);
+  Silence s;  // load_env_state prints the agents' pids / names
+  try {
+    if (reset_ids) agario::Ball::global_id = 1;
+    e->clock.offset += (long long)e->eng().state.ticks;  // Engine::load_env_state zeroes state.ticks: keep the clock monotonic
+    e->load_env_state(path);
+    return 0;
+  } catch (const std::exception &ex) { std::cerr << "ref_env_load_json: " << ex.what() << std::endl; return -1; }
+}
+
 void ref_set_global_id(int v) { agario::Ball::global_id = v; }
 int ref_get_global_id() { return agario::Ball::global_id; }
 

@@ -47,6 +47,8 @@ def lib():
         L.ref_dump.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.ref_load.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.ref_set_global_id.argtypes = [C.c_int]
+        L.ref_env_save_json.argtypes = [C.c_void_p, C.c_char_p]
+        L.ref_env_load_json.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.ref_run_random.restype = C.c_longlong
         L.ref_run_random.argtypes = [C.c_void_p, C.c_longlong, C.c_double, C.c_uint, C.c_int]
         _lib = L
@@ -129,6 +131,16 @@ class RefEnv:
             self._buf = np.zeros(-n + 1024, dtype=np.uint32)
             n = self.L.ref_dump(self.h, self._buf.ctypes.data, len(self._buf))
         return self._buf[:n].copy()
+
+    def save_json(self, path):
+        """BaseEnvironment::save_env_state (BaseEnvironment.hpp:213-310)."""
+        if self.L.ref_env_save_json(self.h, str(path).encode()) != 0:
+            raise RuntimeError("save_env_state failed")
+
+    def load_json(self, path, reset_ids=True):
+        """BaseEnvironment::load_env_state (BaseEnvironment.hpp:312-343); reset() is a no-op afterwards."""
+        if self.L.ref_env_load_json(self.h, str(path).encode(), 1 if reset_ids else 0) != 0:
+            raise RuntimeError("load_env_state failed")
 
     def load(self, blob):
         blob = np.ascontiguousarray(blob, dtype=np.uint32)

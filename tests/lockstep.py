@@ -177,6 +177,8 @@ def golden_files(gpu_capable_only=False):
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     out = []
     for p in sorted(glob.glob(os.path.join(here, "*.npz"))):
+        if os.path.basename(p).startswith("snapshot_"):   # JSON snapshot vectors: tests/snapshot_cases.py
+            continue
         if gpu_capable_only:
             cfg = json.loads(str(np.load(p)["cfg"]))
             if cfg.get("num_agents", 1) + cfg.get("num_bots", 0) > 16:

@@ -82,6 +82,17 @@ def test_front_kernel_on_off_equivalence(hip_engine_cls, monkeypatch):
         assert np.array_equal(b0, b1)
 
 
+from snapshot_cases import replay_snapshot_case, snapshot_cases  # noqa: E402
+
+
+@pytest.mark.parametrize("base", snapshot_cases(), ids=lambda p: os.path.basename(p))
+def test_hip_snapshot_golden(hip_engine_cls, base):
+    """a snapshot written by the real reference is loaded into one arena of the HIP engine, which then
+    follows the reference's recorded continuation bit for bit and re-serialises to the reference's own JSON."""
+    ok, msg = replay_snapshot_case(hip_engine_cls, base)
+    assert ok, msg
+
+
 def test_masked_reset_and_reseed(hip_engine_cls, oracle_lib):
     """reset(mask) touches only the selected arenas; ids keep growing like the reference's global counter."""
     A = 8
