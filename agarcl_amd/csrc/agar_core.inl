@@ -1286,6 +1286,7 @@ template <int NS, bool AV> AG_DEV void sort_cells_by_id(AgCtx<NS, AV> &c, int p)
 struct QState {  // per arena: wave-uniform in k_step, uniform over the arena's lane group in k_quiet
   unsigned m, m_move;  // mass; mass at the last tick's move (Player::min_mass bookkeeping)
   int action, nv, np, ticks, elapsed, fcd, scd, last_decay, nvt, food_eaten, hm, last_ev, done;
+  int mtidx, idc;      // mt19937_64 read index and entity id counter (pellet regeneration)
   float x, y, svx, svy, vx, vy, r, hi, tx, ty, slack, sx0, sy0;  // slack = S, (sx0, sy0) = centre of the pellet-free disc
   double rate;
   bool pel_changed;
@@ -1310,7 +1311,7 @@ template <bool AV> AG_DEV void pel_accumulate(const PelQuery &k, float qx, float
 // The tick loop is written in phases so that the pellet pass sits at a point every lane of the wave reaches together
 // (`pel.any`, `pel.scan`, `pel.swap_pop` are wave-level calls; everything inside `if (active)` is per-arena code):
 // k_quiet advances several arenas per wavefront and lets the whole wave scan for whichever of them needs it.
-template <bool AV, class PelT, class LutT> AG_DEV void quiet_ticks(QState &q, const AgParams &g, LutT lut_r, LutT lut_ms, PelT &pel, int max_ticks, bool active = true) {
+template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QState &q, const AgParams &g, LutT lut_r, LutT lut_ms, MtT mt, PelT &pel, int max_ticks, bool active = true) {
   const float dt = g.dt, W = g.W;
   const bool regen = g.regen != 0, decay = g.mass_decay != 0;
   const int tgt_p = g.target_pellets, tgt_v = g.target_viruses;
@@ -1318,6 +1319,7 @@ template <bool AV, class PelT, class LutT> AG_DEV void quiet_ticks(QState &q, co
   if (!AV) q.slack = 0.0f;
   float s2 = q.slack * q.slack;
   q.done = 0; q.last_ev = -1; q.m_move = q.m; q.pel_changed = false;
+  const float pel_r = lut(lut_r, AG_PELLET_MASS); const float pel_span = W - 2.0f * pel_r;  // random_location(radius), Engine.hpp:143-148
   while (pel.any(active)) {
     bool need = false, regen_tick = false, decay_tick = false;
     float nx = q.x, ny = q.y, nvx = 0.0f, nvy = 0.0f, nsx = q.svx, nsy = q.svy;
@@ -1328,7 +1330,9 @@ template <bool AV, class PelT, class LutT> AG_DEV void quiet_ticks(QState &q, co
       if (q.done >= max_ticks) active = false;
       else if (q.m >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0) active = false;  // eject needs >= 35, split >= 50
       else if (q.m >= 111u && q.nv != 0) active = false;                                  // virus contact needs >= 111
-      else if (regen_tick && (tgt_p - q.np > 0 || tgt_v - q.nv > 0)) active = false;      // something to spawn: needs the RNG
+      // regeneration (Engine.hpp:236-239): viruses need the general path; pellets are topped up inline (below) as long as
+      // the generator's buffered outputs suffice (2 draws per pellet, one more pellet may be eaten this very tick)
+      else if (regen_tick && (tgt_v - q.nv > 0 || q.mtidx + 2 * (tgt_p - q.np + 1) > 312)) active = false;
       else if (decay_tick && q.nvt != 0) active = false;                                  // anti-team bookkeeping
       if (active) {
         move_one(nx, ny, nvx, nvy, nsx, nsy, q.hi, q.r, q.tx, q.ty, dt, W);
@@ -1349,7 +1353,7 @@ template <bool AV, class PelT, class LutT> AG_DEV void quiet_ticks(QState &q, co
       float nslack = 0.0f;
       if (need) {
         if (rr >= sc.dmin2) {  // somebody is inside the radius: a plain single eat, or the general path's business
-          if (regen_tick || sc.cnt != 1 || sc.cnt1 != 1 || (nm >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0)) active = false;
+          if (sc.cnt != 1 || sc.cnt1 != 1 || (nm >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0)) active = false;
           else ev = sc.first;
         } else {
           float sl = ag_sqrtf(sc.dmin2) - q.r; sl = sl - 0.01f;
@@ -1380,6 +1384,18 @@ template <bool AV, class PelT, class LutT> AG_DEV void quiet_ticks(QState &q, co
       }
     }
     pel.swap_pop(pop, ev, np_before);
+    if (active && regen_tick && tgt_p - q.np > 0) {  // add_pellets(target - n): random_location(r) per pellet, Engine.hpp:418-424
+      const int n_new = tgt_p - q.np;
+      for (int j = 0; j < n_new; j++) {
+        float px = mt_to_float(mt_temper(mt[q.mtidx]), pel_span) + pel_r;
+        float py = mt_to_float(mt_temper(mt[q.mtidx + 1]), pel_span) + pel_r;
+        q.mtidx += 2; q.idc += 1;
+        pel.append(q.np, px, py, q.idc);
+        q.np += 1;
+      }
+      q.pel_changed = true; q.slack = 0.0f; s2 = 0.0f;  // a new pellet may lie inside the old pellet-free disc
+    }
+    pel.publish(active && regen_tick);
   }
 }
 
@@ -1400,6 +1416,13 @@ template <int NS, bool AV> struct RegPel {
     out.dmin2 = u2f((int)dmin); out.cnt = c0; out.cnt1 = c1; out.first = (int)first;
     return out;
   }
+  AG_MEM void append(int idx, float x, float y, int id) {  // pellets.emplace_back
+    ensure_pellets(c);
+    AG_PEL_FOR(s, lane, i) { if (i == idx) { PELX(c, s, lane) = x; PELY(c, s, lane) = y; } }
+    auto gid = g_pid(c); AG_SERIAL { gid[idx] = id; }
+    c.pel_dirty = true;
+  }
+  AG_MEM void publish(bool) {}
   AG_MEM void swap_pop(bool doit, int ev, int np) {
     if (!doit) return;
     if (np > 1 && ev < np - 1) { pel_move(c, ev, np - 1); auto gid = g_pid(c); AG_SERIAL { gid[ev] = gid[np - 1]; } }
@@ -1426,8 +1449,9 @@ template <int NS, bool AV> AG_DEV int quiet_run(AgCtx<NS, AV> &c, int max_ticks)
   q.ticks = SR(c, AR_TICKS); q.elapsed = PR(c, PL_ELAPSED); q.fcd = PR(c, PL_FEED_CD); q.scd = PR(c, PL_SPLIT_CD);
   q.last_decay = PR(c, PL_LAST_DECAY); q.nvt = PR(c, PL_NVTICKS); q.food_eaten = PR(c, PL_FOOD_EATEN); q.hm = PR(c, PL_HIGHEST_MASS);
   q.rate = (double)PRF(c, PL_ANTI_TEAM); q.slack = u2f(SR(c, AR_SAFE)); q.sx0 = PRF(c, PL_SAFE_X); q.sy0 = PRF(c, PL_SAFE_Y);
+  q.mtidx = SR(c, AR_MTIDX); q.idc = SR(c, AR_IDC);
   RegPel<NS, AV> pel{c};
-  quiet_ticks<AV>(q, c.gs->g, g_lut_r(c), g_lut_ms(c), pel, max_ticks);
+  quiet_ticks<AV>(q, c.gs->g, g_lut_r(c), g_lut_ms(c), (const AG_GLOBAL uint64_t *)g_mt(c), pel, max_ticks);
   if (q.done == 0) return 0;
   int *evp = L_I(c, L_EVP);
   AG_SERIAL {
@@ -1439,6 +1463,7 @@ template <int NS, bool AV> AG_DEV int quiet_run(AgCtx<NS, AV> &c, int max_ticks)
   }
   SW(c, AR_NEVP, q.last_ev >= 0 ? 1 : 0); SW(c, AR_NEVV, 0); SW(c, AR_NPEL, q.np);
   SW(c, AR_TICKS, q.ticks); SW(c, AR_CLOCK, SR(c, AR_CLOCK) + q.done); SW(c, AR_SAFE, f2u(q.slack));
+  SW(c, AR_MTIDX, q.mtidx); SW(c, AR_IDC, q.idc);
   ag_lds_order();
   if (q.pel_changed) ag_mem_fence();
   return q.done;

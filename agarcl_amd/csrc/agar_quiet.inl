@@ -64,6 +64,10 @@ template <int NS> struct GrpPel {
     return out;
   }
 #endif
+  AG_MEM void append(int idx, float x, float y, int pid) {  // pellets.emplace_back (the group's first lane writes)
+    if (lead()) { xy[2 * idx] = x; xy[2 * idx + 1] = y; id[idx] = pid; }
+  }
+  AG_MEM void publish(bool wrote) { if (any(wrote)) ag_mem_fence(); }  // later passes of this wave must see the new pellets
   AG_MEM void swap_pop(bool doit, int ev, int np) {  // Engine.hpp:1002-1009 for one event
     if (doit && lead()) {
       if (np > 1 && ev < np - 1) { xy[2 * ev] = xy[2 * (np - 1)]; xy[2 * ev + 1] = xy[2 * (np - 1) + 1]; id[ev] = id[np - 1]; }
@@ -94,7 +98,7 @@ template <int NS, bool AV> AG_DEV void quiet_arena(const AgState *gs, int arena,
   q.action = P[PL_ACTION]; q.tx = u2f(P[PL_TX]); q.ty = u2f(P[PL_TY]);
   q.elapsed = P[PL_ELAPSED]; q.fcd = P[PL_FEED_CD]; q.scd = P[PL_SPLIT_CD]; q.last_decay = P[PL_LAST_DECAY]; q.nvt = P[PL_NVTICKS];
   q.food_eaten = P[PL_FOOD_EATEN]; q.hm = P[PL_HIGHEST_MASS]; q.rate = (double)u2f(P[PL_ANTI_TEAM]); q.sx0 = u2f(P[PL_SAFE_X]); q.sy0 = u2f(P[PL_SAFE_Y]);
-  q.nv = S[AR_NVIR]; q.np = S[AR_NPEL]; q.ticks = S[AR_TICKS]; q.slack = u2f(S[AR_SAFE]);
+  q.nv = S[AR_NVIR]; q.np = S[AR_NPEL]; q.ticks = S[AR_TICKS]; q.slack = u2f(S[AR_SAFE]); q.mtidx = S[AR_MTIDX]; q.idc = S[AR_IDC];
   int clock = S[AR_CLOCK], done_flag = S[AR_DONE];
   float dx = 0.0f, dy = 0.0f; int action = 0;
   const bool acting = with_env && act;
@@ -113,7 +117,7 @@ template <int NS, bool AV> AG_DEV void quiet_arena(const AgState *gs, int arena,
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   unsigned t1_ = (unsigned)__builtin_readcyclecounter();
 #endif
-  quiet_ticks<AV>(q, gs->g, (const AG_GLOBAL float *)gs->lut_r, (const AG_GLOBAL float *)gs->lut_ms, pel, ticks, ok);
+  quiet_ticks<AV>(q, gs->g, (const AG_GLOBAL float *)gs->lut_r, (const AG_GLOBAL float *)gs->lut_ms, (const AG_GLOBAL uint64_t *)(gs->mt + (size_t)arena * 312), pel, ticks, ok);
 #if defined(AGAR_PROFILE) && !defined(AGAR_CPU_EMU)
   unsigned t2_ = (unsigned)__builtin_readcyclecounter();
   if (lead && gs->prof) { gs->prof[(size_t)arena * 16 + 4] = w0_; gs->prof[(size_t)arena * 16 + 5] = wall_clock64(); gs->prof[(size_t)arena * 16 + 0] += t1_ - t0_; gs->prof[(size_t)arena * 16 + 1] += t2_ - t1_; gs->prof[(size_t)arena * 16 + 2] += (unsigned long long)q.done; }
@@ -128,7 +132,7 @@ template <int NS, bool AV> AG_DEV void quiet_arena(const AgState *gs, int arena,
       C[CF_CMC * AG_CC] = q.m; C[CF_CRAD * AG_CC] = (uint32_t)f2u(q.r); C[CF_CMS * AG_CC] = (uint32_t)f2u(q.hi);
       P[PL_ELAPSED] = q.elapsed; P[PL_MIN_MASS] = (int)q.m_move; P[PL_HIGHEST_MASS] = q.hm; P[PL_FEED_CD] = q.fcd; P[PL_SPLIT_CD] = q.scd;
       P[PL_FOOD_EATEN] = q.food_eaten; P[PL_LAST_DECAY] = q.last_decay; P[PL_SAFE_X] = f2u(q.sx0); P[PL_SAFE_Y] = f2u(q.sy0);
-      S[AR_NEVP] = q.last_ev >= 0 ? 1 : 0; S[AR_NEVV] = 0; S[AR_NPEL] = q.np; S[AR_TICKS] = q.ticks; S[AR_CLOCK] = clock + q.done; S[AR_SAFE] = f2u(q.slack);
+      S[AR_NEVP] = q.last_ev >= 0 ? 1 : 0; S[AR_NEVV] = 0; S[AR_NPEL] = q.np; S[AR_TICKS] = q.ticks; S[AR_CLOCK] = clock + q.done; S[AR_SAFE] = f2u(q.slack); S[AR_MTIDX] = q.mtidx; S[AR_IDC] = q.idc;
       if (q.last_ev >= 0) { auto ge = (AG_GLOBAL int32_t *)(gs->ev_p + (size_t)arena * AG_EV_CAP); ge[0] = q.last_ev; }
       auto cn = (AG_GLOBAL int32_t *)(gs->counts + (size_t)arena * 4);
       cn[0] = q.np; cn[1] = q.nv; cn[2] = 0; cn[3] = 1;
