@@ -89,10 +89,17 @@ template <int NS, bool AV, class F> static void for_each_arena_ns(agarcl_env *e,
 }
 #else
 extern __shared__ __align__(16) unsigned char ag_lds[];
+// k_step is register-hungry (pellet registers + every rule inlined: ~210 VGPRs => 2 waves/SIMD).  Measured on the full
+// rule set (C3 / mode 6, 4096 arenas): capping it at 128 VGPRs (4 waves/SIMD = all 4096 arenas resident at once; the
+// compiler spills ~290 rarely-live registers to scratch) is 1.32x faster, 3 waves 1.11x, 5 waves same as 4, 6 and 8 slower;
+// the quiet-dominated C2 step is unaffected (it runs in k_quiet).
+#ifndef AG_KSTEP_ATTR
+#define AG_KSTEP_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
 #define AG_KERNEL_PROLOGUE AgCtx<NS, AV> c; ag_ctx_init(c, gs, (int)blockIdx.x, ag_lds, act_dxdy, act);
 
 // use_q: k_quiet ran in front of this launch; arenas it finished exit on their first load, the others resume.
-template <int NS, bool AV> __global__ void __launch_bounds__(64) k_step(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int use_q) {
+template <int NS, bool AV> __global__ void __launch_bounds__(64) AG_KSTEP_ATTR k_step(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int use_q) {
   int q_done = -1, q_before = 0;
   if (use_q) {
     auto qi = (const AG_GLOBAL int32_t *)(gs->qinfo + (size_t)blockIdx.x * 2);
