@@ -63,6 +63,7 @@ struct agarcl_env {
   float *lut_r, *lut_ms, *lut_ss, *lut_anti;
   int32_t *obs_buf; size_t obs_cap;  // staging for host-side grid observations
   std::vector<uint32_t> seeds;  // last seed of every arena (BaseEnvironment::seed_, written into JSON snapshots)
+  int parity;     // launch parity of the k_quiet / k_step pair (selects the unfinished-arena counter)
   bool no_front;  // AGARCL_NO_FRONT=1 in the environment: skip k_quiet (diagnostics / A-B timing only)
 };
 
@@ -99,9 +100,14 @@ extern __shared__ __align__(16) unsigned char ag_lds[];
 #define AG_KERNEL_PROLOGUE AgCtx<NS, AV> c; ag_ctx_init(c, gs, (int)blockIdx.x, ag_lds, act_dxdy, act);
 
 // use_q: k_quiet ran in front of this launch; arenas it finished exit on their first load, the others resume.
-template <int NS, bool AV> __global__ void __launch_bounds__(64) AG_KSTEP_ATTR k_step(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int use_q) {
+template <int NS, bool AV> __global__ void __launch_bounds__(64) AG_KSTEP_ATTR k_step(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int use_q, int parity) {
   int q_done = -1, q_before = 0;
   if (use_q) {
+    // the usual case in quiet-dominated workloads: k_quiet finished every arena => one scalar load and out
+    // (workgroup 0 re-arms the other parity's counter for the next step's k_quiet)
+    const int left = gs->qcount[parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) gs->qcount[parity ^ 1] = 0;
+    if (left == 0) return;
     auto qi = (const AG_GLOBAL int32_t *)(gs->qinfo + (size_t)blockIdx.x * 2);
     q_done = qi[0]; q_before = qi[1];
     if (q_done == ticks) return;
@@ -123,11 +129,11 @@ template <int NS, bool AV> __global__ void __launch_bounds__(64) AG_KSTEP_ATTR k
 #endif
 }
 // 256 threads = 16 arenas per workgroup, AG_QG lanes each (agar_quiet.inl)
-template <int NS, bool AV> __global__ void __launch_bounds__(256) k_quiet(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot) {
+template <int NS, bool AV> __global__ void __launch_bounds__(256) k_quiet(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int parity) {
   int arena = (int)blockIdx.x * (256 / AG_QG) + (int)threadIdx.x / AG_QG;
   const int A = gs->d.A; const bool valid = arena < A;
   if (!valid) arena = A - 1;
-  quiet_arena<NS, AV>(gs, arena, (int)threadIdx.x % AG_QG, valid, (const AG_GLOBAL float *)act_dxdy, (const AG_GLOBAL int32_t *)act, ticks, with_env != 0, slot);
+  quiet_arena<NS, AV>(gs, arena, (int)threadIdx.x % AG_QG, valid, (const AG_GLOBAL float *)act_dxdy, (const AG_GLOBAL int32_t *)act, ticks, with_env != 0, slot, parity);
 }
 template <int NS, bool AV> __global__ void __launch_bounds__(64) k_reset(const AgState *__restrict__ gs, const uint8_t *mask, int reset_ids) {
   if (mask && !mask[blockIdx.x]) return;
@@ -163,13 +169,14 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
 #else
   const int use_q = e->d.P == 1 && !e->no_front;
   if (use_q) {
-#define CALL(N, V) hipLaunchKernelGGL((k_quiet<N, V>), dim3((e->d.A + 256 / AG_QG - 1) / (256 / AG_QG)), dim3(256), 0, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot)
+#define CALL(N, V) hipLaunchKernelGGL((k_quiet<N, V>), dim3((e->d.A + 256 / AG_QG - 1) / (256 / AG_QG)), dim3(256), 0, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, e->parity)
     AG_DISPATCH_NS(e->ns, CALL);
 #undef CALL
   }
-#define CALL(N, V) hipLaunchKernelGGL((k_step<N, V>), dim3(e->d.A), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, use_q)
+#define CALL(N, V) hipLaunchKernelGGL((k_step<N, V>), dim3(e->d.A), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, use_q, e->parity)
   AG_DISPATCH_NS(e->ns, CALL);
 #undef CALL
+  if (use_q) e->parity ^= 1;
   HIPCHK(hipGetLastError());
 #endif
   return 0;
@@ -329,6 +336,7 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   s.act_dxdy = nullptr; s.act = nullptr;
   s.prof = alloc<unsigned long long>(e, (size_t)d.A * 16);
   s.qinfo = alloc<int32_t>(e, (size_t)d.A * 2);
+  s.qcount = alloc<int32_t>(e, 2); e->parity = 0;
   { const char *nf = getenv("AGARCL_NO_FRONT"); e->no_front = nf && nf[0] == '1'; }
 #ifdef AGAR_CPU_EMU
   e->d_state = &e->s;
@@ -538,6 +546,11 @@ extern "C" int agarcl_debug_prof(agarcl_env *e, unsigned long long *out16, int r
   if (d2h(h.data(), e->s.prof, h.size() * 8, e->stream)) return AGARCL_E_HIP;
   for (int i = 0; i < 16; i++) { out16[i] = 0; for (int a = 0; a < e->d.A; a++) out16[i] += h[(size_t)a * 16 + i]; }
   if (reset) { std::fill(h.begin(), h.end(), 0ull); if (h2d(e->s.prof, h.data(), h.size() * 8, e->stream)) return AGARCL_E_HIP; }
+  return AGARCL_OK;
+}
+extern "C" int agarcl_debug_qinfo(agarcl_env *e, int32_t *out) {  // [A][2]: the front kernel's hand-over words of the last step (diagnostics)
+  if (!e || !out) return AGARCL_E_INVALID;
+  if (d2h(out, e->s.qinfo, (size_t)e->d.A * 2 * 4, e->stream)) return AGARCL_E_HIP;
   return AGARCL_OK;
 }
 extern "C" int agarcl_debug_prof_raw(agarcl_env *e, unsigned long long *out) {  // [A][16], diagnostic builds

@@ -79,7 +79,7 @@ template <int NS> struct GrpPel {
 
 // `sub` = this lane's index within its arena's lane group (0 in the host emulation, which runs the same text as
 // scalar code); `valid` = false for the padding groups of the last wavefront (they run along but never store).
-template <int NS, bool AV> AG_DEV void quiet_arena(const AgState *gs, int arena, int sub, bool valid, const AG_GLOBAL float *act_dxdy, const AG_GLOBAL int32_t *act, int ticks, bool with_env, int slot) {
+template <int NS, bool AV> AG_DEV void quiet_arena(const AgState *gs, int arena, int sub, bool valid, const AG_GLOBAL float *act_dxdy, const AG_GLOBAL int32_t *act, int ticks, bool with_env, int slot, int parity = 0) {
   auto S = (AG_GLOBAL int32_t *)(gs->ar + (size_t)arena * AR_WORDS);
   auto P = (AG_GLOBAL int32_t *)(gs->pl + (size_t)arena * PL_WORDS);
   auto C = (AG_GLOBAL uint32_t *)(gs->cells + (size_t)arena * (CF_ALL * AG_CC));   // field f of cell 0 = C[f * AG_CC]
@@ -125,6 +125,9 @@ template <int NS, bool AV> AG_DEV void quiet_arena(const AgState *gs, int arena,
   const bool finished = q.done == ticks;
   if (finished && with_env && mode == 3 && q.m >= 23000u) done_flag = 1;
   if (lead && !ok) { qi[0] = -1; qi[1] = 0; }
+#ifndef AGAR_CPU_EMU
+  if (lead && !(ok && finished)) atomicAdd(gs->qcount + parity, 1);  // k_step has work to do
+#endif
   if (lead && ok) {
     if (q.done > 0) {
       C[CF_X * AG_CC] = (uint32_t)f2u(q.x); C[CF_Y * AG_CC] = (uint32_t)f2u(q.y); C[CF_VX * AG_CC] = (uint32_t)f2u(q.vx); C[CF_VY * AG_CC] = (uint32_t)f2u(q.vy);

@@ -24,6 +24,12 @@ __global__ void k_spin(const Desc *d, int iters, unsigned long long *out) {  // 
   if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = w1 - w0; }
   d->b[blockIdx.x * blockDim.x + threadIdx.x] = x;
 }
+// early-exit kernel that nevertheless declares k_step's resources (dynamic LDS + 128 VGPRs): what does dispatch cost?
+__global__ void __attribute__((amdgpu_num_vgpr(128))) k_heavy_exit(const Desc *d) {
+  extern __shared__ unsigned char lds[];
+  if (d->c[0] == 0) return;
+  lds[threadIdx.x] = 1; d->b[blockIdx.x * blockDim.x + threadIdx.x] = lds[(threadIdx.x + 1) % blockDim.x];
+}
 template <class F> static float timeit(hipStream_t s, int n, F f) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 20; i++) f();
@@ -51,6 +57,12 @@ int main() {
          timeit(s, 1000, [&] { hipLaunchKernelGGL(k_empty, dim3(4096), dim3(64), 0, s); }),
          timeit(s, 1000, [&] { hipLaunchKernelGGL(k_chain, dim3(4096), dim3(64), 0, s, d); }),
          timeit(s, 1000, [&] { hipLaunchKernelGGL(k_direct, dim3(4096), dim3(64), 0, s, 4096 * 64, a, b); }));
+  CK(hipMemset(c, 0, 64)); CK(hipDeviceSynchronize());
+  printf("early exit with k_step-like resources: 4096 x 64 thr, 8848 B LDS: %.2f us;  1024 x 256 thr, 35392 B LDS: %.2f us;  4096 x 64 thr, no LDS: %.2f us;  256 x 64, 8848 B LDS: %.2f us\n",
+         timeit(s, 1000, [&] { hipLaunchKernelGGL(k_heavy_exit, dim3(4096), dim3(64), 8848, s, d); }),
+         timeit(s, 1000, [&] { hipLaunchKernelGGL(k_heavy_exit, dim3(1024), dim3(256), 35392, s, d); }),
+         timeit(s, 1000, [&] { hipLaunchKernelGGL(k_heavy_exit, dim3(4096), dim3(64), 0, s, d); }),
+         timeit(s, 1000, [&] { hipLaunchKernelGGL(k_heavy_exit, dim3(256), dim3(64), 8848, s, d); }));
   printf("two kernels per step (empty + empty): %.2f us\n", timeit(s, 1000, [&] { hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, s); hipLaunchKernelGGL(k_empty, dim3(4096), dim3(64), 0, s); }));
   for (int iters : {1000, 100000}) {
     hipLaunchKernelGGL(k_spin, dim3(1024), dim3(64), 0, s, d, iters, out); CK(hipStreamSynchronize(s));
