@@ -37,9 +37,11 @@ AG_DEV float ag_sqrtf(float x) { return sqrtf(x); }
 AG_DEV float ag_divf(float a, float b) { return a / b; }
 #else
 #define AG_DEV __device__ __forceinline__
+// lane within the wavefront (kernels may pack several wavefronts = several arenas into one workgroup)
+#define AG_LANE ((int)threadIdx.x & 63)
 #define AG_MEM __device__ __forceinline__
-#define AG_LANES(i, n) for (int i = (int)threadIdx.x; i < (n); i += 64)
-#define AG_SERIAL if (threadIdx.x == 0)
+#define AG_LANES(i, n) for (int i = AG_LANE; i < (n); i += 64)
+#define AG_SERIAL if (AG_LANE == 0)
 AG_DEV int ag_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 AG_DEV unsigned ag_uniu(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 AG_DEV float ag_unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
@@ -85,21 +87,21 @@ template <class P, class S> AG_DEV int wave_compact(int n, P pred, S sink) { int
 AG_DEV int wred_add(int v) { AG_DPP_REDUCE(v, 0, AG_OP_ADD) return __builtin_amdgcn_readlane(v, 63); }
 AG_DEV unsigned wred_max(unsigned u) { int v = (int)u; AG_DPP_REDUCE(v, 0, AG_OP_UMAX) return (unsigned)__builtin_amdgcn_readlane(v, 63); }
 AG_DEV unsigned wred_min(unsigned u) { int v = (int)u; AG_DPP_REDUCE(v, -1, AG_OP_UMIN) return (unsigned)__builtin_amdgcn_readlane(v, 63); }
-template <class F> AG_DEV int wave_sum(int n, F f) { int s = 0; for (int i = (int)threadIdx.x; i < n; i += 64) s += f(i); return wred_add(s); }
+template <class F> AG_DEV int wave_sum(int n, F f) { int s = 0; for (int i = AG_LANE; i < n; i += 64) s += f(i); return wred_add(s); }
 template <class F> AG_DEV int wave_count(int n, F f) {
   int c = 0;
-  for (int base = 0; base < n; base += 64) { int i = base + (int)threadIdx.x; bool p = (i < n) && f(i); c += __popcll(__ballot(p)); }
+  for (int base = 0; base < n; base += 64) { int i = base + AG_LANE; bool p = (i < n) && f(i); c += __popcll(__ballot(p)); }
   return c;
 }
-template <class F> AG_DEV unsigned wave_max(int n, F f) { unsigned s = 0; for (int i = (int)threadIdx.x; i < n; i += 64) { unsigned v = f(i); s = v > s ? v : s; } return wred_max(s); }
-template <class F> AG_DEV unsigned wave_min(int n, F f) { unsigned s = UINT_MAX; for (int i = (int)threadIdx.x; i < n; i += 64) { unsigned v = f(i); s = v < s ? v : s; } return wred_min(s); }
-template <class F> AG_DEV bool wave_any(int n, F f) { bool a = false; for (int i = (int)threadIdx.x; i < n; i += 64) a = a | (bool)f(i); return __ballot(a) != 0ull; }
+template <class F> AG_DEV unsigned wave_max(int n, F f) { unsigned s = 0; for (int i = AG_LANE; i < n; i += 64) { unsigned v = f(i); s = v > s ? v : s; } return wred_max(s); }
+template <class F> AG_DEV unsigned wave_min(int n, F f) { unsigned s = UINT_MAX; for (int i = AG_LANE; i < n; i += 64) { unsigned v = f(i); s = v < s ? v : s; } return wred_min(s); }
+template <class F> AG_DEV bool wave_any(int n, F f) { bool a = false; for (int i = AG_LANE; i < n; i += 64) a = a | (bool)f(i); return __ballot(a) != 0ull; }
 // ordered stream compaction: sink(i, rank) for every i with pred(i), rank = number of earlier hits
 template <class P, class S> AG_DEV int wave_compact(int n, P pred, S sink) {
   int count = 0;
-  const unsigned long long lt = (1ull << threadIdx.x) - 1ull;
+  const unsigned long long lt = (1ull << AG_LANE) - 1ull;
   for (int base = 0; base < n; base += 64) {
-    int i = base + (int)threadIdx.x;
+    int i = base + AG_LANE;
     bool p = (i < n) && pred(i);
     unsigned long long m = __ballot(p);
     if (p) sink(i, count + __popcll(m & lt));
@@ -119,9 +121,9 @@ template <class PT> AG_DEV void ub_store(const UBlock &b, PT dst, int n) { for (
 #else
 struct UBlock { int v; };
 AG_DEV int ub_get(const UBlock &b, int k) { return __builtin_amdgcn_readlane(b.v, k); }
-AG_DEV void ub_set(UBlock &b, int k, int v) { b.v = ((int)threadIdx.x == k) ? v : b.v; }
-template <class PT> AG_DEV void ub_load(UBlock &b, PT src, int n) { int l = (int)threadIdx.x; b.v = l < n ? src[l] : 0; }
-template <class PT> AG_DEV void ub_store(const UBlock &b, PT dst, int n) { int l = (int)threadIdx.x; if (l < n) dst[l] = b.v; }
+AG_DEV void ub_set(UBlock &b, int k, int v) { b.v = (AG_LANE == k) ? v : b.v; }
+template <class PT> AG_DEV void ub_load(UBlock &b, PT src, int n) { int l = AG_LANE; b.v = l < n ? src[l] : 0; }
+template <class PT> AG_DEV void ub_store(const UBlock &b, PT dst, int n) { int l = AG_LANE; if (l < n) dst[l] = b.v; }
 #endif
 
 // ---- numerics: C++ std::min/max/clamp on floats with their NaN behaviour (R: core/utils.hpp:19-21)
@@ -187,7 +189,7 @@ template <int NS> struct Pel {
 #define PELX(c, s, lane) (c).pel.x[s][lane]
 #define PELY(c, s, lane) (c).pel.y[s][lane]
 #else
-#define AG_PEL_FOR(s, lane, i) _Pragma("unroll") for (int s = 0; s < NS; s++) for (int lane = (int)threadIdx.x, i = s * 64 + (int)threadIdx.x, once_ = 1; once_; once_ = 0)
+#define AG_PEL_FOR(s, lane, i) _Pragma("unroll") for (int s = 0; s < NS; s++) for (int lane = AG_LANE, i = s * 64 + AG_LANE, once_ = 1; once_; once_ = 0)
 #define PELX(c, s, lane) (c).pel.x[s]
 #define PELY(c, s, lane) (c).pel.y[s]
 #endif
@@ -290,7 +292,7 @@ template <int NS, bool AV, class F, class S> AG_DEV int pel_compact(const AgCtx<
 #ifdef AGAR_CPU_EMU
   AG_PEL_FOR(s, lane, i) { if (pred(PELX(c, s, lane), PELY(c, s, lane), i)) { sink(PELX(c, s, lane), PELY(c, s, lane), i, count); count++; } }
 #else
-  const unsigned long long lt = (1ull << threadIdx.x) - 1ull;
+  const unsigned long long lt = (1ull << AG_LANE) - 1ull;
   AG_PEL_FOR(s, lane, i) {
     bool p = pred(PELX(c, s, lane), PELY(c, s, lane), i);
     unsigned long long m = __ballot(p);
@@ -314,7 +316,7 @@ template <int NS, bool AV> AG_DEV void pel_move(AgCtx<NS, AV> &c, int dst, int s
 #else
   int ss = src >> 6, sl = src & 63, ds = dst >> 6, dl = dst & 63; float vx = 0.0f, vy = 0.0f;
   _Pragma("unroll") for (int s = 0; s < NS; s++) if (s == ss) { vx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.pel.x[s]), sl)); vy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.pel.y[s]), sl)); }
-  _Pragma("unroll") for (int s = 0; s < NS; s++) if (s == ds && (int)threadIdx.x == dl) { c.pel.x[s] = vx; c.pel.y[s] = vy; }
+  _Pragma("unroll") for (int s = 0; s < NS; s++) if (s == ds && AG_LANE == dl) { c.pel.x[s] = vx; c.pel.y[s] = vy; }
 #endif
 }
 // uniform read of pellet i
@@ -407,7 +409,7 @@ template <int NS, bool AV> AG_DEV void mt_twist(AgCtx<NS, AV> &c) {  // three de
 #ifdef AGAR_CPU_EMU
     for (int i = base; i < lim; i++) mt[i] = mt_mix(mt[i], mt[i + 1], mt[i + 156]);
 #else
-    int i = base + (int)threadIdx.x; uint64_t v = 0;
+    int i = base + AG_LANE; uint64_t v = 0;
     if (i < lim) v = mt_mix(mt[i], mt[i + 1], mt[i + 156]);
     ag_mem_fence();
     if (i < lim) mt[i] = v;
@@ -419,7 +421,7 @@ template <int NS, bool AV> AG_DEV void mt_twist(AgCtx<NS, AV> &c) {  // three de
 #ifdef AGAR_CPU_EMU
     for (int i = base; i < lim; i++) mt[i] = mt_mix(mt[i], mt[i + 1], mt[i - 156]);
 #else
-    int i = base + (int)threadIdx.x; uint64_t v = 0;
+    int i = base + AG_LANE; uint64_t v = 0;
     if (i < lim) v = mt_mix(mt[i], mt[i + 1], mt[i - 156]);
     ag_mem_fence();
     if (i < lim) mt[i] = v;

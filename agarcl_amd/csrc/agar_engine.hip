@@ -63,6 +63,7 @@ struct agarcl_env {
   float *lut_r, *lut_ms, *lut_ss, *lut_anti;
   int32_t *obs_buf; size_t obs_cap;  // staging for host-side grid observations
   std::vector<uint32_t> seeds;  // last seed of every arena (BaseEnvironment::seed_, written into JSON snapshots)
+  bool fused;     // single-launch step (k_fused) instead of k_quiet + k_step: see k_fused
   int parity;     // launch parity of the k_quiet / k_step pair (selects the unfinished-arena counter)
   bool no_front;  // AGARCL_NO_FRONT=1 in the environment: skip k_quiet (diagnostics / A-B timing only)
 };
@@ -135,6 +136,34 @@ template <int NS, bool AV> __global__ void __launch_bounds__(256) k_quiet(const 
   if (!valid) arena = A - 1;
   quiet_arena<NS, AV>(gs, arena, (int)threadIdx.x % AG_QG, valid, (const AG_GLOBAL float *)act_dxdy, (const AG_GLOBAL int32_t *)act, ticks, with_env != 0, slot, parity);
 }
+#ifndef AG_KFUSED_ATTR
+#define AG_KFUSED_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
+// Fused step for quiet-dominated single-player envs: ONE launch.  The front part is k_quiet's; whatever it leaves
+// unfinished (in the C2 workload: 0.02 arenas per 4096-arena step) is completed right here by the same wavefront
+// running the general engine as a wave, one arena after the other.  Saves the second dependent launch (>= 3.4 us:
+// scripts/microbench/launch_floor.hip) at the price of serialising a wavefront's unfinished arenas -- the wrong trade
+// when most arenas need the general path every step (mass-1000 modes), where the two-kernel step is used.
+template <int NS, bool AV> __global__ void __launch_bounds__(256) AG_KFUSED_ATTR k_fused(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int lds_per_wave) {
+  int arena = (int)blockIdx.x * (256 / AG_QG) + (int)threadIdx.x / AG_QG;
+  const int A = gs->d.A; const bool valid = arena < A;
+  if (!valid) arena = A - 1;
+  const int sub = (int)threadIdx.x % AG_QG;
+  QHandOver h = quiet_arena<NS, AV>(gs, arena, sub, valid, (const AG_GLOBAL float *)act_dxdy, (const AG_GLOBAL int32_t *)act, ticks, with_env != 0, slot, -1);
+  unsigned long long todo = __ballot(valid && sub == 0 && h.done != ticks);
+  if (!todo) return;
+  ag_mem_fence();  // the front part's stores precede the general part's loads of the same arena
+  unsigned char *lds = ag_lds + ((int)threadIdx.x >> 6) * lds_per_wave;
+  while (todo) {
+    const int src = (int)__builtin_ctzll(todo); todo &= todo - 1ull;
+    const int ar = __builtin_amdgcn_readlane(arena, src), qd = __builtin_amdgcn_readlane(h.done, src), qb = __builtin_amdgcn_readlane(h.before, src);
+    AgCtx<NS, AV> c; ag_ctx_init(c, gs, ar, lds, act_dxdy, act, slot);
+    arena_load(c, true);
+    env_step(c, ticks, with_env != 0, qd, qb);
+    arena_store(c);
+    ag_lds_order();
+  }
+}
 template <int NS, bool AV> __global__ void __launch_bounds__(64) k_reset(const AgState *__restrict__ gs, const uint8_t *mask, int reset_ids) {
   if (mask && !mask[blockIdx.x]) return;
   const float *act_dxdy = nullptr; const int32_t *act = nullptr;
@@ -168,6 +197,14 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
 #undef CALL
 #else
   const int use_q = e->d.P == 1 && !e->no_front;
+  if (use_q && e->fused) {
+    const unsigned lpw = (unsigned)((e->lds_bytes + 15) & ~(size_t)15);
+#define CALL(N, V) hipLaunchKernelGGL((k_fused<N, V>), dim3((e->d.A + 256 / AG_QG - 1) / (256 / AG_QG)), dim3(256), 4 * lpw, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, (int)lpw)
+    AG_DISPATCH_NS(e->ns, CALL);
+#undef CALL
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   if (use_q) {
 #define CALL(N, V) hipLaunchKernelGGL((k_quiet<N, V>), dim3((e->d.A + 256 / AG_QG - 1) / (256 / AG_QG)), dim3(256), 0, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, e->parity)
     AG_DISPATCH_NS(e->ns, CALL);
@@ -338,6 +375,9 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   s.qinfo = alloc<int32_t>(e, (size_t)d.A * 2);
   s.qcount = alloc<int32_t>(e, 2); e->parity = 0;
   { const char *nf = getenv("AGARCL_NO_FRONT"); e->no_front = nf && nf[0] == '1'; }
+  // modes 0-4 start agents at mass 25 (quiet-dominated); 5 and 6 start at mass 1000 (general path every step)
+  e->fused = d.P == 1 && cfg->mode_number <= 4;
+  { const char *fu = getenv("AGARCL_FUSED"); if (fu && (fu[0] == '0' || fu[0] == '1')) e->fused = fu[0] == '1'; }
 #ifdef AGAR_CPU_EMU
   e->d_state = &e->s;
 #else

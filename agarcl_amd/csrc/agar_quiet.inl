@@ -79,7 +79,10 @@ template <int NS> struct GrpPel {
 
 // `sub` = this lane's index within its arena's lane group (0 in the host emulation, which runs the same text as
 // scalar code); `valid` = false for the padding groups of the last wavefront (they run along but never store).
-template <int NS, bool AV> AG_DEV void quiet_arena(const AgState *gs, int arena, int sub, bool valid, const AG_GLOBAL float *act_dxdy, const AG_GLOBAL int32_t *act, int ticks, bool with_env, int slot, int parity = 0) {
+// Returns the hand-over (per lane, uniform over the group): ticks done (-1: nothing, == ticks: step finished) and the
+// agent's mass before the step.  parity >= 0: also count unfinished arenas in gs->qcount[parity] (two-kernel step).
+struct QHandOver { int done, before; };
+template <int NS, bool AV> AG_DEV QHandOver quiet_arena(const AgState *gs, int arena, int sub, bool valid, const AG_GLOBAL float *act_dxdy, const AG_GLOBAL int32_t *act, int ticks, bool with_env, int slot, int parity = -1) {
   auto S = (AG_GLOBAL int32_t *)(gs->ar + (size_t)arena * AR_WORDS);
   auto P = (AG_GLOBAL int32_t *)(gs->pl + (size_t)arena * PL_WORDS);
   auto C = (AG_GLOBAL uint32_t *)(gs->cells + (size_t)arena * (CF_ALL * AG_CC));   // field f of cell 0 = C[f * AG_CC]
@@ -126,7 +129,7 @@ template <int NS, bool AV> AG_DEV void quiet_arena(const AgState *gs, int arena,
   if (finished && with_env && mode == 3 && q.m >= 23000u) done_flag = 1;
   if (lead && !ok) { qi[0] = -1; qi[1] = 0; }
 #ifndef AGAR_CPU_EMU
-  if (lead && !(ok && finished)) atomicAdd(gs->qcount + parity, 1);  // k_step has work to do
+  if (parity >= 0 && lead && !(ok && finished)) atomicAdd(gs->qcount + parity, 1);  // k_step has work to do
 #endif
   if (lead && ok) {
     if (q.done > 0) {
@@ -146,4 +149,6 @@ template <int NS, bool AV> AG_DEV void quiet_arena(const AgState *gs, int arena,
     if (finished && with_env) emit_agent_result(gs, slot, arena, 1, 0, q.m, before, 0, done_flag);
     qi[0] = q.done; qi[1] = (int)before;
   }
+  QHandOver h; h.done = ok ? q.done : -1; h.before = (int)before;
+  return h;
 }
