@@ -219,7 +219,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "kernel": "k_quiet + k_step (the two launches of one env step)", "kernel_ms": kernel_ms,
+                         "kernel": "k_fused (one launch per env step)" if args.workload in ("C2", "C3m0") else "k_quiet + k_step (the two launches of one env step)", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_arena_tick": b_tick,
                          "moved_frac": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "note": "achieved = SURVEY 8(d) streaming-model bytes / time; frac > 1 is possible because the engine does "
