@@ -64,6 +64,9 @@ struct agarcl_env {
   int32_t *obs_buf; size_t obs_cap;  // staging for host-side grid observations
   std::vector<uint32_t> seeds;  // last seed of every arena (BaseEnvironment::seed_, written into JSON snapshots)
   bool fused;     // single-launch step (k_fused) instead of k_quiet + k_step: see k_fused
+  bool fused_fixed;                // AGARCL_FUSED=0/1 pins the choice
+  int32_t *h_stat; void *stat_ev;  // pinned copy of qstat + the event that says it has arrived
+  bool stat_pending; long step_no, stat_req_step, stat_last_step; int32_t stat_last_total;
   int parity;     // launch parity of the k_quiet / k_step pair (selects the unfinished-arena counter)
   bool no_front;  // AGARCL_NO_FRONT=1 in the environment: skip k_quiet (diagnostics / A-B timing only)
 };
@@ -186,6 +189,29 @@ __global__ void k_set_word(int32_t *base, int stride, int n, int value) {
 }
 #endif
 
+#ifndef AGAR_CPU_EMU
+// Fused or two-kernel step?  The front part counts the arena-steps it leaves unfinished (qstat).  Every 64 steps the
+// host asks for that counter with an asynchronous copy into pinned memory and, once the copy has landed (event query,
+// never a wait), compares it with the previous sample: a wavefront of k_fused completes its unfinished arenas one
+// after the other, which only pays while they are rare.  Results do not depend on the choice, only the time does.
+static void adapt_step_mode(agarcl_env *e) {
+  e->step_no++;
+  if (e->stat_pending) {
+    if (hipEventQuery((hipEvent_t)e->stat_ev) != hipSuccess) return;
+    e->stat_pending = false;
+    const long steps = e->stat_req_step - e->stat_last_step;
+    if (steps > 0) {
+      const double frac = (double)(uint32_t)(e->h_stat[0] - e->stat_last_total) / ((double)steps * (double)e->d.A);
+      if (e->fused && frac > 0.05) e->fused = false; else if (!e->fused && frac < 0.01) e->fused = true;
+    }
+    e->stat_last_total = e->h_stat[0]; e->stat_last_step = e->stat_req_step;
+  } else if (e->step_no % 64 == 0) {
+    if (hipMemcpyAsync(e->h_stat, e->s.qstat, 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess) return;
+    if (hipEventRecord((hipEvent_t)e->stat_ev, e->stream) != hipSuccess) return;
+    e->stat_pending = true; e->stat_req_step = e->step_no;
+  }
+}
+#endif
 static int launch_step(agarcl_env *e, int ticks, int with_env) {
 #ifdef AGAR_CPU_EMU
   const int use_q = e->d.P == 1 && !e->no_front;  // the lean front kernel handles single-player arenas' quiet steps
@@ -197,6 +223,7 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
 #undef CALL
 #else
   const int use_q = e->d.P == 1 && !e->no_front;
+  if (use_q && !e->fused_fixed && e->h_stat) adapt_step_mode(e);
   if (use_q && e->fused) {
     const unsigned lpw = (unsigned)((e->lds_bytes + 15) & ~(size_t)15);
 #define CALL(N, V) hipLaunchKernelGGL((k_fused<N, V>), dim3((e->d.A + 256 / AG_QG - 1) / (256 / AG_QG)), dim3(256), 4 * lpw, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, (int)lpw)
@@ -294,6 +321,8 @@ extern "C" int agarcl_destroy(agarcl_env *e) {
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->stream);
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
+  if (e->stat_ev) (void)hipEventDestroy((hipEvent_t)e->stat_ev);
+  if (e->h_stat) (void)hipHostFree(e->h_stat);
 #endif
   for (void *p : e->allocs) dfree(p);
 #ifndef AGAR_CPU_EMU
@@ -376,8 +405,17 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   s.qcount = alloc<int32_t>(e, 2); e->parity = 0;
   { const char *nf = getenv("AGARCL_NO_FRONT"); e->no_front = nf && nf[0] == '1'; }
   // modes 0-4 start agents at mass 25 (quiet-dominated); 5 and 6 start at mass 1000 (general path every step)
-  e->fused = d.P == 1 && cfg->mode_number <= 4;
-  { const char *fu = getenv("AGARCL_FUSED"); if (fu && (fu[0] == '0' || fu[0] == '1')) e->fused = fu[0] == '1'; }
+  e->fused = d.P == 1 && cfg->mode_number <= 4;  // starting point; adapt_step_mode follows what the arenas actually do
+  e->fused_fixed = false; e->h_stat = nullptr; e->stat_ev = nullptr; e->stat_pending = false; e->step_no = e->stat_req_step = e->stat_last_step = 0; e->stat_last_total = 0;
+  { const char *fu = getenv("AGARCL_FUSED"); if (fu && (fu[0] == '0' || fu[0] == '1')) { e->fused = fu[0] == '1'; e->fused_fixed = true; } }
+  s.qstat = alloc<int32_t>(e, 1);
+#ifndef AGAR_CPU_EMU
+  if (d.P == 1 && !e->fused_fixed) {
+    hipEvent_t ev;
+    if (hipHostMalloc((void **)&e->h_stat, 8) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) { e->h_stat[0] = 0; e->stat_ev = (void *)ev; }
+    else { if (e->h_stat) (void)hipHostFree(e->h_stat); e->h_stat = nullptr; }
+  }
+#endif
 #ifdef AGAR_CPU_EMU
   e->d_state = &e->s;
 #else
@@ -588,6 +626,7 @@ extern "C" int agarcl_debug_prof(agarcl_env *e, unsigned long long *out16, int r
   if (reset) { std::fill(h.begin(), h.end(), 0ull); if (h2d(e->s.prof, h.data(), h.size() * 8, e->stream)) return AGARCL_E_HIP; }
   return AGARCL_OK;
 }
+extern "C" int agarcl_debug_fused(agarcl_env *e) { return e ? (e->fused ? 1 : 0) : -1; }  // current step mode (diagnostics / tests)
 extern "C" int agarcl_debug_qinfo(agarcl_env *e, int32_t *out) {  // [A][2]: the front kernel's hand-over words of the last step (diagnostics)
   if (!e || !out) return AGARCL_E_INVALID;
   if (d2h(out, e->s.qinfo, (size_t)e->d.A * 2 * 4, e->stream)) return AGARCL_E_HIP;

@@ -129,7 +129,10 @@ template <int NS, bool AV> AG_DEV QHandOver quiet_arena(const AgState *gs, int a
   if (finished && with_env && mode == 3 && q.m >= 23000u) done_flag = 1;
   if (lead && !ok) { qi[0] = -1; qi[1] = 0; }
 #ifndef AGAR_CPU_EMU
-  if (parity >= 0 && lead && !(ok && finished)) atomicAdd(gs->qcount + parity, 1);  // k_step has work to do
+  if (lead && !(ok && finished)) {
+    if (parity >= 0) atomicAdd(gs->qcount + parity, 1);  // k_step has work to do
+    atomicAdd(gs->qstat, 1);                              // statistics for the host's fused / two-kernel choice
+  }
 #endif
   if (lead && ok) {
     if (q.done > 0) {

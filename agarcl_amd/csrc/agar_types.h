@@ -102,6 +102,7 @@ struct AgState {
   // read-only tables (mass -> fp32), host generated (Engine.hpp:1296-1302, core/utils.hpp:8-11)
   const float *lut_r, *lut_ms, *lut_ss, *lut_anti;
   int32_t *qinfo;         // [A][2] hand-over from k_quiet to k_step: ticks done (-1: nothing), agent mass before the step
+  int32_t *qstat;         // [1] running total of arena-steps the front part left unfinished (host reads it now and then)
   int32_t *qcount;        // [2] number of arenas k_quiet left unfinished, ping-pong by launch parity (k_step exits at once on 0)
   unsigned long long *prof;  // [16] phase cycle sums (diagnostic builds only; may be null)
 };

@@ -62,6 +62,37 @@ def test_front_kernel_odd_arena_counts_long_quiet_rollout(hip_engine_cls, oracle
     eng.close()
 
 
+def test_step_mode_adapts_and_results_do_not_depend_on_it(hip_engine_cls, oracle_lib):
+    """Mode-0 arenas whose agents have become big (mass 3000 with random split / eject actions) need the general engine
+    every step: the engine starts with the fused single-launch step, notices through its asynchronous statistics that
+    the front part finishes almost nothing, and switches to the two-kernel step -- bit-exact results throughout."""
+    import ctypes as C
+    from oracle import blob
+    A, steps = 64, 400
+    eng = hip_engine_cls(A, **C3)
+    eng.L.agarcl_debug_fused.argtypes = [C.c_void_p]
+    oras = [oracle_lib.OraEnv(**C3) for _ in range(A)]
+    seeds = (900 + np.arange(A)).astype(np.uint32)
+    eng.seed(seeds); eng.reset(reset_ids=True)
+    for a, o in enumerate(oras):
+        o.seed(int(seeds[a])); o.reset(True)
+        d = blob.parse(o.dump()); d["players"][0]["cell_mass"][0] = 3000
+        b = blob.build(d); o.load(b); eng.load(b, a)
+    assert eng.L.agarcl_debug_fused(eng.h) == 1
+    rng = np.random.RandomState(1)
+    for t in range(steps):
+        dxdy = rng.uniform(-1, 1, size=(A, 1, 2)).astype(np.float32); act = rng.randint(0, 3, size=(A, 1)).astype(np.int32)
+        eng.set_actions(dxdy, act); eng.step()
+        r = eng.rewards()
+        for a in range(A):
+            oras[a].take_actions(dxdy[a], act[a]); ro = oras[a].step()
+            assert r[a, 0] == ro[0], (t, a)
+    for a in range(A):
+        assert blob.diff(oras[a].dump(), eng.dump(a)) is None, a
+    assert eng.L.agarcl_debug_fused(eng.h) == 0, "the engine should have left the fused step mode"
+    eng.close()
+
+
 def test_front_kernel_on_off_equivalence(hip_engine_cls, monkeypatch):
     """AGARCL_NO_FRONT=1 (diagnostic switch) runs everything through k_step; results must not depend on it."""
     A, steps = 64, 300
