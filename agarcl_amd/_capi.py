@@ -29,7 +29,7 @@ class Config(C.Structure):
         ("pellet_regen", C.c_int32), ("num_pellets", C.c_int32), ("num_viruses", C.c_int32),
         ("num_bots", C.c_int32), ("reward_type", C.c_int32), ("c_death", C.c_int32),
         ("mode_number", C.c_int32), ("dt", C.c_double), ("cap_cells", C.c_int32),
-        ("cap_viruses", C.c_int32), ("cap_foods", C.c_int32), ("reserved", C.c_int32 * 5),
+        ("cap_viruses", C.c_int32), ("cap_foods", C.c_int32), ("screen_respawn", C.c_int32), ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -61,6 +61,7 @@ SYMBOLS = [
     ("agarcl_get_counts", C.c_int, [C.c_void_p, C.c_void_p]),
     ("agarcl_get_events", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     ("agarcl_grid_obs", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    ("agarcl_screen_obs", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     ("agarcl_dump_arena", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     ("agarcl_load_arena", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     ("agarcl_adopt_arena", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
@@ -111,10 +112,10 @@ class BatchedEngine:
 
     def __init__(self, num_arenas, num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True,
                  num_pellets=1000, num_viruses=0, num_bots=0, reward_type=1, c_death=0, mode=0, dt=1.0 / 30,
-                 device=0, cap_cells=0, cap_viruses=0, cap_foods=0, lib=None):
+                 device=0, cap_cells=0, cap_viruses=0, cap_foods=0, screen_respawn=False, lib=None):
         self.L = lib if lib is not None else hip_lib()
         self.cfg = Config(num_agents, ticks_per_step, arena_size, int(bool(pellet_regen)), num_pellets, num_viruses,
-                          num_bots, int(reward_type), c_death, mode, dt, cap_cells, cap_viruses, cap_foods)
+                          num_bots, int(reward_type), c_death, mode, dt, cap_cells, cap_viruses, cap_foods, int(bool(screen_respawn)))
         self.h = C.c_void_p()
         self.num_arenas = num_arenas
         self.num_agents = num_agents
@@ -223,6 +224,15 @@ class BatchedEngine:
             return ch.value
         out = np.zeros((self.num_arenas, self.num_agents, ch.value, grid_size, grid_size), dtype=np.int32)
         self._chk(self.L.agarcl_grid_obs(self.h, grid_size, int(cells), int(others), int(viruses), int(pellets), _ptr(out), 0, C.byref(ch)))
+        return out
+
+    def screen_obs(self, width=84, height=84, out_ptr=None):
+        """uint8 [A, n_agents, height, width, 3] (rows bottom-up, like glReadPixels), host copy or written to HBM `out_ptr`."""
+        if out_ptr is not None:
+            self._chk(self.L.agarcl_screen_obs(self.h, width, height, C.c_void_p(out_ptr), 1))
+            return None
+        out = np.zeros((self.num_arenas, self.num_agents, height, width, 3), dtype=np.uint8)
+        self._chk(self.L.agarcl_screen_obs(self.h, width, height, _ptr(out), 0))
         return out
 
     def device_ptrs(self):

@@ -9,8 +9,8 @@ import numpy as np
 
 from . import _capi, snapshot
 
-# the OpenGL ScreenEnvironment is outside the hot path
-has_screen_env = False
+# ScreenEnvironment is provided through a rule-based HIP rasteriser (csrc/agar_screen.inl), not OpenGL
+has_screen_env = True
 
 # Test seam only: CPU tests point this at the test-only wave-emulation build of the kernel source.  The default
 # (None) is the HIP library, and there is no automatic fallback: without libagarcl_hip.so / a GPU construction raises.
@@ -19,7 +19,7 @@ _LIB = None
 
 class _Environment:
     def __init__(self, num_agents, ticks_per_step, arena_size, pellet_regen, num_pellets, num_viruses, num_bots,
-                 reward_type, c_death=0, mode_number=0, device=0):
+                 reward_type, c_death=0, mode_number=0, device=0, screen_respawn=False):
         self._num_agents = int(num_agents)
         self._cfg = dict(num_agents=int(num_agents), ticks_per_step=int(ticks_per_step), arena_size=int(arena_size), num_bots=int(num_bots),
                          reward_type=bool(reward_type), c_death=int(c_death), pellet_regen=bool(pellet_regen),
@@ -28,7 +28,7 @@ class _Environment:
         self._names = None               # player names in iteration order once a snapshot has been loaded
         self._engine = _capi.BatchedEngine(1, int(num_agents), int(ticks_per_step), int(arena_size), bool(pellet_regen),
                                            int(num_pellets), int(num_viruses), int(num_bots), int(bool(reward_type)) if isinstance(reward_type, bool) else int(reward_type),
-                                           int(c_death), int(mode_number), device=device, lib=_LIB)
+                                           int(c_death), int(mode_number), device=device, screen_respawn=screen_respawn, lib=_LIB)
 
     def seed(self, s):                       # bindings.cpp:103
         self._engine.seed(np.asarray([int(s) & 0xFFFFFFFF], dtype=np.uint32))
@@ -113,9 +113,27 @@ class GridEnvironment(_Environment):
         return [obs[0, i].copy() for i in range(self._num_agents)]
 
 
-class ScreenEnvironment:
-    def __init__(self, *a, **k):
-        raise RuntimeError("agarcl was not compiled to include ScreenEnvironment (has_screen_env is False)")
+class ScreenEnvironment(_Environment):
+    """agarcl.ScreenEnvironment (bindings.cpp:142-171; environment/envs/ScreenEnvironment.hpp:130-245): RGB frames from
+    the agent's perspective, drawn by the rule-based rasteriser of csrc/agar_screen.inl instead of OpenGL, plus this
+    class's respawn hook (a dead agent is respawned right after the ticks in every mode, ScreenEnvironment.hpp:233-243)."""
+
+    def __init__(self, num_agents, frames_per_step, arena_size, pellet_regen, num_pellets, num_viruses, num_bots,
+                 reward_type, c_death, mode_number, load_env_snapshot, screen_width, screen_height, agent_view):
+        if agent_view:
+            raise RuntimeError("agent_view (4-channel) screen observations are not provided (SURVEY.md section 8f, row N4)")
+        super().__init__(num_agents, frames_per_step, arena_size, pellet_regen, num_pellets, num_viruses, num_bots,
+                         reward_type, c_death, mode_number, screen_respawn=True)
+        self._w, self._h = int(screen_width), int(screen_height)
+        self._loaded = bool(load_env_snapshot)   # BaseEnvironment(..., load_env_snapshot): reset() is a no-op from the start
+
+    def observation_shape(self):             # bindings.cpp:156 -> (num_frames, width, height, channels)
+        return (1, self._w, self._h, 3)
+
+    def get_state(self):                     # bindings.cpp:157-168: the frame buffer's bytes viewed as uint8 (1, W, H, 3)
+        frames = self._engine.screen_obs(self._w, self._h)   # [1][n_agents][H][W][3], rows bottom-up (glReadPixels)
+        # the reference keeps ONE frame buffer that every agent's render overwrites in turn: the last agent's frame remains
+        return frames[0, self._num_agents - 1].reshape(1, self._w, self._h, 3)
 
 
 class GoBiggerEnvironment:

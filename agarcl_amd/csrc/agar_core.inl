@@ -1557,6 +1557,9 @@ template <int NS, bool AV> AG_DEV void env_step(AgCtx<NS, AV> &c, int ticks, boo
     arena_tick(c); t++;
   }
   if (with_env) {
+    if (c.gs->g.screen_respawn) {  // R: ScreenEnvironment.hpp:233-243 via BaseEnvironment.hpp:96-97: per agent, after the ticks
+      for (int i = 0; i < na; i++) if (ag_uni(PLS(c, i)[PL_NCELLS]) == 0) { respawn(c, i); SW(c, AR_RESPAWNED, 1); }
+    }
     if (mode == 0) respawn_dead(c);
     else if (mode > 6) {  // BaseEnvironment.hpp:103-114
       int done = SR(c, AR_DONE);

@@ -23,6 +23,7 @@
 #include "agar_core.inl"
 #include "agar_quiet.inl"
 #include "agar_obs.inl"
+#include "agar_screen.inl"
 
 // ---- thread-local error string -------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -357,7 +358,7 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   g.target_pellets = cfg->num_pellets; g.target_viruses = cfg->num_viruses; g.mode = cfg->mode_number;
   g.dt = (float)dt; g.dt10 = (float)(dt * 10);
   g.recomb_ticks = (int)ceil(10.0 / dt - 1e-9);
-  g.reward_type = cfg->reward_type != 0; g.c_death = cfg->c_death;
+  g.reward_type = cfg->reward_type != 0; g.c_death = cfg->c_death; g.screen_respawn = cfg->screen_respawn != 0;
   // grid dims exactly as the reference computes them in float (Engine.hpp:964-965, 1210-1211)
   g.pgw = g.pgh = (int)((g.W + (float)AG_PELLET_GRID - 1.0f) / (float)AG_PELLET_GRID);
   g.vgw = g.vgh = (int)((g.W + (float)AG_VIRUS_GRID - 1.0f) / (float)AG_VIRUS_GRID);
@@ -778,6 +779,33 @@ __global__ void __launch_bounds__(256) k_grid_obs(const AgState *__restrict__ gs
   grid_obs_agent(gs, b / na, b % na, o, out + (size_t)b * obs_channels(o) * o.G * o.G);
 }
 #endif
+
+extern "C" int agarcl_screen_obs(agarcl_env *e, int32_t width, int32_t height, uint8_t *out, int32_t on_device) {
+  if (!e || !out) return fail(AGARCL_E_INVALID, "agarcl_screen_obs: null pointer");
+  if (width < 1 || height < 1 || width > 1024 || height > 1024) return fail(AGARCL_E_INVALID, "agarcl_screen_obs: screen size must be in [1, 1024]");
+#ifdef AGAR_CPU_EMU
+  (void)on_device;
+  return fail(AGARCL_E_UNSUPPORTED, "agarcl_screen_obs: the screen rasteriser exists only as a HIP kernel");
+#else
+  HIPCHK(hipSetDevice(e->device));
+  size_t n = (size_t)e->d.A * e->d.n_agents, bytes = n * (size_t)width * height * 3;
+  uint8_t *dst = out;
+  if (!on_device) {
+    size_t words = (bytes + 3) / 4;
+    if (e->obs_cap < words) {
+      if (e->obs_buf) { HIPCHK(hipStreamSynchronize(e->stream)); (void)hipFree(e->obs_buf); e->obs_buf = nullptr; e->obs_cap = 0; }
+      if (hipMalloc((void **)&e->obs_buf, words * 4) != hipSuccess) return fail(AGARCL_E_NOMEM, "agarcl_screen_obs: staging allocation failed");
+      e->obs_cap = words;
+    }
+    dst = (uint8_t *)e->obs_buf;
+  }
+  AgScreenCfg o; o.W = width; o.H = height;
+  hipLaunchKernelGGL(k_screen_obs, dim3((unsigned)n), dim3(256), 0, e->stream, e->d_state, o, dst);
+  HIPCHK(hipGetLastError());
+  if (!on_device && d2h(out, dst, bytes, e->stream)) return fail(AGARCL_E_HIP, "agarcl_screen_obs: copy failed");
+  return AGARCL_OK;
+#endif
+}
 
 extern "C" int agarcl_grid_obs(agarcl_env *e, int32_t G, int32_t cells, int32_t others, int32_t viruses, int32_t pellets,
                                int32_t *out, int32_t on_device, int32_t *channels) {

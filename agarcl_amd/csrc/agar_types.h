@@ -67,6 +67,7 @@ struct AgParams {
   float dt, dt10;          // (float)dt and (float)(dt*10) (Engine.hpp:613,674)
   int recomb_ticks;        // 10 s in ticks
   int reward_type, c_death;
+  int screen_respawn;      // ScreenEnvironment's hook: respawn dead agents right after the ticks, in every mode (ScreenEnvironment.hpp:233-243)
   int pgw, pgh, vgw, vgh;  // pellet / virus grid dims (Engine.hpp:964-965,1210-1211)
 };
 

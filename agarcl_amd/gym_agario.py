@@ -76,8 +76,13 @@ class AgarioEnv(_Base):
             env.configure_observation(cfg)
             channels, width, height = env.observation_shape()
             return env, (width, height, channels)
-        if obs_type == "screen":
-            raise ValueError("agarcl was not compiled to include ScreenEnvironment")  # AgarioEnv.py:232-233
+        if obs_type == "screen":             # AgarioEnv.py:235-250
+            if not agarcl.has_screen_env:
+                raise ValueError("agarcl was not compiled to include ScreenEnvironment")
+            screen_len = kwargs.get("screen_len", 84)
+            self.agent_view = kwargs.get("agent_view", False)
+            env = agarcl.ScreenEnvironment(*(args + (self.load_env_snapshot, screen_len, screen_len, self.agent_view)))
+            return env, env.observation_shape()
         raise ValueError("obs_type %r is not provided by the HIP engine" % obs_type)
 
     # -- AgarioEnv.py:270-296 (validation; the reference samples noise and then discards it) --------------
@@ -99,7 +104,9 @@ class AgarioEnv(_Base):
     def _make_observations(self):
         states = self._env.get_state()
         assert len(states) == self.num_agents
-        return [np.transpose(s, [1, 2, 0]) for s in states]  # NCHW -> NHWC, AgarioEnv.py:192-194
+        if self.obs_type == "grid":
+            return [np.transpose(s, [1, 2, 0]) for s in states]  # NCHW -> NHWC, AgarioEnv.py:192-194
+        return states                                            # screen: the (1, W, H, 3) frame as is, AgarioEnv.py:196-197
 
     def step(self, actions):
         assert self.steps is not None, "Cannot call step() before calling reset()"

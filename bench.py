@@ -33,6 +33,8 @@ WORKLOADS = {
                  desc="C3/mode 6: %d arenas/GPU x 1 agent (mass 1000), 1000x1000, 1000 pellets, 25 viruses, mode 6, 4 ticks/step, random (dx,dy), action ~ U{0,1,2}"),
     "C5": dict(num_viruses=25, mode_number=6, rand_act=True, grid_obs=True,
                desc="C5: C3/mode 6 + int32 grid observation [%d][8][128][128] written once per step"),
+    "C5s": dict(num_viruses=25, mode_number=6, rand_act=True, screen_obs=True,
+                desc="C5 (screen): C3/mode 6 + uint8 screen observation [%d][84][84][3] written once per step"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
 
@@ -110,7 +112,7 @@ def main():
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS), help="C2 = the headline metric's configuration")
     args = ap.parse_args()
     wl = dict(WORKLOADS[args.workload])
-    desc, rand_act, with_obs = wl.pop("desc"), wl.pop("rand_act", False), wl.pop("grid_obs", False)
+    desc, rand_act, with_obs, with_screen = wl.pop("desc"), wl.pop("rand_act", False), wl.pop("grid_obs", False), wl.pop("screen_obs", False)
     CFG.update(wl)
 
     import torch
@@ -153,6 +155,7 @@ def main():
     if rand_act:
         act = torch.randint(0, 3, (K + Wm, A, 1), generator=g, device=dev, dtype=torch.int32)
     obs = torch.empty((A, 8, 128, 128), dtype=torch.int32, device=dev) if with_obs else None
+    scr = torch.empty((A, 84, 84, 3), dtype=torch.uint8, device=dev) if with_screen else None
     gather = agdist.ResultGatherer(A, dev) if world > 1 else None
     eng = env.engine
 
@@ -163,6 +166,8 @@ def main():
         eng.step(CFG["ticks_per_step"])
         if obs is not None:
             eng.grid_obs(128, True, True, True, True, out_ptr=obs.data_ptr())
+        if scr is not None:
+            eng.screen_obs(84, 84, out_ptr=scr.data_ptr())
         if gather is not None:                  # RCCL gather of (reward, done) straight from engine memory; overlaps step k+1
             gather.gather_packed(k & 1, env.packed[eng.last_slot()])
 
@@ -228,6 +233,11 @@ def main():
                                  "bound, not HBM bound: see DESIGN.md section 5"},
             "capacity_flags_raised": int((flags != 0).sum()),
         }
+        if with_screen:
+            out["roofline"]["algorithmic_bytes_per_launch"] = bytes_per_launch + A * 84 * 84 * 3
+            out["roofline"]["achieved"] = out["roofline"]["algorithmic_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
+            out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
+            out["roofline"]["kernel"] = "k_quiet + k_step + k_screen_obs"
         if with_obs:
             out["roofline"]["algorithmic_bytes_per_launch"] = bytes_per_launch + A * 8 * 128 * 128 * 4
             out["roofline"]["achieved"] = out["roofline"]["algorithmic_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9

@@ -55,7 +55,10 @@ typedef struct agarcl_config {
   int32_t cap_cells;      /* cells per player, 0 -> 32 (reference: unbounded vector, nominal limit 14) */
   int32_t cap_viruses;    /* 0 -> num_viruses + 64 */
   int32_t cap_foods;      /* 0 -> 256 */
-  int32_t reserved[5];
+  /* ScreenEnvironment semantics (environment/envs/ScreenEnvironment.hpp:233-243): a dead agent is respawned right
+   * after the ticks of a step in EVERY mode, and that step's rewards get + c_death (BaseEnvironment.hpp:116-120) */
+  int32_t screen_respawn;
+  int32_t reserved[4];
 } agarcl_config;
 
 typedef struct agarcl_env agarcl_env;
@@ -130,6 +133,13 @@ int agarcl_get_events(agarcl_env *env, int32_t *n_events_host, int32_t *pellet_i
 int agarcl_grid_obs(agarcl_env *env, int32_t grid_size, int32_t observe_cells, int32_t observe_others,
                     int32_t observe_viruses, int32_t observe_pellets, int32_t *out, int32_t on_device,
                     int32_t *channels);
+
+/* replaces: ScreenEnvironment::get_state() (bindings.cpp:157-168) = one frame of Renderer::render_screen read back with
+ * glReadPixels (agario/rendering/renderer.hpp:163-185, FrameBufferObject.hpp:105), restated as rasterisation rules
+ * (agarcl_amd/csrc/agar_screen.inl; rule-level parity only: see that file).  Writes u8[num_arenas][num_agents][height]
+ * [width][3], rows bottom-up, i.e. per agent exactly the bytes ScreenObservation exposes as uint8 [1][W][H][3]
+ * (environment/envs/ScreenEnvironment.hpp:24-128).  `out` is an HBM pointer if on_device != 0, else a host buffer. */
+int agarcl_screen_obs(agarcl_env *env, int32_t width, int32_t height, uint8_t *out, int32_t on_device);
 
 /* full-state exchange for parity tests and snapshots (layout: oracle/BLOB_FORMAT.md); synchronising */
 int agarcl_dump_arena(agarcl_env *env, int32_t arena, uint32_t *buf_host, int32_t cap_words);

@@ -86,6 +86,7 @@ struct OArena {
   uint64_t mt[313]; int32_t rnd[35];
   unsigned long ticks; int next_pid; int id_counter; int main_agent_pid;
   int *pids; uint8_t *dones; int respawned_flag;
+  int screen_hook; /* ScreenEnvironment::_partial_observation: a dead agent is respawned right after the ticks (E5) */
   /* event log of last tick */
   int *ev_p; int n_ev_p, cap_ev_p; int *ev_v; int n_ev_v, cap_ev_v;
 };
@@ -1144,6 +1145,12 @@ int ora_step(OArena *a, double *rewards_out) { /* R: BaseEnvironment.hpp:89-122 
   a->respawned_flag = 0;
   env_masses(a, before); /* masses<float>: exact for masses < 2^24 */
   for (int t = 0; t < a->ticks_per_step; t++) ora_tick(a, 1.0 / 30.0);
+  if (a->screen_hook) { /* R: environment/envs/ScreenEnvironment.hpp:233-243, called per agent at BaseEnvironment.hpp:96-97 */
+    for (int i = 0; i < a->num_agents; i++) {
+      OPlayer *p = find_player(a, a->pids[i]);
+      if (p && p->n_cells == 0) { respawn(a, p); a->respawned_flag = 1; }
+    }
+  }
   if (a->mode == 0) ora_respawn_dead(a);
   else if (a->mode > 6) {
     for (int n = a->pmap.head; n != -1; n = a->pmap.next[n]) {
@@ -1160,6 +1167,7 @@ int ora_step(OArena *a, double *rewards_out) { /* R: BaseEnvironment.hpp:89-122 
   free(before);
   return k;
 }
+void ora_set_screen_hook(OArena *a, int on) { a->screen_hook = on != 0; }
 void ora_dones(OArena *a, uint8_t *out) { for (int i = 0; i < a->num_agents; i++) out[i] = a->dones[i]; }
 int ora_pids(OArena *a, int *out) { for (int i = 0; i < a->num_agents; i++) out[i] = a->pids[i]; return a->num_agents; }
 int ora_set_player(OArena *a, int pid, float tx, float ty, int action) { OPlayer *p = find_player(a, pid); if (!p) return -1; p->tx = tx; p->ty = ty; p->action = action; return 0; }

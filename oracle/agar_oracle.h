@@ -65,6 +65,9 @@ int ora_rand_next(int32_t *st);
 /* iteration order of a fresh-or-reused libstdc++ unordered_map<unsigned short,...> after inserting
  * the given keys in order; `bucket_count_io`/`next_resize_io` carry the rehash-policy state across
  * clear() calls (pass 1 and 0 for a brand-new map). */
+/* E5: the respawn hook of ScreenEnvironment::_partial_observation (ScreenEnvironment.hpp:233-243); parity UNPINNED
+ * (that class needs OpenGL and cannot be built here) */
+void ora_set_screen_hook(OArena *a, int on);
 int ora_hash_order(const int *keys, int n, int *order_out, int *bucket_count_io, int *next_resize_io);
 /* libstdc++ std::sort (introsort) on (key=float, payload=int) pairs, comparator key< */
 void ora_std_sort_by_float(float *keys, int *payload, int n);

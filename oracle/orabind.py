@@ -93,6 +93,10 @@ class OraEnv:
         except Exception:
             pass
 
+    def set_screen_hook(self, on=True):
+        self.L.ora_set_screen_hook.argtypes = [C.c_void_p, C.c_int]
+        self.L.ora_set_screen_hook(self.h, 1 if on else 0)
+
     def seed(self, s):
         self.L.ora_seed(self.h, s)
 

@@ -28,7 +28,7 @@ def _exercise(agarcl, gym_agario, oracle_lib):
     env.close()
     with pytest.raises(RuntimeError):
         agarcl.GridEnvironment(1, 4, 300, True, 300, 5, 0, 1, 0, 42)   # invalid mode, Engine.hpp:413-414
-    assert agarcl.has_screen_env is False
+    assert agarcl.has_screen_env is True          # provided by the rule-based HIP rasteriser (csrc/agar_screen.inl)
     # gym wrapper
     g = gym_agario.AgarioEnv(obs_type="grid", difficulty="trivial", grid_size=16, number_steps=5)
     with pytest.raises(AssertionError):

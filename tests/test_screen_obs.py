@@ -1,0 +1,72 @@
+"""Screen observation.  Rule-level parity only and UNPINNED (no OpenGL here): the HIP
+rasteriser is compared with the numpy restatement of the same rules (oracle/screen_oracle.py) within a tolerance on
+polygon-edge pixels, plus structural properties of the frame; the respawn hook is compared with the oracle."""
+import numpy as np
+import pytest
+
+from lockstep import run_batched_lockstep
+
+
+def test_screen_respawn_hook_on_emulated_kernels(emu_lib, oracle_lib):
+    """E5: with the hook a dead agent is respawned after the ticks in a mode that never respawns otherwise, and that
+    step's reward carries + c_death (BaseEnvironment.hpp:116-120)."""
+    from agarcl_amd import _capi
+    cfg = dict(num_agents=2, arena_size=120, num_pellets=150, num_viruses=2, num_bots=0, mode=4, c_death=-50)
+    A = 4
+    eng = _capi.BatchedEngine(A, lib=emu_lib, screen_respawn=True, **cfg)
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    for o in oras:
+        o.set_screen_hook(True)
+    ok, msg = run_batched_lockstep(eng, oras, 700, seeds=np.arange(300, 300 + A), sticky=6, every=5)
+    assert ok, msg
+    eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,steps", [
+    (dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode=6), 40),
+    (dict(num_agents=2, arena_size=200, num_pellets=300, num_viruses=5, num_bots=3, mode=0), 60),
+    (dict(arena_size=60, num_pellets=100, num_viruses=2, mode=0), 10),      # arena smaller than the view: grid + outside
+])
+def test_hip_screen_frames_follow_the_rules(hip_engine_cls, cfg, steps):
+    from oracle import screen_oracle
+    A = 3
+    na = cfg.get("num_agents", 1)
+    eng = hip_engine_cls(A, **cfg)
+    eng.seed(None, 77); eng.reset(reset_ids=True)
+    rng = np.random.RandomState(2)
+    for t in range(steps):
+        eng.set_actions(rng.uniform(-1, 1, size=(A, na, 2)).astype(np.float32), rng.randint(0, 3, size=(A, na)).astype(np.int32)); eng.step()
+    for (W, H) in ((84, 84), (96, 64)):
+        frames = eng.screen_obs(W, H)
+        assert frames.shape == (A, na, H, W, 3) and frames.dtype == np.uint8
+        for a in range(A):
+            ar, pl = eng.arena_words(a)
+            b = eng.dump(a)
+            kinds = [int(pl[int(ar[13 + k]), 16]) for k in range(pl.shape[0])]      # PL_KIND in iteration order
+            for i in range(na):
+                ref = screen_oracle.render(b, cfg["arena_size"], int(pl[i, 15]), kinds, W, H)   # PL_PID of agent slot i
+                diff = (ref != frames[a, i]).any(axis=2).mean()
+                assert diff <= 0.004, "arena %d agent %d %dx%d: %.2f%% of the pixels differ" % (a, i, W, H, 100 * diff)
+                # structural: the agent's own colour at the view centre (its centroid lies inside one of its cells or between them)
+                assert frames[a, i].reshape(-1, 3).max() == 255
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_agarcl_screen_environment_mirror():
+    from agarcl_amd import agarcl
+    assert agarcl.has_screen_env
+    env = agarcl.ScreenEnvironment(1, 4, 1000, True, 1000, 25, 0, True, 0, 6, False, 84, 84, False)
+    env.seed(3); env.reset()
+    for t in range(10):
+        env.take_actions([(0.3, -0.2, 0)]); env.step()
+    assert env.observation_shape() == (1, 84, 84, 3)
+    s = env.get_state()
+    assert s.shape == (1, 84, 84, 3) and s.dtype == np.uint8
+    img = s.reshape(84, 84, 3)
+    assert (img == 255).all(axis=2).mean() > 0.3            # white background dominates
+    assert not (img[40:44, 40:44] == 255).all()             # the agent's cells sit at the view centre
+    with pytest.raises(RuntimeError):
+        agarcl.ScreenEnvironment(1, 4, 1000, True, 1000, 25, 0, True, 0, 6, False, 84, 84, True)
+    env.close()
