@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_SO = os.path.join(_HERE, "libagarcl_hip.so")
 
 E_UNSUPPORTED = -3
+PACKED_SLOTS = 16   # include/agarcl_batch.h AGARCL_PACKED_SLOTS
 
 
 class AgarclError(RuntimeError):
@@ -238,7 +239,7 @@ class BatchedEngine:
     def device_ptrs(self):
         return {"rewards": self.L.agarcl_rewards_dev(self.h), "dones": self.L.agarcl_dones_dev(self.h),
                 "masses": self.L.agarcl_masses_dev(self.h), "flags": self.L.agarcl_flags_dev(self.h),
-                "packed0": self.L.agarcl_packed_dev(self.h, 0), "packed1": self.L.agarcl_packed_dev(self.h, 1)}
+                "packed": self.L.agarcl_packed_dev(self.h, 0)}   # base of the ring of PACKED_SLOTS buffers
 
     def last_slot(self):
         return int(self.L.agarcl_last_slot(self.h))

@@ -58,7 +58,7 @@ struct agarcl_env {
   int device;
   ag_stream_t stream; bool own_stream;
   size_t lds_bytes; int ns; bool all_vis;
-  int slot;  // ping-pong index of the packed result buffer written by the NEXT step
+  int slot;  // ring index of the packed result buffer written by the NEXT step
   std::vector<void *> allocs;
   float *d_act_dxdy; int32_t *d_act;  // env-owned action buffers (host-copy path)
   float *lut_r, *lut_ms, *lut_ss, *lut_anti;
@@ -394,7 +394,7 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   s.scratch = d.P > 1 ? alloc<int32_t>(e, A * (size_t)AGM_WORDS) : nullptr;
   if (d.P > 1 && !s.scratch) { agarcl_destroy(e); return fail(AGARCL_E_NOMEM, "device allocation failed"); }
   s.rewards = alloc<double>(e, A * d.n_agents); s.dones = alloc<uint8_t>(e, A * d.n_agents); s.masses = alloc<int32_t>(e, A * d.n_agents);
-  s.packed = alloc<float>(e, 2 * A * d.n_agents * 2);
+  s.packed = alloc<float>(e, (size_t)AG_PACKED_SLOTS * A * d.n_agents * 2);
   s.counts = alloc<int32_t>(e, A * 4); s.ev_p = alloc<int32_t>(e, A * AG_EV_CAP); s.ev_v = alloc<int32_t>(e, A * AG_EVV_CAP);
   e->d_act_dxdy = alloc<float>(e, A * d.n_agents * 2); e->d_act = alloc<int32_t>(e, A * d.n_agents);
   e->lut_r = alloc<float>(e, AG_LUT_SIZE); e->lut_ms = alloc<float>(e, AG_LUT_SIZE); e->lut_ss = alloc<float>(e, AG_LUT_SIZE); e->lut_anti = alloc<float>(e, AG_ANTI_LUT);
@@ -548,11 +548,11 @@ extern "C" int agarcl_step(agarcl_env *e, int32_t ticks) {
   HIPCHK(hipSetDevice(e->device));
 #endif
   int rc = launch_step(e, ticks > 0 ? ticks : e->cfg.ticks_per_step, 1);
-  e->slot ^= 1;
+  e->slot = (e->slot + 1) % AG_PACKED_SLOTS;
   return rc;
 }
-extern "C" const float *agarcl_packed_dev(agarcl_env *e, int32_t slot) { return e ? e->s.packed + (size_t)(slot & 1) * e->d.A * e->d.n_agents * 2 : nullptr; }
-extern "C" int agarcl_last_slot(agarcl_env *e) { return e ? (e->slot ^ 1) : 0; }
+extern "C" const float *agarcl_packed_dev(agarcl_env *e, int32_t slot) { return e ? e->s.packed + (size_t)(((slot % AG_PACKED_SLOTS) + AG_PACKED_SLOTS) % AG_PACKED_SLOTS) * e->d.A * e->d.n_agents * 2 : nullptr; }
+extern "C" int agarcl_last_slot(agarcl_env *e) { return e ? (e->slot + AG_PACKED_SLOTS - 1) % AG_PACKED_SLOTS : 0; }
 extern "C" int agarcl_tick(agarcl_env *e, int32_t ticks) {
   if (!e) return fail(AGARCL_E_INVALID, "null env");
 #ifndef AGAR_CPU_EMU

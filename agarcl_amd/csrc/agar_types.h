@@ -37,6 +37,7 @@ enum {
   AR_WORDS = 32
 };
 #define AG_MAX_PLAYERS 16
+#define AG_PACKED_SLOTS 16  // ring of packed (reward, done) result buffers: step k of an env writes slot k % 16
 #define AG_CC 32        // cell capacity per player (reference: unbounded vector, nominal limit 14)
 #define AG_EV_CAP 256   // pellet eat events per arena-tick
 #define AG_EVV_CAP 16   // virus eat events per arena-tick (<= players)
@@ -96,7 +97,7 @@ struct AgState {
   double *rewards;        // [A][n_agents]
   uint8_t *dones;         // [A][n_agents]
   int32_t *masses;        // [A][n_agents]
-  float *packed;          // [2][A][n_agents][2] (reward, done) as f32, ping-pong by step parity: what gets gathered across GPUs
+  float *packed;          // [AG_PACKED_SLOTS][A][n_agents][2] (reward, done) as f32, ring indexed by step number: what gets gathered across GPUs
   int32_t *counts;        // [A][4]
   int32_t *ev_p;          // [A][AG_EV_CAP]
   int32_t *ev_v;          // [A][AG_EVV_CAP]
