@@ -62,7 +62,7 @@ SYMBOLS = [
     ("agarcl_get_counts", C.c_int, [C.c_void_p, C.c_void_p]),
     ("agarcl_get_events", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     ("agarcl_grid_obs", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
-    ("agarcl_screen_obs", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    ("agarcl_screen_obs", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     ("agarcl_dump_arena", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     ("agarcl_load_arena", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     ("agarcl_adopt_arena", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
@@ -227,13 +227,13 @@ class BatchedEngine:
         self._chk(self.L.agarcl_grid_obs(self.h, grid_size, int(cells), int(others), int(viruses), int(pellets), _ptr(out), 0, C.byref(ch)))
         return out
 
-    def screen_obs(self, width=84, height=84, out_ptr=None):
-        """uint8 [A, n_agents, height, width, 3] (rows bottom-up, like glReadPixels), host copy or written to HBM `out_ptr`."""
+    def screen_obs(self, width=84, height=84, out_ptr=None, agent_view=False):
+        """uint8 [A, n_agents, height, width, 3 or 4] (rows bottom-up, like glReadPixels), host copy or written to HBM `out_ptr`."""
         if out_ptr is not None:
-            self._chk(self.L.agarcl_screen_obs(self.h, width, height, C.c_void_p(out_ptr), 1))
+            self._chk(self.L.agarcl_screen_obs(self.h, width, height, int(bool(agent_view)), C.c_void_p(out_ptr), 1))
             return None
-        out = np.zeros((self.num_arenas, self.num_agents, height, width, 3), dtype=np.uint8)
-        self._chk(self.L.agarcl_screen_obs(self.h, width, height, _ptr(out), 0))
+        out = np.zeros((self.num_arenas, self.num_agents, height, width, 4 if agent_view else 3), dtype=np.uint8)
+        self._chk(self.L.agarcl_screen_obs(self.h, width, height, int(bool(agent_view)), _ptr(out), 0))
         return out
 
     def device_ptrs(self):

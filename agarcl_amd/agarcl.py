@@ -120,20 +120,19 @@ class ScreenEnvironment(_Environment):
 
     def __init__(self, num_agents, frames_per_step, arena_size, pellet_regen, num_pellets, num_viruses, num_bots,
                  reward_type, c_death, mode_number, load_env_snapshot, screen_width, screen_height, agent_view):
-        if agent_view:
-            raise RuntimeError("agent_view (4-channel) screen observations are not provided (SURVEY.md section 8f, row N4)")
+        self._agent_view = bool(agent_view)
         super().__init__(num_agents, frames_per_step, arena_size, pellet_regen, num_pellets, num_viruses, num_bots,
                          reward_type, c_death, mode_number, screen_respawn=True)
         self._w, self._h = int(screen_width), int(screen_height)
         self._loaded = bool(load_env_snapshot)   # BaseEnvironment(..., load_env_snapshot): reset() is a no-op from the start
 
     def observation_shape(self):             # bindings.cpp:156 -> (num_frames, width, height, channels)
-        return (1, self._w, self._h, 3)
+        return (1, self._w, self._h, 4 if self._agent_view else 3)
 
     def get_state(self):                     # bindings.cpp:157-168: the frame buffer's bytes viewed as uint8 (1, W, H, 3)
-        frames = self._engine.screen_obs(self._w, self._h)   # [1][n_agents][H][W][3], rows bottom-up (glReadPixels)
+        frames = self._engine.screen_obs(self._w, self._h, agent_view=self._agent_view)   # [1][n_agents][H][W][3|4], rows bottom-up
         # the reference keeps ONE frame buffer that every agent's render overwrites in turn: the last agent's frame remains
-        return frames[0, self._num_agents - 1].reshape(1, self._w, self._h, 3)
+        return frames[0, self._num_agents - 1].reshape(1, self._w, self._h, 4 if self._agent_view else 3)
 
 
 class GoBiggerEnvironment:

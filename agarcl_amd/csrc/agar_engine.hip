@@ -780,7 +780,7 @@ __global__ void __launch_bounds__(256) k_grid_obs(const AgState *__restrict__ gs
 }
 #endif
 
-extern "C" int agarcl_screen_obs(agarcl_env *e, int32_t width, int32_t height, uint8_t *out, int32_t on_device) {
+extern "C" int agarcl_screen_obs(agarcl_env *e, int32_t width, int32_t height, int32_t agent_view, uint8_t *out, int32_t on_device) {
   if (!e || !out) return fail(AGARCL_E_INVALID, "agarcl_screen_obs: null pointer");
   if (width < 1 || height < 1 || width > 1024 || height > 1024) return fail(AGARCL_E_INVALID, "agarcl_screen_obs: screen size must be in [1, 1024]");
 #ifdef AGAR_CPU_EMU
@@ -788,7 +788,7 @@ extern "C" int agarcl_screen_obs(agarcl_env *e, int32_t width, int32_t height, u
   return fail(AGARCL_E_UNSUPPORTED, "agarcl_screen_obs: the screen rasteriser exists only as a HIP kernel");
 #else
   HIPCHK(hipSetDevice(e->device));
-  size_t n = (size_t)e->d.A * e->d.n_agents, bytes = n * (size_t)width * height * 3;
+  size_t n = (size_t)e->d.A * e->d.n_agents, bytes = n * (size_t)width * height * (agent_view ? 4 : 3);
   uint8_t *dst = out;
   if (!on_device) {
     size_t words = (bytes + 3) / 4;
@@ -799,7 +799,7 @@ extern "C" int agarcl_screen_obs(agarcl_env *e, int32_t width, int32_t height, u
     }
     dst = (uint8_t *)e->obs_buf;
   }
-  AgScreenCfg o; o.W = width; o.H = height;
+  AgScreenCfg o; o.W = width; o.H = height; o.agent_view = agent_view != 0;
   hipLaunchKernelGGL(k_screen_obs, dim3((unsigned)n), dim3(256), 0, e->stream, e->d_state, o, dst);
   HIPCHK(hipGetLastError());
   if (!on_device && d2h(out, dst, bytes, e->stream)) return fail(AGARCL_E_HIP, "agarcl_screen_obs: copy failed");

@@ -140,8 +140,10 @@ int agarcl_grid_obs(agarcl_env *env, int32_t grid_size, int32_t observe_cells, i
  * glReadPixels (agario/rendering/renderer.hpp:163-185, FrameBufferObject.hpp:105), restated as rasterisation rules
  * (agarcl_amd/csrc/agar_screen.inl; rule-level parity only: see that file).  Writes u8[num_arenas][num_agents][height]
  * [width][3], rows bottom-up, i.e. per agent exactly the bytes ScreenObservation exposes as uint8 [1][W][H][3]
- * (environment/envs/ScreenEnvironment.hpp:24-128).  `out` is an HBM pointer if on_device != 0, else a host buffer. */
-int agarcl_screen_obs(agarcl_env *env, int32_t width, int32_t height, uint8_t *out, int32_t on_device);
+ * (environment/envs/ScreenEnvironment.hpp:24-128).  agent_view != 0: the 4-channel frame of
+ * Renderer::multi_channel_render_screen (renderer.hpp:128-155) after ScreenObservation::post_processing_frame_data
+ * (ScreenEnvironment.hpp:48-88), u8[...][height][width][4].  `out` is an HBM pointer if on_device != 0, else a host buffer. */
+int agarcl_screen_obs(agarcl_env *env, int32_t width, int32_t height, int32_t agent_view, uint8_t *out, int32_t on_device);
 
 /* full-state exchange for parity tests and snapshots (layout: oracle/BLOB_FORMAT.md); synchronising */
 int agarcl_dump_arena(agarcl_env *env, int32_t arena, uint32_t *buf_host, int32_t cap_words);

@@ -33,8 +33,10 @@ def _inside(dx, dy, r, n):
     return (d2 <= r * r) & ((d2 <= apo * apo) | (proj <= apo))
 
 
-def render(blob_words, arena_size, agent_pid, kinds, W=84, H=84):
-    """uint8 [H][W][3], rows bottom-up.  kinds: AG_KIND_* per player in the blob's (map iteration) order."""
+def render(blob_words, arena_size, agent_pid, kinds, W=84, H=84, agent_view=False, main_pid=None):
+    """uint8 [H][W][3] (or [H][W][4] with agent_view: Renderer::multi_channel_render_screen, renderer.hpp:128-155, followed
+    by ScreenObservation::post_processing_frame_data, ScreenEnvironment.hpp:48-88), rows bottom-up.
+    kinds: AG_KIND_* per player in the blob's (map iteration) order; main_pid: state.main_agent_pid (the last agent added)."""
     f = np.float32
     d = blob.parse(blob_words)
     pl = [p for p in d["players"] if p["pid"] == agent_pid][0]
@@ -48,7 +50,8 @@ def render(blob_words, arena_size, agent_pid, kinds, W=84, H=84):
     cols = np.arange(W, dtype=np.float32); rows = np.arange(H, dtype=np.float32)
     wx = (px + ((cols + f(0.5)) / f(W) * f(2) - f(1)) * half_w).astype(np.float32)[None, :].repeat(H, 0)
     wy = (py + ((rows + f(0.5)) / f(H) * f(2) - f(1)) * half_h).astype(np.float32)[:, None].repeat(W, 1)
-    img = np.full((H, W, 3), 255, dtype=np.uint8)
+    img = np.full((H, W, 3), 255, dtype=np.uint8) if not agent_view else np.zeros((H, W, 3), dtype=np.uint8)
+    drawn = np.zeros((H, W), dtype=bool)
     Wd = f(arena_size); spacing = f(Wd / f(7))
     in_x = (wx >= 0) & (wx <= Wd); in_y = (wy >= 0) & (wy <= Wd)
     sxs = f(f(W) * f(0.5) / half_w); sys_ = f(f(H) * f(0.5) / half_h)
@@ -56,23 +59,42 @@ def render(blob_words, arena_size, agent_pid, kinds, W=84, H=84):
     for i in range(8):
         g = f(f(i) * spacing)
         gc = int(np.floor(f(f(g - px) * sxs + f(W) * f(0.5)))); gr = int(np.floor(f(f(g - py) * sys_ + f(H) * f(0.5))))
-        img[((ci == gc) & in_y) | ((ri == gr) & in_x)] = (26, 0, 0)
+        gm = ((ci == gc) & in_y) | ((ri == gr) & in_x)
+        img[gm] = (26, 0, 0); drawn[gm] = True
 
     def draw(x, y, r, n, color):
         x = f(x); y = f(y); r = f(r)
         if abs(x - px) > half_w + r or abs(y - py) > half_h + r:
             return
         m = _inside((wx - x).astype(np.float32), (wy - y).astype(np.float32), r, n)
-        img[m] = color
+        img[m] = color; drawn[m] = True
     r_pel, r_food = radius(1), radius(10)
     for x, y, i in zip(d["pellet_x"], d["pellet_y"], d["pellet_id"]):
-        draw(x, y, r_pel, 5, PALETTE[int(i) % 6])
+        draw(x, y, r_pel, 5, (255, 0, 0) if agent_view else PALETTE[int(i) % 6])
     for x, y, i in zip(d["food_x"], d["food_y"], d["food_id"]):
-        draw(x, y, r_food, 7, PALETTE[int(i) % 6])
-    for p, kind in zip(d["players"], kinds):
-        color = PALETTE[p["pid"] % 6] if kind == 0 else PALETTE[BOT_COLOR[kind]]
+        draw(x, y, r_food, 7, (255, 0, 0) if agent_view else PALETTE[int(i) % 6])
+    order = list(zip(d["players"], kinds))
+    if agent_view:   # the main agent first (type 3), then everybody else (type 1)
+        order = [pk for pk in order if pk[0]["pid"] == main_pid] + [pk for pk in order if pk[0]["pid"] != main_pid]
+    for p, kind in order:
+        if agent_view:
+            color = (230, 0, 0) if p["pid"] == main_pid else (0, 255, 0)
+        else:
+            color = PALETTE[p["pid"] % 6] if kind == 0 else PALETTE[BOT_COLOR[kind]]
         for (x, y), m in zip(p["cell_f"][:, :2], p["cell_mass"]):
             draw(x, y, radius(int(m)), 50, color)
     for x, y, m in zip(d["virus_x"], d["virus_y"], d["virus_mass"]):
-        draw(x, y, radius(int(m)), 150, PALETTE[3])
-    return img
+        draw(x, y, radius(int(m)), 150, (0, 0, 255) if agent_view else PALETTE[3])
+    if not agent_view:
+        return img
+    data = np.concatenate([img, np.where(drawn, 255, 0).astype(np.uint8)[:, :, None]], axis=2).reshape(-1).copy()
+    n = W * H * 4
+    for i in range(n):   # ScreenObservation::post_processing_frame_data, byte for byte (ScreenEnvironment.hpp:48-88)
+        if i % 4 != 3 and data[i] != 0:
+            if data[i] <= 230:
+                data[i + (3 - i % 4)] = data[i]; data[i] = 0
+            else:
+                prev = i - i % 4 - 1; prev2 = prev - 4
+                if prev2 >= 0 and data[prev2] <= 30 and data[prev] <= 30:
+                    data[i + (3 - i % 4)] = data[prev]
+    return data.reshape(H, W, 4)

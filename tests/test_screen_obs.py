@@ -48,8 +48,22 @@ def test_hip_screen_frames_follow_the_rules(hip_engine_cls, cfg, steps):
                 ref = screen_oracle.render(b, cfg["arena_size"], int(pl[i, 15]), kinds, W, H)   # PL_PID of agent slot i
                 diff = (ref != frames[a, i]).any(axis=2).mean()
                 assert diff <= 0.004, "arena %d agent %d %dx%d: %.2f%% of the pixels differ" % (a, i, W, H, 100 * diff)
-                # structural: the agent's own colour at the view centre (its centroid lies inside one of its cells or between them)
                 assert frames[a, i].reshape(-1, 3).max() == 255
+    # agent view (N4): 4 channels by type + the reference's byte-level post-processing
+    W = H = 84
+    frames = eng.screen_obs(W, H, agent_view=True)
+    assert frames.shape == (A, na, H, W, 4)
+    for a in range(A):
+        ar, pl = eng.arena_words(a)
+        b = eng.dump(a)
+        kinds = [int(pl[int(ar[13 + k]), 16]) for k in range(pl.shape[0])]
+        for i in range(na):
+            ref = screen_oracle.render(b, cfg["arena_size"], int(pl[i, 15]), kinds, W, H, agent_view=True, main_pid=int(pl[na - 1, 15]))
+            diff = (ref != frames[a, i]).any(axis=2).mean()
+            assert diff <= 0.006, "agent view, arena %d agent %d: %.2f%% of the pixels differ" % (a, i, 100 * diff)
+            f = frames[a, i]
+            assert set(np.unique(f[:, :, 0])) <= {0, 255} and set(np.unique(f[:, :, 1])) <= {0, 255} and set(np.unique(f[:, :, 2])) <= {0, 255}
+            assert (f[:, :, 3] == 230).any() or i != na - 1       # the main agent lives in the alpha channel
     eng.close()
 
 
@@ -67,6 +81,8 @@ def test_agarcl_screen_environment_mirror():
     img = s.reshape(84, 84, 3)
     assert (img == 255).all(axis=2).mean() > 0.3            # white background dominates
     assert not (img[40:44, 40:44] == 255).all()             # the agent's cells sit at the view centre
-    with pytest.raises(RuntimeError):
-        agarcl.ScreenEnvironment(1, 4, 1000, True, 1000, 25, 0, True, 0, 6, False, 84, 84, True)
+    env.close()
+    env = agarcl.ScreenEnvironment(1, 4, 1000, True, 1000, 25, 0, True, 0, 6, False, 84, 84, True)   # agent view: 4 channels
+    env.seed(3); env.reset(); env.take_actions([(0.3, -0.2, 0)]); env.step()
+    assert env.observation_shape() == (1, 84, 84, 4) and env.get_state().shape == (1, 84, 84, 4)
     env.close()
