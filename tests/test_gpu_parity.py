@@ -124,6 +124,21 @@ def test_hip_snapshot_golden(hip_engine_cls, base):
     assert ok, msg
 
 
+def test_baseline_config_c1_population(hip_engine_cls, oracle_lib):
+    """BASELINE.json configs[0] / SURVEY 8(d) C1 -- the reference's own CPU-runnable case: 250x250 arena, 500 pellets,
+    10 viruses, one agent + the four bot kinds, random targets and actions, dead players respawned (mode 0), 10 000
+    ticks -- in lock-step with the oracle on the GPU, driven through the env API (whose tick length is the reference's
+    fixed 1/30 s; the 1/60 s engine-level variant of bench/main.cpp is covered by tests/test_oracle_vs_reference.py and
+    the emulation tests on the CPU)."""
+    cfg = dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0)
+    A = 4
+    eng = hip_engine_cls(A, **cfg)
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    ok, msg = run_batched_lockstep(eng, oras, 2500, seeds=np.array([42, 43, 44, 45]), sticky=1, every=50)
+    eng.close()
+    assert ok, msg
+
+
 def test_masked_reset_and_reseed(hip_engine_cls, oracle_lib):
     """reset(mask) touches only the selected arenas; ids keep growing like the reference's global counter."""
     A = 8
