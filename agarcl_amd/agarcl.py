@@ -135,6 +135,49 @@ class ScreenEnvironment(_Environment):
         return frames[0, self._num_agents - 1].reshape(1, self._w, self._h, 4 if self._agent_view else 3)
 
 
-class GoBiggerEnvironment:
-    def __init__(self, *a, **k):
-        raise RuntimeError("GoBiggerEnvironment is not provided by the HIP engine (SURVEY.md section 8f, row N3)")
+class GoBiggerEnvironment(_Environment):
+    """agarcl.GoBiggerEnvironment (bindings.cpp:321-375; environment/envs/GoBiggerEnvironment.hpp:551-737): the engine
+    with the GoBigger-style structured observation (object view, agarcl_amd/gobigger.py).  get_frame (an OpenGL
+    512x512 frame) is served by the rule-based rasteriser."""
+
+    def __init__(self, map_width, map_height, frame_limit, num_agents, ticks_per_step, arena_size, pellet_regen, num_pellets,
+                 num_viruses, num_bots, reward_type, c_death=0, mode_number=0, load_env_snapshot=False, agent_view=False):
+        from . import gobigger
+        # _partial_observation zeroes c_death_ on every call (GoBiggerEnvironment.hpp:624): death is never penalised here
+        super().__init__(num_agents, ticks_per_step, arena_size, pellet_regen, num_pellets, num_viruses, num_bots, reward_type, 0, mode_number)
+        self._gb = gobigger
+        self._global = gobigger.GlobalState(map_width, map_height, frame_limit, 0, num_agents)
+        self._states = gobigger.PlayerStates()
+        self._grid_size = 128
+        self._no_frames = 0
+        self._loaded = bool(load_env_snapshot)   # (nothing is observed before the first reset(): the base constructor's reset runs the base hook)
+
+    def configure_observation(self, config):  # bindings.cpp:341-352
+        self._grid_size = int(config.get("grid_size", 128))
+
+    def _observe(self):                       # _partial_observation per agent -> GoBiggerObservation::add_frame (:519-541, 618-636)
+        blob = self._engine.dump(0)
+        for _ in range(self._num_agents):
+            self._gb.add_frame(self._states, blob, self._grid_size)
+            self._no_frames += 1
+        self._global.update_last_frame_count(0)
+
+    def reset(self):
+        super().reset()
+        if not self._loaded:
+            self._observe()
+
+    def step(self):
+        r = super().step()
+        self._observe()
+        return r
+
+    def observation_shape(self):              # GoBiggerObservation::shape (:411-416): (frames added so far, map_height, map_width)
+        return (self._no_frames, self._global.get_map_height(), self._global.get_map_width())
+
+    def get_state(self):                      # bindings.cpp:28-47
+        return [{"global_state": self._global, "player_states": self._states}]
+
+    def get_frame(self):                      # bindings.cpp:354-363: uint8 (1, 512, 512, 3) from the last agent's perspective
+        f = self._engine.screen_obs(512, 512)
+        return f[0, self._num_agents - 1].reshape(1, 512, 512, 3)

@@ -59,3 +59,37 @@ def test_host_mirror_gpu(oracle_lib):
     from agarcl_amd import agarcl, gym_agario
     assert agarcl._LIB is None
     _exercise(agarcl, gym_agario, oracle_lib)
+
+
+def test_gobigger_object_view(emu_lib, monkeypatch):
+    """SURVEY 8f N3 (object view, parity unpinned): structure and invariants of the GoBigger-style observation."""
+    from agarcl_amd import agarcl
+    monkeypatch.setattr(agarcl, "_LIB", emu_lib)
+    env = agarcl.GoBiggerEnvironment(512, 512, 1000, 1, 4, 300, True, 400, 6, 2, True, 0, 0)
+    env.seed(5); env.reset()
+    for t in range(40):
+        env.take_actions([(0.4, 0.3, t % 3)]); env.step()
+    st = env.get_state()
+    assert isinstance(st, list) and set(st[0]) == {"global_state", "player_states"}
+    gs, ps = st[0]["global_state"], st[0]["player_states"]
+    assert gs.get_map_width() == 512 and gs.get_frame_limit() == 1000 and gs.get_team_num() == 1
+    states = ps.get_all_player_states()
+    assert len(states) == 3                                     # the agent and both bots, keyed by pid
+    from oracle import blob
+    d = blob.parse(env._engine.dump(0))
+    for p in d["players"]:
+        s = states[p["pid"]]
+        assert s.get_team_name() == "dummy" and s.canEject() and s.canSplit()
+        if p["n_cells"]:
+            assert s.get_score() == float(p["cell_mass"].sum())
+            clones = s.get_clone_infos()
+            assert 1 <= len(clones) <= p["n_cells"] and all(c.owner == p["pid"] and c.teamId == 0 for c in clones)
+            assert sum(c.score for c in clones) <= p["cell_mass"].sum()
+            # one-cell players sit at their own centre
+            if p["n_cells"] == 1:
+                assert abs(clones[0].get_position_x()) < 1e-3 and abs(clones[0].get_position_y()) < 1e-3
+            assert all(f.score == 1 and abs(f.radius - 0.5641896) < 1e-5 for f in s.get_food_infos())
+            view = min(max(2.0 * p["cell_mass"].sum(), 100.0), 300.0)
+            assert all(abs(f.get_position_x()) <= view / 2 + 1e-3 and abs(f.get_position_y()) <= view / 2 + 1e-3 for f in s.get_food_infos())
+    assert env.observation_shape()[1:] == (512, 512) and env.observation_shape()[0] == 41     # one frame per reset / step
+    env.close()
