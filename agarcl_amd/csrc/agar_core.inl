@@ -1321,14 +1321,16 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
   if (!AV) q.slack = 0.0f;
   float s2 = q.slack * q.slack;
   q.done = 0; q.last_ev = -1; q.m_move = q.m; q.pel_changed = false;
-  const float pel_r = lut(lut_r, AG_PELLET_MASS); const float pel_span = W - 2.0f * pel_r;  // random_location(radius), Engine.hpp:143-148
+  const float pel_r = g.pel_r; const float pel_span = W - 2.0f * pel_r;  // random_location(radius), Engine.hpp:143-148
+  // countdowns instead of two integer modulos per tick: ticks until the next regeneration tick / decay check
+  int to_regen = regen ? (120 - q.ticks % 120) % 120 : -1, to_decay = decay ? 59 - q.elapsed % 60 : -1;
   while (pel.any(active)) {
     bool need = false, regen_tick = false, decay_tick = false;
     float nx = q.x, ny = q.y, nvx = 0.0f, nvy = 0.0f, nsx = q.svx, nsy = q.svy;
     unsigned nm = q.m; PelQuery k{0.0f, 0.0f, 0.0f, 0.0f, 0, 0};
     if (active) {
-      regen_tick = regen && q.ticks % 120 == 0;
-      decay_tick = decay && (q.elapsed + 1) % 60 == 0;
+      regen_tick = to_regen == 0;   // regen && ticks % 120 == 0
+      decay_tick = to_decay == 0;   // decay && (elapsed + 1) % 60 == 0
       if (q.done >= max_ticks) active = false;
       else if (q.m >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0) active = false;  // eject needs >= 35, split >= 50
       else if (q.m >= 111u && q.nv != 0) active = false;                                  // virus contact needs >= 111
@@ -1383,6 +1385,7 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
           if (um != q.m) { q.m = um; q.r = lut(lut_r, q.m); q.hi = lut(lut_ms, q.m); rr = q.r * q.r; }  // a smaller radius keeps the disc valid
         }
         q.ticks += 1;
+        to_regen = to_regen == 0 ? 119 : to_regen - 1; to_decay = to_decay == 0 ? 59 : to_decay - 1;
       }
     }
     pel.swap_pop(pop, ev, np_before);

@@ -66,6 +66,7 @@ struct agarcl_env {
   std::vector<uint32_t> seeds;  // last seed of every arena (BaseEnvironment::seed_, written into JSON snapshots)
   bool fused;     // single-launch step (k_fused) instead of k_quiet + k_step: see k_fused
   bool fused_fixed;                // AGARCL_FUSED=0/1 pins the choice
+  int fused_wg;                    // threads per workgroup of k_fused (64, 128 or 256)
   int32_t *h_stat; void *stat_ev;  // pinned copy of qstat + the event that says it has arrived
   bool stat_pending; long step_no, stat_req_step, stat_last_step; int32_t stat_last_total;
   int parity;     // launch parity of the k_quiet / k_step pair (selects the unfinished-arena counter)
@@ -149,7 +150,7 @@ template <int NS, bool AV> __global__ void __launch_bounds__(256) k_quiet(const 
 // scripts/microbench/launch_floor.hip) at the price of serialising a wavefront's unfinished arenas -- the wrong trade
 // when most arenas need the general path every step (mass-1000 modes), where the two-kernel step is used.
 template <int NS, bool AV> __global__ void __launch_bounds__(256) AG_KFUSED_ATTR k_fused(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int lds_per_wave) {
-  int arena = (int)blockIdx.x * (256 / AG_QG) + (int)threadIdx.x / AG_QG;
+  int arena = (int)blockIdx.x * ((int)blockDim.x / AG_QG) + (int)threadIdx.x / AG_QG;
   const int A = gs->d.A; const bool valid = arena < A;
   if (!valid) arena = A - 1;
   const int sub = (int)threadIdx.x % AG_QG;
@@ -227,7 +228,8 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
   if (use_q && !e->fused_fixed && e->h_stat) adapt_step_mode(e);
   if (use_q && e->fused) {
     const unsigned lpw = (unsigned)((e->lds_bytes + 15) & ~(size_t)15);
-#define CALL(N, V) hipLaunchKernelGGL((k_fused<N, V>), dim3((e->d.A + 256 / AG_QG - 1) / (256 / AG_QG)), dim3(256), 4 * lpw, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, (int)lpw)
+    const int wg = e->fused_wg, apw = wg / AG_QG;  // threads and arenas per workgroup
+#define CALL(N, V) hipLaunchKernelGGL((k_fused<N, V>), dim3((e->d.A + apw - 1) / apw), dim3(wg), (wg / 64) * lpw, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, (int)lpw)
     AG_DISPATCH_NS(e->ns, CALL);
 #undef CALL
     HIPCHK(hipGetLastError());
@@ -359,6 +361,7 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   g.dt = (float)dt; g.dt10 = (float)(dt * 10);
   g.recomb_ticks = (int)ceil(10.0 / dt - 1e-9);
   g.reward_type = cfg->reward_type != 0; g.c_death = cfg->c_death; g.screen_respawn = cfg->screen_respawn != 0;
+  g.pel_r = (float)sqrt((double)AG_PELLET_MASS / 1.0 / 3.14159265358979323846);  // == lut_r[AG_PELLET_MASS] below
   // grid dims exactly as the reference computes them in float (Engine.hpp:964-965, 1210-1211)
   g.pgw = g.pgh = (int)((g.W + (float)AG_PELLET_GRID - 1.0f) / (float)AG_PELLET_GRID);
   g.vgw = g.vgh = (int)((g.W + (float)AG_VIRUS_GRID - 1.0f) / (float)AG_VIRUS_GRID);
@@ -410,6 +413,7 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   e->fused_fixed = false; e->h_stat = nullptr; e->stat_ev = nullptr; e->stat_pending = false; e->step_no = e->stat_req_step = e->stat_last_step = 0; e->stat_last_total = 0;
   { const char *fu = getenv("AGARCL_FUSED"); if (fu && (fu[0] == '0' || fu[0] == '1')) { e->fused = fu[0] == '1'; e->fused_fixed = true; } }
   s.qstat = alloc<int32_t>(e, 1);
+  e->fused_wg = 256; { const char *w = getenv("AGARCL_FUSED_WG"); if (w) { int v = atoi(w); if (v == 64 || v == 128 || v == 256) e->fused_wg = v; } }
 #ifndef AGAR_CPU_EMU
   if (d.P == 1 && !e->fused_fixed) {
     hipEvent_t ev;

@@ -123,7 +123,7 @@ template <int NS, bool AV> AG_DEV QHandOver quiet_arena(const AgState *gs, int a
   quiet_ticks<AV>(q, gs->g, (const AG_GLOBAL float *)gs->lut_r, (const AG_GLOBAL float *)gs->lut_ms, (const AG_GLOBAL uint64_t *)(gs->mt + (size_t)arena * 312), pel, ticks, ok);
 #if defined(AGAR_PROFILE) && !defined(AGAR_CPU_EMU)
   unsigned t2_ = (unsigned)__builtin_readcyclecounter();
-  if (lead && gs->prof) { gs->prof[(size_t)arena * 16 + 4] = w0_; gs->prof[(size_t)arena * 16 + 5] = wall_clock64(); gs->prof[(size_t)arena * 16 + 0] += t1_ - t0_; gs->prof[(size_t)arena * 16 + 1] += t2_ - t1_; gs->prof[(size_t)arena * 16 + 2] += (unsigned long long)q.done; }
+  if (lead && gs->prof) { gs->prof[(size_t)arena * 16 + 4] = w0_; gs->prof[(size_t)arena * 16 + 5] = wall_clock64(); gs->prof[(size_t)arena * 16 + 7] = (unsigned long long)(q.food_eaten); gs->prof[(size_t)arena * 16 + 0] += t1_ - t0_; gs->prof[(size_t)arena * 16 + 1] += t2_ - t1_; gs->prof[(size_t)arena * 16 + 2] += (unsigned long long)q.done; }
 #endif
   const bool finished = q.done == ticks;
   if (finished && with_env && mode == 3 && q.m >= 23000u) done_flag = 1;

@@ -68,6 +68,7 @@ struct AgParams {
   float dt, dt10;          // (float)dt and (float)(dt*10) (Engine.hpp:613,674)
   int recomb_ticks;        // 10 s in ticks
   int reward_type, c_death;
+  float pel_r;             // radius of a pellet (lut_r[1]): random_location's margin when pellets regenerate
   int screen_respawn;      // ScreenEnvironment's hook: respawn dead agents right after the ticks, in every mode (ScreenEnvironment.hpp:233-243)
   int pgw, pgh, vgw, vgh;  // pellet / virus grid dims (Engine.hpp:964-965,1210-1211)
 };
