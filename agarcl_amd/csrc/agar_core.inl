@@ -1285,6 +1285,9 @@ template <int NS, bool AV> AG_DEV void sort_cells_by_id(AgCtx<NS, AV> &c, int p)
 // general path takes over.
 // quiet_ticks() is shared by two callers that differ only in where the pellets live (the `Pel` accessor):
 // k_step's quiet_run (pellets in the wave's registers) and the lean kernel k_quiet (pellets streamed from HBM/L2).
+#ifndef AG_QUIET_BURST
+#define AG_QUIET_BURST 1   // ticks an arena may run ahead of the others of its wavefront between two wave-level sync points
+#endif
 struct QState {  // per arena: wave-uniform in k_step, uniform over the arena's lane group in k_quiet
   unsigned m, m_move;  // mass; mass at the last tick's move (Player::min_mass bookkeeping)
   int action, nv, np, ticks, elapsed, fcd, scd, last_decay, nvt, food_eaten, hm, last_ev, done;
@@ -1310,8 +1313,11 @@ template <bool AV> AG_DEV void pel_accumulate(const PelQuery &k, float qx, float
   if (k.rr1 >= d2) c1 += 1;
 }
 
-// The tick loop is written in phases so that the pellet pass sits at a point every lane of the wave reaches together
-// (`pel.any`, `pel.scan`, `pel.swap_pop` are wave-level calls; everything inside `if (active)` is per-arena code):
+// The loop alternates two phases so that the pellet pass sits at a point every lane of the wave reaches together
+// (`pel.any` and `pel.scan` are wave-level calls; everything else is per-arena code):
+//   A  each arena runs plain quiet ticks on its own until it is finished, has to stop, or has moved out of its
+//      pellet-free disc (then the moved-but-uncommitted tick waits for a pass);
+//   B  one wave-level pass serves every arena that waits, which then resolves its pending tick (eat / new disc).
 // k_quiet advances several arenas per wavefront and lets the whole wave scan for whichever of them needs it.
 template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QState &q, const AgParams &g, LutT lut_r, LutT lut_ms, MtT mt, PelT &pel, int max_ticks, bool active = true) {
   const float dt = g.dt, W = g.W;
@@ -1324,72 +1330,36 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
   const float pel_r = g.pel_r; const float pel_span = W - 2.0f * pel_r;  // random_location(radius), Engine.hpp:143-148
   // countdowns instead of two integer modulos per tick: ticks until the next regeneration tick / decay check
   int to_regen = regen ? (120 - q.ticks % 120) % 120 : -1, to_decay = decay ? 59 - q.elapsed % 60 : -1;
-  while (pel.any(active)) {
-    bool need = false, regen_tick = false, decay_tick = false;
-    float nx = q.x, ny = q.y, nvx = 0.0f, nvy = 0.0f, nsx = q.svx, nsy = q.svy;
-    unsigned nm = q.m; PelQuery k{0.0f, 0.0f, 0.0f, 0.0f, 0, 0};
-    if (active) {
-      regen_tick = to_regen == 0;   // regen && ticks % 120 == 0
-      decay_tick = to_decay == 0;   // decay && (elapsed + 1) % 60 == 0
-      if (q.done >= max_ticks) active = false;
-      else if (q.m >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0) active = false;  // eject needs >= 35, split >= 50
-      else if (q.m >= 111u && q.nv != 0) active = false;                                  // virus contact needs >= 111
-      // regeneration (Engine.hpp:236-239): viruses need the general path; pellets are topped up inline (below) as long as
-      // the generator's buffered outputs suffice (2 draws per pellet, one more pellet may be eaten this very tick)
-      else if (regen_tick && (tgt_v - q.nv > 0 || q.mtidx + 2 * (tgt_p - q.np + 1) > 312)) active = false;
-      else if (decay_tick && q.nvt != 0) active = false;                                  // anti-team bookkeeping
-      if (active) {
-        move_one(nx, ny, nvx, nvy, nsx, nsy, q.hi, q.r, q.tx, q.ty, dt, W);
-        if (q.np != 0) {
-          float ox = nx - q.sx0, oy = ny - q.sy0; float o2 = ox * ox, o2b = oy * oy; o2 = o2 + o2b;
-          if (!(AV && o2 < s2)) {  // left the pellet-free disc (or none known): look at the pellets
-            need = true;
-            nm = clamp_mass(q.m + AG_PELLET_MASS);
-            float r1 = lut(lut_r, nm);
-            k.x = nx; k.y = ny; k.rr = rr; k.rr1 = r1 * r1; k.gx = f2i(nx) / AG_PELLET_GRID; k.gy = f2i(ny) / AG_PELLET_GRID;
-          }
-        }
-      }
+  // the pending tick of phase B: where the cell moved to, what it would weigh after one pellet
+  float nx = q.x, ny = q.y, nvx = 0.0f, nvy = 0.0f, nsx = q.svx, nsy = q.svy;
+  unsigned nm = q.m; PelQuery k{0.0f, 0.0f, 0.0f, 0.0f, 0, 0};
+  bool need = false;
+
+  // everything of a tick after the pellets have been dealt with (ev: index of the eaten pellet or -1)
+  auto finish_tick = [&](int ev, bool rescanned, float nslack) {
+    const bool regen_tick = to_regen == 0, decay_tick = to_decay == 0;
+    q.m_move = q.m;
+    q.x = nx; q.y = ny; q.vx = nvx; q.vy = nvy; q.svx = nsx; q.svy = nsy;
+    if (rescanned) { q.slack = nslack; q.sx0 = nx; q.sy0 = ny; s2 = nslack * nslack; }
+    q.elapsed += 1; q.done += 1; q.last_ev = ev;
+    if (ev >= 0) {  // Engine.hpp:991-994 (eat), :1002-1009 (swap-pop)
+      q.m = nm; q.food_eaten += 1;
+      q.r = lut(lut_r, q.m); q.hi = lut(lut_ms, q.m); rr = q.r * q.r;
+      pel.swap_pop(ev, q.np);
+      q.np -= 1; q.pel_changed = true; q.slack = 0.0f; s2 = 0.0f;
     }
-    PelScan sc = pel.template scan<AV>(need, k);
-    int ev = -1; bool pop = false; int np_before = q.np;
-    if (active) {
-      float nslack = 0.0f;
-      if (need) {
-        if (rr >= sc.dmin2) {  // somebody is inside the radius: a plain single eat, or the general path's business
-          if (sc.cnt != 1 || sc.cnt1 != 1 || (nm >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0)) active = false;
-          else ev = sc.first;
-        } else {
-          float sl = ag_sqrtf(sc.dmin2) - q.r; sl = sl - 0.01f;
-          nslack = sl > 0.0f ? sl : 0.0f;
-        }
-      }
-      if (active) {  // ---- the tick is quiet: commit it ----
-        q.m_move = q.m;
-        q.x = nx; q.y = ny; q.vx = nvx; q.vy = nvy; q.svx = nsx; q.svy = nsy;
-        if (need) { q.slack = nslack; q.sx0 = nx; q.sy0 = ny; s2 = nslack * nslack; }
-        q.elapsed += 1; q.done += 1; q.last_ev = ev;
-        if (ev >= 0) {  // Engine.hpp:991-994 (eat), :1002-1009 (swap-pop, below)
-          q.m = nm; q.food_eaten += 1;
-          q.r = lut(lut_r, q.m); q.hi = lut(lut_ms, q.m); rr = q.r * q.r;
-          pop = true;
-          q.np -= 1; q.pel_changed = true; q.slack = 0.0f; s2 = 0.0f;
-        }
-        if ((unsigned)q.hm < q.m) q.hm = (int)q.m;
-        if (q.fcd > 0) q.fcd -= 1; if (q.action == 1 && q.fcd == 0) q.fcd = 10;   // Engine.hpp:1046-1054 (nothing can be ejected: mass < 35)
-        if (q.scd > 0) q.scd -= 1; if (q.action == 2 && q.scd == 0) q.scd = 30;   // Engine.hpp:1056-1064 (nothing can split: mass < 50)
-        if (decay_tick && q.elapsed - q.last_decay >= 60) {                       // Engine.hpp:575-584, Entities.hpp:199-203
-          double dm = (double)q.m * (1 - 0.002 * q.rate); unsigned um = (unsigned)dm;
-          um = um > AG_CELL_MIN_SIZE ? um : AG_CELL_MIN_SIZE;
-          q.last_decay = q.elapsed;
-          if (um != q.m) { q.m = um; q.r = lut(lut_r, q.m); q.hi = lut(lut_ms, q.m); rr = q.r * q.r; }  // a smaller radius keeps the disc valid
-        }
-        q.ticks += 1;
-        to_regen = to_regen == 0 ? 119 : to_regen - 1; to_decay = to_decay == 0 ? 59 : to_decay - 1;
-      }
+    if ((unsigned)q.hm < q.m) q.hm = (int)q.m;
+    if (q.fcd > 0) q.fcd -= 1; if (q.action == 1 && q.fcd == 0) q.fcd = 10;   // Engine.hpp:1046-1054 (nothing can be ejected: mass < 35)
+    if (q.scd > 0) q.scd -= 1; if (q.action == 2 && q.scd == 0) q.scd = 30;   // Engine.hpp:1056-1064 (nothing can split: mass < 50)
+    if (decay_tick && q.elapsed - q.last_decay >= 60) {                       // Engine.hpp:575-584, Entities.hpp:199-203
+      double dm = (double)q.m * (1 - 0.002 * q.rate); unsigned um = (unsigned)dm;
+      um = um > AG_CELL_MIN_SIZE ? um : AG_CELL_MIN_SIZE;
+      q.last_decay = q.elapsed;
+      if (um != q.m) { q.m = um; q.r = lut(lut_r, q.m); q.hi = lut(lut_ms, q.m); rr = q.r * q.r; }  // a smaller radius keeps the disc valid
     }
-    pel.swap_pop(pop, ev, np_before);
-    if (active && regen_tick && tgt_p - q.np > 0) {  // add_pellets(target - n): random_location(r) per pellet, Engine.hpp:418-424
+    q.ticks += 1;
+    to_regen = to_regen == 0 ? 119 : to_regen - 1; to_decay = to_decay == 0 ? 59 : to_decay - 1;
+    if (regen_tick && tgt_p - q.np > 0) {  // add_pellets(target - n): random_location(r) per pellet, Engine.hpp:418-424, 236-239
       const int n_new = tgt_p - q.np;
       for (int j = 0; j < n_new; j++) {
         float px = mt_to_float(mt_temper(mt[q.mtidx]), pel_span) + pel_r;
@@ -1400,7 +1370,48 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
       }
       q.pel_changed = true; q.slack = 0.0f; s2 = 0.0f;  // a new pellet may lie inside the old pellet-free disc
     }
-    pel.publish(active && regen_tick);
+  };
+
+  for (;;) {
+    // ---- phase A: one quiet tick per arena (all arenas of the wave stay on the same tick, so a pass never has to
+    // wait for the others to finish their whole run) ----
+    for (int once = 0; active && once < AG_QUIET_BURST; once++) {
+      if (q.done >= max_ticks) { active = false; break; }
+      if (q.m >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0) { active = false; break; }  // eject needs >= 35, split >= 50
+      if (q.m >= 111u && q.nv != 0) { active = false; break; }                                  // virus contact needs >= 111
+      // regeneration (Engine.hpp:236-239): viruses need the general path; pellets are topped up inline as long as the
+      // generator's buffered outputs suffice (2 draws per pellet, one more pellet may be eaten this very tick)
+      if (to_regen == 0 && (tgt_v - q.nv > 0 || q.mtidx + 2 * (tgt_p - q.np + 1) > 312)) { active = false; break; }
+      if (to_decay == 0 && q.nvt != 0) { active = false; break; }                               // anti-team bookkeeping
+      nx = q.x; ny = q.y; nsx = q.svx; nsy = q.svy;
+      move_one(nx, ny, nvx, nvy, nsx, nsy, q.hi, q.r, q.tx, q.ty, dt, W);
+      if (q.np != 0) {
+        float ox = nx - q.sx0, oy = ny - q.sy0; float o2 = ox * ox, o2b = oy * oy; o2 = o2 + o2b;
+        if (!(AV && o2 < s2)) {  // left the pellet-free disc (or none known): look at the pellets
+          need = true;
+          nm = clamp_mass(q.m + AG_PELLET_MASS);
+          float r1 = lut(lut_r, nm);
+          k.x = nx; k.y = ny; k.rr = rr; k.rr1 = r1 * r1; k.gx = f2i(nx) / AG_PELLET_GRID; k.gy = f2i(ny) / AG_PELLET_GRID;
+          break;
+        }
+      }
+      finish_tick(-1, false, 0.0f);
+    }
+    // ---- phase B: one pass for everybody who waits ----
+    if (!pel.any(need || active)) break;
+    PelScan sc = pel.template scan<AV>(need, k);
+    if (need) {
+      need = false;
+      int ev = -1; float nslack = 0.0f;
+      if (rr >= sc.dmin2) {  // somebody is inside the radius: a plain single eat, or the general path's business
+        if (sc.cnt != 1 || sc.cnt1 != 1 || (nm >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0)) active = false;  // (nothing of this tick is committed)
+        else ev = sc.first;
+      } else {
+        float sl = ag_sqrtf(sc.dmin2) - q.r; sl = sl - 0.01f;
+        nslack = sl > 0.0f ? sl : 0.0f;
+      }
+      if (active) finish_tick(ev, true, nslack);
+    }
   }
 }
 
@@ -1427,9 +1438,7 @@ template <int NS, bool AV> struct RegPel {
     auto gid = g_pid(c); AG_SERIAL { gid[idx] = id; }
     c.pel_dirty = true;
   }
-  AG_MEM void publish(bool) {}
-  AG_MEM void swap_pop(bool doit, int ev, int np) {
-    if (!doit) return;
+  AG_MEM void swap_pop(int ev, int np) {
     if (np > 1 && ev < np - 1) { pel_move(c, ev, np - 1); auto gid = g_pid(c); AG_SERIAL { gid[ev] = gid[np - 1]; } }
     int lastp = np - 1;
     AG_PEL_FOR(sl_, lane, i) { if (i == lastp) { PELX(c, sl_, lane) = AG_PEL_SENTINEL; PELY(c, sl_, lane) = AG_PEL_SENTINEL; } }

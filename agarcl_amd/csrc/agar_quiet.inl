@@ -42,6 +42,7 @@ template <int NS> struct GrpPel {
   template <bool AV> AG_MEM PelScan scan(bool need, const PelQuery &k) {
     PelScan out{3.0e38f, 0, 0, -1};
     unsigned long long todo = __ballot(need);
+    if (todo) ag_mem_fence();  // pellets this wave wrote earlier (swap-pop, regeneration) must be visible to the pass
     const int lane = (int)threadIdx.x & 63;
     while (todo) {
       const int src = (int)__builtin_ctzll(todo);  // first lane of the first group that still waits
@@ -67,13 +68,11 @@ template <int NS> struct GrpPel {
   AG_MEM void append(int idx, float x, float y, int pid) {  // pellets.emplace_back (the group's first lane writes)
     if (lead()) { xy[2 * idx] = x; xy[2 * idx + 1] = y; id[idx] = pid; }
   }
-  AG_MEM void publish(bool wrote) { if (any(wrote)) ag_mem_fence(); }  // later passes of this wave must see the new pellets
-  AG_MEM void swap_pop(bool doit, int ev, int np) {  // Engine.hpp:1002-1009 for one event
-    if (doit && lead()) {
+  AG_MEM void swap_pop(int ev, int np) {  // Engine.hpp:1002-1009 for one event (per-arena code; the next pass fences)
+    if (lead()) {
       if (np > 1 && ev < np - 1) { xy[2 * ev] = xy[2 * (np - 1)]; xy[2 * ev + 1] = xy[2 * (np - 1) + 1]; id[ev] = id[np - 1]; }
       xy[2 * (np - 1)] = AG_PEL_SENTINEL; xy[2 * (np - 1) + 1] = AG_PEL_SENTINEL;
     }
-    if (any(doit)) ag_mem_fence();
   }
 };
 
