@@ -1298,21 +1298,37 @@ struct QState {  // per arena: wave-uniform in k_step, uniform over the arena's 
 };
 // One fused pass over an arena's pellets as seen from (x, y): squared distance to the nearest one, how many lie
 // within rr and within rr1 (the radius after eating one), and the index of the first one within rr.
-struct PelScan { float dmin2; int cnt, cnt1, first; };
+struct PelScan { float dmin2, dsec2; int cnt, cnt1, first; };  // dsec2: squared distance to the SECOND nearest pellet
 struct PelQuery { float x, y, rr, rr1; int gx, gy; };  // gx, gy: the cell's pellet bucket (used only without AV)
 template <bool AV> AG_DEV bool pel_visible(const PelQuery &k, float qx, float qy) {  // R: Engine.hpp:976-990 (3x3 bucket walk)
   if constexpr (AV) return true;
   else { int ddx = f2i(qx) / AG_PELLET_GRID - k.gx, ddy = f2i(qy) / AG_PELLET_GRID - k.gy; return ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1; }
 }
 // lane-level accumulation of one pellet into the partial results (dmin as float bits: orders like the value for d2 >= 0)
-template <bool AV> AG_DEV void pel_accumulate(const PelQuery &k, float qx, float qy, unsigned idx, unsigned &dmin, int &c0, int &c1, unsigned &first) {
+template <bool AV> AG_DEV void pel_accumulate(const PelQuery &k, float qx, float qy, unsigned idx, unsigned &dmin, unsigned &dsec, int &c0, int &c1, unsigned &first) {
   if (!pel_visible<AV>(k, qx, qy)) return;
   float d2 = sqr_dist(k.x, k.y, qx, qy);
-  unsigned b = (unsigned)f2u(d2); dmin = b < dmin ? b : dmin;
+  unsigned b = (unsigned)f2u(d2);
+  unsigned hi = b > dmin ? b : dmin; dsec = hi < dsec ? hi : dsec; dmin = b < dmin ? b : dmin;  // two smallest, lane-private
   if (k.rr >= d2) { c0 += 1; first = idx < first ? idx : first; }
   if (k.rr1 >= d2) c1 += 1;
 }
 
+#ifndef AGAR_CPU_EMU
+// wave-wide combination of the lane-private partials of one pass (all 64 lanes active)
+AG_DEV void pel_reduce(float rr, unsigned &dmin, unsigned &dsec, int &c0, int &c1, unsigned &first) {
+  const unsigned lane_min = dmin;
+  dmin = wred_min(dmin);
+  if (rr >= u2f((int)dmin)) {  // (uniform branch) only when somebody is in reach
+    c0 = wred_add(c0); c1 = wred_add(c1); first = wred_min(first);
+    // second smallest overall: the lane that owns the minimum offers its own second, every other lane its minimum
+    // (two lanes holding the same minimal value would mean two pellets at that distance: c0 >= 2, no inline eat)
+    const unsigned long long owners = __ballot(lane_min == dmin);
+    const bool owner = AG_LANE == (int)__builtin_ctzll(owners);
+    dsec = wred_min(owner ? dsec : lane_min);
+  }
+}
+#endif
 // The loop alternates two phases so that the pellet pass sits at a point every lane of the wave reaches together
 // (`pel.any` and `pel.scan` are wave-level calls; everything else is per-arena code):
 //   A  each arena runs plain quiet ticks on its own until it is finished, has to stop, or has moved out of its
@@ -1333,7 +1349,7 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
   // the pending tick of phase B: where the cell moved to, what it would weigh after one pellet
   float nx = q.x, ny = q.y, nvx = 0.0f, nvy = 0.0f, nsx = q.svx, nsy = q.svy;
   unsigned nm = q.m; PelQuery k{0.0f, 0.0f, 0.0f, 0.0f, 0, 0};
-  bool need = false;
+  bool need = false; float dsec_pending = 0.0f;
 
   // everything of a tick after the pellets have been dealt with (ev: index of the eaten pellet or -1)
   auto finish_tick = [&](int ev, bool rescanned, float nslack) {
@@ -1346,7 +1362,11 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
       q.m = nm; q.food_eaten += 1;
       q.r = lut(lut_r, q.m); q.hi = lut(lut_ms, q.m); rr = q.r * q.r;
       pel.swap_pop(ev, q.np);
-      q.np -= 1; q.pel_changed = true; q.slack = 0.0f; s2 = 0.0f;
+      q.np -= 1; q.pel_changed = true;
+      // the eaten pellet was the nearest one: the pass also saw the second nearest, which bounds the new pellet-free disc
+      // around this very position -- no second pass on the next tick
+      float sl = ag_sqrtf(dsec_pending) - q.r; sl = sl - 0.01f; sl = sl > 0.0f ? sl : 0.0f;
+      q.slack = sl; s2 = sl * sl;
     }
     if ((unsigned)q.hm < q.m) q.hm = (int)q.m;
     if (q.fcd > 0) q.fcd -= 1; if (q.action == 1 && q.fcd == 0) q.fcd = 10;   // Engine.hpp:1046-1054 (nothing can be ejected: mass < 35)
@@ -1405,7 +1425,7 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
       int ev = -1; float nslack = 0.0f;
       if (rr >= sc.dmin2) {  // somebody is inside the radius: a plain single eat, or the general path's business
         if (sc.cnt != 1 || sc.cnt1 != 1 || (nm >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0)) active = false;  // (nothing of this tick is committed)
-        else ev = sc.first;
+        else { ev = sc.first; dsec_pending = sc.dsec2; }
       } else {
         float sl = ag_sqrtf(sc.dmin2) - q.r; sl = sl - 0.01f;
         nslack = sl > 0.0f ? sl : 0.0f;
@@ -1420,16 +1440,15 @@ template <int NS, bool AV> struct RegPel {
   AgCtx<NS, AV> &c;
   AG_MEM bool any(bool p) const { return p; }
   template <bool AV2> AG_MEM PelScan scan(bool need, const PelQuery &k) {
-    PelScan out{3.0e38f, 0, 0, -1};
+    PelScan out{3.0e38f, 3.0e38f, 0, 0, -1};
     if (!need) return out;
     ensure_pellets(c); pel_launder(c);
-    unsigned dmin = 0x7f800000u, first = 0xffffffffu; int c0 = 0, c1 = 0;
-    AG_PEL_FOR(s, lane, i) { pel_accumulate<AV>(k, PELX(c, s, lane), PELY(c, s, lane), (unsigned)i, dmin, c0, c1, first); }
+    unsigned dmin = 0x7f800000u, dsec = 0x7f800000u, first = 0xffffffffu; int c0 = 0, c1 = 0;
+    AG_PEL_FOR(s, lane, i) { pel_accumulate<AV>(k, PELX(c, s, lane), PELY(c, s, lane), (unsigned)i, dmin, dsec, c0, c1, first); }
 #ifndef AGAR_CPU_EMU
-    dmin = wred_min(dmin);
-    if (k.rr >= u2f((int)dmin)) { c0 = wred_add(c0); c1 = wred_add(c1); first = wred_min(first); }  // (uniform branch) only when somebody is in reach
+    pel_reduce(k.rr, dmin, dsec, c0, c1, first);
 #endif
-    out.dmin2 = u2f((int)dmin); out.cnt = c0; out.cnt1 = c1; out.first = (int)first;
+    out.dmin2 = u2f((int)dmin); out.dsec2 = u2f((int)dsec); out.cnt = c0; out.cnt1 = c1; out.first = (int)first;
     return out;
   }
   AG_MEM void append(int idx, float x, float y, int id) {  // pellets.emplace_back

@@ -28,11 +28,11 @@ template <int NS> struct GrpPel {
   AG_MEM bool lead() const { return true; }
   AG_MEM bool any(bool p) const { return p; }
   template <bool AV> AG_MEM PelScan scan(bool need, const PelQuery &k) {
-    PelScan out{3.0e38f, 0, 0, -1};
+    PelScan out{3.0e38f, 3.0e38f, 0, 0, -1};
     if (!need) return out;
-    unsigned dmin = 0x7f800000u, first = 0xffffffffu; int c0 = 0, c1 = 0;
-    for (int i = 0; i < NS * 64; i++) pel_accumulate<AV>(k, xy[2 * i], xy[2 * i + 1], (unsigned)i, dmin, c0, c1, first);
-    out.dmin2 = u2f((int)dmin); out.cnt = c0; out.cnt1 = c1; out.first = (int)first;
+    unsigned dmin = 0x7f800000u, dsec = 0x7f800000u, first = 0xffffffffu; int c0 = 0, c1 = 0;
+    for (int i = 0; i < NS * 64; i++) pel_accumulate<AV>(k, xy[2 * i], xy[2 * i + 1], (unsigned)i, dmin, dsec, c0, c1, first);
+    out.dmin2 = u2f((int)dmin); out.dsec2 = u2f((int)dsec); out.cnt = c0; out.cnt1 = c1; out.first = (int)first;
     return out;
   }
 #else
@@ -40,7 +40,7 @@ template <int NS> struct GrpPel {
   AG_MEM bool lead() const { return sub == 0; }
   AG_MEM bool any(bool p) const { return __ballot(p) != 0ull; }
   template <bool AV> AG_MEM PelScan scan(bool need, const PelQuery &k) {
-    PelScan out{3.0e38f, 0, 0, -1};
+    PelScan out{3.0e38f, 3.0e38f, 0, 0, -1};
     unsigned long long todo = __ballot(need);
     if (todo) ag_mem_fence();  // pellets this wave wrote earlier (swap-pop, regeneration) must be visible to the pass
     const int lane = (int)threadIdx.x & 63;
@@ -56,11 +56,10 @@ template <int NS> struct GrpPel {
       auto gp = (const AG_GLOBAL XY *)(((unsigned long long)hi << 32) | lo) + lane;
       XY p[NS];
       _Pragma("unroll") for (int s = 0; s < NS; s++) p[s] = gp[s * 64];
-      unsigned dmin = 0x7f800000u, first = 0xffffffffu; int c0 = 0, c1 = 0;
-      _Pragma("unroll") for (int s = 0; s < NS; s++) pel_accumulate<AV>(b, p[s].x, p[s].y, (unsigned)(s * 64 + lane), dmin, c0, c1, first);
-      dmin = wred_min(dmin);
-      if (b.rr >= u2f((int)dmin)) { c0 = wred_add(c0); c1 = wred_add(c1); first = wred_min(first); }  // (uniform branch) only when somebody is in reach
-      if ((lane & ~(AG_QG - 1)) == src) { out.dmin2 = u2f((int)dmin); out.cnt = c0; out.cnt1 = c1; out.first = (int)first; }
+      unsigned dmin = 0x7f800000u, dsec = 0x7f800000u, first = 0xffffffffu; int c0 = 0, c1 = 0;
+      _Pragma("unroll") for (int s = 0; s < NS; s++) pel_accumulate<AV>(b, p[s].x, p[s].y, (unsigned)(s * 64 + lane), dmin, dsec, c0, c1, first);
+      pel_reduce(b.rr, dmin, dsec, c0, c1, first);
+      if ((lane & ~(AG_QG - 1)) == src) { out.dmin2 = u2f((int)dmin); out.dsec2 = u2f((int)dsec); out.cnt = c0; out.cnt1 = c1; out.first = (int)first; }
     }
     return out;
   }
