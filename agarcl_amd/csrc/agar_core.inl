@@ -1151,7 +1151,18 @@ template <int NS, bool AV> AG_DEV void tick_player(AgCtx<NS, AV> &c, int p) {
   if ((unsigned)PR(c, PL_HIGHEST_MASS) < total) PW(c, PL_HIGHEST_MASS, (int)total);
   // per-cell: auto split (mass >= 22500) then eat ejected food.  R: Engine.hpp:520-525, 592-601
   bool big = total >= AG_MAX_MASS && wave_any(n, [&](int i) { return s.m[i] >= AG_MAX_MASS; });
-  if (big || SR(c, AR_NFOOD) > 0) {
+  bool food_work = big;
+  if (!big && SR(c, AR_NFOOD) > 0) {
+    // one pass over the foods (a lane each) against all cells proves the common case -- nobody touches any food --
+    // instead of one HBM round trip per cell; without an auto-split no mass changes between here and a cell's own turn
+    auto fx = g_fx(c); auto fy = g_fy(c); const float fr = radius_of(c, AG_FOOD_MASS);
+    food_work = wave_any(SR(c, AR_NFOOD), [&](int j) {
+      float x = fx[j], y = fy[j]; bool h = false;
+      for (int i = 0; i < n; i++) { unsigned m = s.m[i]; h = h | (m >= AG_FOOD_MASS && can_eat_mass(m, AG_FOOD_MASS) && collides(s.x[i], s.y[i], cell_rad(c, s, i), x, y, fr)); }
+      return h;
+    });
+  }
+  if (food_work) {
     float tx = PRF(c, PL_TX), ty = PRF(c, PL_TY);
     int fe_total = 0;
     for (int k = 0; k < n; k++) {
