@@ -92,6 +92,10 @@ def hip_lib():
     __graft_entry__ as g; g.build()' or agarcl_amd/build.py)."""
     global _hip
     if _hip is None:
+        try:  # if PyTorch is going to be used in this process, its HIP runtime must be the one that is loaded first
+            import torch  # noqa: F401
+        except Exception:
+            pass
         if not os.path.exists(HIP_SO):
             raise AgarclError(-4, "HIP extension %s is missing -- build it with agarcl_amd/build.py "
                                   "(there is no CPU fallback)" % HIP_SO)

@@ -57,16 +57,30 @@ OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o,
   float centering = (float)(G / 2.0);
   float W = gs->g.W;
   // phase 1: channel 0 = out-of-bounds mask (:235-248), all other channels 0
-  OBS_FOR(k, GG) {
+  auto oob = [&](int k) -> int32_t {
     int i = k / G, j = k - i * G;
     float xd = (float)i - centering, yd = (float)j - centering;
     float dx = xd * view; dx = dx / (float)G;
     float dy = yd * view; dy = dy / (float)G;
     float lx = px + dx, ly = py + dy;
     bool inb = 0 <= lx && lx < W && 0 <= ly && ly < W;
-    out[k] = inb ? 0 : -1;
+    return inb ? 0 : -1;
+  };
+#ifndef AGAR_CPU_EMU
+  if ((GG & 3) == 0 && (((size_t)out) & 15) == 0) {
+    // 16 bytes per lane per store (1 KiB per wave-instruction), streaming (non-temporal): the tensor is written once
+    // and read by somebody else
+    typedef int32_t v4 __attribute__((ext_vector_type(4)));
+    v4 *o4 = (v4 *)out;
+    OBS_FOR(q, GG / 4) { v4 v; v.x = oob(4 * q); v.y = oob(4 * q + 1); v.z = oob(4 * q + 2); v.w = oob(4 * q + 3); __builtin_nontemporal_store(v, &o4[q]); }
+    const v4 z = {0, 0, 0, 0};
+    OBS_FOR(q, (C - 1) * (GG / 4)) __builtin_nontemporal_store(z, &o4[GG / 4 + q]);
+  } else
+#endif
+  {
+    OBS_FOR(k, GG) out[k] = oob(k);
+    OBS_FOR(k, (C - 1) * GG) out[GG + k] = 0;
   }
-  OBS_FOR(k, (C - 1) * GG) out[GG + k] = 0;
   OBS_BARRIER();
   // world -> grid (:258-268)
   auto w2g = [&](float ex, float ey, int &gx, int &gy) {

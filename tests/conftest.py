@@ -5,6 +5,11 @@ import sys
 
 import pytest
 
+try:  # load order: PyTorch brings its own HIP runtime; importing it before libagarcl_hip.so keeps ONE runtime in the
+    import torch  # noqa: F401   # process (a test that initialises torch.cuda after the engine would otherwise find no GPU)
+except Exception:  # torch is only needed by the tensor-facing tests
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
