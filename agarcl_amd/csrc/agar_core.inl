@@ -276,16 +276,6 @@ template <int NS, bool AV, class F> AG_DEV int pel_count(const AgCtx<NS, AV> &c,
   return n;
 #endif
 }
-// minimum over all pellets of a non-negative float (as its bit pattern, which orders like the value)
-template <int NS, bool AV, class F> AG_DEV unsigned pel_min_bits(const AgCtx<NS, AV> &c, F f) {
-  unsigned b = 0x7f800000u;
-  AG_PEL_FOR(s, lane, i) { unsigned v = (unsigned)f2u(f(PELX(c, s, lane), PELY(c, s, lane), i)); b = v < b ? v : b; }
-#ifdef AGAR_CPU_EMU
-  return b;
-#else
-  return wred_min(b);
-#endif
-}
 // ordered compaction in ascending pellet index: sink(x, y, i, rank)
 template <int NS, bool AV, class F, class S> AG_DEV int pel_compact(const AgCtx<NS, AV> &c, F pred, S sink) {
   int count = 0;
