@@ -339,7 +339,7 @@ template <int NS, bool AV> AG_DEV void arena_load(AgCtx<NS, AV> &c, bool want_pe
 #ifndef AGAR_CPU_EMU
 #pragma unroll
 #endif
-      for (int f = 0; f < CF_ALL; f++) l[f * AG_CC + i] = g[f * AG_CC + i];
+      for (int f = 0; f < CF_ALL; f++) l[f * AG_CC + i] = g[AG_CELL_W(f, i)];
     }
   }
   c.pel_dirty = false; c.ncreated = 0;
@@ -369,7 +369,7 @@ template <int NS, bool AV> AG_DEV void arena_store(AgCtx<NS, AV> &c) {
 #ifndef AGAR_CPU_EMU
 #pragma unroll
 #endif
-      for (int f = 0; f < CF_ALL; f++) g[f * AG_CC + i] = l[f * AG_CC + i];
+      for (int f = 0; f < CF_ALL; f++) g[AG_CELL_W(f, i)] = l[f * AG_CC + i];
     }
   }
   ub_store(c.S, g_ar(c), AR_WORDS);

@@ -690,8 +690,8 @@ extern "C" int agarcl_dump_arena(agarcl_env *e, int32_t arena, uint32_t *buf, in
     for (int i = 0; i < P[PL_NVTICKS]; i++) o.push_back((uint32_t)h.vt[(size_t)p * AG_VT_CAP + i]);
     const uint32_t *C = &h.cells[(size_t)p * CF_ALL * AG_CC];
     for (int i = 0; i < P[PL_NCELLS]; i++) {
-      for (int f = CF_X; f <= CF_ID; f++) o.push_back(C[f * AG_CC + i]);
-      uint32_t dl = C[CF_DL * AG_CC + i];
+      for (int f = CF_X; f <= CF_ID; f++) o.push_back(C[AG_CELL_W(f, i)]);
+      uint32_t dl = C[AG_CELL_W(CF_DL, i)];
       o.push_back(dl > clock ? dl - clock : 0u);
     }
   }
@@ -751,8 +751,8 @@ static int load_arena_impl(agarcl_env *e, int32_t arena, const uint32_t *b, int3
     p += 17 + nt;
     uint32_t *C = &h.cells[(size_t)slot * CF_ALL * AG_CC];
     for (uint32_t i = 0; i < ncell; i++, p += 9) {
-      for (int f = CF_X; f <= CF_SY; f++) C[f * AG_CC + i] = p[f];
-      C[CF_M * AG_CC + i] = p[6] > AG_CELL_MIN_SIZE ? p[6] : AG_CELL_MIN_SIZE; C[CF_ID * AG_CC + i] = p[7]; C[CF_DL * AG_CC + i] = clock + p[8];
+      for (int f = CF_X; f <= CF_SY; f++) C[AG_CELL_W(f, i)] = p[f];
+      C[AG_CELL_W(CF_M, i)] = p[6] > AG_CELL_MIN_SIZE ? p[6] : AG_CELL_MIN_SIZE; C[AG_CELL_W(CF_ID, i)] = p[7]; C[AG_CELL_W(CF_DL, i)] = clock + p[8];
     }
   }
   if (p - b != words) return fail(AGARCL_E_INVALID, "agarcl_load_arena: blob length mismatch");

@@ -42,8 +42,8 @@ OBS_DEV void obs_player(const AgState *gs, int arena, int p, float &px, float &p
   const uint32_t *C = gs->cells + ((size_t)arena * gs->d.P + p) * (CF_ALL * AG_CC);
   int n = pl[PL_NCELLS]; float sx = 0.0f, sy = 0.0f; unsigned tm = 0;
   for (int i = 0; i < n; i++) {
-    union { uint32_t u; float f; } x, y; x.u = C[CF_X * AG_CC + i]; y.u = C[CF_Y * AG_CC + i];
-    unsigned m = C[CF_M * AG_CC + i]; float fm = (float)m;
+    union { uint32_t u; float f; } x, y; x.u = C[AG_CELL_W(CF_X, i)]; y.u = C[AG_CELL_W(CF_Y, i)];
+    unsigned m = C[AG_CELL_W(CF_M, i)]; float fm = (float)m;
     float t = x.f * fm; sx += t; t = y.f * fm; sy += t; tm += m;
   }
   px = sx / (float)tm; py = sy / (float)tm; mass = tm;
@@ -109,8 +109,8 @@ OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o,
       const uint32_t *Cc = gs->cells + ((size_t)arena * gs->d.P + p) * (CF_ALL * AG_CC);
       int n = pl[PL_NCELLS];
       for (int i = 0; i < n; i++) {
-        union { uint32_t u; float f; } x, y; x.u = Cc[CF_X * AG_CC + i]; y.u = Cc[CF_Y * AG_CC + i];
-        int m = (int)Cc[CF_M * AG_CC + i], gx, gy;
+        union { uint32_t u; float f; } x, y; x.u = Cc[AG_CELL_W(CF_X, i)]; y.u = Cc[AG_CELL_W(CF_Y, i)];
+        int m = (int)Cc[AG_CELL_W(CF_M, i)], gx, gy;
         if (!w2g(x.f, y.f, gx, gy)) continue;
         int32_t *d = &dst[gx * G + gy];
         if (mode == 0) *d += m; else if (mode == 1) *d = (*d == 0) ? m : (*d < m ? *d : m); else *d = (*d > m ? *d : m);

@@ -83,7 +83,7 @@ struct QHandOver { int done, before; };
 template <int NS, bool AV> AG_DEV QHandOver quiet_arena(const AgState *gs, int arena, int sub, bool valid, const AG_GLOBAL float *act_dxdy, const AG_GLOBAL int32_t *act, int ticks, bool with_env, int slot, int parity = -1) {
   auto S = (AG_GLOBAL int32_t *)(gs->ar + (size_t)arena * AR_WORDS);
   auto P = (AG_GLOBAL int32_t *)(gs->pl + (size_t)arena * PL_WORDS);
-  auto C = (AG_GLOBAL uint32_t *)(gs->cells + (size_t)arena * (CF_ALL * AG_CC));   // field f of cell 0 = C[f * AG_CC]
+  auto C = (AG_GLOBAL uint32_t *)(gs->cells + (size_t)arena * (CF_ALL * AG_CC));   // field f of cell 0 = C[AG_CELL_W(f, 0)]: one 48-byte run
   auto qi = (AG_GLOBAL int32_t *)(gs->qinfo + (size_t)arena * 2);
   GrpPel<NS> pel{(AG_GLOBAL float *)(gs->pel_xy + (size_t)arena * 2 * (NS * 64)), (AG_GLOBAL int32_t *)(gs->pel_id + (size_t)arena * (NS * 64)), sub};
   const bool lead = pel.lead() && valid;
@@ -91,11 +91,11 @@ template <int NS, bool AV> AG_DEV QHandOver quiet_arena(const AgState *gs, int a
   unsigned t0_ = (unsigned)__builtin_readcyclecounter(); unsigned long long w0_ = wall_clock64();
 #endif
   QState q;
-  q.m = C[CF_M * AG_CC];
-  int ncells = P[PL_NCELLS], nfood = S[AR_NFOOD]; unsigned cmc = C[CF_CMC * AG_CC];
+  q.m = C[AG_CELL_W(CF_M, 0)];
+  int ncells = P[PL_NCELLS], nfood = S[AR_NFOOD]; unsigned cmc = C[AG_CELL_W(CF_CMC, 0)];
   // everything the step needs, requested up front: one round trip
-  q.x = u2f((int)C[CF_X * AG_CC]); q.y = u2f((int)C[CF_Y * AG_CC]); q.vx = u2f((int)C[CF_VX * AG_CC]); q.vy = u2f((int)C[CF_VY * AG_CC]);
-  q.svx = u2f((int)C[CF_SX * AG_CC]); q.svy = u2f((int)C[CF_SY * AG_CC]); q.r = u2f((int)C[CF_CRAD * AG_CC]); q.hi = u2f((int)C[CF_CMS * AG_CC]);
+  q.x = u2f((int)C[AG_CELL_W(CF_X, 0)]); q.y = u2f((int)C[AG_CELL_W(CF_Y, 0)]); q.vx = u2f((int)C[AG_CELL_W(CF_VX, 0)]); q.vy = u2f((int)C[AG_CELL_W(CF_VY, 0)]);
+  q.svx = u2f((int)C[AG_CELL_W(CF_SX, 0)]); q.svy = u2f((int)C[AG_CELL_W(CF_SY, 0)]); q.r = u2f((int)C[AG_CELL_W(CF_CRAD, 0)]); q.hi = u2f((int)C[AG_CELL_W(CF_CMS, 0)]);
   q.action = P[PL_ACTION]; q.tx = u2f(P[PL_TX]); q.ty = u2f(P[PL_TY]);
   q.elapsed = P[PL_ELAPSED]; q.fcd = P[PL_FEED_CD]; q.scd = P[PL_SPLIT_CD]; q.last_decay = P[PL_LAST_DECAY]; q.nvt = P[PL_NVTICKS];
   q.food_eaten = P[PL_FOOD_EATEN]; q.hm = P[PL_HIGHEST_MASS]; q.rate = (double)u2f(P[PL_ANTI_TEAM]); q.sx0 = u2f(P[PL_SAFE_X]); q.sy0 = u2f(P[PL_SAFE_Y]);
@@ -134,9 +134,9 @@ template <int NS, bool AV> AG_DEV QHandOver quiet_arena(const AgState *gs, int a
 #endif
   if (lead && ok) {
     if (q.done > 0) {
-      C[CF_X * AG_CC] = (uint32_t)f2u(q.x); C[CF_Y * AG_CC] = (uint32_t)f2u(q.y); C[CF_VX * AG_CC] = (uint32_t)f2u(q.vx); C[CF_VY * AG_CC] = (uint32_t)f2u(q.vy);
-      C[CF_SX * AG_CC] = (uint32_t)f2u(q.svx); C[CF_SY * AG_CC] = (uint32_t)f2u(q.svy); C[CF_M * AG_CC] = q.m;
-      C[CF_CMC * AG_CC] = q.m; C[CF_CRAD * AG_CC] = (uint32_t)f2u(q.r); C[CF_CMS * AG_CC] = (uint32_t)f2u(q.hi);
+      C[AG_CELL_W(CF_X, 0)] = (uint32_t)f2u(q.x); C[AG_CELL_W(CF_Y, 0)] = (uint32_t)f2u(q.y); C[AG_CELL_W(CF_VX, 0)] = (uint32_t)f2u(q.vx); C[AG_CELL_W(CF_VY, 0)] = (uint32_t)f2u(q.vy);
+      C[AG_CELL_W(CF_SX, 0)] = (uint32_t)f2u(q.svx); C[AG_CELL_W(CF_SY, 0)] = (uint32_t)f2u(q.svy); C[AG_CELL_W(CF_M, 0)] = q.m;
+      C[AG_CELL_W(CF_CMC, 0)] = q.m; C[AG_CELL_W(CF_CRAD, 0)] = (uint32_t)f2u(q.r); C[AG_CELL_W(CF_CMS, 0)] = (uint32_t)f2u(q.hi);
       P[PL_ELAPSED] = q.elapsed; P[PL_MIN_MASS] = (int)q.m_move; P[PL_HIGHEST_MASS] = q.hm; P[PL_FEED_CD] = q.fcd; P[PL_SPLIT_CD] = q.scd;
       P[PL_FOOD_EATEN] = q.food_eaten; P[PL_LAST_DECAY] = q.last_decay; P[PL_SAFE_X] = f2u(q.sx0); P[PL_SAFE_Y] = f2u(q.sy0);
       S[AR_NEVP] = q.last_ev >= 0 ? 1 : 0; S[AR_NEVV] = 0; S[AR_NPEL] = q.np; S[AR_TICKS] = q.ticks; S[AR_CLOCK] = clock + q.done; S[AR_SAFE] = f2u(q.slack); S[AR_MTIDX] = q.mtidx; S[AR_IDC] = q.idc;

@@ -89,8 +89,8 @@ __global__ void __launch_bounds__(256) k_screen_obs(const AgState *__restrict__ 
       const unsigned col = (av ? (kk < 0 ? 0x0000E6u /* 0.9 -> 230 */ : 0x00FF00u)
                                : (kind == 0 ? scr_palette(pl[PL_PID]) : kind == 1 ? scr_palette(4) : kind == 2 ? scr_palette(5) : kind == 3 ? scr_palette(0) : scr_palette(1))) | (50u << 24);
       bool v = lane < n;
-      unsigned m = v ? C[CF_M * AG_CC + lane] : 0u;
-      emit(v, v ? __uint_as_float(C[CF_X * AG_CC + lane]) : 0.f, v ? __uint_as_float(C[CF_Y * AG_CC + lane]) : 0.f, v ? gs->lut_r[m < AG_LUT_SIZE ? m : AG_LUT_SIZE - 1] : 0.f, col);
+      unsigned m = v ? C[AG_CELL_W(CF_M, lane)] : 0u;
+      emit(v, v ? __uint_as_float(C[AG_CELL_W(CF_X, lane)]) : 0.f, v ? __uint_as_float(C[AG_CELL_W(CF_Y, lane)]) : 0.f, v ? gs->lut_r[m < AG_LUT_SIZE ? m : AG_LUT_SIZE - 1] : 0.f, col);
     }
     { size_t vo = (size_t)arena * gs->d.VC;
       for (int b = 0; b < nv; b += 64) { int i = b + lane; bool v = i < nv; unsigned m = v ? (unsigned)gs->vir_mass[vo + i] : 0u;

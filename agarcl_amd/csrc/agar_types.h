@@ -51,6 +51,10 @@ enum { CF_X = 0, CF_Y, CF_VX, CF_VY, CF_SX, CF_SY, CF_M, CF_ID, CF_DL, CF_FIELDS
        // derived, persisted so a launch needs no dependent table lookups: radius / max-speed cache of the cell,
        // valid iff CF_CMC == CF_M (agar_core.inl: Cells::cmc/crad/cms)
        CF_CMC = CF_FIELDS, CF_CRAD, CF_CMS, CF_ALL };
+// word index of field f of cell slot i inside a player's HBM cell block: CELL-major, so that one cell's 12 words are one
+// contiguous 48-byte run (a single-cell arena touches one cache line instead of twelve; a lane that stages slot i into LDS
+// reads three 16-byte words).  The LDS copy stays field-major.
+#define AG_CELL_W(f, i) ((i) * CF_ALL + (f))
 
 struct AgDims {
   int A;         // arenas
@@ -83,7 +87,7 @@ struct AgState {
   float *vir_x, *vir_y, *vir_vx, *vir_vy; int32_t *vir_mass, *vir_hits, *vir_id;
   // foods [A][FC]
   float *food_x, *food_y, *food_vx, *food_vy; int32_t *food_id;
-  // cells [A][P][CF_ALL][AG_CC] as 32-bit words
+  // cells [A][P][AG_CC][CF_ALL] as 32-bit words (AG_CELL_W)
   uint32_t *cells;
   int32_t *pl;      // [A][P][PL_WORDS]
   int32_t *vticks;  // [A][P][AG_VT_CAP]
