@@ -778,9 +778,19 @@ extern "C" int64_t agarcl_state_bytes(agarcl_env *e) {
 }
 
 #ifndef AGAR_CPU_EMU
-__global__ void __launch_bounds__(256) k_grid_obs(const AgState *__restrict__ gs, AgObsCfg o, int32_t *out) {
+__global__ void __launch_bounds__(256) k_grid_obs(const AgState *__restrict__ gs, AgObsCfg o, int32_t *out, int zero_fill) {
   int b = (int)blockIdx.x, na = gs->d.n_agents;
-  grid_obs_agent(gs, b / na, b % na, o, out + (size_t)b * obs_channels(o) * o.G * o.G);
+  grid_obs_agent(gs, b / na, b % na, o, out + (size_t)b * obs_channels(o) * o.G * o.G, zero_fill != 0);
+}
+// zeros for channels 1 .. C-1 of every frame: a plain streaming fill (grid-stride, 16 bytes per lane), which reaches the
+// write bandwidth of a memset; channel 0 and the entities are written afterwards by k_grid_obs
+__global__ void __launch_bounds__(256) k_grid_zero(int32_t *out, size_t frames, size_t frame_v4, size_t skip_v4) {
+  typedef int32_t v4 __attribute__((ext_vector_type(4)));
+  (void)frames;  // blockIdx.y = frame, blockIdx.x = slice of that frame's zero region
+  const unsigned per = (unsigned)(frame_v4 - skip_v4);
+  const v4 z = {0, 0, 0, 0};
+  v4 *o4 = (v4 *)out + (size_t)blockIdx.y * frame_v4 + skip_v4;
+  for (unsigned off = blockIdx.x * blockDim.x + threadIdx.x; off < per; off += gridDim.x * blockDim.x) __builtin_nontemporal_store(z, &o4[off]);
 }
 #endif
 
@@ -835,7 +845,10 @@ extern "C" int agarcl_grid_obs(agarcl_env *e, int32_t G, int32_t cells, int32_t 
     }
     dst = e->obs_buf;
   }
-  hipLaunchKernelGGL(k_grid_obs, dim3((unsigned)n), dim3(256), 0, e->stream, e->d_state, o, dst);
+  const size_t GG = (size_t)G * G;
+  const bool split = (GG & 3) == 0 && C > 1 && (((size_t)dst) & 15) == 0;
+  if (split) hipLaunchKernelGGL(k_grid_zero, dim3(8, (unsigned)n), dim3(256), 0, e->stream, dst, n, (size_t)C * GG / 4, GG / 4);
+  hipLaunchKernelGGL(k_grid_obs, dim3((unsigned)n), dim3(256), 0, e->stream, e->d_state, o, dst, split ? 0 : 1);
   HIPCHK(hipGetLastError());
   if (!on_device && d2h(out, dst, words * 4, e->stream)) return fail(AGARCL_E_HIP, "agarcl_grid_obs: copy failed");
   return AGARCL_OK;
