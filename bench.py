@@ -6,7 +6,7 @@ Workload = BASELINE.json configs[1] / SURVEY.md 8(d) "C2": 4096 arenas per GPU, 
 action "none", (dx,dy) ~ U(-1,1)^2 pre-generated in HBM, arena seeds = 10000 + global arena index.
 A bench "step" is one agarcl_step launch = 4 engine ticks of every arena.
 
-    python bench.py --gpus 1 --steps 400 --warmup 40
+    python bench.py --gpus 1 --steps 1000 --warmup 100
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the roofline / cpu_baseline fields).
@@ -105,8 +105,8 @@ def cpu_baseline(seconds_budget=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--arenas", type=int, default=ARENAS_PER_GPU, help="arenas per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS), help="C2 = the headline metric's configuration")
