@@ -62,6 +62,43 @@ def test_front_kernel_odd_arena_counts_long_quiet_rollout(hip_engine_cls, oracle
     eng.close()
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(arena_size=1400, num_pellets=1500, num_viruses=0, mode=0),     # 32 pellet slots per lane, 3x3 pellet grid (bucket visibility)
+    dict(arena_size=1400, num_pellets=2000, num_viruses=30, mode=0),    # near the pellet capacity
+    dict(arena_size=100, num_pellets=60, num_viruses=0, mode=0),        # 4 slots, crowded: frequent eats and regeneration
+    dict(arena_size=500, num_pellets=450, num_viruses=3, mode=3),       # 8 slots, mode 3 (no decay)
+    dict(arena_size=300, num_pellets=400, num_viruses=0, mode=1),       # squared pellets, no regeneration, no decay
+])
+def test_quiet_rollout_other_instantiations(hip_engine_cls, oracle_lib, cfg):
+    """Every pellet-slot instantiation (4 / 8 / 16 / 32) and the bucket-visibility variant of the front part under the
+    C2 policy for 800 steps, bit-exact against the oracle."""
+    A = 6
+    eng = hip_engine_cls(A, **cfg)
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    ok, msg = run_quiet_rollout(eng, oras, 800, 7000 + np.arange(A), rng_seed=3)
+    eng.close()
+    assert ok, "%s: %s" % (cfg, msg)
+
+
+def test_random_configurations_fuzz(hip_engine_cls, oracle_lib):
+    """Differential fuzz: random single- and multi-player configurations, random actions, 150 steps each."""
+    rng = np.random.RandomState(2024)
+    for trial in range(14):
+        na = int(rng.choice([1, 1, 1, 2, 3]))
+        mode = int(rng.choice([0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]))
+        nb = int(rng.randint(0, 5)) if mode == 0 else 0
+        if mode > 6:
+            na = 1
+        cfg = dict(num_agents=na, arena_size=int(rng.choice([80, 150, 250, 400, 1000, 1100])), num_pellets=int(rng.choice([50, 64, 200, 500, 1000, 1300])),
+                   num_viruses=int(rng.choice([0, 3, 10, 25])), num_bots=nb, mode=mode, reward_type=int(rng.randint(0, 2)), c_death=int(rng.choice([0, -20])))
+        A = 4
+        eng = hip_engine_cls(A, **cfg)
+        oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+        ok, msg = run_batched_lockstep(eng, oras, 150, seeds=rng.randint(1, 1 << 30, size=A), policy_seed=int(rng.randint(1, 1000)), sticky=int(rng.choice([1, 4, 8])), every=10)
+        eng.close()
+        assert ok, "trial %d %s: %s" % (trial, cfg, msg)
+
+
 def test_step_mode_adapts_and_results_do_not_depend_on_it(hip_engine_cls, oracle_lib):
     """Mode-0 arenas whose agents have become big (mass 3000 with random split / eject actions) need the general engine
     every step: the engine starts with the fused single-launch step, notices through its asynchronous statistics that
