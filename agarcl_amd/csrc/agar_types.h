@@ -42,9 +42,9 @@ enum {
 #define AG_EV_CAP 256   // pellet eat events per arena-tick
 #define AG_EVV_CAP 16   // virus eat events per arena-tick (<= players)
 #define AG_CAND_CAP 1024 // words of the ordered-replay candidate list: 256 records of (key, index, x, y)
-#define AG_VT_CAP 32    // virus_eaten_ticks kept per player
+#define AG_VT_CAP 256   // virus_eaten_ticks kept per player (the reference vector is unbounded; > 256 virus meals inside 3600 ticks raises a flag)
 #define AG_LUT_SIZE (1 << 19)
-#define AG_ANTI_LUT 64
+#define AG_ANTI_LUT 256
 
 // cell fields, player-major in LDS and HBM: [player][field][AG_CC]
 enum { CF_X = 0, CF_Y, CF_VX, CF_VY, CF_SX, CF_SY, CF_M, CF_ID, CF_DL, CF_FIELDS,
