@@ -49,6 +49,10 @@ def emu_lib():
 
 @pytest.fixture(scope="session")
 def hip_engine_cls():
-    from agarcl_amd import _capi
+    """The product: agarcl_amd/libagarcl_hip.so through its C ABI.  Built in-tree first if the snapshot came without it
+    (hipcc, ~1.5 min); a missing library or GPU makes every -m gpu test fail loudly -- there is nothing to fall back to."""
+    from agarcl_amd import _capi, build as hip_build
+    if not os.path.exists(_capi.HIP_SO):
+        hip_build.build()
     _capi.hip_lib()
     return _capi.BatchedEngine
