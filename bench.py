@@ -117,6 +117,9 @@ def main():
 
     import torch
     import numpy as np
+    from agarcl_amd import _capi as _c, build as _hip_build
+    if not os.path.exists(_c.HIP_SO) and int(os.environ.get("RANK", "0")) == 0:
+        _hip_build.build()          # normally prebuilt by __graft_entry__.build(); never rebuilt when present
     from agarcl_amd.vec_env import VecEnvironment
     from agarcl_amd import dist as agdist
 
