@@ -264,6 +264,22 @@ def main():
             out["roofline"]["achieved"] = out["roofline"]["algorithmic_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
             out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
             out["roofline"]["kernel"] = "k_step + k_grid_obs"
+        if world == 1:  # measured roofline next to the nominal one: device stream copy and fill of 1 GiB
+            try:
+                src = torch.empty(1 << 28, dtype=torch.int32, device=dev); dst = torch.empty_like(src)
+                def _bw(fn, nbytes):
+                    for _ in range(2):
+                        fn()
+                    torch.cuda.synchronize(); t = time.perf_counter()
+                    for _ in range(5):
+                        fn()
+                    torch.cuda.synchronize()
+                    return nbytes * 5 / (time.perf_counter() - t) / 1e9
+                out["roofline"]["measured_copy_GBs"] = _bw(lambda: dst.copy_(src), 2 * src.numel() * 4)
+                out["roofline"]["measured_fill_GBs"] = _bw(lambda: dst.fill_(1), src.numel() * 4)
+                del src, dst
+            except Exception:
+                pass
         if world == 1 and not args.no_cpu_baseline and args.workload == "C2":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
