@@ -86,3 +86,18 @@ def test_agarcl_screen_environment_mirror():
     env.seed(3); env.reset(); env.take_actions([(0.3, -0.2, 0)]); env.step()
     assert env.observation_shape() == (1, 84, 84, 4) and env.get_state().shape == (1, 84, 84, 4)
     env.close()
+
+
+@pytest.mark.gpu
+def test_gym_wrapper_screen_observation():
+    """AgarioEnv(obs_type="screen") as gym_agario builds it (AgarioEnv.py:235-250): (1, W, H, 3) uint8 frames."""
+    from agarcl_amd import gym_agario
+    g = gym_agario.AgarioEnv(obs_type="screen", difficulty="normal", screen_len=64, number_steps=4)
+    g.seed(2)
+    obs, info = g.reset()
+    assert obs.shape == (64, 64, 3) or obs.shape == (1, 64, 64, 3)
+    assert obs.dtype == np.uint8 and info == {}
+    for k in range(3):
+        obs, rew, done, trunc, info = g.step(((0.2, -0.4), 0))
+        assert obs.dtype == np.uint8 and isinstance(rew, float) and trunc is False
+    g.close()
