@@ -56,9 +56,17 @@ template <int NS> struct GrpPel {
       auto gp = (const AG_GLOBAL XY *)(((unsigned long long)hi << 32) | lo) + lane;
       XY p[NS];
       _Pragma("unroll") for (int s = 0; s < NS; s++) p[s] = gp[s * 64];
+      // the usual outcome is "nothing in reach": a lean minimum first, the full accumulation only when something is
       unsigned dmin = 0x7f800000u, dsec = 0x7f800000u, first = 0xffffffffu; int c0 = 0, c1 = 0;
-      _Pragma("unroll") for (int s = 0; s < NS; s++) pel_accumulate<AV>(b, p[s].x, p[s].y, (unsigned)(s * 64 + lane), dmin, dsec, c0, c1, first);
-      pel_reduce(b.rr, dmin, dsec, c0, c1, first);
+      _Pragma("unroll") for (int s = 0; s < NS; s++) {
+        if (pel_visible<AV>(b, p[s].x, p[s].y)) { unsigned v = (unsigned)f2u(sqr_dist(b.x, b.y, p[s].x, p[s].y)); dmin = v < dmin ? v : dmin; }
+      }
+      dmin = wred_min(dmin);
+      if (b.rr >= u2f((int)dmin)) {  // (uniform branch)
+        dmin = 0x7f800000u;
+        _Pragma("unroll") for (int s = 0; s < NS; s++) pel_accumulate<AV>(b, p[s].x, p[s].y, (unsigned)(s * 64 + lane), dmin, dsec, c0, c1, first);
+        pel_reduce(b.rr, dmin, dsec, c0, c1, first);
+      }
       if ((lane & ~(AG_QG - 1)) == src) { out.dmin2 = u2f((int)dmin); out.dsec2 = u2f((int)dsec); out.cnt = c0; out.cnt1 = c1; out.first = (int)first; }
     }
     return out;
