@@ -58,6 +58,8 @@ AG_DEV float ag_divf(float a, float b) { return a / b; }
 
 #include "agar_libm.inl"
 
+#define AG_RARE(x) __builtin_expect(!!(x), 0)  // keeps rare branches out of the hot instruction stream
+
 // Pointers fetched from the HBM-resident descriptor are generic to the compiler (flat_load/flat_store); every
 // accessor below casts them to the global address space so they become global_load / global_store.
 #ifdef AGAR_CPU_EMU
@@ -1359,7 +1361,7 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
     q.x = nx; q.y = ny; q.vx = nvx; q.vy = nvy; q.svx = nsx; q.svy = nsy;
     if (rescanned) { q.slack = nslack; q.sx0 = nx; q.sy0 = ny; s2 = nslack * nslack; }
     q.elapsed += 1; q.done += 1; q.last_ev = ev;
-    if (ev >= 0) {  // Engine.hpp:991-994 (eat), :1002-1009 (swap-pop)
+    if (AG_RARE(ev >= 0)) {  // Engine.hpp:991-994 (eat), :1002-1009 (swap-pop)
       q.m = nm; q.food_eaten += 1;
       q.r = lut(lut_r, q.m); q.hi = lut(lut_ms, q.m); rr = q.r * q.r;
       pel.swap_pop(ev, q.np);
@@ -1372,7 +1374,7 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
     if ((unsigned)q.hm < q.m) q.hm = (int)q.m;
     if (q.fcd > 0) q.fcd -= 1; if (q.action == 1 && q.fcd == 0) q.fcd = 10;   // Engine.hpp:1046-1054 (nothing can be ejected: mass < 35)
     if (q.scd > 0) q.scd -= 1; if (q.action == 2 && q.scd == 0) q.scd = 30;   // Engine.hpp:1056-1064 (nothing can split: mass < 50)
-    if (decay_tick && q.elapsed - q.last_decay >= 60) {                       // Engine.hpp:575-584, Entities.hpp:199-203
+    if (AG_RARE(decay_tick && q.elapsed - q.last_decay >= 60)) {             // Engine.hpp:575-584, Entities.hpp:199-203
       double dm = (double)q.m * (1 - 0.002 * q.rate); unsigned um = (unsigned)dm;
       um = um > AG_CELL_MIN_SIZE ? um : AG_CELL_MIN_SIZE;
       q.last_decay = q.elapsed;
@@ -1380,7 +1382,7 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
     }
     q.ticks += 1;
     to_regen = to_regen == 0 ? 119 : to_regen - 1; to_decay = to_decay == 0 ? 59 : to_decay - 1;
-    if (regen_tick && tgt_p - q.np > 0) {  // add_pellets(target - n): random_location(r) per pellet, Engine.hpp:418-424, 236-239
+    if (AG_RARE(regen_tick && tgt_p - q.np > 0)) {  // add_pellets(target - n): random_location(r) per pellet, Engine.hpp:418-424, 236-239
       const int n_new = tgt_p - q.np;
       for (int j = 0; j < n_new; j++) {
         float px = mt_to_float(mt_temper(mt[q.mtidx]), pel_span) + pel_r;
@@ -1408,7 +1410,7 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
       move_one(nx, ny, nvx, nvy, nsx, nsy, q.hi, q.r, q.tx, q.ty, dt, W);
       if (q.np != 0) {
         float ox = nx - q.sx0, oy = ny - q.sy0; float o2 = ox * ox, o2b = oy * oy; o2 = o2 + o2b;
-        if (!(AV && o2 < s2)) {  // left the pellet-free disc (or none known): look at the pellets
+        if (AG_RARE(!(AV && o2 < s2))) {  // left the pellet-free disc (or none known): look at the pellets
           need = true;
           nm = clamp_mass(q.m + AG_PELLET_MASS);
           float r1 = lut(lut_r, nm);
