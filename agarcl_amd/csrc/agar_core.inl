@@ -1351,7 +1351,7 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
   int to_regen = regen ? (120 - q.ticks % 120) % 120 : -1, to_decay = decay ? 59 - q.elapsed % 60 : -1;
   // the pending tick of phase B: where the cell moved to, what it would weigh after one pellet
   float nx = q.x, ny = q.y, nvx = 0.0f, nvy = 0.0f, nsx = q.svx, nsy = q.svy;
-  unsigned nm = q.m; PelQuery k{0.0f, 0.0f, 0.0f, 0.0f, 0, 0};
+  unsigned nm = q.m; float rr1_pending = 0.0f;
   bool need = false; float dsec_pending = 0.0f;
 
   // everything of a tick after the pellets have been dealt with (ev: index of the eaten pellet or -1)
@@ -1413,8 +1413,7 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
         if (AG_RARE(!(AV && o2 < s2))) {  // left the pellet-free disc (or none known): look at the pellets
           need = true;
           nm = clamp_mass(q.m + AG_PELLET_MASS);
-          float r1 = lut(lut_r, nm);
-          k.x = nx; k.y = ny; k.rr = rr; k.rr1 = r1 * r1; k.gx = f2i(nx) / AG_PELLET_GRID; k.gy = f2i(ny) / AG_PELLET_GRID;
+          float r1 = lut(lut_r, nm); rr1_pending = r1 * r1;
           break;
         }
       }
@@ -1422,6 +1421,9 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
     }
     // ---- phase B: one pass for everybody who waits ----
     if (!pel.any(need || active)) break;
+    // (the query is assembled here from the pending tick, so that nothing but the pending tick itself stays live across
+    // the phases; the bucket indices matter only without AV)
+    PelQuery k{nx, ny, rr, rr1_pending, AV ? 0 : f2i(nx) / AG_PELLET_GRID, AV ? 0 : f2i(ny) / AG_PELLET_GRID};
     PelScan sc = pel.template scan<AV>(need, k);
     if (need) {
       need = false;
