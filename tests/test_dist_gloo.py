@@ -59,6 +59,40 @@ def _worker(rank, world, port, q):
                 ok = ok and torch.equal(got[:, 0], torch.arange(0, world * n_local, dtype=torch.float32) * 2 + (k - 1))
                 ok = ok and bool((got[:, 1] == float((k - 1) % 2)).all())
     g.wait_all()
+    # bench.py's pattern: the engine's 16-slot result ring, one asynchronous gather per block of 8 steps (the ring half the
+    # engine is not writing), and a flush of the partial last block
+    SLOTS, BLK, A = 16, 8, 5
+    ring = torch.zeros((SLOTS, A, 2), dtype=torch.float32)
+    gb = agdist.ResultGatherer(BLK * A, torch.device("cpu"), depth=2)
+    seen = {}
+    last = SLOTS - 1
+    for step in range(21):                       # 21 is not a multiple of 8
+        nxt = (last + 1) % SLOTS
+        if nxt % BLK == 0:
+            gb.wait_slot(nxt // BLK)             # about to overwrite this half
+            if rank == 0 and nxt // BLK in seen:
+                blk0, h = seen.pop(nxt // BLK)
+                got = gb.gathered(h).reshape(world, BLK, A, 2)
+                for r in range(world):
+                    for j in range(BLK):
+                        ok = ok and bool((got[r, j, :, 0] == float(1000 * r + blk0 + j)).all())
+        ring[nxt, :, 0] = float(1000 * rank + step); ring[nxt, :, 1] = 0.0   # "the engine" writes step `step`
+        last = nxt
+        if last % BLK == BLK - 1:
+            h = last // BLK
+            gb.gather_packed(h, ring[h * BLK:(h + 1) * BLK].reshape(-1, 2))
+            seen[h] = (step - BLK + 1, h)
+    if last % BLK != BLK - 1:                    # flush
+        h = last // BLK
+        gb.wait_slot(h); gb.gather_packed(h, ring[h * BLK:(h + 1) * BLK].reshape(-1, 2))
+        gb.wait_slot(h)
+        if rank == 0:
+            got = gb.gathered(h).reshape(world, BLK, A, 2)
+            first = 21 - (last % BLK + 1)
+            for r in range(world):
+                for j in range(last % BLK + 1):
+                    ok = ok and bool((got[r, j, :, 0] == float(1000 * r + first + j)).all())
+    gb.wait_all()
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
