@@ -1288,9 +1288,6 @@ template <int NS, bool AV> AG_DEV void sort_cells_by_id(AgCtx<NS, AV> &c, int p)
 // general path takes over.
 // quiet_ticks() is shared by two callers that differ only in where the pellets live (the `Pel` accessor):
 // k_step's quiet_run (pellets in the wave's registers) and the lean kernel k_quiet (pellets streamed from HBM/L2).
-#ifndef AG_QUIET_BURST
-#define AG_QUIET_BURST 1   // ticks an arena may run ahead of the others of its wavefront between two wave-level sync points
-#endif
 struct QState {  // per arena: wave-uniform in k_step, uniform over the arena's lane group in k_quiet
   unsigned m, m_move;  // mass; mass at the last tick's move (Player::min_mass bookkeeping)
   int action, nv, np, ticks, elapsed, fcd, scd, last_decay, nvt, food_eaten, hm, last_ev, done;
@@ -1398,7 +1395,7 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
   for (;;) {
     // ---- phase A: one quiet tick per arena (all arenas of the wave stay on the same tick, so a pass never has to
     // wait for the others to finish their whole run) ----
-    for (int once = 0; active && once < AG_QUIET_BURST; once++) {
+    if (active) do {
       if (q.done >= max_ticks) { active = false; break; }
       if (q.m >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0) { active = false; break; }  // eject needs >= 35, split >= 50
       if (q.m >= 111u && q.nv != 0) { active = false; break; }                                  // virus contact needs >= 111
@@ -1418,7 +1415,7 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
         }
       }
       finish_tick(-1, false, 0.0f);
-    }
+    } while (0);
     // ---- phase B: one pass for everybody who waits ----
     if (!pel.any(need || active)) break;
     // (the query is assembled here from the pending tick, so that nothing but the pending tick itself stays live across
