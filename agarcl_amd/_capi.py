@@ -44,6 +44,7 @@ SYMBOLS = [
     ("agarcl_sync", C.c_int, [C.c_void_p]),
     ("agarcl_seed", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     ("agarcl_reset", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    ("agarcl_reset_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     ("agarcl_set_actions", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     ("agarcl_step", C.c_int, [C.c_void_p, C.c_int32]),
     ("agarcl_tick", C.c_int, [C.c_void_p, C.c_int32]),
@@ -59,6 +60,7 @@ SYMBOLS = [
     ("agarcl_get_dones", C.c_int, [C.c_void_p, C.c_void_p]),
     ("agarcl_get_masses", C.c_int, [C.c_void_p, C.c_void_p]),
     ("agarcl_get_flags", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("agarcl_poll_flags", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     ("agarcl_get_counts", C.c_int, [C.c_void_p, C.c_void_p]),
     ("agarcl_get_events", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     ("agarcl_grid_obs", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
@@ -72,6 +74,11 @@ SYMBOLS = [
     ("agarcl_num_arenas", C.c_int, [C.c_void_p]),
     ("agarcl_players_per_arena", C.c_int, [C.c_void_p]),
     ("agarcl_state_bytes", C.c_int64, [C.c_void_p]),
+    ("agarcl_debug_fused", C.c_int, [C.c_void_p]),
+    ("agarcl_debug_qinfo", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("agarcl_debug_prof", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    ("agarcl_debug_prof_raw", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("agarcl_debug_work", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
 ]
 
 
@@ -163,6 +170,10 @@ class BatchedEngine:
             assert mask.shape == (self.num_arenas,)
         self._chk(self.L.agarcl_reset(self.h, _ptr(mask), int(reset_ids)))
 
+    def reset_device(self, mask_ptr, reset_ids=False):
+        """mask_ptr: raw HBM pointer (int) to u8[num_arenas]; stream-ordered, no copy, no synchronisation"""
+        self._chk(self.L.agarcl_reset_device(self.h, C.c_void_p(int(mask_ptr)), int(reset_ids)))
+
     def set_actions(self, dxdy, act):
         """host arrays: dxdy [A, n_agents, 2] f32, act [A, n_agents] i32"""
         dxdy = np.ascontiguousarray(dxdy, dtype=np.float32).reshape(self.num_arenas, self.num_agents, 2)
@@ -206,6 +217,19 @@ class BatchedEngine:
     def flags(self):
         out = np.zeros(self.num_arenas, dtype=np.uint32)
         self._chk(self.L.agarcl_get_flags(self.h, _ptr(out)))
+        return out
+
+    def poll_flags(self):
+        """OR of the capacity flags the engine's asynchronous watch has seen so far (never blocks; may lag ~64 steps)"""
+        v = C.c_uint32(0)
+        self._chk(self.L.agarcl_poll_flags(self.h, C.byref(v)))
+        return int(v.value)
+
+    def work(self, reset=False):
+        """diagnostics: [arena-steps finished by the front part, arena-steps through the general engine, pellet-array
+        transfers] since the counters were last reset"""
+        out = np.zeros(4, dtype=np.int64)
+        self._chk(self.L.agarcl_debug_work(self.h, _ptr(out), int(reset)))
         return out
 
     def counts(self):

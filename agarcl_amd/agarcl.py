@@ -131,8 +131,9 @@ class ScreenEnvironment(_Environment):
 
     def get_state(self):                     # bindings.cpp:157-168: the frame buffer's bytes viewed as uint8 (1, W, H, 3)
         frames = self._engine.screen_obs(self._w, self._h, agent_view=self._agent_view)   # [1][n_agents][H][W][3|4], rows bottom-up
-        # the reference keeps ONE frame buffer that every agent's render overwrites in turn: the last agent's frame remains
-        return frames[0, self._num_agents - 1].reshape(1, self._w, self._h, 4 if self._agent_view else 3)
+        # the reference keeps ONE frame buffer that every agent's render overwrites in turn: the last agent's frame remains.
+        # The binding returns a py::list holding that one array (bindings.cpp:157-168), so gym_agario's obs[0] is (1, W, H, C).
+        return [frames[0, self._num_agents - 1].reshape(1, self._w, self._h, 4 if self._agent_view else 3)]
 
 
 class GoBiggerEnvironment(_Environment):

@@ -6,8 +6,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "agar_engine.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("agar_core.inl", "agar_quiet.inl", "agar_multi.inl", "agar_obs.inl", "agar_libm.inl", "agar_types.h")] + \
-       [os.path.join(HERE, "..", "include", "agarcl_batch.h")]
+import glob
+# every file under csrc/ is a dependency (one translation unit that #includes the .inl / .h files)
+DEPS = sorted(glob.glob(os.path.join(HERE, "csrc", "*"))) + [os.path.join(HERE, "..", "include", "agarcl_batch.h")]
 OUT = os.path.join(HERE, "libagarcl_hip.so")
 
 FLAGS = [

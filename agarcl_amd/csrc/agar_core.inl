@@ -35,6 +35,7 @@ AG_DEV void ag_mem_fence() {}
 AG_DEV void ag_lds_order() {}
 AG_DEV float ag_sqrtf(float x) { return sqrtf(x); }
 AG_DEV float ag_divf(float a, float b) { return a / b; }
+AG_DEV void ag_atomic_or(int32_t *p, int v) { *p |= v; }
 #else
 #define AG_DEV __device__ __forceinline__
 // lane within the wavefront (kernels may pack several wavefronts = several arenas into one workgroup)
@@ -54,6 +55,7 @@ AG_DEV void ag_lds_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront
 // which ROCm's headers map to the approximate __ocml_native_sqrt_f32.
 AG_DEV float ag_sqrtf(float x) { return __builtin_sqrtf(x); }
 AG_DEV float ag_divf(float a, float b) { return a / b; }
+AG_DEV void ag_atomic_or(int32_t *p, int v) { atomicOr(p, v); }
 #endif
 
 #include "agar_libm.inl"
@@ -375,6 +377,12 @@ template <int NS, bool AV> AG_DEV void arena_store(AgCtx<NS, AV> &c) {
     }
   }
   ub_store(c.S, g_ar(c), AR_WORDS);
+  {  // diagnostics (agarcl_debug_work): pellet-array transfers of this launch; flag watch word (agarcl_poll_flags)
+    const int moved = (c.pel_loaded ? 1 : 0) + (c.pel_dirty ? 1 : 0);
+    if (moved) { AG_SERIAL { PLS(c, 0)[PL_PASSES] += moved; } ag_lds_order(); }
+    const int fl = SR(c, AR_FLAGS);
+    if (AG_RARE(fl != 0)) { AG_SERIAL { ag_atomic_or(c.gs->qstat + 1, fl); } }
+  }
   auto gpl = g_pl(c);
   AG_LANES(i, c.P * PL_WORDS) gpl[i] = PLS(c, 0)[i];
   int nevp = SR(c, AR_NEVP), nevv = SR(c, AR_NEVV);
@@ -1292,6 +1300,7 @@ struct QState {  // per arena: wave-uniform in k_step, uniform over the arena's 
   unsigned m, m_move;  // mass; mass at the last tick's move (Player::min_mass bookkeeping)
   int action, nv, np, ticks, elapsed, fcd, scd, last_decay, nvt, food_eaten, hm, last_ev, done;
   int mtidx, idc;      // mt19937_64 read index and entity id counter (pellet regeneration)
+  int passes;          // diagnostics: pellet passes that read the arena's pellet array from memory (PL_PASSES)
   float x, y, svx, svy, vx, vy, r, hi, tx, ty, slack, sx0, sy0;  // slack = S, (sx0, sy0) = centre of the pellet-free disc
   double rate;
   bool pel_changed;
@@ -1423,7 +1432,7 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
     PelQuery k{nx, ny, rr, rr1_pending, AV ? 0 : f2i(nx) / AG_PELLET_GRID, AV ? 0 : f2i(ny) / AG_PELLET_GRID};
     PelScan sc = pel.template scan<AV>(need, k);
     if (need) {
-      need = false;
+      need = false; q.passes += pel.pass_cost();
       int ev = -1; float nslack = 0.0f;
       if (rr >= sc.dmin2) {  // somebody is inside the radius: a plain single eat, or the general path's business
         if (sc.cnt != 1 || sc.cnt1 != 1 || (nm >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0)) active = false;  // (nothing of this tick is committed)
@@ -1441,6 +1450,7 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
 template <int NS, bool AV> struct RegPel {
   AgCtx<NS, AV> &c;
   AG_MEM bool any(bool p) const { return p; }
+  AG_MEM int pass_cost() const { return 0; }  // register-resident: the load is counted once per launch in arena_store
   template <bool AV2> AG_MEM PelScan scan(bool need, const PelQuery &k) {
     PelScan out{3.0e38f, 3.0e38f, 0, 0, -1};
     if (!need) return out;
@@ -1484,7 +1494,7 @@ template <int NS, bool AV> AG_DEV int quiet_run(AgCtx<NS, AV> &c, int max_ticks)
   q.ticks = SR(c, AR_TICKS); q.elapsed = PR(c, PL_ELAPSED); q.fcd = PR(c, PL_FEED_CD); q.scd = PR(c, PL_SPLIT_CD);
   q.last_decay = PR(c, PL_LAST_DECAY); q.nvt = PR(c, PL_NVTICKS); q.food_eaten = PR(c, PL_FOOD_EATEN); q.hm = PR(c, PL_HIGHEST_MASS);
   q.rate = (double)PRF(c, PL_ANTI_TEAM); q.slack = u2f(SR(c, AR_SAFE)); q.sx0 = PRF(c, PL_SAFE_X); q.sy0 = PRF(c, PL_SAFE_Y);
-  q.mtidx = SR(c, AR_MTIDX); q.idc = SR(c, AR_IDC);
+  q.mtidx = SR(c, AR_MTIDX); q.idc = SR(c, AR_IDC); q.passes = 0;
   RegPel<NS, AV> pel{c};
   quiet_ticks<AV>(q, c.gs->g, g_lut_r(c), g_lut_ms(c), (const AG_GLOBAL uint64_t *)g_mt(c), pel, max_ticks);
   if (q.done == 0) return 0;

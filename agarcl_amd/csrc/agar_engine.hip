@@ -33,7 +33,7 @@ extern "C" const char *agarcl_last_error(void) { return g_err.c_str(); }
 // ---- memory / launch abstraction -----------------------------------------------------------------
 #ifdef AGAR_CPU_EMU
 typedef void *ag_stream_t;
-static void *dmalloc(size_t n) { return calloc(1, n ? n : 1); }
+static void *dmalloc(size_t n, ag_stream_t) { return calloc(1, n ? n : 1); }
 static void dfree(void *p) { free(p); }
 static int h2d(void *d, const void *h, size_t n, ag_stream_t) { memcpy(d, h, n); return 0; }
 static int d2h(void *h, const void *d, size_t n, ag_stream_t) { memcpy(h, d, n); return 0; }
@@ -41,9 +41,9 @@ static int dsync(ag_stream_t) { return 0; }
 #else
 typedef hipStream_t ag_stream_t;
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(AGARCL_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
-// zero-filled device memory; the fill is drained before returning: hipMemset runs on the NULL stream, which does
-// NOT order against the env's non-blocking stream (a late fill would wipe data uploaded through that stream)
-static void *dmalloc(size_t n) { void *p = nullptr; if (hipMalloc(&p, n ? n : 1) != hipSuccess) return nullptr; if (hipMemset(p, 0, n ? n : 1) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; } return p; }
+// zero-filled device memory; the fill is enqueued on the env's own stream, so it orders against everything the env
+// uploads or launches later (a hipMemset on the NULL stream would not: the env's stream is non-blocking)
+static void *dmalloc(size_t n, hipStream_t s) { void *p = nullptr; if (hipMalloc(&p, n ? n : 1) != hipSuccess) return nullptr; if (hipMemsetAsync(p, 0, n ? n : 1, s) != hipSuccess) { (void)hipFree(p); return nullptr; } return p; }
 static void dfree(void *p) { if (p) (void)hipFree(p); }
 static int h2d(void *d, const void *h, size_t n, ag_stream_t s) { return hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
 static int d2h(void *h, const void *d, size_t n, ag_stream_t s) { return hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
@@ -67,10 +67,14 @@ struct agarcl_env {
   bool fused;     // single-launch step (k_fused) instead of k_quiet + k_step: see k_fused
   bool fused_fixed;                // AGARCL_FUSED=0/1 pins the choice
   int fused_wg;                    // threads per workgroup of k_fused (64, 128 or 256)
-  int32_t *h_stat; void *stat_ev;  // pinned copy of qstat + the event that says it has arrived
-  bool stat_pending; long step_no, stat_req_step, stat_last_step; int32_t stat_last_total;
+  int32_t *h_stat; void *stat_ev;  // pinned copy of {qstat, flag watch word} + the event that says it has arrived
+  uint8_t *d_mask;                 // [A] reset mask staging (host masks are copied here, stream-ordered)
+  uint32_t flags_seen;             // OR of every flag watch sample so far (agarcl_poll_flags)
+  long work_step0, work_front0; int32_t work_unf0; int64_t work_pass0;  // agarcl_debug_work baselines
+  bool stat_pending; long step_no, front_runs, stat_req_front, stat_last_front; int32_t stat_last_total;
   int parity;     // launch parity of the k_quiet / k_step pair (selects the unfinished-arena counter)
   bool no_front;  // AGARCL_NO_FRONT=1 in the environment: skip k_quiet (diagnostics / A-B timing only)
+  bool front_off; // adaptive: the front part finishes (almost) no arena-step, so the two-kernel step runs k_step alone
 };
 
 // ---- kernels ----------------------------------------------------------------------------------------
@@ -192,25 +196,31 @@ __global__ void k_set_word(int32_t *base, int stride, int n, int value) {
 #endif
 
 #ifndef AGAR_CPU_EMU
-// Fused or two-kernel step?  The front part counts the arena-steps it leaves unfinished (qstat).  Every 64 steps the
-// host asks for that counter with an asynchronous copy into pinned memory and, once the copy has landed (event query,
-// never a wait), compares it with the previous sample: a wavefront of k_fused completes its unfinished arenas one
-// after the other, which only pays while they are rare.  Results do not depend on the choice, only the time does.
-static void adapt_step_mode(agarcl_env *e) {
+// Asynchronous statistics.  The kernels keep two running words in HBM (AgState::qstat): [0] the arena-steps the front
+// part left unfinished, [1] the OR of every capacity flag raised.  Every 64 steps the host asks for them with an
+// asynchronous copy into pinned memory and, once the copy has landed (event query, never a wait), uses them:
+//   * flag watch (agarcl_poll_flags): a diverged arena becomes visible to the host without a synchronising query;
+//   * fused or two-kernel step: a wavefront of k_fused completes its unfinished arenas one after the other, which only
+//     pays while they are rare.  Results do not depend on the choice, only the time does.
+static void poll_stats(agarcl_env *e, bool adapt) {
   e->step_no++;
+  if (!e->h_stat) return;
   if (e->stat_pending) {
     if (hipEventQuery((hipEvent_t)e->stat_ev) != hipSuccess) return;
     e->stat_pending = false;
-    const long steps = e->stat_req_step - e->stat_last_step;
-    if (steps > 0) {
+    e->flags_seen |= (uint32_t)e->h_stat[1];
+    const long steps = e->stat_req_front - e->stat_last_front;  // steps in which the front part actually ran
+    if (adapt && steps > 0) {
       const double frac = (double)(uint32_t)(e->h_stat[0] - e->stat_last_total) / ((double)steps * (double)e->d.A);
       if (e->fused && frac > 0.05) e->fused = false; else if (!e->fused && frac < 0.01) e->fused = true;
+      // the two-kernel step's front launch is pure overhead when it finishes (almost) nothing: mass-1000 modes
+      e->front_off = !e->fused && frac > 0.99;
     }
-    e->stat_last_total = e->h_stat[0]; e->stat_last_step = e->stat_req_step;
+    e->stat_last_total = e->h_stat[0]; e->stat_last_front = e->stat_req_front;
   } else if (e->step_no % 64 == 0) {
-    if (hipMemcpyAsync(e->h_stat, e->s.qstat, 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess) return;
+    if (hipMemcpyAsync(e->h_stat, e->s.qstat, 8, hipMemcpyDeviceToHost, e->stream) != hipSuccess) return;
     if (hipEventRecord((hipEvent_t)e->stat_ev, e->stream) != hipSuccess) return;
-    e->stat_pending = true; e->stat_req_step = e->step_no;
+    e->stat_pending = true; e->stat_req_front = e->front_runs;
   }
 }
 #endif
@@ -224,8 +234,12 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
   AG_DISPATCH_NS(e->ns, CALL);
 #undef CALL
 #else
-  const int use_q = e->d.P == 1 && !e->no_front;
-  if (use_q && !e->fused_fixed && e->h_stat) adapt_step_mode(e);
+  const bool front_ok = e->d.P == 1 && !e->no_front;
+  poll_stats(e, front_ok && !e->fused_fixed);
+  // front_off: the statistics say the front part finishes < 1 % of the arena-steps, so its launch is skipped; every 256th
+  // step it runs again so that the statistics notice when the arenas have become quiet
+  const int use_q = front_ok && !(e->front_off && !e->fused && (e->step_no & 255) != 0);
+  if (use_q) e->front_runs++;
   if (use_q && e->fused) {
     const unsigned lpw = (unsigned)((e->lds_bytes + 15) & ~(size_t)15);
     const int wg = e->fused_wg, apw = wg / AG_QG;  // threads and arenas per workgroup
@@ -278,7 +292,7 @@ static int launch_respawn(agarcl_env *e) {
 }
 
 // ---- host helpers -------------------------------------------------------------------------------------
-template <class T> static T *alloc(agarcl_env *e, size_t n) { T *p = (T *)dmalloc(n * sizeof(T)); if (p) e->allocs.push_back(p); return p; }
+template <class T> static T *alloc(agarcl_env *e, size_t n) { T *p = (T *)dmalloc(n * sizeof(T), e->stream); if (p) e->allocs.push_back(p); return p; }
 
 // glibc srand(): TYPE_3 additive-feedback state after the 310 discarded outputs, as the 34-word ring the device
 // continues (agar_multi.inl: ag_rand_next).  Engine::seed calls std::srand(s) (Engine.hpp:242-245).
@@ -409,22 +423,25 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   s.qcount = alloc<int32_t>(e, 2); e->parity = 0;
   { const char *nf = getenv("AGARCL_NO_FRONT"); e->no_front = nf && nf[0] == '1'; }
   // modes 0-4 start agents at mass 25 (quiet-dominated); 5 and 6 start at mass 1000 (general path every step)
-  e->fused = d.P == 1 && cfg->mode_number <= 4;  // starting point; adapt_step_mode follows what the arenas actually do
-  e->fused_fixed = false; e->h_stat = nullptr; e->stat_ev = nullptr; e->stat_pending = false; e->step_no = e->stat_req_step = e->stat_last_step = 0; e->stat_last_total = 0;
+  e->fused = d.P == 1 && cfg->mode_number <= 4;  // starting point; poll_stats follows what the arenas actually do
+  e->front_off = d.P == 1 && cfg->mode_number > 4;
+  e->work_step0 = e->work_front0 = 0; e->work_unf0 = 0; e->work_pass0 = 0;
+  e->flags_seen = 0; e->d_mask = alloc<uint8_t>(e, (size_t)d.A);
+  e->fused_fixed = false; e->h_stat = nullptr; e->stat_ev = nullptr; e->stat_pending = false; e->step_no = e->front_runs = e->stat_req_front = e->stat_last_front = 0; e->stat_last_total = 0;
   { const char *fu = getenv("AGARCL_FUSED"); if (fu && (fu[0] == '0' || fu[0] == '1')) { e->fused = fu[0] == '1'; e->fused_fixed = true; } }
-  s.qstat = alloc<int32_t>(e, 1);
+  s.qstat = alloc<int32_t>(e, 4);
   e->fused_wg = 256; { const char *w = getenv("AGARCL_FUSED_WG"); if (w) { int v = atoi(w); if (v == 64 || v == 128 || v == 256) e->fused_wg = v; } }
 #ifndef AGAR_CPU_EMU
-  if (d.P == 1 && !e->fused_fixed) {
+  {
     hipEvent_t ev;
-    if (hipHostMalloc((void **)&e->h_stat, 8) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) { e->h_stat[0] = 0; e->stat_ev = (void *)ev; }
+    if (hipHostMalloc((void **)&e->h_stat, 8) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) { e->h_stat[0] = 0; e->h_stat[1] = 0; e->stat_ev = (void *)ev; }
     else { if (e->h_stat) (void)hipHostFree(e->h_stat); e->h_stat = nullptr; }
   }
 #endif
 #ifdef AGAR_CPU_EMU
   e->d_state = &e->s;
 #else
-  e->d_state = (AgState *)dmalloc(sizeof(AgState));
+  e->d_state = (AgState *)dmalloc(sizeof(AgState), e->stream);
   if (!e->d_state) { agarcl_destroy(e); return fail(AGARCL_E_NOMEM, "device allocation failed"); }
   e->allocs.push_back(e->d_state);
   if (h2d(e->d_state, &e->s, sizeof(AgState), e->stream)) { agarcl_destroy(e); return fail(AGARCL_E_HIP, "descriptor upload failed"); }
@@ -526,15 +543,24 @@ extern "C" int agarcl_reset(agarcl_env *e, const uint8_t *mask_host, int32_t res
   uint8_t *mask_dev = nullptr;
 #ifndef AGAR_CPU_EMU
   HIPCHK(hipSetDevice(e->device));
-  if (mask_host) {
-    mask_dev = (uint8_t *)dmalloc((size_t)e->d.A);
-    if (!mask_dev) return fail(AGARCL_E_NOMEM, "mask alloc failed");
-    if (h2d(mask_dev, mask_host, (size_t)e->d.A, e->stream)) { dfree(mask_dev); return fail(AGARCL_E_HIP, "mask upload failed"); }
+  if (mask_host) {  // stream-ordered upload into the env's own mask buffer: no allocation, no device-wide sync
+    mask_dev = e->d_mask;
+    HIPCHK(hipMemcpyAsync(mask_dev, mask_host, (size_t)e->d.A, hipMemcpyHostToDevice, e->stream));
+  } else {
+    e->flags_seen = 0;
+    HIPCHK(hipMemsetAsync(e->s.qstat + 1, 0, 4, e->stream));  // a full reset clears every arena's flags: restart the watch
   }
 #endif
-  int rc = launch_reset(e, mask_dev, mask_host, reset_ids);
-  if (mask_dev) { dsync(e->stream); dfree(mask_dev); }
-  return rc;
+  return launch_reset(e, mask_dev, mask_host, reset_ids);
+}
+extern "C" int agarcl_reset_device(agarcl_env *e, const uint8_t *mask_dev, int32_t reset_ids) {
+  if (!e || !mask_dev) return fail(AGARCL_E_INVALID, "agarcl_reset_device: null pointer");
+#ifdef AGAR_CPU_EMU
+  return launch_reset(e, nullptr, mask_dev, reset_ids);  // (test-only host build: "device" memory is host memory)
+#else
+  HIPCHK(hipSetDevice(e->device));
+  return launch_reset(e, mask_dev, nullptr, reset_ids);
+#endif
 }
 
 extern "C" int agarcl_set_actions(agarcl_env *e, const float *dxdy, const int32_t *act, int32_t on_device) {
@@ -608,6 +634,17 @@ extern "C" int agarcl_get_flags(agarcl_env *e, uint32_t *out) {
   return AGARCL_OK;
 }
 
+extern "C" int agarcl_poll_flags(agarcl_env *e, uint32_t *out) {
+  if (!e || !out) return fail(AGARCL_E_INVALID, "agarcl_poll_flags: null pointer");
+#ifdef AGAR_CPU_EMU
+  *out = (uint32_t)e->s.qstat[1];
+#else
+  if (e->stat_pending && hipEventQuery((hipEvent_t)e->stat_ev) == hipSuccess) e->flags_seen |= (uint32_t)e->h_stat[1];
+  *out = e->flags_seen;
+#endif
+  return AGARCL_OK;
+}
+
 extern "C" int agarcl_get_events(agarcl_env *e, int32_t *n_events_host, int32_t *pellet_idx_host, int32_t cap, int32_t *virus_idx_host, int32_t cap_v) {
   if (!e || !n_events_host) return fail(AGARCL_E_INVALID, "agarcl_get_events: null pointer");
   size_t A = (size_t)e->d.A;
@@ -640,6 +677,21 @@ extern "C" int agarcl_debug_qinfo(agarcl_env *e, int32_t *out) {  // [A][2]: the
 extern "C" int agarcl_debug_prof_raw(agarcl_env *e, unsigned long long *out) {  // [A][16], diagnostic builds
   if (!e || !out) return AGARCL_E_INVALID;
   if (d2h(out, e->s.prof, (size_t)e->d.A * 16 * 8, e->stream)) return AGARCL_E_HIP;
+  return AGARCL_OK;
+}
+// Work the step kernels did since the last reset of these counters, counted by the kernels themselves (bench.py turns it
+// into "bytes requested": DESIGN.md section 5).  [0] arena-steps the lean front part finished, [1] arena-steps that needed the
+// general engine, [2] pellet passes (each reads the arena's pellet array once), [3] spare.
+extern "C" int agarcl_debug_work(agarcl_env *e, int64_t *out4, int reset) {
+  if (!e || !out4) return AGARCL_E_INVALID;
+  const size_t n = (size_t)e->d.A * e->d.P * PL_WORDS;
+  std::vector<int32_t> pl(n); int32_t st[4];
+  if (d2h(pl.data(), e->s.pl, n * 4, e->stream) || d2h(st, e->s.qstat, 16, e->stream)) return AGARCL_E_HIP;
+  int64_t passes = 0;
+  for (size_t i = 0; i < (size_t)e->d.A * e->d.P; i++) passes += (uint32_t)pl[i * PL_WORDS + PL_PASSES];
+  const int64_t steps = (int64_t)(e->step_no - e->work_step0) * e->d.A, unfinished = (int64_t)(uint32_t)(st[0] - e->work_unf0) + (int64_t)(e->step_no - e->work_step0 - (e->front_runs - e->work_front0)) * e->d.A;
+  out4[0] = steps - unfinished; out4[1] = unfinished; out4[2] = passes - e->work_pass0; out4[3] = 0;
+  if (reset) { e->work_step0 = e->step_no; e->work_front0 = e->front_runs; e->work_unf0 = st[0]; e->work_pass0 = passes; }
   return AGARCL_OK;
 }
 extern "C" int agarcl_num_arenas(agarcl_env *e) { return e ? e->d.A : 0; }
@@ -709,7 +761,10 @@ static int load_arena_impl(agarcl_env *e, int32_t arena, const uint32_t *b, int3
   const AgDims &d = e->d; const AgState &s = e->s; size_t a = (size_t)arena; ArenaHost h;
   uint32_t np = b[4], nv = b[5], nf = b[6], npl = b[7];
   if ((int)npl != d.P) return fail(AGARCL_E_INVALID, "agarcl_load_arena: player count mismatch");
-  if ((int)np > d.PC || (int)nv > d.VC || (int)nf > d.FC) return fail(AGARCL_E_CAPACITY, "agarcl_load_arena: blob exceeds arena capacities");
+  if (np > (uint32_t)d.PC || nv > (uint32_t)d.VC || nf > (uint32_t)d.FC) return fail(AGARCL_E_CAPACITY, "agarcl_load_arena: blob exceeds arena capacities");
+  // the entity tables and every player's 17 header words must lie inside the blob before anything of them is read
+  if ((uint64_t)8 + 3ull * np + 7ull * nv + 5ull * nf + 17ull * npl > (uint64_t)words) return fail(AGARCL_E_INVALID, "agarcl_load_arena: blob length mismatch");
+  const uint32_t *const b_end = b + words;
   if (pull(e, h.ar, s.ar, a * AR_WORDS, AR_WORDS) || pull(e, h.pl, s.pl, a * d.P * PL_WORDS, (size_t)d.P * PL_WORDS)) return fail(AGARCL_E_HIP, "copy failed");
   h.vt.assign((size_t)d.P * AG_VT_CAP, 0);
   auto U2F = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
@@ -739,6 +794,7 @@ static int load_arena_impl(agarcl_env *e, int32_t arena, const uint32_t *b, int3
     int slot = h.ar[AR_ORDER0 + k]; int32_t *P = &h.pl[(size_t)slot * PL_WORDS];
     if (kinds) { for (int w = 0; w < PL_WORDS; w++) P[w] = 0; P[PL_PID] = (int32_t)p[0]; P[PL_KIND] = kinds[k]; }
     else if ((int32_t)p[0] != P[PL_PID]) return fail(AGARCL_E_INVALID, "agarcl_load_arena: pid / iteration order mismatch");
+    if (p + 17 > b_end) return fail(AGARCL_E_INVALID, "agarcl_load_arena: blob length mismatch");
     uint32_t ncell = p[2];
     if ((int)ncell > AG_CC) return fail(AGARCL_E_CAPACITY, "agarcl_load_arena: too many cells");
     P[PL_NCELLS] = (int32_t)ncell; P[PL_ACTION] = (int32_t)p[3]; P[PL_TX] = (int32_t)p[4]; P[PL_TY] = (int32_t)p[5]; P[PL_SPLIT_CD] = (int32_t)p[6]; P[PL_FEED_CD] = (int32_t)p[7];
@@ -746,6 +802,7 @@ static int load_arena_impl(agarcl_env *e, int32_t arena, const uint32_t *b, int3
     P[PL_CELLS_EATEN] = (int32_t)p[13]; P[PL_VIRUSES_EATEN] = (int32_t)p[14]; P[PL_MIN_MASS] = (int32_t)p[15];
     uint32_t nt = p[16];
     if (nt > AG_VT_CAP) return fail(AGARCL_E_CAPACITY, "agarcl_load_arena: too many virus ticks");
+    if (p + 17 + nt + 9ull * ncell > b_end) return fail(AGARCL_E_INVALID, "agarcl_load_arena: blob length mismatch");
     P[PL_NVTICKS] = (int32_t)nt;
     for (uint32_t i = 0; i < nt; i++) h.vt[(size_t)slot * AG_VT_CAP + i] = (int32_t)p[17 + i];
     p += 17 + nt;
@@ -786,11 +843,11 @@ __global__ void __launch_bounds__(256) k_grid_obs(const AgState *__restrict__ gs
 // write bandwidth of a memset; channel 0 and the entities are written afterwards by k_grid_obs
 __global__ void __launch_bounds__(256) k_grid_zero(int32_t *out, size_t frames, size_t frame_v4, size_t skip_v4) {
   typedef int32_t v4 __attribute__((ext_vector_type(4)));
-  (void)frames;  // blockIdx.y = frame, blockIdx.x = slice of that frame's zero region
-  const unsigned per = (unsigned)(frame_v4 - skip_v4);
+  (void)frames;  // blockIdx.x = frame * 8 + slice of that frame's zero region (no 65535-frame limit of gridDim.y)
+  const unsigned per = (unsigned)(frame_v4 - skip_v4), frame = blockIdx.x >> 3, slice = blockIdx.x & 7u;
   const v4 z = {0, 0, 0, 0};
-  v4 *o4 = (v4 *)out + (size_t)blockIdx.y * frame_v4 + skip_v4;
-  for (unsigned off = blockIdx.x * blockDim.x + threadIdx.x; off < per; off += gridDim.x * blockDim.x) __builtin_nontemporal_store(z, &o4[off]);
+  v4 *o4 = (v4 *)out + (size_t)frame * frame_v4 + skip_v4;
+  for (unsigned off = slice * blockDim.x + threadIdx.x; off < per; off += 8u * blockDim.x) __builtin_nontemporal_store(z, &o4[off]);
 }
 #endif
 
@@ -847,7 +904,7 @@ extern "C" int agarcl_grid_obs(agarcl_env *e, int32_t G, int32_t cells, int32_t 
   }
   const size_t GG = (size_t)G * G;
   const bool split = (GG & 3) == 0 && C > 1 && (((size_t)dst) & 15) == 0;
-  if (split) hipLaunchKernelGGL(k_grid_zero, dim3(8, (unsigned)n), dim3(256), 0, e->stream, dst, n, (size_t)C * GG / 4, GG / 4);
+  if (split) hipLaunchKernelGGL(k_grid_zero, dim3(8u * (unsigned)n), dim3(256), 0, e->stream, dst, n, (size_t)C * GG / 4, GG / 4);
   hipLaunchKernelGGL(k_grid_obs, dim3((unsigned)n), dim3(256), 0, e->stream, e->d_state, o, dst, split ? 0 : 1);
   HIPCHK(hipGetLastError());
   if (!on_device && d2h(out, dst, words * 4, e->stream)) return fail(AGARCL_E_HIP, "agarcl_grid_obs: copy failed");

@@ -26,6 +26,7 @@ template <int NS> struct GrpPel {
   AG_GLOBAL float *xy; AG_GLOBAL int32_t *id; int sub;
 #ifdef AGAR_CPU_EMU
   AG_MEM bool lead() const { return true; }
+  AG_MEM int pass_cost() const { return 1; }
   AG_MEM bool any(bool p) const { return p; }
   template <bool AV> AG_MEM PelScan scan(bool need, const PelQuery &k) {
     PelScan out{3.0e38f, 3.0e38f, 0, 0, -1};
@@ -38,6 +39,7 @@ template <int NS> struct GrpPel {
 #else
   typedef float XY __attribute__((ext_vector_type(2)));
   AG_MEM bool lead() const { return sub == 0; }
+  AG_MEM int pass_cost() const { return 1; }
   AG_MEM bool any(bool p) const { return __ballot(p) != 0ull; }
   template <bool AV> AG_MEM PelScan scan(bool need, const PelQuery &k) {
     PelScan out{3.0e38f, 3.0e38f, 0, 0, -1};
@@ -106,7 +108,7 @@ template <int NS, bool AV> AG_DEV QHandOver quiet_arena(const AgState *gs, int a
   q.svx = u2f((int)C[AG_CELL_W(CF_SX, 0)]); q.svy = u2f((int)C[AG_CELL_W(CF_SY, 0)]); q.r = u2f((int)C[AG_CELL_W(CF_CRAD, 0)]); q.hi = u2f((int)C[AG_CELL_W(CF_CMS, 0)]);
   q.action = P[PL_ACTION]; q.tx = u2f(P[PL_TX]); q.ty = u2f(P[PL_TY]);
   q.elapsed = P[PL_ELAPSED]; q.fcd = P[PL_FEED_CD]; q.scd = P[PL_SPLIT_CD]; q.last_decay = P[PL_LAST_DECAY]; q.nvt = P[PL_NVTICKS];
-  q.food_eaten = P[PL_FOOD_EATEN]; q.hm = P[PL_HIGHEST_MASS]; q.rate = (double)u2f(P[PL_ANTI_TEAM]); q.sx0 = u2f(P[PL_SAFE_X]); q.sy0 = u2f(P[PL_SAFE_Y]);
+  q.food_eaten = P[PL_FOOD_EATEN]; q.hm = P[PL_HIGHEST_MASS]; q.rate = (double)u2f(P[PL_ANTI_TEAM]); q.sx0 = u2f(P[PL_SAFE_X]); q.sy0 = u2f(P[PL_SAFE_Y]); q.passes = P[PL_PASSES];
   q.nv = S[AR_NVIR]; q.np = S[AR_NPEL]; q.ticks = S[AR_TICKS]; q.slack = u2f(S[AR_SAFE]); q.mtidx = S[AR_MTIDX]; q.idc = S[AR_IDC];
   int clock = S[AR_CLOCK], done_flag = S[AR_DONE];
   float dx = 0.0f, dy = 0.0f; int action = 0;
@@ -146,7 +148,7 @@ template <int NS, bool AV> AG_DEV QHandOver quiet_arena(const AgState *gs, int a
       C[AG_CELL_W(CF_SX, 0)] = (uint32_t)f2u(q.svx); C[AG_CELL_W(CF_SY, 0)] = (uint32_t)f2u(q.svy); C[AG_CELL_W(CF_M, 0)] = q.m;
       C[AG_CELL_W(CF_CMC, 0)] = q.m; C[AG_CELL_W(CF_CRAD, 0)] = (uint32_t)f2u(q.r); C[AG_CELL_W(CF_CMS, 0)] = (uint32_t)f2u(q.hi);
       P[PL_ELAPSED] = q.elapsed; P[PL_MIN_MASS] = (int)q.m_move; P[PL_HIGHEST_MASS] = q.hm; P[PL_FEED_CD] = q.fcd; P[PL_SPLIT_CD] = q.scd;
-      P[PL_FOOD_EATEN] = q.food_eaten; P[PL_LAST_DECAY] = q.last_decay; P[PL_SAFE_X] = f2u(q.sx0); P[PL_SAFE_Y] = f2u(q.sy0);
+      P[PL_FOOD_EATEN] = q.food_eaten; P[PL_LAST_DECAY] = q.last_decay; P[PL_SAFE_X] = f2u(q.sx0); P[PL_SAFE_Y] = f2u(q.sy0); P[PL_PASSES] = q.passes;
       S[AR_NEVP] = q.last_ev >= 0 ? 1 : 0; S[AR_NEVV] = 0; S[AR_NPEL] = q.np; S[AR_TICKS] = q.ticks; S[AR_CLOCK] = clock + q.done; S[AR_SAFE] = f2u(q.slack); S[AR_MTIDX] = q.mtidx; S[AR_IDC] = q.idc;
       if (q.last_ev >= 0) { auto ge = (AG_GLOBAL int32_t *)(gs->ev_p + (size_t)arena * AG_EV_CAP); ge[0] = q.last_ev; }
       auto cn = (AG_GLOBAL int32_t *)(gs->counts + (size_t)arena * 4);

@@ -26,6 +26,7 @@ enum {
   PL_NCELLS = 0, PL_ACTION, PL_TX, PL_TY, PL_SPLIT_CD, PL_FEED_CD, PL_ELAPSED, PL_LAST_DECAY, PL_ANTI_TEAM,
   PL_FOOD_EATEN, PL_HIGHEST_MASS, PL_CELLS_EATEN, PL_VIRUSES_EATEN, PL_MIN_MASS, PL_NVTICKS, PL_PID, PL_KIND,
   PL_SAFE_X, PL_SAFE_Y,  // single-player arenas: where the pellet-free disc of radius AR_SAFE was measured (agar_core.inl quiet_ticks)
+  PL_PASSES,             // diagnostics: how often this arena's pellet array has been read from memory (slot 0 only; never part of a blob)
   PL_WORDS = 20
 };
 // per-arena int32 words ([A][AR_WORDS])
@@ -109,7 +110,8 @@ struct AgState {
   // read-only tables (mass -> fp32), host generated (Engine.hpp:1296-1302, core/utils.hpp:8-11)
   const float *lut_r, *lut_ms, *lut_ss, *lut_anti;
   int32_t *qinfo;         // [A][2] hand-over from k_quiet to k_step: ticks done (-1: nothing), agent mass before the step
-  int32_t *qstat;         // [1] running total of arena-steps the front part left unfinished (host reads it now and then)
+  int32_t *qstat;         // [4] running totals the host samples now and then: [0] arena-steps the front part left unfinished,
+                          //     [1] OR of every capacity flag raised (the flag watch of agarcl_poll_flags)
   int32_t *qcount;        // [2] number of arenas k_quiet left unfinished, ping-pong by launch parity (k_step exits at once on 0)
   unsigned long long *prof;  // [16] phase cycle sums (diagnostic builds only; may be null)
 };

@@ -42,6 +42,12 @@ class ResultGatherer:
                          for _ in range(depth)]
         self.work = [None] * depth
         self.n_local = n_local
+        # dist.gather needs equally sized contributions: shard_bounds() gives unequal blocks when total % world != 0,
+        # so such a job must pad its shards to the largest one (or pick a divisible arena count).  Fail at construction.
+        sizes = [None] * self.world
+        dist.all_gather_object(sizes, int(n_local), group=group)
+        if any(s != sizes[0] for s in sizes):
+            raise ValueError("ResultGatherer: every rank must contribute the same number of rows, got %s" % (sizes,))
 
     def pack(self, k, rewards, dones):
         s = k % self.depth

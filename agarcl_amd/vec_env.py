@@ -22,7 +22,7 @@ class _DevArray:
 class VecEnvironment:
     def __init__(self, num_arenas, num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True,
                  num_pellets=1000, num_viruses=0, num_bots=0, reward_type=1, c_death=0, mode_number=0,
-                 device=0, dt=1.0 / 30, use_torch_stream=True, **caps):
+                 device=0, dt=1.0 / 30, use_torch_stream=True, strict_flags=True, **caps):
         import torch
         self.torch = torch
         self.device = torch.device("cuda", device)
@@ -43,12 +43,25 @@ class VecEnvironment:
         self.packed_ring = torch.as_tensor(_DevArray(p["packed"], (_capi.PACKED_SLOTS, A * n, 2), "<f4"), device=self.device)
         self.packed = [self.packed_ring[k] for k in range(_capi.PACKED_SLOTS)]
         self._act_keep = None
+        # a capacity flag means that arena has left the reference's (unbounded-vector) semantics: by default that is an error
+        # the caller hears about (within ~64 steps, without any synchronisation), not a silently diverged arena
+        self.strict_flags = strict_flags
 
     def seed(self, seeds=None, base_seed=0):
         self.engine.seed(seeds, base_seed)
 
     def reset(self, mask=None, reset_ids=False):
-        self.engine.reset(mask, reset_ids)
+        """mask: None (all arenas), a host uint8/bool array, or a CUDA uint8 tensor [A] such as self.dones_u8[:, 0] made
+        contiguous -- the device form is a pure stream-ordered launch (no copy, no synchronisation)."""
+        torch = self.torch
+        if isinstance(mask, torch.Tensor) and mask.is_cuda:
+            m = mask.to(torch.uint8).contiguous().reshape(-1)
+            if m.numel() != self.num_arenas:
+                raise ValueError("mask must have one entry per arena")
+            self._mask_keep = m
+            self.engine.reset_device(m.data_ptr(), reset_ids)
+        else:
+            self.engine.reset(None if mask is None else np.asarray(mask), reset_ids)
 
     def take_actions(self, dxdy, act):
         """dxdy: float32 [A, n_agents, 2]; act: int32 [A, n_agents]; torch CUDA tensors (zero copy) or
@@ -74,6 +87,11 @@ class VecEnvironment:
         """Enqueue one env step (ticks_per_step engine ticks); results land in self.rewards /
         self.dones_u8 / self.masses (HBM, valid once the stream reaches this point)."""
         self.engine.step(ticks)
+        if self.strict_flags:
+            fl = self.engine.poll_flags()
+            if fl:
+                raise _capi.AgarclError(-6, "capacity flags 0x%x were raised in at least one arena (it has diverged from the reference's "
+                                            "unbounded containers): read engine.flags() and reset those arenas" % fl)
         return self.rewards
 
     def dones(self):

@@ -84,6 +84,10 @@ int agarcl_seed(agarcl_env *env, const uint32_t *seeds_host, uint32_t base_seed)
  * mask_host[num_arenas] (nullable = all).  reset_ids != 0 restarts the arena's entity-id counter
  * (the reference's is process-global and never restarts, core/Ball.hpp:15). */
 int agarcl_reset(agarcl_env *env, const uint8_t *mask_host, int32_t reset_ids);
+/* The same with a device-resident mask u8[num_arenas] (e.g. agarcl_dones_dev of a single-agent env): a pure
+ * stream-ordered launch, no copy and no synchronisation -- what a vectorised RL loop calls every step to restart
+ * finished arenas.  The mask is read when the launch executes. */
+int agarcl_reset_device(agarcl_env *env, const uint8_t *mask_dev, int32_t reset_ids);
 
 /* replaces: take_actions(list[(dx,dy,a)]), bindings.cpp:117-119 -> BaseEnvironment.hpp:141-176.
  * dxdy[num_arenas][num_agents][2] f32, act[num_arenas][num_agents] i32 (0 none, 1 feed, 2 split:
@@ -120,6 +124,11 @@ int agarcl_get_rewards(agarcl_env *env, double *out_host);
 int agarcl_get_dones(agarcl_env *env, uint8_t *out_host);
 int agarcl_get_masses(agarcl_env *env, int32_t *out_host);
 int agarcl_get_flags(agarcl_env *env, uint32_t *out_host);
+/* Cheap watch on the flags: every kernel ORs the flags it raises into one device word, which the engine fetches
+ * asynchronously (pinned memory, never waited for) every few steps.  Returns through *or_of_flags the OR of all
+ * flags seen so far (0 = none); never blocks; may lag the device by up to ~64 steps.  agarcl_get_flags is the exact,
+ * synchronising query; agarcl_reset (unmasked) clears the watch word. */
+int agarcl_poll_flags(agarcl_env *env, uint32_t *or_of_flags);
 /* live entity counts of the last step: i32[num_arenas][4] = pellets, viruses, foods, cells(all players) */
 int agarcl_get_counts(agarcl_env *env, int32_t *out_host);
 /* eat events of the LAST tick executed, per arena (pellets_to_remove / viruses_to_remove order,
@@ -172,6 +181,20 @@ int agarcl_num_arenas(agarcl_env *env);
 int agarcl_players_per_arena(agarcl_env *env);
 /* HBM bytes the engine reads+writes per arena-tick under the streaming model of DESIGN.md */
 int64_t agarcl_state_bytes(agarcl_env *env);
+
+
+/* ---- diagnostics (not part of the drop-in surface; used by tests/ and scripts/) --------------------------------------- */
+/* 1 = the single-launch fused step is in use, 0 = the two-kernel step (the choice never changes results) */
+int agarcl_debug_fused(agarcl_env *env);
+/* i32[num_arenas][2]: the front kernel's hand-over words of the last step (ticks done or -1, mass before) */
+int agarcl_debug_qinfo(agarcl_env *env, int32_t *out_host);
+/* -DAGAR_PROFILE builds only: per-phase cycle sums, u64[16] summed over arenas / u64[num_arenas][16] raw */
+int agarcl_debug_prof(agarcl_env *env, unsigned long long *out16, int reset);
+int agarcl_debug_prof_raw(agarcl_env *env, unsigned long long *out_host);
+/* bytes the step kernels requested from memory since the last call with reset != 0, counted by the kernels themselves:
+ * out[0] = arena-steps finished by the lean front part, out[1] = arena-steps that needed the general engine,
+ * out[2] = pellet passes (each reads the arena's whole pellet array), out[3] = general ticks executed */
+int agarcl_debug_work(agarcl_env *env, int64_t *out4, int reset);
 
 #ifdef __cplusplus
 }

@@ -214,3 +214,47 @@ def run_quiet_rollout(eng, oras, steps, seeds, rng_seed, check_every=100):
                 if d:
                     return False, "step %d arena %d: %s" % (t, a, d)
     return True, gains   # on success: the number of (arena, step) pairs with a mass gain (evidence that pellets were eaten)
+
+
+def run_engine_level_lockstep(engine, oracles, ticks, seeds, policy_seed=7, every=10, respawn=True):
+    """The bench/main.cpp path (SURVEY 3.6 / 8d C1) in batched lock-step: Engine::tick driven directly (agarcl_tick /
+    ora_tick with the envs' own dt, e.g. 1/60 s), no BaseEnvironment::step around it.  Per tick: dead players are
+    respawned (the mode-0 rule), the RL agents get target = centroid + 10 * U(-1,1)^2 and a random action, bots choose
+    for themselves.  The agents' absolute targets are taken from the oracle's take_action and handed to the engine
+    through agarcl_set_targets; every other player's words are the engine's own.  Blobs are compared every `every` ticks."""
+    A = len(oracles)
+    engine.seed(np.asarray(seeds, dtype=np.uint32)); engine.reset(reset_ids=True)
+    for o, s in zip(oracles, seeds):
+        o.seed(int(s)); o.reset(True)
+    P, n = engine.players, engine.num_agents
+    for t in range(ticks):
+        if respawn:
+            engine.respawn_dead()
+            for o in oracles:
+                o.respawn_dead()
+        txy = np.zeros((A, P, 2), np.float32); act = np.zeros((A, P), np.int32)
+        for a, o in enumerate(oracles):
+            dxdy, ac = policy(policy_seed + 7919 * a, t, n, True, 1)
+            for i, pid in enumerate(o.pids()):
+                o.take_action(pid, float(dxdy[i, 0]), float(dxdy[i, 1]), int(ac[i]))
+            want = {p["pid"]: p for p in blob.parse(o.dump())["players"]}
+            _, pl = engine.arena_words(a)
+            for slot in range(P):
+                pid, kind = int(pl[slot, 15]), int(pl[slot, 16])      # PL_PID, PL_KIND (agar_types.h)
+                if kind == 0:                                         # RL agent: the oracle's take_action result
+                    txy[a, slot] = want[pid]["target"]; act[a, slot] = want[pid]["action"]
+                else:                                                 # bot: whatever the engine's own bot logic chose
+                    txy[a, slot] = pl[slot, 2:4].view(np.float32); act[a, slot] = pl[slot, 1]
+        engine.set_targets(txy, act)
+        engine.tick(1)
+        for o in oracles:
+            o.tick()
+        if (t + 1) % every == 0 or t == ticks - 1:
+            fl = engine.flags()
+            if fl.any():
+                return False, "tick %d: capacity flags raised %s" % (t, fl.tolist())
+            for a in range(A):
+                d = blob.diff(oracles[a].dump(), engine.dump(a))
+                if d:
+                    return False, "tick %d: arena %d: %s" % (t, a, d)
+    return True, "ok"

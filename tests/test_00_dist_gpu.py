@@ -1,0 +1,56 @@
+"""Multi-GPU path, shard equivalence (VERDICT r1 #1b): two rank processes, each owning the arena block
+agarcl_amd.dist.shard_bounds gives it and seeding it with arena_seeds, produce exactly the arenas -- state blobs and the
+per-step (reward, done) rows gathered to rank 0 -- that ONE process stepping all arenas produces.  gloo, both ranks on
+GPU 0.  This file sorts first on purpose: the rank children are started BEFORE this process makes any GPU call."""
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+WORKER = os.path.join(HERE, "helpers", "shard_worker.py")
+
+
+def run_two_ranks(lib, total, steps):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = tempfile.mkdtemp(prefix="agar_shard_")
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), "2", str(port), str(total), str(steps), lib, out]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    return [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(2)]
+
+
+def check_against_single_process(lib, parts, total, steps):
+    sys.path.insert(0, os.path.join(HERE, "helpers"))
+    import shard_worker
+    rows = []
+    blobs = shard_worker.run_shard(lib, 0, total, total, steps, lambda t, r, d: rows.append(np.stack([r[:, 0].astype(np.float32), d[:, 0].astype(np.float32)], axis=1)))
+    assert parts[0]["lo"] == 0 and parts[0]["hi"] == parts[1]["lo"] and parts[1]["hi"] == total
+    k = 0
+    for part in parts:
+        for i in range(int(part["n"])):
+            assert np.array_equal(part["blob_%d" % i], blobs[k]), "arena %d differs between the sharded and the single-process run" % k
+            k += 1
+    assert k == total
+    assert np.array_equal(parts[0]["gathered"], np.stack(rows))       # what rank 0 received == the single process's results, every step
+
+
+@pytest.mark.gpu
+def test_two_rank_shards_equal_one_rank_run_gpu():
+    from agarcl_amd import _capi, build as hip_build
+    if not os.path.exists(_capi.HIP_SO):              # (checked by path only: loading the library is left to the children)
+        hip_build.build()
+    total, steps = 64, 120
+    parts = run_two_ranks("hip", total, steps)        # children first: this process has not touched the GPU yet
+    check_against_single_process("hip", parts, total, steps)
+
+
+def test_two_rank_shards_equal_one_rank_run_emulated(emu_lib):
+    """the same on the CPU with the test-only host build of the kernel source (world size 2, gloo)"""
+    total, steps = 10, 60
+    parts = run_two_ranks("emu", total, steps)
+    check_against_single_process("emu", parts, total, steps)

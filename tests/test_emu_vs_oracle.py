@@ -2,7 +2,7 @@
 (tests/emu, test-only) against the oracle in batched lock-step.  The GPU tests repeat this on hardware."""
 import numpy as np
 import pytest
-from lockstep import run_batched_lockstep, run_quiet_rollout
+from lockstep import run_batched_lockstep, run_engine_level_lockstep, run_quiet_rollout
 
 CASES = [
     (dict(arena_size=1000, num_pellets=1000, num_viruses=0, mode=0), 300, 4),
@@ -51,3 +51,21 @@ def test_emulated_quiet_path_long_rollout(emu_lib, oracle_lib, cfg):
     ok, msg = run_quiet_rollout(eng, oras, 1500, 31000 + np.arange(A), rng_seed=17)
     assert ok, "%s: %s" % (cfg, msg)
     assert msg > 0    # somebody ate
+
+
+def test_emulated_engine_level_60hz(emu_lib, oracle_lib):
+    """BASELINE configs[0] as bench/main.cpp drives it: Engine::tick at dt = 1/60 s (600-tick recombine deadlines), agent +
+    the four bot kinds on the default 250x250 arena, through agarcl_set_targets / agarcl_tick on the kernel source."""
+    from agarcl_amd import _capi
+    cfg = dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0, dt=1.0 / 60)
+    A = 2
+    eng = _capi.BatchedEngine(A, lib=emu_lib, **cfg)
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    ok, msg = run_engine_level_lockstep(eng, oras, 1500, seeds=[42, 43], every=25)
+    assert ok, msg
+    # a single mass-1000 agent: splits at tick ~0, so recombination needs the full 600-tick deadline
+    cfg = dict(num_agents=1, arena_size=300, num_pellets=300, num_viruses=5, mode=6, dt=1.0 / 60)
+    eng = _capi.BatchedEngine(A, lib=emu_lib, **cfg)
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    ok, msg = run_engine_level_lockstep(eng, oras, 1400, seeds=[5, 6], every=25, respawn=False)
+    assert ok, msg

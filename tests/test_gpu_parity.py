@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from lockstep import EngineAsEnv, golden_files, replay_golden, run_batched_lockstep, run_quiet_rollout, policy
+from lockstep import EngineAsEnv, golden_files, replay_golden, run_batched_lockstep, run_engine_level_lockstep, run_quiet_rollout, policy
 
 pytestmark = pytest.mark.gpu
 
@@ -165,8 +165,7 @@ def test_baseline_config_c1_population(hip_engine_cls, oracle_lib):
     """BASELINE.json configs[0] / SURVEY 8(d) C1 -- the reference's own CPU-runnable case: 250x250 arena, 500 pellets,
     10 viruses, one agent + the four bot kinds, random targets and actions, dead players respawned (mode 0), 10 000
     ticks -- in lock-step with the oracle on the GPU, driven through the env API (whose tick length is the reference's
-    fixed 1/30 s; the 1/60 s engine-level variant of bench/main.cpp is covered by tests/test_oracle_vs_reference.py and
-    the emulation tests on the CPU)."""
+    fixed 1/30 s; bench/main.cpp's engine-level 1/60 s variant is test_engine_level_60hz_bench_path below)."""
     cfg = dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0)
     A = 4
     eng = hip_engine_cls(A, **cfg)
@@ -174,6 +173,63 @@ def test_baseline_config_c1_population(hip_engine_cls, oracle_lib):
     ok, msg = run_batched_lockstep(eng, oras, 2500, seeds=np.array([42, 43, 44, 45]), sticky=1, every=50)
     eng.close()
     assert ok, msg
+
+
+def test_engine_level_60hz_bench_path(hip_engine_cls, oracle_lib):
+    """BASELINE configs[0] exactly as bench/main.cpp:14-38 drives it: Engine::tick at dt = 1/60 s (600-tick recombine
+    deadlines) through agarcl_set_targets / agarcl_tick, agent + the four bot kinds, dead players respawned every tick;
+    then a lone mass-1000 agent whose split cells wait out the full 600-tick deadline."""
+    cfg = dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0, dt=1.0 / 60)
+    A = 3
+    eng = hip_engine_cls(A, **cfg)
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    ok, msg = run_engine_level_lockstep(eng, oras, 2000, seeds=[42, 43, 44], every=20)
+    eng.close()
+    assert ok, msg
+    cfg = dict(num_agents=1, arena_size=300, num_pellets=300, num_viruses=5, mode=6, dt=1.0 / 60)
+    eng = hip_engine_cls(A, **cfg)
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    ok, msg = run_engine_level_lockstep(eng, oras, 1500, seeds=[5, 6, 7], every=20, respawn=False)
+    eng.close()
+    assert ok, msg
+
+
+def test_masked_reset_device_mask(hip_engine_cls, oracle_lib):
+    """agarcl_reset_device: the mask stays in HBM (here: a torch tensor), the reset is a stream-ordered launch"""
+    import torch
+    from oracle import blob
+    A = 6
+    eng = hip_engine_cls(A, **C3)
+    oras = [oracle_lib.OraEnv(**C3) for _ in range(A)]
+    ok, msg = run_batched_lockstep(eng, oras, 20, seeds=np.arange(60, 60 + A), sticky=4, every=20)
+    assert ok, msg
+    mask = torch.tensor([0, 1, 1, 0, 0, 1], dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    eng.reset_device(mask.data_ptr(), reset_ids=False)
+    for a in range(A):
+        if int(mask[a]):
+            oras[a].reset(False)
+        assert blob.diff(oras[a].dump(), eng.dump(a)) is None, "arena %d after the device-masked reset" % a
+    eng.close()
+
+
+def test_flag_watch_reports_overflow(hip_engine_cls):
+    """A capacity overflow (here: more foods than cap_foods) raises the arena's sticky flag AND reaches the host through the
+    asynchronous watch word without a synchronising query (agarcl_poll_flags)."""
+    A = 8
+    eng = hip_engine_cls(A, arena_size=200, num_pellets=100, num_viruses=0, mode=6, cap_foods=4)
+    eng.seed(None, 3); eng.reset(reset_ids=True)
+    assert eng.poll_flags() == 0
+    dxdy = np.tile(np.array([[[0.7, 0.1]]], np.float32), (A, 1, 1)); act = np.ones((A, 1), np.int32)     # feed, feed, feed
+    for t in range(200):
+        eng.set_actions(dxdy, act); eng.step()
+    assert (eng.flags() & 2).any()             # AGARCL_F_FOODS_OVERFLOW
+    eng.sync()
+    for t in range(70):                        # the watch samples every 64 steps
+        eng.step()
+    eng.sync(); eng.step()
+    assert eng.poll_flags() & 2
+    eng.close()
 
 
 def test_masked_reset_and_reseed(hip_engine_cls, oracle_lib):
@@ -284,6 +340,31 @@ def test_mode6_full_size_vs_oracle_sample(hip_engine_cls, oracle_lib):
     assert not eng.flags().any()
     for arena in (0, 5, 777, 4095):
         o = oracle_lib.OraEnv(**C3M6); o.seed(777 + arena); o.reset(True)
+        for dxdy, a in acts:
+            o.take_actions(dxdy[arena], a[arena]); o.step()
+        assert blob.diff(o.dump(), eng.dump(arena)) is None, "arena %d" % arena
+    eng.close()
+
+
+def test_config4_single_gpu_half_32768_arenas_mode6(hip_engine_cls, oracle_lib):
+    """BASELINE configs[3]'s per-node size on ONE GPU: 32 768 arenas of the full ruleset (mode 6); sampled arenas equal the
+    oracle run alone on the same seed and action stream, no capacity flag anywhere."""
+    from oracle import blob
+    A, steps = 32768, 40
+    eng = hip_engine_cls(A, **C3M6)
+    eng.seed(None, 31000); eng.reset(reset_ids=True)
+    acts = []
+    for t in range(steps):
+        rng = np.random.RandomState(2000 + t // 8)
+        dxdy = rng.uniform(-1, 1, size=(A, 1, 2)).astype(np.float32)
+        a = rng.randint(0, 3, size=(A, 1)).astype(np.int32)
+        acts.append((dxdy, a))
+        eng.set_actions(dxdy, a); eng.step()
+    assert not eng.flags().any()
+    counts = eng.counts()
+    assert (counts[:, 3] >= 1).all() and counts[:, 3].mean() > 3       # the agents really split (full ruleset at work)
+    for arena in (0, 1, 4095, 4096, 20011, 32767):
+        o = oracle_lib.OraEnv(**C3M6); o.seed(31000 + arena); o.reset(True)
         for dxdy, a in acts:
             o.take_actions(dxdy[arena], a[arena]); o.step()
         assert blob.diff(o.dump(), eng.dump(arena)) is None, "arena %d" % arena

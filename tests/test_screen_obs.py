@@ -23,6 +23,22 @@ def test_screen_respawn_hook_on_emulated_kernels(emu_lib, oracle_lib):
 
 
 @pytest.mark.gpu
+def test_screen_respawn_hook_hip(hip_engine_cls, oracle_lib):
+    """E5 on the GPU: ScreenEnvironment's hook (ScreenEnvironment.hpp:233-243) in lock-step with the oracle, in a mode that
+    never respawns otherwise (mode 4) and in mode 0 with bots, where BaseEnvironment's own respawn follows the hook."""
+    for cfg, steps in ((dict(num_agents=2, arena_size=120, num_pellets=150, num_viruses=2, num_bots=0, mode=4, c_death=-50), 700),
+                       (dict(num_agents=1, arena_size=150, num_pellets=200, num_viruses=3, num_bots=3, mode=0, c_death=-7), 500)):
+        A = 8
+        eng = hip_engine_cls(A, screen_respawn=True, **cfg)
+        oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+        for o in oras:
+            o.set_screen_hook(True)
+        ok, msg = run_batched_lockstep(eng, oras, steps, seeds=np.arange(300, 300 + A), sticky=6, every=5)
+        eng.close()
+        assert ok, "%s: %s" % (cfg, msg)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg,steps", [
     (dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode=6), 40),
     (dict(num_agents=2, arena_size=200, num_pellets=300, num_viruses=5, num_bots=3, mode=0), 60),
@@ -77,6 +93,8 @@ def test_agarcl_screen_environment_mirror():
         env.take_actions([(0.3, -0.2, 0)]); env.step()
     assert env.observation_shape() == (1, 84, 84, 3)
     s = env.get_state()
+    assert isinstance(s, list) and len(s) == 1            # bindings.cpp:157-168: a list holding the one frame buffer
+    s = s[0]
     assert s.shape == (1, 84, 84, 3) and s.dtype == np.uint8
     img = s.reshape(84, 84, 3)
     assert (img == 255).all(axis=2).mean() > 0.3            # white background dominates
@@ -84,7 +102,7 @@ def test_agarcl_screen_environment_mirror():
     env.close()
     env = agarcl.ScreenEnvironment(1, 4, 1000, True, 1000, 25, 0, True, 0, 6, False, 84, 84, True)   # agent view: 4 channels
     env.seed(3); env.reset(); env.take_actions([(0.3, -0.2, 0)]); env.step()
-    assert env.observation_shape() == (1, 84, 84, 4) and env.get_state().shape == (1, 84, 84, 4)
+    assert env.observation_shape() == (1, 84, 84, 4) and env.get_state()[0].shape == (1, 84, 84, 4)
     env.close()
 
 
@@ -95,9 +113,10 @@ def test_gym_wrapper_screen_observation():
     g = gym_agario.AgarioEnv(obs_type="screen", difficulty="normal", screen_len=64, number_steps=4)
     g.seed(2)
     obs, info = g.reset()
-    assert obs.shape == (64, 64, 3) or obs.shape == (1, 64, 64, 3)
+    assert obs.shape == (1, 64, 64, 3)       # the reference yields the (num_frames, W, H, C) buffer as is (AgarioEnv.py:196-197)
     assert obs.dtype == np.uint8 and info == {}
+    assert g.observation_shape == (1, 64, 64, 3)
     for k in range(3):
         obs, rew, done, trunc, info = g.step(((0.2, -0.4), 0))
-        assert obs.dtype == np.uint8 and isinstance(rew, float) and trunc is False
+        assert obs.shape == (1, 64, 64, 3) and obs.dtype == np.uint8 and isinstance(rew, float) and trunc is False
     g.close()
