@@ -82,3 +82,30 @@ class ResultGatherer:
         if self.rank != 0:
             return None
         return self.torch.cat(self.recv[slot], dim=0)
+
+
+class TensorGatherer:
+    """Per-step gather of one fixed-shape tensor per rank to rank 0 -- the observation path of a learner that lives on
+    rank 0 (uint8 screen frames are 21 KB per arena; the int32 grid tensor, 512 KB per arena, is better left
+    on the producing GPU).  One collective in flight: gather(t) starts it, wait() completes it before `t` is reused."""
+
+    def __init__(self, shape, dtype, device, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.recv = [torch.empty(tuple(shape), dtype=dtype, device=device) for _ in range(self.world)] if self.rank == 0 else None
+        self.work = None
+
+    def gather(self, tensor):
+        self.wait()
+        self.work = self.dist.gather(tensor, self.recv, dst=0, group=self.group, async_op=True)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+
+    def gathered(self):
+        """rank 0: [world * A_local, ...] after wait()"""
+        return self.torch.cat(self.recv, dim=0) if self.rank == 0 else None

@@ -4,16 +4,19 @@
 Workload = BASELINE.json configs[1] / SURVEY.md 8(d) "C2": 4096 arenas per GPU, each 1000x1000,
 1000 pellets, 0 viruses, 1 agent, no bots, pellet regen, mode 0, dt = 1/30, 4 ticks per env step,
 action "none", (dx,dy) ~ U(-1,1)^2 pre-generated in HBM, arena seeds = 10000 + global arena index.
-A bench "step" is one agarcl_step launch = 4 engine ticks of every arena.
+A bench "step" is one agarcl_step = 4 engine ticks of every arena.
 
     python bench.py --gpus 1 --steps 1000 --warmup 100
+    python bench.py --gpus 8 ...        (WORLD_SIZE unset: starts the 8 rank processes itself through torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the roofline / cpu_baseline fields).
+Rank 0 prints ONE JSON line (DESIGN.md section 5 explains the roofline / cpu_baseline fields).
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import threading
 import time
@@ -22,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ARENAS_PER_GPU = 4096
+LARGE_ARENAS = 65536        # the "roofline_large" block: north star ">= 50k parallel arenas"
 CFG = dict(num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True, num_pellets=1000, num_viruses=0,
            num_bots=0, reward_type=1, c_death=0, mode_number=0)
 # The headline line is C2.  The other SURVEY 8(d) workloads are selectable for DESIGN.md's measurement table only.
@@ -35,8 +39,38 @@ WORKLOADS = {
                desc="C5: C3/mode 6 + int32 grid observation [%d][8][128][128] written once per step"),
     "C5s": dict(num_viruses=25, mode_number=6, rand_act=True, screen_obs=True,
                 desc="C5 (screen): C3/mode 6 + uint8 screen observation [%d][84][84][3] written once per step"),
+    # BASELINE configs[0] batched: the reference's own bench/main.cpp population (agent + the four bot kinds on the default
+    # 250x250 arena, Engine::tick at dt = 1/60 s), 4 ticks per launch
+    "C1": dict(arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, dt=1.0 / 60, rand_act=True,
+               desc="C1 batched: %d arenas/GPU x (1 agent + 4 bots), 250x250, 500 pellets, 10 viruses, mode 0, dt 1/60 s, 4 ticks/step"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
+
+
+def source_sha():
+    """Identifies the kernel source a profile was recorded on (profiles/*.json carry it; a stale one is not quoted)."""
+    import glob
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "agarcl_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def requested_bytes(work, counts, P, n_agents, ticks, pellet_cap):
+    """Bytes the step kernels REQUEST from memory, from the kernels' own work counters (agarcl_debug_work) -- what this
+    implementation's algorithm needs, as opposed to the streaming model of SURVEY 8(d) (every entity once per tick).
+    Never more than the HBM traffic the PMC counters see (requests are rounded up to 64/128-byte sectors), so the
+    fraction built on it cannot exceed 1.  Constants = the loads / stores written in agar_quiet.inl (front part) and
+    agar_core.inl arena_load / arena_store (general engine); the shared mass tables stay in L2 and are not counted."""
+    front_steps, general_steps, pellet_moves = (float(x) for x in work[:3])
+    n_pel, n_vir, n_food, n_cells = counts
+    # front part, per arena-step: loads cell 0 (48) + 15 player words (60) + 9 arena words (36) + action (12);
+    # stores cell (40) + player (52) + arena (40) + counts (16) + results f64/i32/u8/packed (21) + hand-over (8)
+    front = 156.0 + 177.0
+    # general engine, per arena-step: arena words r+w (256), player words r+w (160 P), all 32 cell slots read (1536 P) +
+    # live cells written (48 N_c), results (29 A) + counts (16); per tick: viruses x/y/mass (12 N_v) and foods (20 N_f) read
+    general = 256.0 + 160.0 * P + 1536.0 * P + 48.0 * n_cells + 29.0 * n_agents + 16.0 + ticks * (12.0 * n_vir + 20.0 * n_food)
+    return front * front_steps + general * general_steps + pellet_moves * pellet_cap * 8.0
 
 
 def cpu_baseline(seconds_budget=12.0):
@@ -60,20 +94,25 @@ def cpu_baseline(seconds_budget=12.0):
         use_ref = False
     if use_ref:
         from oracle import refbind as B
-        mk = lambda: B.RefEnv(num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True, num_pellets=1000,
-                              num_viruses=0, num_bots=0, reward_type=1, c_death=0, mode=0)
-        kind = "reference"
+        Env, kind = B.RefEnv, "reference"
     else:
         from oracle import orabind as B
         if not B.available():
             B.build()
-        mk = lambda: B.OraEnv(num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True, num_pellets=1000,
-                              num_viruses=0, num_bots=0, reward_type=1, c_death=0, mode=0)
-        kind = "port"
+        Env, kind = B.OraEnv, "port"
+    mk = lambda: Env(num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True, num_pellets=1000,
+                     num_viruses=0, num_bots=0, reward_type=1, c_death=0, mode=0)
     # calibrate on one core
     e = mk(); e.seed(10000); e.reset(True)
     t0 = time.perf_counter(); e.run_random(4000, policy_seed=1, allow_actions=False); dt1 = time.perf_counter() - t0
     rate1 = 4000 / dt1
+    # BASELINE configs[0] as bench/main.cpp:14-38 runs it: default engine (250x250, 500 pellets, 10 viruses, mode 0), agent +
+    # the four bot kinds, dt = 1/60 s, random policy, 10 000 ticks, one core
+    c1 = Env(num_agents=1, ticks_per_step=4, arena_size=250, pellet_regen=True, num_pellets=500, num_viruses=10, num_bots=4,
+             reward_type=1, c_death=0, mode=0, dt=1.0 / 60)
+    c1.seed(42); c1.reset(True)
+    t0 = time.perf_counter(); n1 = c1.run_random(10000, policy_seed=7, allow_actions=True); c1_rate = n1 / (time.perf_counter() - t0)
+    c1.close()
     chunk = 2000
     done = [0] * cores
     mk_lock = threading.Lock()
@@ -99,7 +138,149 @@ def cpu_baseline(seconds_budget=12.0):
     return {"value": total / el, "unit": "env-steps/s", "cores": cores, "kind": kind,
             "sample": "%.0f s of the C2 workload (1000x1000, 1000 pellets, 1 agent, random dx/dy, action none), one engine "
                       "per host thread, %d threads, %d arena-ticks in total; single-thread rate %.0f ticks/s"
-                      % (seconds_budget, cores, total, rate1)}
+                      % (seconds_budget, cores, total, rate1),
+            "c1_ticks_per_s_1core": c1_rate,
+            "c1_sample": "BASELINE configs[0] as bench/main.cpp runs it: 250x250, 500 pellets, 10 viruses, agent + 4 bot kinds, "
+                         "dt 1/60 s, random policy, 10000 ticks on one core"}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes (before this process has made any GPU
+    call) and return their exit code; never silently run fewer ranks than asked for."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, Wm, cfg, rand_act, with_obs, with_screen,
+                 gather_mode, gather_obs):
+    """Builds the env, runs Wm untimed + K timed steps, returns the measurements of this rank."""
+    import torch.distributed as dist
+    lo, hi = rank * A, (rank + 1) * A  # weak scaling: every GPU owns `A` arenas
+    env = env_cls(A, device=dev_index, strict_flags=False, **cfg)
+    env.seed(agdist.arena_seeds(10000, lo, hi))
+    env.reset(reset_ids=True)
+    # synthetic random policy, resident in HBM before the timed region: counter-based per (arena, step)
+    g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
+    na = cfg["num_agents"]
+    dxdy = (torch.rand((K + Wm, A, na, 2), generator=g, device=dev, dtype=torch.float32) * 2.0 - 1.0).contiguous()
+    act = torch.zeros((K + Wm, A, na), dtype=torch.int32, device=dev)
+    if rand_act:
+        act = torch.randint(0, 3, (K + Wm, A, na), generator=g, device=dev, dtype=torch.int32)
+    obs = torch.empty((A, 8, 128, 128), dtype=torch.int32, device=dev) if with_obs else None
+    want_screen = with_screen or (world > 1 and gather_obs == "screen")
+    scr = torch.empty((A, 84, 84, 3), dtype=torch.uint8, device=dev) if want_screen else None
+    # Multi-GPU result path (the only exchange there is: arenas never interact).
+    #   block: (reward, done) of 8 consecutive steps -- one contiguous block of the engine's 16-slot result ring, zero copy --
+    #          per asynchronous RCCL gather, double-buffered by ring half: for a synthetic policy, where nobody waits for them
+    #   step : one gather per step straight from the slot the step wrote (what a learner on rank 0 needs; ~20 us of latency each)
+    #   --gather-obs screen: additionally every step's uint8 frames [A][84][84][3] go to rank 0 (21 KB per arena)
+    BLK = 8
+    eng = env.engine
+    gather = obs_gather = None
+    if world > 1:
+        gather = agdist.ResultGatherer(BLK * A * na if gather_mode == "block" else A * na, dev, depth=2)
+        if gather_obs == "screen":
+            obs_gather = agdist.TensorGatherer((A, 84, 84, 3), torch.uint8, dev)
+
+    def one_step(k):
+        eng.set_actions_device(dxdy[k].data_ptr(), act[k].data_ptr())
+        if gather is not None and gather_mode == "block":
+            nxt = (eng.last_slot() + 1) % (2 * BLK)
+            if nxt % BLK == 0:
+                gather.wait_slot(nxt // BLK)    # the engine is about to overwrite this half of the ring
+        eng.step(cfg["ticks_per_step"])
+        if obs is not None:
+            eng.grid_obs(128, True, True, True, True, out_ptr=obs.data_ptr())
+        if scr is not None:
+            if obs_gather is not None:
+                obs_gather.wait()               # the previous step's frames have left before they are overwritten
+            eng.screen_obs(84, 84, out_ptr=scr.data_ptr())
+            if obs_gather is not None:
+                obs_gather.gather(scr)
+        if gather is not None:
+            s_ = eng.last_slot()
+            if gather_mode == "step":
+                gather.wait_slot(s_ & 1)
+                gather.gather_packed(s_ & 1, env.packed_ring[s_])
+            elif s_ % BLK == BLK - 1:           # RCCL gather of 8 steps of (reward, done) straight from engine memory
+                h_ = s_ // BLK
+                gather.gather_packed(h_, env.packed_ring[h_ * BLK:(h_ + 1) * BLK].reshape(-1, 2))
+
+    def flush():                                # results of a partial last block still go to rank 0
+        s_ = eng.last_slot()
+        if gather is not None and gather_mode == "block" and s_ % BLK != BLK - 1:
+            h_ = s_ // BLK
+            gather.wait_slot(h_)
+            gather.gather_packed(h_, env.packed_ring[h_ * BLK:(h_ + 1) * BLK].reshape(-1, 2))
+
+    def drain():
+        if gather is not None:
+            gather.wait_all()
+        if obs_gather is not None:
+            obs_gather.wait()
+
+    for k in range(Wm):
+        one_step(k)
+    flush(); drain()
+    eng.work(reset=True)                        # (synchronising) the kernels' work counters restart with the timed region
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for k in range(Wm, Wm + K):
+        one_step(k)
+    flush()
+    ev1.record()
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / K  # HIP events on the launch stream (the engine adopts torch's current stream): avg per step
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    res = dict(elapsed=elapsed, kernel_ms=kernel_ms, work=eng.work(), flags=eng.flags(),
+               counts=eng.counts().astype(np.float64).mean(axis=0), players=eng.players, fused=int(eng.L.agarcl_debug_fused(eng.h)),
+               pellet_cap=(cfg["num_pellets"] + 63) // 64 * 64)
+    env.close()
+    return res
+
+
+def roofline_block(res, A, K, ticks, cfg, workload, extra_bytes=0.0, kernel=None):
+    """roofline object for one measured run (see requested_bytes)."""
+    n_pel, n_vir, n_food, n_cells = res["counts"]
+    P, na = res["players"], cfg["num_agents"]
+    req = requested_bytes(res["work"], res["counts"], P, na, ticks, res["pellet_cap"]) / K + extra_bytes
+    t = res["kernel_ms"] * 1e-3
+    # SURVEY 8(d) streaming model (every live entity once per tick): 8 N_p + 12 N_v + 72 N_c + 40 N_f + 112 P + 24 A
+    b_tick = 8 * n_pel + 12 * n_vir + 72 * n_cells + 40 * n_food + 112 * P + 24 * na
+    model = b_tick * A * ticks + extra_bytes
+    traffic = tag = None
+    try:  # HBM bytes per step from the PMC counters, recorded separately by scripts/profile_round.sh on THIS kernel source
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        ent = tj["runs"].get("%s@%d" % (workload, A))
+        if ent and tj.get("source_sha") == source_sha():
+            traffic, tag = ent["traffic_bytes_per_step"], "%s, source %s" % (tj.get("recorded", "?"), tj["source_sha"])
+    except Exception:
+        pass
+    moved = traffic if traffic else req
+    out = {"bound": "hbm", "achieved": moved / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved / t / 1e9 / HBM_PEAK_GBS,
+           "traffic": traffic, "traffic_source": tag, "requested_bytes_per_step": req, "kernel_ms": res["kernel_ms"],
+           "kernel": kernel or ("k_fused (one launch per env step)" if res["fused"] and P == 1 else ("k_quiet + k_step" if P == 1 else "k_step")),
+           "arenas": A, "streaming_model_bytes_per_step": model, "streaming_model_bytes_per_arena_tick": b_tick,
+           "model_speedup": model / t / 1e9 / HBM_PEAK_GBS,
+           "work_per_step": {"front_finished_arena_steps": float(res["work"][0]) / K, "general_engine_arena_steps": float(res["work"][1]) / K,
+                             "pellet_array_transfers": float(res["work"][2]) / K}}
+    return out
 
 
 def main():
@@ -109,25 +290,24 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--arenas", type=int, default=ARENAS_PER_GPU, help="arenas per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large", action="store_true", help="skip the %d-arena roofline_large run" % LARGE_ARENAS)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS), help="C2 = the headline metric's configuration")
+    ap.add_argument("--gather", default="block", choices=["block", "step"], help="multi-GPU: how (reward, done) reaches rank 0")
+    ap.add_argument("--gather-obs", default="none", choices=["none", "screen"], help="multi-GPU: also gather every step's uint8 frames")
     args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))            # children first: no GPU call has been made in this process
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the number of rank processes must equal --gpus" % (args.gpus, world))
     wl = dict(WORKLOADS[args.workload])
     desc, rand_act, with_obs, with_screen = wl.pop("desc"), wl.pop("rand_act", False), wl.pop("grid_obs", False), wl.pop("screen_obs", False)
-    CFG.update(wl)
+    cfg = dict(CFG); cfg.update(wl)
 
     import torch
     import numpy as np
-    from agarcl_amd import _capi as _c, build as _hip_build
-    if not os.path.exists(_c.HIP_SO) and int(os.environ.get("RANK", "0")) == 0:
-        _hip_build.build()          # normally prebuilt by __graft_entry__.build(); never rebuilt when present
-    from agarcl_amd.vec_env import VecEnvironment
-    from agarcl_amd import dist as agdist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
     # one process per GPU.  (AGAR_BENCH_BACKEND=gloo + fewer GPUs than ranks is only for exercising the
@@ -143,127 +323,56 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-
-    A = args.arenas
-    K, Wm = args.steps, args.warmup
-    lo, hi = rank * A, (rank + 1) * A  # weak scaling: every GPU owns `A` arenas
-    env = VecEnvironment(A, device=dev_index, **CFG)
-    env.seed(agdist.arena_seeds(10000, lo, hi))
-    env.reset(reset_ids=True)
-
-    # synthetic random policy, resident in HBM before the timed region: counter-based per (arena, step)
-    g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
-    dxdy = (torch.rand((K + Wm, A, 1, 2), generator=g, device=dev, dtype=torch.float32) * 2.0 - 1.0).contiguous()
-    act = torch.zeros((K + Wm, A, 1), dtype=torch.int32, device=dev)
-    if rand_act:
-        act = torch.randint(0, 3, (K + Wm, A, 1), generator=g, device=dev, dtype=torch.int32)
-    obs = torch.empty((A, 8, 128, 128), dtype=torch.int32, device=dev) if with_obs else None
-    scr = torch.empty((A, 84, 84, 3), dtype=torch.uint8, device=dev) if with_screen else None
-    # Multi-GPU: (reward, done) of every step reaches rank 0 through RCCL gathers of 8 steps at a time (one contiguous
-    # block of the engine's 16-slot result ring, zero copy), asynchronous and double-buffered by ring half: a per-step
-    # collective (~20 us of latency) would cost more than the 11 us step itself.
-    BLK = 8
-    gather = agdist.ResultGatherer(BLK * A, dev) if world > 1 else None
-    eng = env.engine
-
-    def one_step(k):
-        eng.set_actions_device(dxdy[k].data_ptr(), act[k].data_ptr())
-        if gather is not None:
-            nxt = (eng.last_slot() + 1) % (2 * BLK)
-            if nxt % BLK == 0:
-                gather.wait_slot(nxt // BLK)    # the engine is about to overwrite this half of the ring
-        eng.step(CFG["ticks_per_step"])
-        if obs is not None:
-            eng.grid_obs(128, True, True, True, True, out_ptr=obs.data_ptr())
-        if scr is not None:
-            eng.screen_obs(84, 84, out_ptr=scr.data_ptr())
-        if gather is not None:                  # RCCL gather of 8 steps of (reward, done) straight from engine memory
-            s_ = eng.last_slot()
-            if s_ % BLK == BLK - 1:
-                h_ = s_ // BLK
-                gather.gather_packed(h_, env.packed_ring[h_ * BLK:(h_ + 1) * BLK].reshape(-1, 2))
-
-    def flush():                                # results of a partial last block still go to rank 0
-        s_ = eng.last_slot()
-        if gather is not None and s_ % BLK != BLK - 1:
-            h_ = s_ // BLK
-            gather.wait_slot(h_)
-            gather.gather_packed(h_, env.packed_ring[h_ * BLK:(h_ + 1) * BLK].reshape(-1, 2))
-
-    for k in range(Wm):
-        one_step(k)
-    flush()
-    if gather is not None:
-        gather.wait_all()
-    torch.cuda.synchronize()
+    from agarcl_amd import _capi as _c, build as _hip_build
+    if not os.path.exists(_c.HIP_SO) and rank == 0:
+        _hip_build.build()          # normally prebuilt by __graft_entry__.build(); never rebuilt when present
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for k in range(Wm, Wm + K):
-        one_step(k)
-    flush()
-    ev1.record()
-    if gather is not None:
-        gather.wait_all()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / K  # HIP events on the launch stream: avg per launch incl. gaps
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        dist.barrier()              # nobody loads the library while rank 0 may still be writing it
+    from agarcl_amd.vec_env import VecEnvironment
+    from agarcl_amd import dist as agdist
 
-    flags = eng.flags()
-    counts = eng.counts().astype(np.float64).mean(axis=0)  # pellets, viruses, foods, cells per arena
-    ticks = CFG["ticks_per_step"]
-    value = world * A * ticks * K / elapsed
+    A, K, Wm = args.arenas, args.steps, args.warmup
+    ticks = cfg["ticks_per_step"]
+    res = run_workload(torch, np, VecEnvironment, agdist, dev, dev_index, rank, world, A, K, Wm, cfg, rand_act, with_obs, with_screen,
+                       args.gather, args.gather_obs)
+    value = world * A * ticks * K / res["elapsed"]
     if rank == 0:
-        # algorithmic bytes per arena-tick, SURVEY.md 8(d): 8 N_p + 12 N_v + 72 N_c + 40 N_f + 112 P + 24 A
-        b_tick = 8 * counts[0] + 12 * counts[1] + 72 * counts[3] + 40 * counts[2] + 112 * 1 + 24 * 1
-        bytes_per_launch = b_tick * A * ticks
-        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        traffic = None  # HBM bytes per launch from the PMC counters (collected separately: profiles/r01_pmc_traffic.json)
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if A == 4096 and ticks == 4 and args.workload == "C2":
-                traffic = tj["traffic_bytes_per_launch"]
-        except Exception:
-            pass
+        extra = (A * 8 * 128 * 128 * 4 if with_obs else 0) + (A * 84 * 84 * 3 if with_screen else 0)
+        kernel = None
+        if with_obs: kernel = "k_step + k_grid_zero + k_grid_obs"
+        if with_screen: kernel = "k_step + k_screen_obs"
+        roof = roofline_block(res, A, K, ticks, cfg, args.workload, float(extra), kernel)
+        roof["note"] = ("achieved = HBM bytes one env step moves (PMC FETCH_SIZE x2 + WRITE_SIZE of the same kernel source when profiles/ "
+                        "holds them -> `traffic`; otherwise the bytes the kernels request, counted by the kernels themselves) / the step's "
+                        "HIP-event time; frac <= 1 by construction.  model_speedup = SURVEY 8(d)'s streaming-model bytes over the same time: "
+                        "it exceeds 1 because the engine does not stream (state stays in registers across the ticks of a step, pellets are "
+                        "read only when a cell leaves its pellet-free disc).  At 4096 arenas the step is launch/latency bound, see "
+                        "roofline_large for the bandwidth-bound regime")
+        if world > 1:
+            par = "arena-sharded x%d; every step's (reward, done) gathered to rank 0 %s%s" % (
+                world, "in asynchronous blocks of 8 steps" if args.gather == "block" else "by one collective per step",
+                ", plus every step's uint8 screen frames" if args.gather_obs == "screen" else "")
+        else:
+            par = "single GPU"
         out = {
             "metric": "env-steps/sec (arenas x ticks/s)", "value": value, "unit": "env-steps/s", "n_gpus": world,
-            "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "steps": K, "warmup": Wm, "ms_per_step": res["elapsed"] / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc % A,
-                       "arenas_total": world * A, "ticks_per_step": ticks,
-                       "parallelism": "arena-sharded x%d, every step's (reward, done) gathered to rank 0 in asynchronous blocks of 8 steps" % world if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "kernel": "k_fused (one launch per env step)" if args.workload in ("C2", "C3m0") else "k_quiet + k_step (the two launches of one env step)", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_arena_tick": b_tick,
-                         "moved_frac": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "note": "achieved = SURVEY 8(d) streaming-model bytes / time; frac > 1 is possible because the engine does "
-                                 "not stream: state stays in registers across the 4 ticks and pellets are read only when a cell "
-                                 "leaves its pellet-free disc (traffic = bytes really moved, PMC).  The step is latency/issue "
-                                 "bound, not HBM bound: see DESIGN.md section 5"},
-            "capacity_flags_raised": int((flags != 0).sum()),
+            "config": {"workload": desc % A, "arenas_total": world * A, "ticks_per_step": ticks, "parallelism": par},
+            "gym_steps_per_s": value / ticks,
+            "roofline": roof,
+            "capacity_flags_raised": int((res["flags"] != 0).sum()),
         }
-        if with_screen:
-            out["roofline"]["algorithmic_bytes_per_launch"] = bytes_per_launch + A * 84 * 84 * 3
-            out["roofline"]["achieved"] = out["roofline"]["algorithmic_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
-            out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
-            out["roofline"]["kernel"] = "k_quiet + k_step + k_screen_obs"
-        if with_obs:
-            out["roofline"]["algorithmic_bytes_per_launch"] = bytes_per_launch + A * 8 * 128 * 128 * 4
-            out["roofline"]["achieved"] = out["roofline"]["algorithmic_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
-            out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
-            out["roofline"]["kernel"] = "k_step + k_grid_obs"
+        if world == 1 and not args.no_large and args.workload == "C2" and A != LARGE_ARENAS:
+            # the same kernel where it is bandwidth- rather than latency-bound: >= 50 k arenas (north star), short run
+            try:
+                big = run_workload(torch, np, VecEnvironment, agdist, dev, dev_index, 0, 1, LARGE_ARENAS, 200, 40, cfg, rand_act, False, False, "block", "none")
+                rl = roofline_block(big, LARGE_ARENAS, 200, ticks, cfg, args.workload)
+                rl["value_env_steps_per_s"] = LARGE_ARENAS * ticks * 200 / big["elapsed"]
+                rl["ms_per_step"] = big["elapsed"] / 200 * 1e3
+                out["roofline_large"] = rl
+            except Exception as ex:  # the headline line must not depend on it
+                out["roofline_large"] = {"error": str(ex)}
         if world == 1:  # measured roofline next to the nominal one: device stream copy and fill of 1 GiB
             try:
                 src = torch.empty(1 << 28, dtype=torch.int32, device=dev); dst = torch.empty_like(src)
@@ -275,15 +384,18 @@ def main():
                         fn()
                     torch.cuda.synchronize()
                     return nbytes * 5 / (time.perf_counter() - t) / 1e9
-                out["roofline"]["measured_copy_GBs"] = _bw(lambda: dst.copy_(src), 2 * src.numel() * 4)
-                out["roofline"]["measured_fill_GBs"] = _bw(lambda: dst.fill_(1), src.numel() * 4)
+                copy_gbs = _bw(lambda: dst.copy_(src), 2 * src.numel() * 4)
+                fill_gbs = _bw(lambda: dst.fill_(1), src.numel() * 4)
                 del src, dst
+                for r in (out["roofline"], out.get("roofline_large")):
+                    if r and "achieved" in r:
+                        r["measured_copy_GBs"] = copy_gbs; r["measured_fill_GBs"] = fill_gbs
+                        r["frac_of_measured_copy"] = r["achieved"] / copy_gbs
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline and args.workload == "C2":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    env.close()
     if world > 1:
         dist.destroy_process_group()
 

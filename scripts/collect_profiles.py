@@ -1,0 +1,83 @@
+"""Condenses scripts/profile_round.sh's rocprofv3 output into the files that get committed under profiles/.
+
+    python3 scripts/collect_profiles.py <tag>       reads gpurun_out/prof_<tag>/, writes gpurun_out/profiles_<tag>/
+
+<tag>_pmc_traffic.json: per run, HBM bytes per env step = (FETCH_SIZE x 2 + WRITE_SIZE) x 1024 summed over the step's kernels
+(every launch of the run, warm-up included) / number of steps.  The x2 on fetches is the gfx950 correction of
+/opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE tallies 128-byte requests at 64 bytes.  The file carries the
+sha of the kernel source it was recorded on; bench.py quotes it only while that sha matches."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+STEP_KERNELS = ("k_fused", "k_quiet", "k_step", "k_grid_zero", "k_grid_obs", "k_screen_obs")
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    dst = os.path.join(ROOT, "gpurun_out", "profiles_" + tag)
+    os.makedirs(dst, exist_ok=True)
+    import bench
+    runs = {}
+    for d in sorted(glob.glob(os.path.join(src, "*_*"))):
+        if not os.path.isdir(d):
+            continue
+        name = os.path.basename(d)
+        w, a = name.rsplit("_", 1)
+        ent = {"workload": w, "arenas": int(a)}
+        for f in glob.glob(os.path.join(d, "kt", "**", "*kernel_stats.csv"), recursive=True):
+            shutil.copy(f, os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, name)))
+            ks = {}
+            for r in csv.DictReader(open(f)):
+                for k in STEP_KERNELS:
+                    if k in r["Name"]:
+                        ks[k] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "total_ms": float(r["TotalDurationNs"]) / 1e6}
+            ent["kernel_stats"] = ks
+        bj = os.path.join(src, name + ".bench.json")
+        try:
+            line = [l for l in open(bj).read().splitlines() if l.startswith("{")][-1]
+            b = json.loads(line)
+            json.dump(b, open(os.path.join(dst, "%s_%s_bench.json" % (tag, name)), "w"), indent=1)
+            ent["steps_total"] = b["steps"] + b["warmup"]
+            ent["bench_ms_per_step_under_profiler"] = b["ms_per_step"]
+            ent["requested_bytes_per_step"] = b["roofline"]["requested_bytes_per_step"]
+        except Exception as ex:
+            ent["bench_error"] = str(ex)
+        tot = collections.defaultdict(float); n = collections.defaultdict(int)
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            for f in glob.glob(os.path.join(d, c, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] != c:
+                        continue
+                    for k in STEP_KERNELS:
+                        if k in r["Kernel_Name"]:
+                            tot[(k, c)] += float(r["Counter_Value"]); n[(k, c)] += 1
+        if tot and ent.get("steps_total"):
+            st = ent["steps_total"]
+            fetch = sum(v for (k, c), v in tot.items() if c == "FETCH_SIZE") * 1024.0 / st
+            write = sum(v for (k, c), v in tot.items() if c == "WRITE_SIZE") * 1024.0 / st
+            ent["fetch_bytes_per_step_raw"] = fetch; ent["write_bytes_per_step"] = write
+            ent["traffic_bytes_per_step"] = 2.0 * fetch + write
+            ent["traffic_bytes_per_step_uncorrected"] = fetch + write
+            ent["per_kernel_KB_per_launch"] = {"%s.%s" % k: tot[k] / max(n[k], 1) for k in tot}
+            ent["launches"] = {"%s.%s" % k: n[k] for k in n}
+        runs["%s@%s" % (w, a)] = ent
+    out = {"source_sha": bench.source_sha(), "recorded": time.strftime("%Y-%m-%d") + " " + tag,
+           "collection": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python3 bench.py --workload W --arenas A ...` "
+                         "(scripts/profile_round.sh); bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the step kernels / steps",
+           "runs": runs}
+    json.dump(out, open(os.path.join(dst, "%s_pmc_traffic.json" % tag), "w"), indent=1)
+    for k, e in runs.items():
+        print(k, {x: e.get(x) for x in ("traffic_bytes_per_step", "requested_bytes_per_step", "kernel_stats")})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Records the round's profiles on the GPU box (run through gpurun):  scripts/profile_round.sh <tag> [runs...]
+# For every run "WORKLOAD:ARENAS:STEPS" three rocprofv3 passes over the SAME command (python3 bench.py ..., the program
+# directly after `--`): --kernel-trace --stats, then --pmc FETCH_SIZE and --pmc WRITE_SIZE on their own (they do not fit one
+# pass on gfx950; counters only, no tracing domains).  scripts/collect_profiles.py turns the output into
+# gpurun_out/profiles_<tag>/ : <tag>_<run>_kernel_stats.csv, <tag>_<run>_bench.json and <tag>_pmc_traffic.json -- copy
+# those into profiles/ and commit them.
+set -u
+TAG=${1:-r02}; shift
+RUNS=${@:-"C2:4096:400 C2:65536:200 C2:262144:100 C3m6:4096:200 C5:4096:100 C1:4096:200"}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for run in $RUNS; do
+  IFS=: read W A S <<< "$run"
+  ARGS="--workload $W --arenas $A --steps $S --warmup 40 --no-cpu-baseline --no-large"
+  name=${W}_${A}
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name/kt -o p -- python3 $ROOT/bench.py $ARGS > $OUT/$name.bench.json 2> $OUT/$name.kt.err
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --pmc $c --output-format csv -d $OUT/$name/$c -o p -- python3 $ROOT/bench.py $ARGS > $OUT/$name.$c.json 2> $OUT/$name.$c.err
+  done
+done
+python3 $ROOT/scripts/collect_profiles.py $TAG

@@ -93,6 +93,36 @@ def _worker(rank, world, port, q):
                 for j in range(last % BLK + 1):
                     ok = ok and bool((got[r, j, :, 0] == float(1000 * r + first + j)).all())
     gb.wait_all()
+    # bench.py --gather step: one collective per step straight from the ring slot the step wrote, parity-buffered
+    gs = agdist.ResultGatherer(A, torch.device("cpu"), depth=2)
+    for step in range(7):
+        slot = step % SLOTS
+        gs.wait_slot(slot & 1)
+        ring[slot, :, 0] = float(5000 * rank + step); ring[slot, :, 1] = float(step & 1)
+        gs.gather_packed(slot & 1, ring[slot])
+        gs.wait_slot(slot & 1)
+        if rank == 0:
+            got = gs.gathered(slot & 1).reshape(world, A, 2)
+            for r in range(world):
+                ok = ok and bool((got[r, :, 0] == float(5000 * r + step)).all()) and bool((got[r, :, 1] == float(step & 1)).all())
+    # bench.py --gather-obs screen: every step's uint8 frames, one collective in flight
+    tg = agdist.TensorGatherer((A, 6, 6, 3), torch.uint8, torch.device("cpu"))
+    frames = torch.zeros((A, 6, 6, 3), dtype=torch.uint8)
+    for step in range(4):
+        tg.wait()
+        frames[:] = 10 * rank + step
+        tg.gather(frames)
+        tg.wait()
+        if rank == 0:
+            got = tg.gathered().reshape(world, A, 6, 6, 3)
+            for r in range(world):
+                ok = ok and bool((got[r] == 10 * r + step).all())
+    # unequal shards are refused at construction (dist.gather needs equal contributions)
+    try:
+        agdist.ResultGatherer(3 + rank, torch.device("cpu"))
+        ok = False
+    except ValueError:
+        pass
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
