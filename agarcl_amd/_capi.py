@@ -65,6 +65,7 @@ SYMBOLS = [
     ("agarcl_get_events", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     ("agarcl_grid_obs", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     ("agarcl_screen_obs", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    ("agarcl_gobigger_obs", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     ("agarcl_dump_arena", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     ("agarcl_load_arena", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     ("agarcl_adopt_arena", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
@@ -262,6 +263,20 @@ class BatchedEngine:
             return None
         out = np.zeros((self.num_arenas, self.num_agents, height, width, 4 if agent_view else 3), dtype=np.uint8)
         self._chk(self.L.agarcl_screen_obs(self.h, width, height, int(bool(agent_view)), _ptr(out), 0))
+        return out
+
+    def gobigger_obs(self, grid_size=128, cap_food=256, cap_virus=64, cap_spore=64, cap_clone=32, out_ptrs=None):
+        """GoBigger observation as padded tensors (include/agarcl_batch.h agarcl_gobigger_obs): dict of host arrays hdr i32
+        [A, P, 8], food / virus / spore f32 [A, P, cap, 4], clone f32 [A, P, cap_clone, 7]; or, with out_ptrs = (hdr, food,
+        virus, spore, clone) raw HBM pointers, written there."""
+        if out_ptrs is not None:
+            self._chk(self.L.agarcl_gobigger_obs(self.h, grid_size, cap_food, cap_virus, cap_spore, cap_clone, *[C.c_void_p(int(p)) for p in out_ptrs], 1))
+            return None
+        A, P = self.num_arenas, self.players
+        out = {"hdr": np.zeros((A, P, 8), np.int32), "food": np.zeros((A, P, cap_food, 4), np.float32), "virus": np.zeros((A, P, cap_virus, 4), np.float32),
+               "spore": np.zeros((A, P, cap_spore, 4), np.float32), "clone": np.zeros((A, P, cap_clone, 7), np.float32)}
+        self._chk(self.L.agarcl_gobigger_obs(self.h, grid_size, cap_food, cap_virus, cap_spore, cap_clone, _ptr(out["hdr"]), _ptr(out["food"]),
+                                             _ptr(out["virus"]), _ptr(out["spore"]), _ptr(out["clone"]), 0))
         return out
 
     def device_ptrs(self):

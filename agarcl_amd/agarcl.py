@@ -89,11 +89,16 @@ class GridEnvironment(_Environment):
         super().__init__(num_agents, ticks_per_step, arena_size, pellet_regen, num_pellets, num_viruses, num_bots,
                          reward_type, 0, mode_number)
         self._obs_cfg = None
+        self._ticks_per_step = int(ticks_per_step)
 
     def configure_observation(self, config):  # bindings.cpp:104-114
         self._obs_cfg = dict(num_frames=int(config.get("num_frames", 1)), grid_size=int(config.get("grid_size", 128)),
                              observe_cells=bool(config.get("observe_cells", True)), observe_others=bool(config.get("observe_others", True)),
-                             observe_viruses=bool(config.get("observe_viruses", True)), observe_pellets=bool(config.get("observe_pellets", True)))
+                             observe_viruses=bool(config.get("observe_viruses", True)), observe_pellets=bool(config.get("observe_pellets", True)),
+                             # extra key (the reference ignores unknown keys): put the frame exactly where the reference's arithmetic does
+                             literal_frame_index=bool(config.get("literal_frame_index", False)))
+        if self._obs_cfg["num_frames"] < 1:
+            raise RuntimeError("num_frames must be positive")
 
     def _channels(self):
         c = self._obs_cfg
@@ -110,7 +115,20 @@ class GridEnvironment(_Environment):
             raise RuntimeError("GridObservation was not configured.")
         c = self._obs_cfg
         obs = self._engine.grid_obs(c["grid_size"], c["observe_cells"], c["observe_others"], c["observe_viruses"], c["observe_pellets"])
-        return [obs[0, i].copy() for i in range(self._num_agents)]
+        # The observation holds num_frames frame slots, cleared at every step (GridEnvironment.hpp:91-123,405-410).  The reference
+        # calls _partial_observation(agent, tick_index = 0) once per step and stores the frame at frame_index =
+        # 0 - (ticks_per_step - num_frames) if that is >= 0 (:417-431): with the default arguments (1 frame, 4 ticks) NO frame is
+        # ever stored and the observation is all zeros.  Default here = the evident intent: the state after the step in the LAST
+        # slot; literal_frame_index=True reproduces the reference's output exactly.
+        nf, C = c["num_frames"], obs.shape[2]
+        slot = nf - self._ticks_per_step if c["literal_frame_index"] else nf - 1
+        out = []
+        for i in range(self._num_agents):
+            a = np.zeros((nf * C,) + obs.shape[3:], dtype=np.int32)
+            if 0 <= slot < nf:
+                a[slot * C:(slot + 1) * C] = obs[0, i]
+            out.append(a)
+        return out
 
 
 class ScreenEnvironment(_Environment):
@@ -157,10 +175,11 @@ class GoBiggerEnvironment(_Environment):
         self._grid_size = int(config.get("grid_size", 128))
 
     def _observe(self):                       # _partial_observation per agent -> GoBiggerObservation::add_frame (:519-541, 618-636)
-        blob = self._engine.dump(0)
-        for _ in range(self._num_agents):
-            self._gb.add_frame(self._states, blob, self._grid_size)
-            self._no_frames += 1
+        # one kernel launch lists every player's entities (padded tensors); the reference calls add_frame once per agent,
+        # each call refreshing ALL players from the same state, so one refresh is equivalent
+        tensors = self._engine.gobigger_obs(self._grid_size)
+        self._gb.add_frame(self._states, tensors, 0)
+        self._no_frames += self._num_agents
         self._global.update_last_frame_count(0)
 
     def reset(self):

@@ -43,8 +43,29 @@ def build(force=False, verbose=False, extra=(), out=OUT):
     return OUT
 
 
+def pybind_out():
+    import sysconfig
+    return os.path.join(HERE, "..", "agarcl" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_pybind(force=False):
+    """g++ -> <repo>/agarcl.<abi>.so: the reference's pybind11 module name (`import agarcl`) over the C ABI of libagarcl_hip.so
+    (csrc/agarcl_pybind.cpp: host-only, links the HIP library, rpath $ORIGIN/agarcl_amd)."""
+    import sysconfig
+    import pybind11
+    src, out = os.path.join(HERE, "csrc", "agarcl_pybind.cpp"), os.path.abspath(pybind_out())
+    if not force and os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(src), os.path.getmtime(os.path.join(HERE, "..", "include", "agarcl_batch.h"))):
+        return out
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"],
+           src, "-o", out, "-L" + HERE, "-l:libagarcl_hip.so", "-Wl,-rpath,$ORIGIN/agarcl_amd"]
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     if "--profile" in sys.argv:
         print(build(True, "-v" in sys.argv, ["-DAGAR_PROFILE"], os.path.join(HERE, "libagarcl_hip_prof.so")))
+    elif "--pybind" in sys.argv:
+        print(build_pybind(True))
     else:
         print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

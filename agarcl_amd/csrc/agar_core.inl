@@ -36,6 +36,7 @@ AG_DEV void ag_lds_order() {}
 AG_DEV float ag_sqrtf(float x) { return sqrtf(x); }
 AG_DEV float ag_divf(float a, float b) { return a / b; }
 AG_DEV void ag_atomic_or(int32_t *p, int v) { *p |= v; }
+AG_DEV bool ag_any(bool p) { return p; }
 #else
 #define AG_DEV __device__ __forceinline__
 // lane within the wavefront (kernels may pack several wavefronts = several arenas into one workgroup)
@@ -56,6 +57,7 @@ AG_DEV void ag_lds_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront
 AG_DEV float ag_sqrtf(float x) { return __builtin_sqrtf(x); }
 AG_DEV float ag_divf(float a, float b) { return a / b; }
 AG_DEV void ag_atomic_or(int32_t *p, int v) { atomicOr(p, v); }
+AG_DEV bool ag_any(bool p) { return __ballot(p) != 0ull; }   // does any ACTIVE lane of the wave want it?
 #endif
 
 #include "agar_libm.inl"
@@ -693,32 +695,57 @@ AG_DEV void prevent_overlap(CellR &A, CellR &B, float dt, float tx, float ty, fl
 }
 // R: Engine.hpp:763-794.  The reference makes up to 5 sweeps over the pairs (a,b), a<b, in lexicographic order
 // (prevent_overlap on touching pairs; stop after a sweep in which nothing touched) and, if the 5th still found an
-// overlap, a 6th sweep of avoid_static_overlap.  Every visit touches only cells a and b.  Two visits commute unless
-// they share a cell, and every earlier visit sharing a cell with (a,b) has a smaller a+b; so all pairs with equal
-// a+b are independent and a sweep runs as 2n-3 "anti-diagonal" levels, one pair per lane -- same result as the
-// sequential sweep.  (Overlapping consecutive sweeps, n levels apart, is also valid and was measured: fewer, fatter
-// steps, but slower on this kernel.)
+// overlap, a 6th sweep of avoid_static_overlap.  Every visit touches only cells a and b, so two visits commute unless
+// they share a cell.
+// Schedule: visit (s, a, b) of sweep s runs at level  t = s * D + a + b,  D = min(n, 2n - 3), one pair per lane.  Any two
+// visits that share a cell keep the reference's order (pairs of one sweep with equal a + b share no cell and every earlier
+// pair sharing a cell has a smaller a + b; across sweeps, cell a's last visit of sweep s is (a, n-1) at s D + a + n - 1 <
+// (s + 1) D + a + b; tests/test_sweep_schedule.py checks all of it exhaustively), so the result equals the sequential
+// loops'.  Consecutive sweeps overlap: 5 D + 2n - 3 levels instead of 6 (2n - 3) -- 74 instead of 114 at n = 11 -- and a
+// level never holds more than n / 2 pairs.  A sweep started before its predecessor is known to have found an overlap is
+// harmless: if the predecessor finds none, no cell has moved and every later visit is a no-op (both prevent_overlap and
+// avoid_static_overlap act on touching pairs only); the loop still ends at the first completed sweep without a hit.
 template <int NS, bool AV> AG_DEV void self_collisions(AgCtx<NS, AV> &c, const Cells &s, int n, float tx, float ty) {
   // (move_player has just refreshed every cell's radius cache, so s.crad[] is valid for all n cells)
   // wave-parallel any-touch test; when no pair touches the reference's first sweep is a no-op
   bool any = wave_any(n * n, [&](int k) { int a = k / n, b = k - a * n; return a < b && touches(s.x[a], s.y[a], s.crad[a], s.x[b], s.y[b], s.crad[b]); });
   if (!any) return;
   const float dt = c.gs->g.dt, W = c.gs->g.W;
-  for (int iter = 0; iter < 6; iter++) {  // sweeps 0-4: prevent_overlap; sweep 5: avoid_static_overlap
-    bool overlap = false;
-    for (int L = 1; L <= 2 * n - 3; L++) {
-      const int a0 = L - (n - 1) > 0 ? L - (n - 1) : 0, a1 = (L - 1) / 2;  // a < b = L - a  <=>  a <= (L-1)/2
-      overlap = wave_any(a1 - a0 + 1, [&](int j) {
-        const int a = a0 + j, b = L - a;
-        CellR A = cellr_load(s, a), B = cellr_load(s, b);
-        if (!touches(A.x, A.y, A.r, B.x, B.y, B.r)) return false;
-        if (iter < 5) prevent_overlap(A, B, dt, tx, ty, W); else avoid_static_overlap(A, B, W);
-        cellr_store(s, a, A); cellr_store(s, b, B);
-        return true;
-      }) || overlap;
-      ag_lds_order();
-    }
-    if (!overlap) break;
+  const int LL = 2 * n - 3, D = n < LL ? n : LL, total = 5 * D + LL;
+  bool hit_even = false, hit_odd = false;   // "a pair touched" of the (at most two, consecutive) sweeps in flight, by sweep parity
+  int sN = 0, LN = 0;                       // newest sweep that has started and its local level (a + b)
+  for (int lev = 1; lev <= total; lev++) {
+    LN++;
+    if (sN < 5 && LN > D) { sN++; LN -= D; if (sN & 1) hit_odd = false; else hit_even = false; }
+    const int sO = sN - 1, LO = LN + D;
+    const bool validO = sO >= 0 && LO <= LL, validN = LN <= LL;
+    // pairs of a local level L: a = a0 .. (L - 1) / 2, b = L - a
+    const int a0O = LO - (n - 1) > 0 ? LO - (n - 1) : 0, wO = validO ? (LO - 1) / 2 - a0O + 1 : 0;
+    const int a0N = LN - (n - 1) > 0 ? LN - (n - 1) : 0, wN = validN ? (LN - 1) / 2 - a0N + 1 : 0;
+    // lane j: a pair of the older sweep first, then of the newer one; only x, y, r are read before the pair is known to touch
+    auto visit = [&](int j, int &sw) -> bool {
+      int a, b;
+      if (j < wO) { a = a0O + j; b = LO - a; sw = sO; } else { a = a0N + (j - wO); b = LN - a; sw = sN; }
+      CellR A, B;
+      A.x = s.x[a]; A.y = s.y[a]; A.r = s.crad[a]; B.x = s.x[b]; B.y = s.y[b]; B.r = s.crad[b];
+      if (!touches(A.x, A.y, A.r, B.x, B.y, B.r)) return false;
+      A.vx = s.vx[a]; A.vy = s.vy[a]; A.sx = s.sx[a]; A.sy = s.sy[a]; A.m = s.m[a];
+      B.vx = s.vx[b]; B.vy = s.vy[b]; B.sx = s.sx[b]; B.sy = s.sy[b]; B.m = s.m[b];
+      if (sw < 5) prevent_overlap(A, B, dt, tx, ty, W); else avoid_static_overlap(A, B, W);
+      cellr_store(s, a, A); cellr_store(s, b, B);
+      return true;
+    };
+    bool he = false, ho = false;
+#ifdef AGAR_CPU_EMU
+    for (int j = 0; j < wO + wN; j++) { int sw = 0; if (visit(j, sw)) { if (sw & 1) ho = true; else he = true; } }
+#else
+    { const int j = AG_LANE; int sw = 0; bool h = false; if (j < wO + wN) h = visit(j, sw); he = __ballot(h && !(sw & 1)) != 0ull; ho = __ballot(h && (sw & 1)) != 0ull; }
+#endif
+    hit_even = hit_even || he; hit_odd = hit_odd || ho;
+    ag_lds_order();
+    // a sweep that has completed without a single touching pair ends the relaxation
+    if (validO && LO == LL && !((sO & 1) ? hit_odd : hit_even)) break;
+    if (validN && LN == LL && !((sN & 1) ? hit_odd : hit_even)) break;
   }
 }
 // Kinematics of ONE cell for one tick (Engine::move_player's loop body, Engine.hpp:616-626).  Shared by the

@@ -24,6 +24,7 @@
 #include "agar_quiet.inl"
 #include "agar_obs.inl"
 #include "agar_screen.inl"
+#include "agar_gobigger.inl"
 
 // ---- thread-local error string -------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -850,6 +851,43 @@ __global__ void __launch_bounds__(256) k_grid_zero(int32_t *out, size_t frames, 
   for (unsigned off = slice * blockDim.x + threadIdx.x; off < per; off += 8u * blockDim.x) __builtin_nontemporal_store(z, &o4[off]);
 }
 #endif
+
+#ifndef AGAR_CPU_EMU
+__global__ void __launch_bounds__(64) k_gobigger_obs(const AgState *__restrict__ gs, AgGbCfg o, int32_t *hdr, float *food, float *virus, float *spore, float *clone) {
+  const int P = gs->d.P, b = (int)blockIdx.x;
+  gobigger_player(gs, b / P, b % P, o, hdr, food, virus, spore, clone);
+}
+#endif
+extern "C" int agarcl_gobigger_obs(agarcl_env *e, int32_t grid_size, int32_t cap_food, int32_t cap_virus, int32_t cap_spore, int32_t cap_clone,
+                                   int32_t *hdr, float *food, float *virus, float *spore, float *clone, int32_t on_device) {
+  if (!e || !hdr || !food || !virus || !spore || !clone) return fail(AGARCL_E_INVALID, "agarcl_gobigger_obs: null pointer");
+  if (grid_size < 1 || cap_food < 1 || cap_virus < 1 || cap_spore < 1 || cap_clone < 1) return fail(AGARCL_E_INVALID, "agarcl_gobigger_obs: grid size and capacities must be positive");
+  AgGbCfg o; o.G = grid_size; o.KF = cap_food; o.KV = cap_virus; o.KS = cap_spore; o.KC = cap_clone;
+  const size_t rows = (size_t)e->d.A * e->d.P;
+#ifdef AGAR_CPU_EMU
+  (void)on_device;
+  for (size_t b = 0; b < rows; b++) gobigger_player(&e->s, (int)(b / e->d.P), (int)(b % e->d.P), o, hdr, food, virus, spore, clone);
+  return AGARCL_OK;
+#else
+  HIPCHK(hipSetDevice(e->device));
+  const size_t nb[5] = {rows * 8 * 4, rows * o.KF * 16, rows * o.KV * 16, rows * o.KS * 16, rows * o.KC * 28};
+  void *host[5] = {hdr, food, virus, spore, clone}, *dev[5] = {hdr, food, virus, spore, clone};
+  if (!on_device) {  // one staging block for the five tensors
+    size_t words = 0; for (int i = 0; i < 5; i++) words += (nb[i] + 15) / 16 * 4;
+    if (e->obs_cap < words) {
+      if (e->obs_buf) { HIPCHK(hipStreamSynchronize(e->stream)); (void)hipFree(e->obs_buf); e->obs_buf = nullptr; e->obs_cap = 0; }
+      if (hipMalloc((void **)&e->obs_buf, words * 4) != hipSuccess) return fail(AGARCL_E_NOMEM, "agarcl_gobigger_obs: staging allocation failed");
+      e->obs_cap = words;
+    }
+    unsigned char *q = (unsigned char *)e->obs_buf;
+    for (int i = 0; i < 5; i++) { dev[i] = q; q += (nb[i] + 15) / 16 * 16; }
+  }
+  hipLaunchKernelGGL(k_gobigger_obs, dim3((unsigned)rows), dim3(64), 0, e->stream, e->d_state, o, (int32_t *)dev[0], (float *)dev[1], (float *)dev[2], (float *)dev[3], (float *)dev[4]);
+  HIPCHK(hipGetLastError());
+  if (!on_device) for (int i = 0; i < 5; i++) if (d2h(host[i], dev[i], nb[i], e->stream)) return fail(AGARCL_E_HIP, "agarcl_gobigger_obs: copy failed");
+  return AGARCL_OK;
+#endif
+}
 
 extern "C" int agarcl_screen_obs(agarcl_env *e, int32_t width, int32_t height, int32_t agent_view, uint8_t *out, int32_t on_device) {
   if (!e || !out) return fail(AGARCL_E_INVALID, "agarcl_screen_obs: null pointer");

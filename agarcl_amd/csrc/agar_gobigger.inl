@@ -1,0 +1,79 @@
+// GoBigger-style structured observation as padded tensors.
+// Reference: GoBiggerObservation::add_frame / _store_entities / _world_to_grid
+// (/root/reference/environment/envs/GoBiggerEnvironment.hpp:419-541): for EVERY player of the arena (in the players map's
+// iteration order) the viruses, pellets ("food"), ejected foods ("spores") and the player's own cells ("clones") that fall
+// inside that player's egocentric grid are listed, in container order, with positions relative to the player's centre.
+// The reference keeps ragged lists of small structs; here one wavefront per (arena, player) writes fixed-capacity rows
+// (ordered stream compaction: ballot + prefix popcount keeps container order), zero padded, plus a header with the true
+// counts -- directly consumable by a batched learner; the reference's Python object view is derived from these rows on
+// the host (agarcl_amd/gobigger.py).
+//
+//   hdr   i32 [A][P][8]      pid, committed, n_virus, n_food, n_spore, n_clone, score (= the player's total mass), player slot
+//   virus f32 [A][P][KV][4]  x - px, y - py, radius, mass
+//   food  f32 [A][P][KF][4]  x - px, y - py, radius, mass (= 1)
+//   spore f32 [A][P][KS][4]  x - px, y - py, radius, mass (= 10)        (velocity is (0,0) and owner = pid in the reference)
+//   clone f32 [A][P][KC][7]  x - px, y - py, radius, mass, vx, vy, Velocity::direction()
+// Row k of the P axis is the k-th player in map iteration order.  "committed" mirrors the reference's commit rule: a
+// player's state is replaced only when at least one entity lies inside its grid (:501-504), e.g. never for a dead player
+// (its centre is 0/0 = NaN).  Counts are the true numbers; rows beyond a capacity are dropped.
+// Parity: restated from the reference's source, UNPINNED (GoBiggerEnvironment.hpp does not compile without OpenGL
+// stand-ins); compared on the GPU with the host restatement oracle/gobigger_oracle.py.
+#pragma once
+
+struct AgGbCfg { int G, KF, KV, KS, KC; };
+
+template <class SinkT> AG_DEV int gb_compact(int n, float px, float py, float view, float centering, int G, int cap, SinkT row,
+                                            const AG_GLOBAL float *ex, const AG_GLOBAL float *ey, int stride) {
+  return wave_compact(n, [&](int i) {
+    float ddx = ex[(size_t)i * stride] - px, ddy = ey[(size_t)i * stride] - py;
+    float t1 = (float)G * ddx; t1 = ag_divf(t1, view); int gx = f2i(t1 + centering);
+    float t2 = (float)G * ddy; t2 = ag_divf(t2, view); int gy = f2i(t2 + centering);
+    return 0 <= gx && gx < G && 0 <= gy && gy < G;
+  }, [&](int i, int rank) { if (rank < cap) row(i, rank); });
+}
+
+// one wavefront: player `k` (map iteration order) of `arena`
+AG_DEV void gobigger_player(const AgState *gs, int arena, int k, AgGbCfg o, int32_t *hdr_, float *food_, float *virus_, float *spore_, float *clone_) {
+  const int P = gs->d.P;
+  const AG_GLOBAL int32_t *ar = (const AG_GLOBAL int32_t *)(gs->ar + (size_t)arena * AR_WORDS);
+  const int p = ar[AR_ORDER0 + k];
+  const AG_GLOBAL int32_t *pl = (const AG_GLOBAL int32_t *)(gs->pl + ((size_t)arena * P + p) * PL_WORDS);
+  const AG_GLOBAL uint32_t *C = (const AG_GLOBAL uint32_t *)(gs->cells + ((size_t)arena * P + p) * (CF_ALL * AG_CC));
+  const AG_GLOBAL float *lut_r = (const AG_GLOBAL float *)gs->lut_r;
+  const size_t row = (size_t)arena * P + k;
+  AG_GLOBAL int32_t *hdr = (AG_GLOBAL int32_t *)hdr_ + row * 8;
+  AG_GLOBAL float *food = (AG_GLOBAL float *)food_ + row * o.KF * 4, *virus = (AG_GLOBAL float *)virus_ + row * o.KV * 4;
+  AG_GLOBAL float *spore = (AG_GLOBAL float *)spore_ + row * o.KS * 4, *clone = (AG_GLOBAL float *)clone_ + row * o.KC * 7;
+  // Player::x / y / mass (core/Player.hpp:102-126): sequential fp32 sums in cell order
+  const int n = pl[PL_NCELLS]; float sx = 0.0f, sy = 0.0f; unsigned tm = 0;
+  for (int i = 0; i < n; i++) { unsigned m = C[AG_CELL_W(CF_M, i)]; float fm = (float)m; float t = u2f((int)C[AG_CELL_W(CF_X, i)]) * fm; sx += t; t = u2f((int)C[AG_CELL_W(CF_Y, i)]) * fm; sy += t; tm += m; }
+  const float px = ag_divf(sx, (float)tm), py = ag_divf(sy, (float)tm);
+  const float view = smaxf(sminf((float)(2u * tm), 300.0f), 100.0f);   // clamp<float>(2 * mass, 100, 300), :424-426
+  const float centering = (float)o.G / 2.0f;
+  const int np = ar[AR_NPEL], nv = ar[AR_NVIR], nf = ar[AR_NFOOD];
+  // zero padding first (rows are rewritten below)
+  AG_LANES(i, o.KF * 4) food[i] = 0.0f;
+  AG_LANES(i, o.KV * 4) virus[i] = 0.0f;
+  AG_LANES(i, o.KS * 4) spore[i] = 0.0f;
+  AG_LANES(i, o.KC * 7) clone[i] = 0.0f;
+  ag_mem_fence();
+  const AG_GLOBAL float *vx = (const AG_GLOBAL float *)(gs->vir_x + (size_t)arena * gs->d.VC), *vy = (const AG_GLOBAL float *)(gs->vir_y + (size_t)arena * gs->d.VC);
+  const AG_GLOBAL int32_t *vm = (const AG_GLOBAL int32_t *)(gs->vir_mass + (size_t)arena * gs->d.VC);
+  const int cv = gb_compact(nv, px, py, view, centering, o.G, o.KV, [&](int i, int r) {
+    unsigned m = (unsigned)vm[i]; virus[4 * r] = vx[i] - px; virus[4 * r + 1] = vy[i] - py; virus[4 * r + 2] = lut(lut_r, m); virus[4 * r + 3] = (float)m; }, vx, vy, 1);
+  const AG_GLOBAL float *pxy = (const AG_GLOBAL float *)(gs->pel_xy + (size_t)arena * gs->d.PC * 2);
+  const float r1 = lut(lut_r, AG_PELLET_MASS), r10 = lut(lut_r, AG_FOOD_MASS);
+  const int cf = gb_compact(np, px, py, view, centering, o.G, o.KF, [&](int i, int r) {
+    food[4 * r] = pxy[2 * i] - px; food[4 * r + 1] = pxy[2 * i + 1] - py; food[4 * r + 2] = r1; food[4 * r + 3] = (float)AG_PELLET_MASS; }, pxy, pxy + 1, 2);
+  const AG_GLOBAL float *fx = (const AG_GLOBAL float *)(gs->food_x + (size_t)arena * gs->d.FC), *fy = (const AG_GLOBAL float *)(gs->food_y + (size_t)arena * gs->d.FC);
+  const int cs = gb_compact(nf, px, py, view, centering, o.G, o.KS, [&](int i, int r) {
+    spore[4 * r] = fx[i] - px; spore[4 * r + 1] = fy[i] - py; spore[4 * r + 2] = r10; spore[4 * r + 3] = (float)AG_FOOD_MASS; }, fx, fy, 1);
+  const AG_GLOBAL float *cx = (const AG_GLOBAL float *)C + CF_X, *cy = (const AG_GLOBAL float *)C + CF_Y;
+  const int cc = gb_compact(n, px, py, view, centering, o.G, o.KC, [&](int i, int r) {
+    unsigned m = C[AG_CELL_W(CF_M, i)]; float cvx = u2f((int)C[AG_CELL_W(CF_VX, i)]), cvy = u2f((int)C[AG_CELL_W(CF_VY, i)]);
+    clone[7 * r] = cx[(size_t)i * CF_ALL] - px; clone[7 * r + 1] = cy[(size_t)i * CF_ALL] - py; clone[7 * r + 2] = lut(lut_r, m); clone[7 * r + 3] = (float)m;
+    clone[7 * r + 4] = cvx; clone[7 * r + 5] = cvy; clone[7 * r + 6] = v_direction(cvx, cvy); }, cx, cy, CF_ALL);
+  AG_SERIAL {
+    hdr[0] = pl[PL_PID]; hdr[1] = (cv + cf + cs + cc) > 0 ? 1 : 0; hdr[2] = cv; hdr[3] = cf; hdr[4] = cs; hdr[5] = cc; hdr[6] = (int32_t)tm; hdr[7] = p;
+  }
+}

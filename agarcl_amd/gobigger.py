@@ -2,13 +2,11 @@
 GoBiggerObservation (/root/reference/environment/envs/GoBiggerEnvironment.hpp:30-548) with the value classes pybind11
 exposes (/root/reference/environment/bindings.cpp:184-318), built on the host from one arena's state.
 
-The observation is a ragged dictionary of Python objects -- host data by nature -- so it is derived from the arena's
-state blob (agarcl_dump_arena) rather than by a kernel; a padded-tensor form for batched training is not provided.
+The entity lists are produced on the GPU as padded tensors (agarcl_gobigger_obs, csrc/agar_gobigger.inl: what a batched learner
+consumes); this module turns one arena's rows into the reference's ragged Python objects.
 Parity: restated from the reference's source, UNPINNED (GoBiggerEnvironment.hpp does not compile without OpenGL
 stand-ins: its constructor initialises a FrameBufferObject, :582)."""
 import numpy as np
-
-from . import snapshot
 
 _f = np.float32
 
@@ -132,56 +130,20 @@ class PlayerStates:                  # :216-259, bindings.cpp:275-296
         return out
 
 
-def _radius(mass):                   # core/utils.hpp:8-11: (distance) sqrt(mass / 1.0 / pi) in double, then float
-    return float(_f(np.sqrt(np.float64(mass) / 1.0 / np.pi)))
-
-
-def _direction(dx, dy):              # Velocity::direction, core/types.hpp:167-174 (atan(dx/dy), not atan2)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        ang = np.arctan(_f(dx) / _f(dy), dtype=np.float32)
-    if dx < 0:
-        ang = _f(np.float64(ang) + np.pi) if dy > 0 else _f(np.float64(ang) - np.pi)
-    return float(ang)
-
-
-def add_frame(player_states, blob_words, grid_size=128):
-    """GoBiggerObservation::add_frame (:519-541): refresh the entity lists of EVERY player in the map, in the map's
-    iteration order; an entity is listed when it falls inside the player's egocentric grid (:446-514)."""
-    d = snapshot.parse_blob(blob_words)
-    G = int(grid_size)
-    centering = _f(G) / _f(2)
-
-    def f2i(v):  # static_cast<int>(float) on x86-64
-        return int(v) if np.isfinite(v) and -2147483904.0 < v < 2147483648.0 else -2147483648
-
-    for pl in d["players"]:
-        cells = pl["cells"]
-        sx = _f(0); sy = _f(0); tm = 0
-        for c in cells:              # Player::x/y/mass (core/Player.hpp:102-126)
-            m = int(c[6]); x = np.array([c[0]], np.uint32).view(np.float32)[0]; y = np.array([c[1]], np.uint32).view(np.float32)[0]
-            sx = _f(sx + _f(x * _f(m))); sy = _f(sy + _f(y * _f(m))); tm += m
-        with np.errstate(divide="ignore", invalid="ignore"):
-            px, py = _f(sx / _f(tm)), _f(sy / _f(tm))
-        view = _f(min(max(_f(2 * tm), _f(100)), _f(300)))   # clamp<float>(2 * mass, 100, 300), :424-426
-
-        def inside(ex, ey):
-            gx = f2i(_f(_f(_f(G) * _f(_f(ex) - px)) / view) + centering); gy = f2i(_f(_f(_f(G) * _f(_f(ey) - py)) / view) + centering)
-            return 0 <= gx < G and 0 <= gy < G
-
-        ps = player_states.get_player_state(pl["pid"])
-        ps._food, ps._virus, ps._spore, ps._clone = [], [], [], []
-        rel = lambda ex, ey: Location(_f(_f(ex) - px), _f(_f(ey) - py))
-        for x, y, m in zip(d["viruses"]["x"], d["viruses"]["y"], d["viruses"]["mass"]):
-            if inside(x, y):
-                ps._virus.append(VirusInfo(rel(x, y), _radius(int(m)), int(m), (0.0, 0.0))); ps._score = float(tm)
-        for x, y in zip(d["pellets"]["x"], d["pellets"]["y"]):
-            if inside(x, y):
-                ps._food.append(FoodInfo(rel(x, y), _radius(1), 1)); ps._score = float(tm)
-        for x, y in zip(d["foods"]["x"], d["foods"]["y"]):
-            if inside(x, y):
-                ps._spore.append(SporeInfo(rel(x, y), _radius(10), 10, (0.0, 0.0), pl["pid"])); ps._score = float(tm)
-        for c in cells:
-            x, y, vx, vy = (np.array([c[k]], np.uint32).view(np.float32)[0] for k in range(4))
-            if inside(x, y):
-                ps._clone.append(CloneInfo(rel(x, y), _radius(int(c[6])), int(c[6]), (float(vx), float(vy)), _direction(vx, vy), pl["pid"], 0)); ps._score = float(tm)
+def add_frame(player_states, tensors, arena=0):
+    """GoBiggerObservation::add_frame (:519-541) for one arena from the tensors of BatchedEngine.gobigger_obs(): the entity
+    lists of every player whose row is marked committed are replaced (the reference commits a refreshed state only when at
+    least one entity lies inside the player's grid, :501-504); the others keep their previous state."""
+    hdr = tensors["hdr"][arena]
+    for k in range(hdr.shape[0]):
+        pid, committed, nv, nf, ns, nc, score = (int(v) for v in hdr[k, :7])
+        ps = player_states.get_player_state(pid)          # creates the "dummy" state on first use (:227-243)
+        if not committed:
+            continue
+        V, F, S, Cn = tensors["virus"][arena, k], tensors["food"][arena, k], tensors["spore"][arena, k], tensors["clone"][arena, k]
+        ps._virus = [VirusInfo(Location(r[0], r[1]), r[2], int(r[3]), (0.0, 0.0)) for r in V[:min(nv, len(V))]]
+        ps._food = [FoodInfo(Location(r[0], r[1]), r[2], int(r[3])) for r in F[:min(nf, len(F))]]
+        ps._spore = [SporeInfo(Location(r[0], r[1]), r[2], int(r[3]), (0.0, 0.0), pid) for r in S[:min(ns, len(S))]]
+        ps._clone = [CloneInfo(Location(r[0], r[1]), r[2], int(r[3]), (float(r[4]), float(r[5])), r[6], pid, 0) for r in Cn[:min(nc, len(Cn))]]
+        ps._score = float(score)
     return player_states

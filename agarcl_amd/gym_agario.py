@@ -9,7 +9,25 @@ Video recording (cv2) and OpenGL rendering are outside the hot path and not prov
 """
 import numpy as np
 
-from . import agarcl
+
+def _binding():
+    """The `agarcl` module this wrapper drives: the compiled pybind11 module over the C ABI (repo root, built by
+    agarcl_amd/build.py:build_pybind) when it is importable, else the ctypes mirror agarcl_amd/agarcl.py -- both are the same
+    HIP engine; AGARCL_BINDING=ctypes|pybind pins the choice."""
+    import os
+    want = os.environ.get("AGARCL_BINDING", "")
+    if want != "ctypes":
+        try:
+            import agarcl as compiled
+            return compiled
+        except ImportError:
+            if want == "pybind":
+                raise
+    from . import agarcl as mirror
+    return mirror
+
+
+agarcl = _binding()
 
 try:  # optional
     import gymnasium as _gym
@@ -39,9 +57,14 @@ class AgarioEnv(_Base):
         self.mode = kwargs.get("mode", 0)
         self.env_type = kwargs.get("env_type", 0)  # 0 episodic, 1 continuing
         self._seed = None
-        if _spaces is not None:
+        if _spaces is not None:   # AgarioEnv.py:226-268
             self.action_space = _spaces.Tuple((_spaces.Box(low=-1, high=1, shape=(2,)), _spaces.Discrete(3)))
-            self.observation_space = _spaces.Box(-1, np.iinfo(np.int32).max, self.observation_shape, dtype=np.int32)
+            if obs_type == "grid":
+                self.observation_space = _spaces.Box(-1, np.iinfo(np.int32).max, self.observation_shape, dtype=np.int32)
+            elif obs_type == "screen":
+                self.observation_space = _spaces.Box(low=0, high=255, shape=self.observation_shape, dtype=np.uint8)
+            else:
+                self.observation_space = _spaces.Box(low=0, high=255, shape=self.observation_shape, dtype=np.float32)
 
     # -- AgarioEnv.py:298-363 -------------------------------------------------------------------------
     def _get_env_args(self, kwargs):
@@ -65,14 +88,15 @@ class AgarioEnv(_Base):
         if type(self.ticks_per_step) is not int or self.ticks_per_step <= 0:
             raise ValueError("ticks_per_step must be a positive integer")
         return (self.num_agents, self.ticks_per_step, self.arena_size, self.pellet_regen, self.num_pellets,
-                self.num_viruses, self.num_bots, self.reward_type, self.c_death, self.mode)
+                self.num_viruses, self.num_bots, self.reward_type, self.c_death, self.mode, self.load_env_snapshot)
 
     def _make_environment(self, obs_type, kwargs):
-        args = self._get_env_args(kwargs)
+        base_args = self._get_env_args(kwargs)
         if obs_type == "grid":
-            env = agarcl.GridEnvironment(*args)
+            # (the reference passes an undefined name here, AgarioEnv.py:226; the evident intent is the ten constructor arguments)
+            env = agarcl.GridEnvironment(*base_args[:10])
             cfg = dict(num_frames=1, grid_size=128, observe_cells=True, observe_others=True, observe_viruses=True, observe_pellets=True)
-            cfg.update({k: kwargs[k] for k in cfg if k in kwargs})
+            cfg.update({k: kwargs[k] for k in list(cfg) + ["literal_frame_index"] if k in kwargs})
             env.configure_observation(cfg)
             channels, width, height = env.observation_shape()
             return env, (width, height, channels)
@@ -81,9 +105,13 @@ class AgarioEnv(_Base):
                 raise ValueError("agarcl was not compiled to include ScreenEnvironment")
             screen_len = kwargs.get("screen_len", 84)
             self.agent_view = kwargs.get("agent_view", False)
-            env = agarcl.ScreenEnvironment(*(args + (self.load_env_snapshot, screen_len, screen_len, self.agent_view)))
-            return env, env.observation_shape()
-        raise ValueError("obs_type %r is not provided by the HIP engine" % obs_type)
+            env = agarcl.ScreenEnvironment(*(base_args + (screen_len, screen_len, self.agent_view)))
+            return env, tuple(env.observation_shape())
+        if obs_type == "gobigger":           # AgarioEnv.py:251-264
+            full_args = (kwargs.get("map_width", 512), kwargs.get("map_height", 512), kwargs.get("frame_limit", 1000)) + base_args + (kwargs.get("agent_view", False),)
+            env = agarcl.GoBiggerEnvironment(*full_args)
+            return env, tuple(env.observation_shape())
+        raise ValueError("obs_type %r is not provided by the HIP engine (the reference rejects \"ram\" too, AgarioEnv.py:211)" % obs_type)
 
     # -- AgarioEnv.py:270-296 (validation; the reference samples noise and then discards it) --------------
     def _sanitize_actions(self, actions):
@@ -153,5 +181,8 @@ def register():
     if _gym is None:
         return False
     from gymnasium.envs.registration import register as _reg
-    _reg(id="agario-grid-v0", entry_point="agarcl_amd.gym_agario:AgarioEnv", kwargs={"obs_type": "grid"})
+    _reg(id="agario-grid-v0", entry_point="gym_agario.AgarioEnv:AgarioEnv", kwargs={"obs_type": "grid"})
+    if agarcl.has_screen_env:  # only register the screen environment if it is available
+        _reg(id="agario-screen-v0", entry_point="gym_agario.AgarioEnv:AgarioEnv", kwargs={"obs_type": "screen"})
+    _reg(id="agario-gobigger-v0", entry_point="gym_agario.AgarioEnv:AgarioEnv", kwargs={"obs_type": "gobigger"})
     return True

@@ -154,6 +154,21 @@ int agarcl_grid_obs(agarcl_env *env, int32_t grid_size, int32_t observe_cells, i
  * (ScreenEnvironment.hpp:48-88), u8[...][height][width][4].  `out` is an HBM pointer if on_device != 0, else a host buffer. */
 int agarcl_screen_obs(agarcl_env *env, int32_t width, int32_t height, int32_t agent_view, uint8_t *out, int32_t on_device);
 
+/* replaces: GoBiggerEnvironment::get_state() (bindings.cpp:28-47,353) -> GoBiggerObservation::add_frame
+ * (environment/envs/GoBiggerEnvironment.hpp:446-541), as padded tensors for EVERY player of every arena (row k of the
+ * player axis = the k-th player in the engine's map iteration order; P = agarcl_players_per_arena):
+ *   hdr   i32[num_arenas][P][8]          pid, committed, n_virus, n_food, n_spore, n_clone, score (total mass), player slot
+ *   food  f32[num_arenas][P][cap_food][4]   x - px, y - py, radius, mass      (pellets, in vector order)
+ *   virus f32[num_arenas][P][cap_virus][4]  x - px, y - py, radius, mass
+ *   spore f32[num_arenas][P][cap_spore][4]  x - px, y - py, radius, mass      (ejected foods; velocity (0,0), owner = pid)
+ *   clone f32[num_arenas][P][cap_clone][7]  x - px, y - py, radius, mass, vx, vy, direction   (the player's own cells)
+ * (px, py) = the player's mass-weighted centre.  An entity is listed iff it falls inside the player's egocentric grid of
+ * grid_size cells (view = clamp(2 * mass, 100, 300)); counts are the true numbers, rows beyond a capacity are dropped,
+ * unused rows are zero.  committed = 0: nothing was inside (e.g. a dead player) -- the reference then keeps that
+ * player's previous state.  Pointers are HBM pointers if on_device != 0, else host buffers. */
+int agarcl_gobigger_obs(agarcl_env *env, int32_t grid_size, int32_t cap_food, int32_t cap_virus, int32_t cap_spore, int32_t cap_clone,
+                        int32_t *hdr, float *food, float *virus, float *spore, float *clone, int32_t on_device);
+
 /* full-state exchange for parity tests and snapshots (layout: oracle/BLOB_FORMAT.md); synchronising */
 int agarcl_dump_arena(agarcl_env *env, int32_t arena, uint32_t *buf_host, int32_t cap_words);
 int agarcl_load_arena(agarcl_env *env, int32_t arena, const uint32_t *blob_host, int32_t words);

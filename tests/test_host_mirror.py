@@ -51,18 +51,123 @@ def _exercise(agarcl, gym_agario, oracle_lib):
 def test_host_mirror_cpu(emu_lib, oracle_lib, monkeypatch):
     from agarcl_amd import agarcl, gym_agario
     monkeypatch.setattr(agarcl, "_LIB", emu_lib)
+    monkeypatch.setattr(gym_agario, "agarcl", agarcl)      # (the wrapper would otherwise pick the compiled module: HIP only)
     _exercise(agarcl, gym_agario, oracle_lib)
 
 
 @pytest.mark.gpu
-def test_host_mirror_gpu(oracle_lib):
+def test_host_mirror_gpu(oracle_lib, monkeypatch):
+    """the ctypes mirror (agarcl_amd/agarcl.py) on the HIP library"""
     from agarcl_amd import agarcl, gym_agario
     assert agarcl._LIB is None
+    monkeypatch.setattr(gym_agario, "agarcl", agarcl)
     _exercise(agarcl, gym_agario, oracle_lib)
 
 
+@pytest.mark.gpu
+def test_compiled_agarcl_module_gpu(oracle_lib, monkeypatch):
+    """`import agarcl`: the compiled pybind11 module over the C ABI (agarcl_amd/csrc/agarcl_pybind.cpp), driven through the
+    reference's own usage sequence -- reset -> seed -> take_actions -> step -> get_state -> dones -- and under the gym wrapper."""
+    from agarcl_amd import build as hip_build, gym_agario
+    hip_build.build_pybind()
+    import agarcl
+    assert agarcl.__file__.endswith(".so") and agarcl.has_screen_env is True
+    monkeypatch.setattr(gym_agario, "agarcl", agarcl)
+    _exercise(agarcl, gym_agario, oracle_lib)
+    # multi-frame observation: the frame slots of GridObservation (GridEnvironment.hpp:91-123)
+    env = agarcl.GridEnvironment(1, 4, 300, True, 300, 5, 0, 1, 0, 0)
+    env.configure_observation({"grid_size": 16, "num_frames": 4})
+    assert env.observation_shape() == (32, 16, 16)
+    env.seed(1); env.reset(); env.take_actions([(0.1, 0.1, 0)]); env.step()
+    st = env.get_state()[0]
+    assert st.shape == (32, 16, 16) and not st[:24].any() and st[24:].any()          # the state after the step fills the last slot
+    env.configure_observation({"grid_size": 16, "num_frames": 4, "literal_frame_index": True})   # frame_index = 0 - (4 - 4) = 0
+    lit = env.get_state()[0]
+    assert np.array_equal(lit[:8], st[24:]) and not lit[8:].any()
+    env.configure_observation({"grid_size": 16, "num_frames": 1, "literal_frame_index": True})   # frame_index = -3: nothing stored
+    assert not env.get_state()[0].any()
+    env.close()
+    # snapshots through the compiled module: written in the reference's JSON format, loaded back, stepping continues
+    import json, os, tempfile
+    a = agarcl.ScreenEnvironment(1, 4, 300, True, 200, 3, 0, True, 0, 6, False, 32, 32, False)
+    a.seed(11); a.reset()
+    for t in range(5):
+        a.take_actions([(0.3, 0.2, t % 3)]); a.step()
+    path = os.path.join(tempfile.mkdtemp(), "snap.json")
+    a.save_env_state(path)
+    snap = json.load(open(path))
+    assert {"players", "pellets", "viruses", "foods", "seed"} <= set(snap)
+    b = agarcl.ScreenEnvironment(1, 4, 300, True, 200, 3, 0, True, 0, 6, True, 32, 32, False)
+    b.load_env_state(path)
+    b.take_actions([(0.0, 0.0, 0)]); r = b.step()
+    assert isinstance(r, list) and len(b.get_state()) == 1 and b.get_state()[0].shape == (1, 32, 32, 3)
+    with pytest.raises(RuntimeError):
+        b.load_env_state("/nonexistent/dir/x.json")
+    a.close(); b.close()
+    # GoBigger: value classes come with the module; get_state follows bindings.cpp:28-47
+    g = agarcl.GoBiggerEnvironment(512, 512, 1000, 1, 4, 300, True, 400, 6, 2, True)
+    g.seed(5); g.reset()
+    for t in range(10):
+        g.take_actions([(0.4, 0.3, t % 3)]); g.step()
+    st = g.get_state()
+    assert set(st[0]) == {"global_state", "player_states"} and isinstance(st[0]["global_state"], agarcl.GlobalState)
+    assert len(st[0]["player_states"].get_all_player_states()) == 3 and g.observation_shape() == (11, 512, 512)
+    g.close()
+
+
+@pytest.mark.gpu
+def test_gym_wrapper_all_three_observation_types():
+    """gym_agario.AgarioEnv as gym.make("agario-{grid,screen,gobigger}-v0") would build it (AgarioEnv.py:202-268)"""
+    import gym_agario  # noqa: F401  (registers the ids when gymnasium is installed)
+    from gym_agario.AgarioEnv import AgarioEnv
+    for obs_type in ("grid", "screen", "gobigger"):
+        g = AgarioEnv(obs_type=obs_type, difficulty="normal", num_viruses=5, number_steps=3)
+        g.seed(4)
+        obs, info = g.reset()
+        for k in range(4):
+            obs, rew, done, trunc, info = g.step(((0.5, 0.5), k % 3))
+            assert isinstance(rew, float) and trunc is False and info["steps"] == k + 1 and done == (k >= 3)
+        if obs_type == "grid":
+            assert obs.shape == (128, 128, 8) and obs.dtype == np.int32
+        elif obs_type == "screen":
+            assert obs.shape == (1, 84, 84, 3) and obs.dtype == np.uint8
+        else:
+            assert set(obs) == {"global_state", "player_states"}
+        g.close()
+    with pytest.raises(ValueError):
+        AgarioEnv(obs_type="ram")             # accepted by the reference's first check, rejected when the env is built (AgarioEnv.py:52,211)
+
+
+def test_registration_with_a_stand_in_gymnasium(monkeypatch):
+    """gymnasium is not installed in this image: a stand-in module records what `import gym_agario` registers
+    (gym_agario/__init__.py:9-23: three ids, one entry point) and the entry point resolves to the wrapper class."""
+    import importlib, sys, types
+    calls = []
+    gymn = types.ModuleType("gymnasium"); gymn.Env = object
+    spaces = types.ModuleType("gymnasium.spaces")
+    for n in ("Box", "Tuple", "Discrete"):
+        setattr(spaces, n, lambda *a, **k: ("space", a, k))
+    reg = types.ModuleType("gymnasium.envs.registration"); reg.register = lambda **kw: calls.append(kw)
+    envs = types.ModuleType("gymnasium.envs"); envs.registration = reg
+    gymn.spaces, gymn.envs = spaces, envs
+    for name, mod in (("gymnasium", gymn), ("gymnasium.spaces", spaces), ("gymnasium.envs", envs), ("gymnasium.envs.registration", reg)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    for name in ("gym_agario", "gym_agario.AgarioEnv", "agarcl_amd.gym_agario"):
+        monkeypatch.delitem(sys.modules, name, raising=False)
+    import gym_agario
+    assert gym_agario.registered is True
+    assert [c["id"] for c in calls] == ["agario-grid-v0", "agario-screen-v0", "agario-gobigger-v0"]
+    assert [c["kwargs"]["obs_type"] for c in calls] == ["grid", "screen", "gobigger"]
+    for c in calls:
+        mod, cls = c["entry_point"].split(":")
+        klass = getattr(importlib.import_module(mod), cls)
+        assert isinstance(klass, type) and klass.__name__ == "AgarioEnv" and hasattr(klass, "step") and hasattr(klass, "reset")
+    for name in ("gym_agario", "gym_agario.AgarioEnv", "agarcl_amd.gym_agario"):      # leave no stand-in-derived classes behind
+        sys.modules.pop(name, None)
+
+
 def test_gobigger_object_view(emu_lib, monkeypatch):
-    """SURVEY 8f N3 (object view, parity unpinned): structure and invariants of the GoBigger-style observation."""
+    """SURVEY 8f N3 (object view derived from the kernel's tensors, parity unpinned): structure and invariants."""
     from agarcl_amd import agarcl
     monkeypatch.setattr(agarcl, "_LIB", emu_lib)
     env = agarcl.GoBiggerEnvironment(512, 512, 1000, 1, 4, 300, True, 400, 6, 2, True, 0, 0)
