@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_SO = os.path.join(_HERE, "libagarcl_hip.so")
+# (AGARCL_HIP_SO: A/B timing of differently compiled builds of the same source, scripts/ only)
+HIP_SO = os.environ.get("AGARCL_HIP_SO") or os.path.join(_HERE, "libagarcl_hip.so")
 
 E_UNSUPPORTED = -3
 PACKED_SLOTS = 16   # include/agarcl_batch.h AGARCL_PACKED_SLOTS

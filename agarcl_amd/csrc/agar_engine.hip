@@ -51,6 +51,7 @@ static int d2h(void *h, const void *d, size_t n, ag_stream_t s) { return hipMemc
 static int dsync(ag_stream_t s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
 #endif
 
+#define AG_FUSED_MAX_ARENAS 32768   // measured cross-over of k_fused vs k_quiet + k_step on C2 (4096: 9.6 vs 12.2 us, 16384: 18.5 vs 19.7, 65536: 53.0 vs 49.6)
 struct agarcl_env {
   agarcl_config cfg;
   AgDims d; AgParams g; AgState s;   // host copy of the descriptor
@@ -110,37 +111,50 @@ extern __shared__ __align__(16) unsigned char ag_lds[];
 #endif
 #define AG_KERNEL_PROLOGUE AgCtx<NS, AV> c; ag_ctx_init(c, gs, (int)blockIdx.x, ag_lds, act_dxdy, act);
 
-// use_q: k_quiet ran in front of this launch; arenas it finished exit on their first load, the others resume.
+// One wavefront per arena, grid-stride: the grid is min(A, 4096) single-wave workgroups -- 4 per SIMD is all the register
+// budget admits, so a larger grid would only queue -- and every workgroup walks its share of the arenas.
+// use_q: k_quiet ran in front of this launch and left a work list (qlist / qcount) of the arenas it did not finish; only
+// those are visited, resuming where the front part stopped.  A quiet-dominated step therefore costs this launch one
+// scalar load per workgroup whatever the arena count.
 template <int NS, bool AV> __global__ void __launch_bounds__(64) AG_KSTEP_ATTR k_step(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int use_q, int parity) {
-  int q_done = -1, q_before = 0;
+  const int A = gs->d.A;
+  int total = A;
   if (use_q) {
-    // the usual case in quiet-dominated workloads: k_quiet finished every arena => one scalar load and out
-    // (workgroup 0 re-arms the other parity's counter for the next step's k_quiet)
-    const int left = gs->qcount[parity];
-    if (blockIdx.x == 0 && threadIdx.x == 0) gs->qcount[parity ^ 1] = 0;
-    if (left == 0) return;
-    auto qi = (const AG_GLOBAL int32_t *)(gs->qinfo + (size_t)blockIdx.x * 2);
-    q_done = qi[0]; q_before = qi[1];
-    if (q_done == ticks) return;
+    total = gs->qcount[parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) gs->qcount[parity ^ 1] = 0;   // re-arm the other parity's counter for the next step's k_quiet
   }
-  AG_KERNEL_PROLOGUE
-  c.slot = slot;
+  for (int it = (int)blockIdx.x; it < total; it += (int)gridDim.x) {
+    int arena = it, q_done = -1, q_before = 0;
+    if (use_q) {
+      arena = ((const AG_GLOBAL int32_t *)gs->qlist)[(size_t)parity * A + it];
+      auto qi = (const AG_GLOBAL int32_t *)(gs->qinfo + (size_t)arena * 2);
+      q_done = qi[0]; q_before = qi[1];
+    }
+    AgCtx<NS, AV> c; ag_ctx_init(c, gs, arena, ag_lds, act_dxdy, act, slot);
 #ifdef AGAR_PROFILE
-  for (int i = 0; i < AG_NPROF; i++) c.tacc[i] = 0;
-  c.tlast = (unsigned)__builtin_readcyclecounter();
+    for (int i = 0; i < AG_NPROF; i++) c.tacc[i] = 0;
+    c.tlast = (unsigned)__builtin_readcyclecounter();
 #endif
-  arena_load(c, use_q != 0);
-  AG_T(c, 0);
-  env_step(c, ticks, with_env != 0, q_done, q_before);
-  AG_T(c, 10);
-  arena_store(c);
-  AG_T(c, 11);
+    arena_load(c, true);   // a general tick is (almost) certain: the pellets join the first round trip
+    AG_T(c, 0);
+    env_step(c, ticks, with_env != 0, q_done, q_before);
+    AG_T(c, 10);
+    arena_store(c);
+    AG_T(c, 11);
 #ifdef AGAR_PROFILE
-  if (threadIdx.x == 0 && gs->prof) for (int i = 0; i < AG_NPROF; i++) gs->prof[(size_t)blockIdx.x * AG_NPROF + i] += c.tacc[i];
+    if (threadIdx.x == 0 && gs->prof) for (int i = 0; i < AG_NPROF; i++) gs->prof[(size_t)arena * AG_NPROF + i] += c.tacc[i];
 #endif
+    ag_lds_order();
+  }
 }
 // 256 threads = 16 arenas per workgroup, AG_QG lanes each (agar_quiet.inl)
-template <int NS, bool AV> __global__ void __launch_bounds__(256) k_quiet(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int parity) {
+// k_quiet stands alone only in the two-kernel step, which is chosen where the arena count is large (>= 32768) or the arenas
+// are not quiet.  Capped at 128 VGPRs (4 waves/SIMD instead of 3, 28 bytes of scratch): measured on MI355X, C2, k_quiet +
+// work-list k_step: 65 536 arenas 52.3 -> 49.6 us per step, 262 144 arenas 160.4 -> 148.8 us (the fused launch: 53.0 / 190.6).
+#ifndef AG_KQUIET_ATTR
+#define AG_KQUIET_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
+template <int NS, bool AV> __global__ void __launch_bounds__(256) AG_KQUIET_ATTR k_quiet(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int parity) {
   int arena = (int)blockIdx.x * (256 / AG_QG) + (int)threadIdx.x / AG_QG;
   const int A = gs->d.A; const bool valid = arena < A;
   if (!valid) arena = A - 1;
@@ -213,7 +227,9 @@ static void poll_stats(agarcl_env *e, bool adapt) {
     const long steps = e->stat_req_front - e->stat_last_front;  // steps in which the front part actually ran
     if (adapt && steps > 0) {
       const double frac = (double)(uint32_t)(e->h_stat[0] - e->stat_last_total) / ((double)steps * (double)e->d.A);
-      if (e->fused && frac > 0.05) e->fused = false; else if (!e->fused && frac < 0.01) e->fused = true;
+      // (from 32768 arenas on the two-kernel step is the faster one even when every arena is quiet: the lean front kernel
+      // keeps 4 waves per SIMD where the fused kernel, which carries the general engine's registers, keeps 2)
+      if (e->fused && frac > 0.05) e->fused = false; else if (!e->fused && frac < 0.01) e->fused = e->d.A < AG_FUSED_MAX_ARENAS;
       // the two-kernel step's front launch is pure overhead when it finishes (almost) nothing: mass-1000 modes
       e->front_off = !e->fused && frac > 0.99;
     }
@@ -255,7 +271,7 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
     AG_DISPATCH_NS(e->ns, CALL);
 #undef CALL
   }
-#define CALL(N, V) hipLaunchKernelGGL((k_step<N, V>), dim3(e->d.A), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, use_q, e->parity)
+#define CALL(N, V) hipLaunchKernelGGL((k_step<N, V>), dim3(e->d.A < 4096 ? e->d.A : 4096), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, use_q, e->parity)
   AG_DISPATCH_NS(e->ns, CALL);
 #undef CALL
   if (use_q) e->parity ^= 1;
@@ -422,9 +438,10 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   s.prof = alloc<unsigned long long>(e, (size_t)d.A * 16);
   s.qinfo = alloc<int32_t>(e, (size_t)d.A * 2);
   s.qcount = alloc<int32_t>(e, 2); e->parity = 0;
+  s.qlist = alloc<int32_t>(e, 2 * (size_t)d.A);
   { const char *nf = getenv("AGARCL_NO_FRONT"); e->no_front = nf && nf[0] == '1'; }
   // modes 0-4 start agents at mass 25 (quiet-dominated); 5 and 6 start at mass 1000 (general path every step)
-  e->fused = d.P == 1 && cfg->mode_number <= 4;  // starting point; poll_stats follows what the arenas actually do
+  e->fused = d.P == 1 && cfg->mode_number <= 4 && d.A < AG_FUSED_MAX_ARENAS;  // starting point; poll_stats follows what the arenas actually do
   e->front_off = d.P == 1 && cfg->mode_number > 4;
   e->work_step0 = e->work_front0 = 0; e->work_unf0 = 0; e->work_pass0 = 0;
   e->flags_seen = 0; e->d_mask = alloc<uint8_t>(e, (size_t)d.A);

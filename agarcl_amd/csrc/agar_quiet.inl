@@ -138,7 +138,7 @@ template <int NS, bool AV> AG_DEV QHandOver quiet_arena(const AgState *gs, int a
   if (lead && !ok) { qi[0] = -1; qi[1] = 0; }
 #ifndef AGAR_CPU_EMU
   if (lead && !(ok && finished)) {
-    if (parity >= 0) atomicAdd(gs->qcount + parity, 1);  // k_step has work to do
+    if (parity >= 0) { const int at = atomicAdd(gs->qcount + parity, 1); gs->qlist[(size_t)parity * gs->d.A + at] = arena; }  // k_step's work list
     atomicAdd(gs->qstat, 1);                              // statistics for the host's fused / two-kernel choice
   }
 #endif

@@ -113,5 +113,6 @@ struct AgState {
   int32_t *qstat;         // [4] running totals the host samples now and then: [0] arena-steps the front part left unfinished,
                           //     [1] OR of every capacity flag raised (the flag watch of agarcl_poll_flags)
   int32_t *qcount;        // [2] number of arenas k_quiet left unfinished, ping-pong by launch parity (k_step exits at once on 0)
+  int32_t *qlist;         // [2][A] the arenas k_quiet left unfinished (same parity), in arrival order: k_step's work list
   unsigned long long *prof;  // [16] phase cycle sums (diagnostic builds only; may be null)
 };

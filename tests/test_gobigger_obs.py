@@ -38,8 +38,8 @@ def _run(engine_cls, lib, steps):
         eng.set_actions(rng.uniform(-1, 1, size=(A, 2, 2)).astype(np.float32), rng.randint(0, 3, size=(A, 2)).astype(np.int32)); eng.step()
         if t % 7 and t < steps - 1:
             continue
-        ten = eng.gobigger_obs(64, cap_food=128, cap_virus=16, cap_spore=32, cap_clone=32)
-        assert ten["hdr"].shape == (A, 4, 8) and ten["food"].shape == (A, 4, 128, 4) and ten["clone"].shape == (A, 4, 32, 7)
+        ten = eng.gobigger_obs(64, cap_food=448, cap_virus=16, cap_spore=64, cap_clone=32)
+        assert ten["hdr"].shape == (A, 4, 8) and ten["food"].shape == (A, 4, 448, 4) and ten["clone"].shape == (A, 4, 32, 7)
         for a in range(A):
             gobigger.add_frame(mine[a], ten, a)
             gobigger_oracle.add_frame(want[a], eng.dump(a), 64)
@@ -52,7 +52,7 @@ def _run(engine_cls, lib, steps):
     assert listed > 100
     # capacities smaller than the lists: counts stay true, rows are truncated in order
     small = eng.gobigger_obs(64, cap_food=4, cap_virus=1, cap_spore=1, cap_clone=2)
-    big = eng.gobigger_obs(64, cap_food=128, cap_virus=16, cap_spore=32, cap_clone=32)
+    big = eng.gobigger_obs(64, cap_food=448, cap_virus=16, cap_spore=64, cap_clone=32)
     assert np.array_equal(small["hdr"], big["hdr"]) and np.array_equal(small["food"], big["food"][:, :, :4]) and np.array_equal(small["clone"], big["clone"][:, :, :2])
     eng.close()
 
