@@ -81,6 +81,7 @@ SYMBOLS = [
     ("agarcl_debug_prof", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     ("agarcl_debug_prof_raw", C.c_int, [C.c_void_p, C.c_void_p]),
     ("agarcl_debug_work", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    ("agarcl_debug_qstat", C.c_int, [C.c_void_p, C.c_void_p]),
 ]
 
 

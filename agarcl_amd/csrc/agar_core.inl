@@ -693,6 +693,85 @@ AG_DEV void prevent_overlap(CellR &A, CellR &B, float dt, float tx, float ty, fl
   boundary(W, A.x, A.y, ra);
   boundary(W, B.x, B.y, rb);
 }
+#ifndef AGAR_CPU_EMU
+// ---- a pair visit on FOUR lanes --------------------------------------------------------------------------------------
+// A level of the relaxation keeps at most n / 2 lanes busy with one pair each, and a visit of a touching pair is a
+// dependent chain of ~500 instructions (8 IEEE divisions, 3 square roots, two cells x two components of everything).
+// The chain, not the lane count, is what a tick waits for.  So a pair gets a QUAD of lanes: lane (c, k) owns component k
+// (0 = x, 1 = y) of cell c (0 = A, the pair's first cell; 1 = B).  Everything per-component / per-cell (un-move, re-move,
+// boundary clamps, products, the new velocity, the push) is done once per lane instead of four times per lane; sums over
+// the two components (squared distances, dot products, |dx| + |dy|) are one DPP add with the neighbour lane, values of the
+// other cell one DPP move.  Same fp32 operations on the same operands as the scalar form (prevent_overlap & co above:
+// the host emulation keeps using those), only distributed: a + b is taken as b + a on the other lane (an exact identity in IEEE
+// arithmetic; B - A is NOT taken as -(A - B): that would turn +0 into -0 when the components are equal).  ~135 instructions per lane instead of ~400.
+AG_DEV float q_comp(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)); }   // quad_perm [1,0,3,2]: the other component
+AG_DEV float q_cell(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)); }   // quad_perm [2,3,0,1]: the other cell
+AG_DEV unsigned q_cellu(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false); }
+struct QuadK { bool cB, kY; float W, dt, tk; };   // lane role (cell B? component y?), arena width, dt, this lane's component of the player's target
+AG_DEV float q_boundary(float p, float r, float W) { return smaxf(0.0f, clampf(p, r, W - r)); }
+// avoid_static_overlap (small) / separate_cells (!small) on this lane's component p (velocity v) of its cell -- Engine.hpp:701-749, 803-848
+AG_DEV void q_push(const QuadK &q, bool want, bool small, float r, float ro, unsigned m, unsigned mo, float &p, float &v) {
+  const float po = q_cell(p);
+  const float d = (q.cB ? p : po) - (q.cB ? po : p);        // B - A, this component (operands selected, not the sign flipped: x - x must stay +0)
+  const float sq = d * d, dist = ag_sqrtf(sq + q_comp(sq));
+  const float target = r + ro;
+  const bool go = want && !(dist > target);
+  const float ad = fabsf(d), den = ad + q_comp(ad);
+  const float xr = ag_divf(d, den);
+  const float depth = target - dist;
+  const float xd = xr * depth;
+  // small: half the depth each, all of it for a cell that sits on a wall (which also loses that velocity component)
+  const bool on = p == r || p == q.W - r;
+  float t = xd * (on ? 1.0f : 0.5f);
+  float ps = q.cB ? p + t : p - t;
+  ps = q_boundary(ps, r, q.W);
+  // large mass difference: the lighter cell gives way
+  const float dd = fabsf(q.tk - p), ds = dd * dd, diff = ds + q_comp(ds), diffo = q_cell(diff);
+  const float diffA = q.cB ? diffo : diff, diffB = q.cB ? diff : diffo;
+  const unsigned mA = q.cB ? mo : m, mB = q.cB ? m : mo;
+  const bool ta = mA < mB;
+  const int s1 = ta ? 1 : -1, s2 = diffA >= diffB ? 1 : -1;
+  const float fs = (float)((s1 == s2) ? s2 : 0);
+  t = xd * fs;
+  const float pl = (d >= 0) ? p - t : p + t;
+  const bool moves = q.cB ? !ta : ta;
+  p = go ? (small ? ps : (moves ? pl : p)) : p;
+  v = (go && small && on) ? 0.0f : v;
+}
+// one visit: t0 = the pair touches (wave-level caller has tested it); stat = the final static sweep
+AG_DEV void q_visit(const QuadK &q, bool t0, bool stat, float r, float ro, unsigned m, unsigned mo, float sv, float &p, float &v) {
+  if (stat) { q_push(q, t0, true, r, ro, m, mo, p, v); return; }   // (wave-uniform except where sweeps 4 and 5 share a level)
+  const float po = q_cell(p);
+  const float d = (q.cB ? p : po) - (q.cB ? po : p);
+  const float sq = d * d, dist = ag_sqrtf(sq + q_comp(sq));
+  const float target = r + ro;
+  const bool go = t0 && !(dist > target);
+  float u = v + sv, t = u * q.dt;
+  float pn = p - t;                                           // take back this tick's move
+  // elastic collision (Engine.hpp:893-938): the lighter cell (both when equal) gets a new velocity
+  const float n = ag_divf(d, dist);
+  const float nsw = q_comp(n), ek = q.kY ? nsw : -nsw;        // tangent: (-ny, nx)
+  const float t1 = v * n, dpN = t1 + q_comp(t1), dpNo = q_cell(dpN);
+  const float t2 = v * ek, dpT = t2 + q_comp(t2);
+  const int mi = (int)m, mio = (int)mo;
+  float q1 = dpN * (float)(mi - mio);
+  float q2 = 2.0f * (float)mio; q2 = q2 * dpNo;
+  const float vn = ag_divf(q1 + q2, (float)(mi + mio));
+  const float uu = ek * dpT, ww = n * vn;
+  float vv = (m <= mo) ? uu + ww : v;
+  u = vv + sv; t = u * q.dt; pn = pn + t;                     // move again with the new velocity
+  const float dk = fabsf(pn - q_cell(pn)), s2 = dk * dk;
+  const float rr = target * target;
+  const bool again = go && rr >= (s2 + q_comp(s2)) + 0.0f;
+  if (ag_any(again)) {
+    const int dm = (int)(m - mo);
+    q_push(q, again, (dm < 0 ? -dm : dm) <= 10, r, ro, m, mo, pn, vv);
+  }
+  pn = q_boundary(pn, r, q.W);
+  p = go ? pn : p; v = go ? vv : v;
+}
+#endif
+
 // R: Engine.hpp:763-794.  The reference makes up to 5 sweeps over the pairs (a,b), a<b, in lexicographic order
 // (prevent_overlap on touching pairs; stop after a sweep in which nothing touched) and, if the 5th still found an
 // overlap, a 6th sweep of avoid_static_overlap.  Every visit touches only cells a and b, so two visits commute unless
@@ -739,9 +818,29 @@ template <int NS, bool AV> AG_DEV void self_collisions(AgCtx<NS, AV> &c, const C
 #ifdef AGAR_CPU_EMU
     for (int j = 0; j < wO + wN; j++) { int sw = 0; if (visit(j, sw)) { if (sw & 1) ho = true; else he = true; } }
 #else
-    { const int j = AG_LANE; int sw = 0; bool h = false; if (j < wO + wN) h = visit(j, sw); he = __ballot(h && !(sw & 1)) != 0ull; ho = __ballot(h && (sw & 1)) != 0ull; }
+    {  // four lanes per pair (q_visit): lane = 4 * pair + 2 * cell + component
+      const int lane = AG_LANE, j = lane >> 2; int sw = 0; bool t0 = false;
+      if (j < wO + wN) {
+        int a, b;
+        if (j < wO) { a = a0O + j; b = LO - a; sw = sO; } else { a = a0N + (j - wO); b = LN - a; sw = sN; }
+        QuadK q; q.cB = (lane & 2) != 0; q.kY = (lane & 1) != 0; q.W = W; q.dt = dt; q.tk = q.kY ? ty : tx;
+        const int self = q.cB ? b : a;
+        float *pp = (q.kY ? s.y : s.x) + self, *vp = (q.kY ? s.vy : s.vx) + self;
+        float p = *pp; const float r = s.crad[self], ro = q_cell(r);
+        { const float dk = fabsf(p - q_cell(p)), s2 = dk * dk; const float rs = r + ro, rr = rs * rs; t0 = rr >= (s2 + q_comp(s2)) + 0.0f; }
+        if (ag_any(t0)) {
+          float v = *vp; const float sv = (q.kY ? s.sy : s.sx)[self]; const unsigned m = s.m[self], mo = q_cellu(m);
+          q_visit(q, t0, sw >= 5, r, ro, m, mo, sv, p, v);
+          if (t0) { *pp = p; *vp = v; }
+        }
+      }
+      he = __ballot(t0 && !(sw & 1)) != 0ull; ho = __ballot(t0 && (sw & 1)) != 0ull;
+    }
 #endif
     hit_even = hit_even || he; hit_odd = hit_odd || ho;
+#if defined(AGAR_PROFILE_LEVELS) && !defined(AGAR_CPU_EMU)
+    AG_SERIAL { atomicAdd(c.gs->qstat + 2, 1); if (he || ho) atomicAdd(c.gs->qstat + 3, 1); }   // diagnostic build: levels walked / levels with a touching pair
+#endif
     ag_lds_order();
     // a sweep that has completed without a single touching pair ends the relaxation
     if (validO && LO == LL && !((sO & 1) ? hit_odd : hit_even)) break;

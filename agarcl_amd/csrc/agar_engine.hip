@@ -712,6 +712,10 @@ extern "C" int agarcl_debug_work(agarcl_env *e, int64_t *out4, int reset) {
   if (reset) { e->work_step0 = e->step_no; e->work_front0 = e->front_runs; e->work_unf0 = st[0]; e->work_pass0 = passes; }
   return AGARCL_OK;
 }
+extern "C" int agarcl_debug_qstat(agarcl_env *e, int32_t *out4) {  // raw statistics words (AgState::qstat); [2], [3] only in -DAGAR_PROFILE_LEVELS builds
+  if (!e || !out4) return AGARCL_E_INVALID;
+  return d2h(out4, e->s.qstat, 16, e->stream) ? AGARCL_E_HIP : AGARCL_OK;
+}
 extern "C" int agarcl_num_arenas(agarcl_env *e) { return e ? e->d.A : 0; }
 extern "C" int agarcl_players_per_arena(agarcl_env *e) { return e ? e->d.P : 0; }
 

@@ -210,6 +210,9 @@ int agarcl_debug_prof_raw(agarcl_env *env, unsigned long long *out_host);
  * out[0] = arena-steps finished by the lean front part, out[1] = arena-steps that needed the general engine,
  * out[2] = pellet passes (each reads the arena's whole pellet array), out[3] = general ticks executed */
 int agarcl_debug_work(agarcl_env *env, int64_t *out4, int reset);
+/* the raw running statistics words: [0] arena-steps the front part left unfinished, [1] OR of raised flags, [2] / [3] levels walked /
+ * levels with a touching pair in the self-collision relaxation (counted only by -DAGAR_PROFILE_LEVELS builds) */
+int agarcl_debug_qstat(agarcl_env *env, int32_t *out4);
 
 #ifdef __cplusplus
 }
