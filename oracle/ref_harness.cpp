@@ -67,6 +67,18 @@ static inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f;
 struct RefEnv : public Base {
   VClock clock;
   using Base::Base;
+  // ScreenEnvironment's respawn hook (environment/envs/ScreenEnvironment.hpp:233-243).  ScreenEnvironment itself needs OpenGL and
+  // cannot be compiled here; the hook is the three statements below, which this harness restates (that much is NOT the
+  // reference's own object code).  Everything around it -- BaseEnvironment::step calling _partial_observation per agent after the
+  // ticks, is_main_player_respawned feeding the c_death reward term and the mode > 6 done flag (BaseEnvironment.hpp:89-122),
+  // Engine::respawn -- is the unmodified reference, so the oracle's E5 path is pinned against it through this switch.
+  bool screen_hook = false;
+  void _partial_observation(int agent_index, int tick_index) override {
+    Base::_partial_observation(agent_index, tick_index);
+    if (!screen_hook) return;
+    auto &player = this->engine_.player(this->pids_[agent_index]);
+    if (player.dead()) { this->engine_.respawn(player); this->is_main_player_respawned = true; }
+  }
   Engine &eng() { return this->engine_; }
   std::vector<agario::pid> &pids() { return this->pids_; }
   void set_done(int i, bool v) { this->dones_[i] = v; }
@@ -119,6 +131,7 @@ void *ref_env_create(int num_agents, int ticks_per_step, int arena_size, int pel
 }
 
 void ref_env_destroy(void *h) { delete (RefEnv *)h; }
+void ref_env_set_screen_hook(void *h, int on) { ((RefEnv *)h)->screen_hook = on != 0; }
 
 void ref_env_seed(void *h, unsigned s) { ((RefEnv *)h)->seed((int)s); }
 

@@ -80,6 +80,11 @@ class RefEnv:
         except Exception:
             pass
 
+    def set_screen_hook(self, on=True):
+        """ScreenEnvironment's respawn hook around the unmodified BaseEnvironment::step (oracle/ref_harness.cpp RefEnv)"""
+        self.L.ref_env_set_screen_hook.argtypes = [C.c_void_p, C.c_int]
+        self.L.ref_env_set_screen_hook(self.h, 1 if on else 0)
+
     def seed(self, s):
         self.L.ref_env_seed(self.h, s)
 

@@ -59,3 +59,28 @@ def test_env_step_rewards_dones(ref_lib, oracle_lib):
             assert np.array_equal(r.dones(), o.dones()), (cfg, t)
             if t % 20 == 0:
                 assert blob.diff(r.dump(), o.dump()) is None
+
+
+def test_screen_respawn_hook_pinned(ref_lib, oracle_lib):
+    """E5: the oracle's ScreenEnvironment hook path against the REAL BaseEnvironment::step with the hook's three statements
+    (ScreenEnvironment.hpp:233-243) plugged into its _partial_observation override: rewards (c_death term), dones, full state."""
+    import numpy as np
+    from lockstep import policy
+    from oracle import blob
+    for cfg in (dict(num_agents=2, arena_size=120, num_pellets=150, num_viruses=2, num_bots=0, mode=4, c_death=-50),
+                dict(num_agents=1, arena_size=150, num_pellets=200, num_viruses=3, num_bots=3, mode=0, c_death=-7),
+                dict(num_agents=1, arena_size=150, num_pellets=200, num_viruses=3, num_bots=1, mode=8, c_death=-3)):
+        r = ref_lib.RefEnv(**cfg); o = oracle_lib.OraEnv(**cfg)
+        r.set_screen_hook(True); o.set_screen_hook(True)
+        for e in (r, o):
+            e.seed(9); e.reset(True)
+        respawns = 0
+        for t in range(700):
+            dxdy, act = policy(4, t, cfg["num_agents"], True, 6)
+            r.take_actions(dxdy, act); o.take_actions(dxdy, act)
+            rr, ro = r.step(), o.step()
+            assert np.array_equal(rr, ro), (cfg, t, rr, ro)
+            assert np.array_equal(r.dones(), o.dones()), (cfg, t)
+            if t % 10 == 0:
+                assert blob.diff(r.dump(), o.dump()) is None, (cfg, t)
+        assert blob.diff(r.dump(), o.dump()) is None
