@@ -383,3 +383,39 @@ def test_error_paths(hip_engine_cls):
     with pytest.raises(Exception):
         e.set_actions(np.zeros((3, 1, 2), np.float32), np.zeros((3, 1), np.int32))
     e.close()
+
+
+def test_vec_environment_device_reset_and_flag_watch(oracle_lib):
+    """VecEnvironment (torch tensors in and out): finished arenas are restarted with a CUDA mask (stream-ordered, no host
+    round trip) and a capacity overflow surfaces as an error from step() through the asynchronous flag watch."""
+    import torch
+    from agarcl_amd.vec_env import VecEnvironment
+    from agarcl_amd._capi import AgarclError
+    from oracle import blob
+    A = 32
+    env = VecEnvironment(A, num_viruses=5, mode_number=0, arena_size=300, num_pellets=300)
+    env.seed(base_seed=77); env.reset(reset_ids=True)
+    g = torch.Generator(device=env.device); g.manual_seed(1)
+    for t in range(30):
+        dxdy = torch.rand((A, 1, 2), generator=g, device=env.device) * 2 - 1
+        env.take_actions(dxdy, torch.zeros((A, 1), dtype=torch.int32, device=env.device)); env.step()
+    mask = (torch.arange(A, device=env.device) % 3 == 0).to(torch.uint8)
+    before = [env.engine.dump(a) for a in range(A)]
+    env.reset(mask)                                   # device mask: agarcl_reset_device
+    env.sync()
+    for a in range(A):
+        now = env.engine.dump(a)
+        if a % 3 == 0:
+            assert blob.parse(now)["ticks"] == 0 and not np.array_equal(now, before[a])
+        else:
+            assert np.array_equal(now, before[a])
+    env.close()
+    env = VecEnvironment(8, arena_size=200, num_pellets=100, mode_number=6, cap_foods=4)     # 4 food slots: feeding overflows
+    env.seed(base_seed=3); env.reset(reset_ids=True)
+    dxdy = torch.full((8, 1, 2), 0.5, device=env.device); act = torch.ones((8, 1), dtype=torch.int32, device=env.device)
+    with pytest.raises(AgarclError):
+        for t in range(400):
+            env.take_actions(dxdy, act); env.step()
+            if t % 50 == 49:
+                env.sync()
+    env.close()
