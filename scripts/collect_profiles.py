@@ -60,6 +60,24 @@ def main():
                     for k in STEP_KERNELS:
                         if k in r["Kernel_Name"]:
                             tot[(k, c)] += float(r["Counter_Value"]); n[(k, c)] += 1
+        sq = collections.defaultdict(float); sqn = collections.defaultdict(int)
+        for f in glob.glob(os.path.join(d, "SQ", "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                for k in STEP_KERNELS:
+                    if k in r["Kernel_Name"]:
+                        sq[(k, r["Counter_Name"])] += float(r["Counter_Value"]); sqn[(k, r["Counter_Name"])] += 1
+        if sq:  # average per launch; derived: share of the VALU issue slots used and lanes busy per VALU instruction
+            per = {}
+            for (k, c), v in sq.items():
+                per.setdefault(k, {})[c] = v / max(sqn[(k, c)], 1)
+            for k, cnt in per.items():
+                us = ent.get("kernel_stats", {}).get(k, {}).get("avg_us")
+                if us and "SQ_INSTS_VALU" in cnt:
+                    # 1024 SIMDs, one wave64 VALU instruction per 2 cycles each, 2.4 GHz nominal
+                    cnt["valu_issue_share_at_2.4GHz"] = cnt["SQ_INSTS_VALU"] * 2.0 / (us * 1e-6 * 2.4e9 * 1024)
+                if cnt.get("SQ_ACTIVE_INST_VALU"):
+                    cnt["thread_cycles_per_active_valu_cycle"] = cnt.get("SQ_THREAD_CYCLES_VALU", 0.0) / cnt["SQ_ACTIVE_INST_VALU"]   # raw ratio (both in the counters' own units)
+            ent["sq_per_launch"] = per
         if tot and ent.get("steps_total"):
             st = ent["steps_total"]
             fetch = sum(v for (k, c), v in tot.items() if c == "FETCH_SIZE") * 1024.0 / st

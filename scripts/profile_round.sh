@@ -20,5 +20,8 @@ for run in $RUNS; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 900 rocprofv3 --pmc $c --output-format csv -d $OUT/$name/$c -o p -- python3 $ROOT/bench.py $ARGS > $OUT/$name.$c.json 2> $OUT/$name.$c.err
   done
+  if [ "$A" = "4096" ]; then   # what the shader engines were doing (8 SQ counters = one pass): instruction mix, lane utilisation
+    timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/$name/SQ -o p -- python3 $ROOT/bench.py $ARGS > $OUT/$name.SQ.json 2> $OUT/$name.SQ.err
+  fi
 done
 python3 $ROOT/scripts/collect_profiles.py $TAG
