@@ -1422,11 +1422,21 @@ template <int NS, bool AV> AG_DEV void sort_cells_by_id(AgCtx<NS, AV> &c, int p)
 // general path takes over.
 // quiet_ticks() is shared by two callers that differ only in where the pellets live (the `Pel` accessor):
 // k_step's quiet_run (pellets in the wave's registers) and the lean kernel k_quiet (pellets streamed from HBM/L2).
+// diagnostic builds (-DAGAR_PROFILE_REASONS): why a quiet run stopped (1 eject/split possible, 2 virus in reach, 3 virus regeneration,
+// 4 generator exhausted at a regeneration tick, 5 anti-team bookkeeping, 6 several pellets in reach, 7 growth reaches a second pellet)
+#ifdef AGAR_PROFILE_REASONS
+#define AG_WHY(q, r) ((q).why = (r))
+#else
+#define AG_WHY(q, r) do { } while (0)
+#endif
 struct QState {  // per arena: wave-uniform in k_step, uniform over the arena's lane group in k_quiet
   unsigned m, m_move;  // mass; mass at the last tick's move (Player::min_mass bookkeeping)
   int action, nv, np, ticks, elapsed, fcd, scd, last_decay, nvt, food_eaten, hm, last_ev, done;
   int mtidx, idc;      // mt19937_64 read index and entity id counter (pellet regeneration)
   int passes;          // diagnostics: pellet passes that read the arena's pellet array from memory (PL_PASSES)
+#ifdef AGAR_PROFILE_REASONS
+  int why;
+#endif
   float x, y, svx, svy, vx, vy, r, hi, tx, ty, slack, sx0, sy0;  // slack = S, (sx0, sy0) = centre of the pellet-free disc
   double rate;
   bool pel_changed;
@@ -1532,12 +1542,12 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
     // wait for the others to finish their whole run) ----
     if (active) do {
       if (q.done >= max_ticks) { active = false; break; }
-      if (q.m >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0) { active = false; break; }  // eject needs >= 35, split >= 50
-      if (q.m >= 111u && q.nv != 0) { active = false; break; }                                  // virus contact needs >= 111
+      if (q.m >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0) { active = false; AG_WHY(q, 1); break; }  // eject needs >= 35, split >= 50
+      if (q.m >= 111u && q.nv != 0) { active = false; AG_WHY(q, 2); break; }                                  // virus contact needs >= 111
       // regeneration (Engine.hpp:236-239): viruses need the general path; pellets are topped up inline as long as the
       // generator's buffered outputs suffice (2 draws per pellet, one more pellet may be eaten this very tick)
-      if (to_regen == 0 && (tgt_v - q.nv > 0 || q.mtidx + 2 * (tgt_p - q.np + 1) > 312)) { active = false; break; }
-      if (to_decay == 0 && q.nvt != 0) { active = false; break; }                               // anti-team bookkeeping
+      if (to_regen == 0 && (tgt_v - q.nv > 0 || q.mtidx + 2 * (tgt_p - q.np + 1) > 312)) { active = false; AG_WHY(q, tgt_v - q.nv > 0 ? 3 : 4); break; }
+      if (to_decay == 0 && q.nvt != 0) { active = false; AG_WHY(q, 5); break; }                               // anti-team bookkeeping
       nx = q.x; ny = q.y; nsx = q.svx; nsy = q.svy;
       move_one(nx, ny, nvx, nvy, nsx, nsy, q.hi, q.r, q.tx, q.ty, dt, W);
       if (q.np != 0) {
@@ -1561,7 +1571,7 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
       need = false; q.passes += pel.pass_cost();
       int ev = -1; float nslack = 0.0f;
       if (rr >= sc.dmin2) {  // somebody is inside the radius: a plain single eat, or the general path's business
-        if (sc.cnt != 1 || sc.cnt1 != 1 || (nm >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0)) active = false;  // (nothing of this tick is committed)
+        if (sc.cnt != 1 || sc.cnt1 != 1 || (nm >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0)) { active = false; AG_WHY(q, sc.cnt != 1 ? 6 : sc.cnt1 != 1 ? 7 : 1); }  // (nothing of this tick is committed)
         else { ev = sc.first; dsec_pending = sc.dsec2; }
       } else {
         float sl = ag_sqrtf(sc.dmin2) - q.r; sl = sl - 0.01f;

@@ -447,7 +447,7 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   e->flags_seen = 0; e->d_mask = alloc<uint8_t>(e, (size_t)d.A);
   e->fused_fixed = false; e->h_stat = nullptr; e->stat_ev = nullptr; e->stat_pending = false; e->step_no = e->front_runs = e->stat_req_front = e->stat_last_front = 0; e->stat_last_total = 0;
   { const char *fu = getenv("AGARCL_FUSED"); if (fu && (fu[0] == '0' || fu[0] == '1')) { e->fused = fu[0] == '1'; e->fused_fixed = true; } }
-  s.qstat = alloc<int32_t>(e, 4);
+  s.qstat = alloc<int32_t>(e, 16);
   e->fused_wg = 256; { const char *w = getenv("AGARCL_FUSED_WG"); if (w) { int v = atoi(w); if (v == 64 || v == 128 || v == 256) e->fused_wg = v; } }
 #ifndef AGAR_CPU_EMU
   {
@@ -712,9 +712,9 @@ extern "C" int agarcl_debug_work(agarcl_env *e, int64_t *out4, int reset) {
   if (reset) { e->work_step0 = e->step_no; e->work_front0 = e->front_runs; e->work_unf0 = st[0]; e->work_pass0 = passes; }
   return AGARCL_OK;
 }
-extern "C" int agarcl_debug_qstat(agarcl_env *e, int32_t *out4) {  // raw statistics words (AgState::qstat); [2], [3] only in -DAGAR_PROFILE_LEVELS builds
-  if (!e || !out4) return AGARCL_E_INVALID;
-  return d2h(out4, e->s.qstat, 16, e->stream) ? AGARCL_E_HIP : AGARCL_OK;
+extern "C" int agarcl_debug_qstat(agarcl_env *e, int32_t *out16) {  // raw statistics words (AgState::qstat); [2..11] only in diagnostic builds
+  if (!e || !out16) return AGARCL_E_INVALID;
+  return d2h(out16, e->s.qstat, 64, e->stream) ? AGARCL_E_HIP : AGARCL_OK;
 }
 extern "C" int agarcl_num_arenas(agarcl_env *e) { return e ? e->d.A : 0; }
 extern "C" int agarcl_players_per_arena(agarcl_env *e) { return e ? e->d.P : 0; }

@@ -101,6 +101,9 @@ template <int NS, bool AV> AG_DEV QHandOver quiet_arena(const AgState *gs, int a
   unsigned t0_ = (unsigned)__builtin_readcyclecounter(); unsigned long long w0_ = wall_clock64();
 #endif
   QState q;
+#ifdef AGAR_PROFILE_REASONS
+  q.why = 0;
+#endif
   q.m = C[AG_CELL_W(CF_M, 0)];
   int ncells = P[PL_NCELLS], nfood = S[AR_NFOOD]; unsigned cmc = C[AG_CELL_W(CF_CMC, 0)];
   // everything the step needs, requested up front: one round trip
@@ -140,6 +143,9 @@ template <int NS, bool AV> AG_DEV QHandOver quiet_arena(const AgState *gs, int a
   if (lead && !(ok && finished)) {
     if (parity >= 0) { const int at = atomicAdd(gs->qcount + parity, 1); gs->qlist[(size_t)parity * gs->d.A + at] = arena; }  // k_step's work list
     atomicAdd(gs->qstat, 1);                              // statistics for the host's fused / two-kernel choice
+#ifdef AGAR_PROFILE_REASONS
+    atomicAdd(gs->qstat + 4 + (ok ? (q.why & 7) : 0), 1);   // [4] not a single-cell / food-free arena, [5..11] AG_WHY
+#endif
   }
 #endif
   if (lead && ok) {

@@ -210,9 +210,10 @@ int agarcl_debug_prof_raw(agarcl_env *env, unsigned long long *out_host);
  * out[0] = arena-steps finished by the lean front part, out[1] = arena-steps that needed the general engine,
  * out[2] = pellet passes (each reads the arena's whole pellet array), out[3] = general ticks executed */
 int agarcl_debug_work(agarcl_env *env, int64_t *out4, int reset);
-/* the raw running statistics words: [0] arena-steps the front part left unfinished, [1] OR of raised flags, [2] / [3] levels walked /
- * levels with a touching pair in the self-collision relaxation (counted only by -DAGAR_PROFILE_LEVELS builds) */
-int agarcl_debug_qstat(agarcl_env *env, int32_t *out4);
+/* the 16 raw running statistics words: [0] arena-steps the front part left unfinished, [1] OR of raised flags; diagnostic builds
+ * only: [2] / [3] levels walked / levels with a touching pair in the self-collision relaxation (-DAGAR_PROFILE_LEVELS), [4..11] why
+ * the front part stopped (-DAGAR_PROFILE_REASONS, agar_core.inl AG_WHY) */
+int agarcl_debug_qstat(agarcl_env *env, int32_t *out16);
 
 #ifdef __cplusplus
 }
