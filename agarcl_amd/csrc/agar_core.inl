@@ -42,6 +42,7 @@ AG_DEV bool ag_any(bool p) { return p; }
 // lane within the wavefront (kernels may pack several wavefronts = several arenas into one workgroup)
 #define AG_LANE ((int)threadIdx.x & 63)
 #define AG_MEM __device__ __forceinline__
+#define AG_MEM_NOINLINE __device__   // (with __attribute__((noinline)): a real call, for rare code whose registers must stay out of a hot loop's budget)
 #define AG_LANES(i, n) for (int i = AG_LANE; i < (n); i += 64)
 #define AG_SERIAL if (AG_LANE == 0)
 AG_DEV int ag_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -1431,7 +1432,7 @@ template <int NS, bool AV> AG_DEV void sort_cells_by_id(AgCtx<NS, AV> &c, int p)
 #endif
 struct QState {  // per arena: wave-uniform in k_step, uniform over the arena's lane group in k_quiet
   unsigned m, m_move;  // mass; mass at the last tick's move (Player::min_mass bookkeeping)
-  int action, nv, np, ticks, elapsed, fcd, scd, last_decay, nvt, food_eaten, hm, last_ev, done;
+  int action, nv, np, ticks, elapsed, fcd, scd, last_decay, nvt, food_eaten, hm, last_ev, last_ev2, done;  // last_ev / last_ev2: pellets eaten by the last tick (-1: none)
   int mtidx, idc;      // mt19937_64 read index and entity id counter (pellet regeneration)
   int passes;          // diagnostics: pellet passes that read the arena's pellet array from memory (PL_PASSES)
 #ifdef AGAR_PROFILE_REASONS
@@ -1474,6 +1475,30 @@ AG_DEV void pel_reduce(float rr, unsigned &dmin, unsigned &dsec, int &c0, int &c
   }
 }
 #endif
+// Second, rare pass: the first one found one or two pellets in reach and exactly two within the radius after one eat, so TWO
+// pellets may be eaten this tick.  It counts the pellets within the radius after two eats (closure under the growth) and finds the
+// two pellets within rr1 that the reference's scan reaches first: key = (bucket visit rank: dx outer, dy inner, Engine.hpp:980-999)
+// * capacity + index (capacity is a power of two).  Kept apart from the first pass so that the common path carries none of it.
+struct PelScan2 { int cnt2; unsigned key1, key2; };
+struct PelQuery2 { float x, y, rr1, rr2; int gx, gy; unsigned cap; };
+template <bool AV> AG_DEV void pel_accumulate2(const PelQuery2 &k, float qx, float qy, unsigned idx, int &c2, unsigned &k1, unsigned &k2) {
+  const int ddx = f2i(qx) / AG_PELLET_GRID - k.gx, ddy = f2i(qy) / AG_PELLET_GRID - k.gy;
+  if (!AV && !(ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1)) return;
+  const float d2 = sqr_dist(k.x, k.y, qx, qy);
+  if (k.rr2 >= d2) c2 += 1;
+  if (k.rr1 >= d2) {
+    const unsigned key = (unsigned)((ddx + 1) * 3 + (ddy + 1)) * k.cap + idx;
+    const unsigned kh = key > k1 ? key : k1; k2 = kh < k2 ? kh : k2; k1 = key < k1 ? key : k1;   // two smallest, lane-private
+  }
+}
+#ifndef AGAR_CPU_EMU
+AG_DEV void pel_reduce2(int &c2, unsigned &k1, unsigned &k2) {
+  c2 = wred_add(c2);
+  const unsigned lane_k1 = k1;
+  k1 = wred_min(k1);
+  k2 = wred_min(lane_k1 == k1 ? k2 : lane_k1);   // (keys are unique: one lane owns the minimum and offers its second)
+}
+#endif
 // The loop alternates two phases so that the pellet pass sits at a point every lane of the wave reaches together
 // (`pel.any` and `pel.scan` are wave-level calls; everything else is per-arena code):
 //   A  each arena runs plain quiet ticks on its own until it is finished, has to stop, or has moved out of its
@@ -1487,7 +1512,7 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
   float rr = q.r * q.r;
   if (!AV) q.slack = 0.0f;
   float s2 = q.slack * q.slack;
-  q.done = 0; q.last_ev = -1; q.m_move = q.m; q.pel_changed = false;
+  q.done = 0; q.last_ev = -1; q.last_ev2 = -1; q.m_move = q.m; q.pel_changed = false;
   const float pel_r = g.pel_r; const float pel_span = W - 2.0f * pel_r;  // random_location(radius), Engine.hpp:143-148
   // countdowns instead of two integer modulos per tick: ticks until the next regeneration tick / decay check
   int to_regen = regen ? (120 - q.ticks % 120) % 120 : -1, to_decay = decay ? 59 - q.elapsed % 60 : -1;
@@ -1496,21 +1521,22 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
   unsigned nm = q.m; float rr1_pending = 0.0f;
   bool need = false; float dsec_pending = 0.0f;
 
-  // everything of a tick after the pellets have been dealt with (ev: index of the eaten pellet or -1)
-  auto finish_tick = [&](int ev, bool rescanned, float nslack) {
+  // everything of a tick after the pellets have been dealt with (ev: index of the eaten pellet or -1; ev2: a second one, eaten after it)
+  auto finish_tick = [&](int ev, int ev2, bool rescanned, float nslack) {
     const bool regen_tick = to_regen == 0, decay_tick = to_decay == 0;
     q.m_move = q.m;
     q.x = nx; q.y = ny; q.vx = nvx; q.vy = nvy; q.svx = nsx; q.svy = nsy;
     if (rescanned) { q.slack = nslack; q.sx0 = nx; q.sy0 = ny; s2 = nslack * nslack; }
-    q.elapsed += 1; q.done += 1; q.last_ev = ev;
-    if (AG_RARE(ev >= 0)) {  // Engine.hpp:991-994 (eat), :1002-1009 (swap-pop)
+    q.elapsed += 1; q.done += 1; q.last_ev = ev; q.last_ev2 = ev2;
+    if (AG_RARE(ev >= 0)) {  // Engine.hpp:991-994 (eat), :1002-1009 (swap-pop, one list entry after the other, stale indices)
       q.m = nm; q.food_eaten += 1;
+      pel.swap_pop(ev, q.np); q.np -= 1;
+      if (AG_RARE(ev2 >= 0)) { q.m = clamp_mass(nm + AG_PELLET_MASS); q.food_eaten += 1; pel.swap_pop(ev2, q.np); q.np -= 1; }
       q.r = lut(lut_r, q.m); q.hi = lut(lut_ms, q.m); rr = q.r * q.r;
-      pel.swap_pop(ev, q.np);
-      q.np -= 1; q.pel_changed = true;
-      // the eaten pellet was the nearest one: the pass also saw the second nearest, which bounds the new pellet-free disc
-      // around this very position -- no second pass on the next tick
-      float sl = ag_sqrtf(dsec_pending) - q.r; sl = sl - 0.01f; sl = sl > 0.0f ? sl : 0.0f;
+      q.pel_changed = true;
+      // one pellet eaten: it was the nearest one and the pass also saw the second nearest, which bounds the new pellet-free disc
+      // around this very position -- no second pass on the next tick.  Two eaten: no bound is known, the next tick looks.
+      float sl = ag_sqrtf(dsec_pending) - q.r; sl = sl - 0.01f; sl = (ev2 < 0 && sl > 0.0f) ? sl : 0.0f;
       q.slack = sl; s2 = sl * sl;
     }
     if ((unsigned)q.hm < q.m) q.hm = (int)q.m;
@@ -1546,7 +1572,7 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
       if (q.m >= 111u && q.nv != 0) { active = false; AG_WHY(q, 2); break; }                                  // virus contact needs >= 111
       // regeneration (Engine.hpp:236-239): viruses need the general path; pellets are topped up inline as long as the
       // generator's buffered outputs suffice (2 draws per pellet, one more pellet may be eaten this very tick)
-      if (to_regen == 0 && (tgt_v - q.nv > 0 || q.mtidx + 2 * (tgt_p - q.np + 1) > 312)) { active = false; AG_WHY(q, tgt_v - q.nv > 0 ? 3 : 4); break; }
+      if (to_regen == 0 && (tgt_v - q.nv > 0 || q.mtidx + 2 * (tgt_p - q.np + 2) > 312)) { active = false; AG_WHY(q, tgt_v - q.nv > 0 ? 3 : 4); break; }   // (up to two pellets may be eaten this very tick)
       if (to_decay == 0 && q.nvt != 0) { active = false; AG_WHY(q, 5); break; }                               // anti-team bookkeeping
       nx = q.x; ny = q.y; nsx = q.svx; nsy = q.svy;
       move_one(nx, ny, nvx, nvy, nsx, nsy, q.hi, q.r, q.tx, q.ty, dt, W);
@@ -1559,7 +1585,7 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
           break;
         }
       }
-      finish_tick(-1, false, 0.0f);
+      finish_tick(-1, -1, false, 0.0f);
     } while (0);
     // ---- phase B: one pass for everybody who waits ----
     if (!pel.any(need || active)) break;
@@ -1567,17 +1593,34 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
     // the phases; the bucket indices matter only without AV)
     PelQuery k{nx, ny, rr, rr1_pending, AV ? 0 : f2i(nx) / AG_PELLET_GRID, AV ? 0 : f2i(ny) / AG_PELLET_GRID};
     PelScan sc = pel.template scan<AV>(need, k);
+    // rare: exactly two pellets within the radius after one eat, at least one of them in reach now -- two may be eaten this tick
+    const bool two = need && rr >= sc.dmin2 && sc.cnt1 == 2;
+    PelScan2 sc2{0, 0xffffffffu, 0xffffffffu};
+    if (AG_RARE(pel.any(two))) {
+      const float r2 = lut(lut_r, clamp_mass(nm + AG_PELLET_MASS));
+      PelQuery2 k2{nx, ny, rr1_pending, r2 * r2, f2i(nx) / AG_PELLET_GRID, f2i(ny) / AG_PELLET_GRID, pel.cap()};
+      sc2 = pel.template scan2<AV>(two, k2);
+    }
     if (need) {
       need = false; q.passes += pel.pass_cost();
-      int ev = -1; float nslack = 0.0f;
-      if (rr >= sc.dmin2) {  // somebody is inside the radius: a plain single eat, or the general path's business
-        if (sc.cnt != 1 || sc.cnt1 != 1 || (nm >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0)) { active = false; AG_WHY(q, sc.cnt != 1 ? 6 : sc.cnt1 != 1 ? 7 : 1); }  // (nothing of this tick is committed)
-        else { ev = sc.first; dsec_pending = sc.dsec2; }
+      int ev = -1, ev2 = -1; float nslack = 0.0f;
+      if (rr >= sc.dmin2) {  // somebody is inside the radius: one or two plain eats, or the general path's business
+        const bool act1 = nm >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0, act2 = nm + AG_PELLET_MASS >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0;
+        if (sc.cnt == 1 && sc.cnt1 == 1 && !act1) { ev = sc.first; dsec_pending = sc.dsec2; }
+        else if (two && sc2.cnt2 == 2 && !act2) {
+          // The reference eats while it scans and the radius grows with every eat (Engine.hpp:991-994): a pellet already inside now is
+          // eaten whenever it is scanned; one that gets inside only through the first eat is eaten iff it is scanned after it.  No third
+          // pellet lies within the radius after two eats, so nothing else can happen.
+          const int iA = (int)(sc2.key1 & (pel.cap() - 1u)), iB = (int)(sc2.key2 & (pel.cap() - 1u));
+          if (sc.cnt == 2 || iA == sc.first) { ev = iA; ev2 = iB; }   // both in reach, or the one in reach is scanned first
+          else { ev = sc.first; dsec_pending = sc.dsec2; }              // the other one was passed before the radius grew: it waits for the next tick
+        }
+        else { active = false; AG_WHY(q, sc.cnt != 1 ? 6 : sc.cnt1 != 1 ? 7 : 1); }  // (nothing of this tick is committed)
       } else {
         float sl = ag_sqrtf(sc.dmin2) - q.r; sl = sl - 0.01f;
         nslack = sl > 0.0f ? sl : 0.0f;
       }
-      if (active) finish_tick(ev, true, nslack);
+      if (active) finish_tick(ev, ev2, true, nslack);
     }
   }
 }
@@ -1587,6 +1630,17 @@ template <int NS, bool AV> struct RegPel {
   AgCtx<NS, AV> &c;
   AG_MEM bool any(bool p) const { return p; }
   AG_MEM int pass_cost() const { return 0; }  // register-resident: the load is counted once per launch in arena_store
+  AG_MEM unsigned cap() const { return (unsigned)(NS * 64); }
+  template <bool AV2> AG_MEM PelScan2 scan2(bool need, const PelQuery2 &k) {
+    PelScan2 out{0, 0xffffffffu, 0xffffffffu};
+    if (!need) return out;
+    ensure_pellets(c); pel_launder(c);
+    AG_PEL_FOR(s, lane, i) { pel_accumulate2<AV>(k, PELX(c, s, lane), PELY(c, s, lane), (unsigned)i, out.cnt2, out.key1, out.key2); }
+#ifndef AGAR_CPU_EMU
+    pel_reduce2(out.cnt2, out.key1, out.key2);
+#endif
+    return out;
+  }
   template <bool AV2> AG_MEM PelScan scan(bool need, const PelQuery &k) {
     PelScan out{3.0e38f, 3.0e38f, 0, 0, -1};
     if (!need) return out;
@@ -1641,8 +1695,9 @@ template <int NS, bool AV> AG_DEV int quiet_run(AgCtx<NS, AV> &c, int max_ticks)
     P[PL_ELAPSED] = q.elapsed; P[PL_MIN_MASS] = (int)q.m_move; P[PL_HIGHEST_MASS] = q.hm; P[PL_FEED_CD] = q.fcd; P[PL_SPLIT_CD] = q.scd;
     P[PL_FOOD_EATEN] = q.food_eaten; P[PL_LAST_DECAY] = q.last_decay; P[PL_SAFE_X] = f2u(q.sx0); P[PL_SAFE_Y] = f2u(q.sy0);
     if (q.last_ev >= 0) evp[0] = q.last_ev;
+    if (q.last_ev2 >= 0) evp[1] = q.last_ev2;
   }
-  SW(c, AR_NEVP, q.last_ev >= 0 ? 1 : 0); SW(c, AR_NEVV, 0); SW(c, AR_NPEL, q.np);
+  SW(c, AR_NEVP, (q.last_ev >= 0 ? 1 : 0) + (q.last_ev2 >= 0 ? 1 : 0)); SW(c, AR_NEVV, 0); SW(c, AR_NPEL, q.np);
   SW(c, AR_TICKS, q.ticks); SW(c, AR_CLOCK, SR(c, AR_CLOCK) + q.done); SW(c, AR_SAFE, f2u(q.slack));
   SW(c, AR_MTIDX, q.mtidx); SW(c, AR_IDC, q.idc);
   ag_lds_order();

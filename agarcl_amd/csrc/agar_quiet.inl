@@ -27,7 +27,14 @@ template <int NS> struct GrpPel {
 #ifdef AGAR_CPU_EMU
   AG_MEM bool lead() const { return true; }
   AG_MEM int pass_cost() const { return 1; }
+  AG_MEM unsigned cap() const { return (unsigned)(NS * 64); }
   AG_MEM bool any(bool p) const { return p; }
+  template <bool AV> AG_MEM PelScan2 scan2(bool need, const PelQuery2 &k) {
+    PelScan2 out{0, 0xffffffffu, 0xffffffffu};
+    if (!need) return out;
+    for (int i = 0; i < NS * 64; i++) pel_accumulate2<AV>(k, xy[2 * i], xy[2 * i + 1], (unsigned)i, out.cnt2, out.key1, out.key2);
+    return out;
+  }
   template <bool AV> AG_MEM PelScan scan(bool need, const PelQuery &k) {
     PelScan out{3.0e38f, 3.0e38f, 0, 0, -1};
     if (!need) return out;
@@ -40,7 +47,31 @@ template <int NS> struct GrpPel {
   typedef float XY __attribute__((ext_vector_type(2)));
   AG_MEM bool lead() const { return sub == 0; }
   AG_MEM int pass_cost() const { return 1; }
+  AG_MEM unsigned cap() const { return (unsigned)(NS * 64); }
   AG_MEM bool any(bool p) const { return __ballot(p) != 0ull; }
+  // the rare second pass (agar_core.inl PelScan2), wave-level like scan(): noinline keeps its registers out of the hot loop's budget
+  template <bool AV> __attribute__((noinline)) AG_MEM_NOINLINE PelScan2 scan2(bool need, const PelQuery2 &k) {
+    PelScan2 out{0, 0xffffffffu, 0xffffffffu};
+    unsigned long long todo = __ballot(need);
+    if (todo) ag_mem_fence();
+    const int lane = (int)threadIdx.x & 63;
+    while (todo) {
+      const int src = (int)__builtin_ctzll(todo);
+      todo &= ~((AG_QG == 64 ? ~0ull : ((1ull << (AG_QG & 63)) - 1ull)) << src);
+      PelQuery2 b;
+      b.x = u2f(__builtin_amdgcn_readlane(f2u(k.x), src)); b.y = u2f(__builtin_amdgcn_readlane(f2u(k.y), src));
+      b.rr1 = u2f(__builtin_amdgcn_readlane(f2u(k.rr1), src)); b.rr2 = u2f(__builtin_amdgcn_readlane(f2u(k.rr2), src));
+      b.gx = __builtin_amdgcn_readlane(k.gx, src); b.gy = __builtin_amdgcn_readlane(k.gy, src); b.cap = k.cap;
+      unsigned long long pa = (unsigned long long)(AG_GLOBAL void *)xy;
+      unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)pa, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(pa >> 32), src);
+      auto gp = (const AG_GLOBAL XY *)(((unsigned long long)hi << 32) | lo) + lane;
+      int c2 = 0; unsigned k1 = 0xffffffffu, k2 = 0xffffffffu;
+      for (int s = 0; s < NS; s++) { const XY p = gp[s * 64]; pel_accumulate2<AV>(b, p.x, p.y, (unsigned)(s * 64 + lane), c2, k1, k2); }
+      pel_reduce2(c2, k1, k2);
+      if ((lane & ~(AG_QG - 1)) == src) { out.cnt2 = c2; out.key1 = k1; out.key2 = k2; }
+    }
+    return out;
+  }
   template <bool AV> AG_MEM PelScan scan(bool need, const PelQuery &k) {
     PelScan out{3.0e38f, 3.0e38f, 0, 0, -1};
     unsigned long long todo = __ballot(need);
@@ -155,8 +186,8 @@ template <int NS, bool AV> AG_DEV QHandOver quiet_arena(const AgState *gs, int a
       C[AG_CELL_W(CF_CMC, 0)] = q.m; C[AG_CELL_W(CF_CRAD, 0)] = (uint32_t)f2u(q.r); C[AG_CELL_W(CF_CMS, 0)] = (uint32_t)f2u(q.hi);
       P[PL_ELAPSED] = q.elapsed; P[PL_MIN_MASS] = (int)q.m_move; P[PL_HIGHEST_MASS] = q.hm; P[PL_FEED_CD] = q.fcd; P[PL_SPLIT_CD] = q.scd;
       P[PL_FOOD_EATEN] = q.food_eaten; P[PL_LAST_DECAY] = q.last_decay; P[PL_SAFE_X] = f2u(q.sx0); P[PL_SAFE_Y] = f2u(q.sy0); P[PL_PASSES] = q.passes;
-      S[AR_NEVP] = q.last_ev >= 0 ? 1 : 0; S[AR_NEVV] = 0; S[AR_NPEL] = q.np; S[AR_TICKS] = q.ticks; S[AR_CLOCK] = clock + q.done; S[AR_SAFE] = f2u(q.slack); S[AR_MTIDX] = q.mtidx; S[AR_IDC] = q.idc;
-      if (q.last_ev >= 0) { auto ge = (AG_GLOBAL int32_t *)(gs->ev_p + (size_t)arena * AG_EV_CAP); ge[0] = q.last_ev; }
+      S[AR_NEVP] = (q.last_ev >= 0 ? 1 : 0) + (q.last_ev2 >= 0 ? 1 : 0); S[AR_NEVV] = 0; S[AR_NPEL] = q.np; S[AR_TICKS] = q.ticks; S[AR_CLOCK] = clock + q.done; S[AR_SAFE] = f2u(q.slack); S[AR_MTIDX] = q.mtidx; S[AR_IDC] = q.idc;
+      if (q.last_ev >= 0) { auto ge = (AG_GLOBAL int32_t *)(gs->ev_p + (size_t)arena * AG_EV_CAP); ge[0] = q.last_ev; if (q.last_ev2 >= 0) ge[1] = q.last_ev2; }
       auto cn = (AG_GLOBAL int32_t *)(gs->counts + (size_t)arena * 4);
       cn[0] = q.np; cn[1] = q.nv; cn[2] = 0; cn[3] = 1;
     }

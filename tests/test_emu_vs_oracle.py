@@ -40,6 +40,9 @@ def test_emulated_kernel_logic_matches_oracle(emu_lib, oracle_lib, case):
     dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode=0),    # C3 / mode 0
     dict(arena_size=1400, num_pellets=1500, num_viruses=0, mode=0),     # 3x3 pellet grid: bucket visibility matters (no AV)
     dict(arena_size=300, num_pellets=400, num_viruses=0, mode=1),       # squared pellets, no regen, no decay
+    dict(arena_size=100, num_pellets=60, num_viruses=0, mode=0),        # crowded: two pellets eaten in one tick (inline), regeneration
+    dict(arena_size=60, num_pellets=200, num_viruses=0, mode=0),        # very crowded: double eats in either scan order, triple eats handed over
+    dict(arena_size=1100, num_pellets=2000, num_viruses=0, mode=3),     # 3x3 pellet grid (bucket ranks decide the eat order), dense
 ])
 def test_emulated_quiet_path_long_rollout(emu_lib, oracle_lib, cfg):
     """The front kernel's logic (agar_quiet.inl + quiet_ticks: pellet-free disc, inline eat / decay, hand-over to the
