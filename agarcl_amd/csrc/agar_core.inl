@@ -556,7 +556,9 @@ template <int NS, bool AV> AG_DEV void respawn(AgCtx<NS, AV> &c, int p) {
   int idc = SR(c, AR_IDC) + 1; SW(c, AR_IDC, idc);
   unsigned clock = (unsigned)SR(c, AR_CLOCK);
   AG_SERIAL {
-    cs.vx[0] = 0; cs.vy[0] = 0; cs.sx[0] = 0; cs.sy[0] = 0; cs.m[0] = clamp_mass(pm); cs.id[0] = idc; cs.dl[0] = clock; cs.cmc[0] = 0u;
+    cs.vx[0] = 0; cs.vy[0] = 0; cs.sx[0] = 0; cs.sy[0] = 0; cs.m[0] = clamp_mass(pm); cs.id[0] = idc; cs.dl[0] = clock;
+    // the radius / speed cache is filled right away, so that the first step after a (re)spawn can already be a quiet one
+    cs.cmc[0] = clamp_mass(pm); cs.crad[0] = lut(g_lut_r(c), clamp_mass(pm)); cs.cms[0] = lut(g_lut_ms(c), clamp_mass(pm));
     P[PL_NCELLS] = 1;
   }
   ag_lds_order();
