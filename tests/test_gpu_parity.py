@@ -419,3 +419,26 @@ def test_vec_environment_device_reset_and_flag_watch(oracle_lib):
             if t % 50 == 49:
                 env.sync()
     env.close()
+
+
+def test_work_counters_account_for_every_arena_step(hip_engine_cls):
+    """agarcl_debug_work (what bench.py's requested-bytes figure is built on): every arena-step is counted exactly once, as
+    finished by the lean front part or as having gone through the general engine; pellet-array transfers are counted."""
+    A, steps = 512, 64
+    for cfg, mostly_front in ((C2, True), (C3M6, False)):
+        eng = hip_engine_cls(A, **cfg)
+        eng.seed(None, 1); eng.reset(reset_ids=True)
+        rng = np.random.RandomState(0)
+        eng.set_actions(rng.uniform(-1, 1, size=(A, 1, 2)).astype(np.float32), np.zeros((A, 1), np.int32)); eng.step()   # first step
+        eng.work(reset=True)
+        for t in range(steps):
+            eng.set_actions(rng.uniform(-1, 1, size=(A, 1, 2)).astype(np.float32), rng.randint(0, 3, size=(A, 1)).astype(np.int32) if not mostly_front else np.zeros((A, 1), np.int32))
+            eng.step()
+        w = eng.work()
+        assert w[0] + w[1] == A * steps, (cfg, w)
+        assert w[2] > 0
+        if mostly_front:
+            assert w[0] > 0.99 * A * steps
+        else:
+            assert w[1] > 0.9 * A * steps and w[2] >= A * steps    # mass-1000 agents: the general engine every step, pellets read every launch
+        eng.close()
