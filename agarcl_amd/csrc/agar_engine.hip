@@ -51,7 +51,9 @@ static int d2h(void *h, const void *d, size_t n, ag_stream_t s) { return hipMemc
 static int dsync(ag_stream_t s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
 #endif
 
-#define AG_FUSED_MAX_ARENAS 32768   // measured cross-over of k_fused vs k_quiet + k_step on C2 (4096: 9.6 vs 12.2 us, 16384: 18.5 vs 19.7, 65536: 53.0 vs 49.6)
+// measured cross-over of k_fused vs k_quiet + k_step on C2 (us per step, fused / two-kernel with the best lanes-per-arena):
+// 4096: 9.2 / 12.5, 8192: 11.2 / 13.5, 12288: 15.7 / 14.6, 16384: 18.1 / 15.0, 32768: 31.0 / 18.1
+#define AG_FUSED_MAX_ARENAS 10240
 struct agarcl_env {
   agarcl_config cfg;
   AgDims d; AgParams g; AgState s;   // host copy of the descriptor
@@ -69,6 +71,7 @@ struct agarcl_env {
   bool fused;     // single-launch step (k_fused) instead of k_quiet + k_step: see k_fused
   bool fused_fixed;                // AGARCL_FUSED=0/1 pins the choice
   int fused_wg;                    // threads per workgroup of k_fused (64, 128 or 256)
+  int quiet_qg;                    // lanes per arena of k_quiet (2, 4, 8 or 16): see agarcl_create
   int32_t *h_stat; void *stat_ev;  // pinned copy of {qstat, flag watch word} + the event that says it has arrived
   uint8_t *d_mask;                 // [A] reset mask staging (host masks are copied here, stream-ordered)
   uint32_t flags_seen;             // OR of every flag watch sample so far (agarcl_poll_flags)
@@ -154,11 +157,11 @@ template <int NS, bool AV> __global__ void __launch_bounds__(64) AG_KSTEP_ATTR k
 #ifndef AG_KQUIET_ATTR
 #define AG_KQUIET_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
-template <int NS, bool AV> __global__ void __launch_bounds__(256) AG_KQUIET_ATTR k_quiet(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int parity) {
-  int arena = (int)blockIdx.x * (256 / AG_QG) + (int)threadIdx.x / AG_QG;
+template <int NS, bool AV, int QG> __global__ void __launch_bounds__(256) AG_KQUIET_ATTR k_quiet(const AgHot hot, const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int parity) {
+  int arena = (int)blockIdx.x * (256 / QG) + (int)threadIdx.x / QG;
   const int A = gs->d.A; const bool valid = arena < A;
   if (!valid) arena = A - 1;
-  quiet_arena<NS, AV>(gs, arena, (int)threadIdx.x % AG_QG, valid, (const AG_GLOBAL float *)act_dxdy, (const AG_GLOBAL int32_t *)act, ticks, with_env != 0, slot, parity);
+  quiet_arena<NS, AV, QG>(hot, gs, arena, (int)threadIdx.x % QG, valid, (const AG_GLOBAL float *)act_dxdy, (const AG_GLOBAL int32_t *)act, ticks, with_env != 0, slot, parity);
 }
 #ifndef AG_KFUSED_ATTR
 #define AG_KFUSED_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -168,12 +171,12 @@ template <int NS, bool AV> __global__ void __launch_bounds__(256) AG_KQUIET_ATTR
 // running the general engine as a wave, one arena after the other.  Saves the second dependent launch (>= 3.4 us:
 // scripts/microbench/launch_floor.hip) at the price of serialising a wavefront's unfinished arenas -- the wrong trade
 // when most arenas need the general path every step (mass-1000 modes), where the two-kernel step is used.
-template <int NS, bool AV> __global__ void __launch_bounds__(256) AG_KFUSED_ATTR k_fused(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int lds_per_wave) {
+template <int NS, bool AV> __global__ void __launch_bounds__(256) AG_KFUSED_ATTR k_fused(const AgHot hot, const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int lds_per_wave) {
   int arena = (int)blockIdx.x * ((int)blockDim.x / AG_QG) + (int)threadIdx.x / AG_QG;
   const int A = gs->d.A; const bool valid = arena < A;
   if (!valid) arena = A - 1;
   const int sub = (int)threadIdx.x % AG_QG;
-  QHandOver h = quiet_arena<NS, AV>(gs, arena, sub, valid, (const AG_GLOBAL float *)act_dxdy, (const AG_GLOBAL int32_t *)act, ticks, with_env != 0, slot, -1);
+  QHandOver h = quiet_arena<NS, AV>(hot, gs, arena, sub, valid, (const AG_GLOBAL float *)act_dxdy, (const AG_GLOBAL int32_t *)act, ticks, with_env != 0, slot, -1);
   unsigned long long todo = __ballot(valid && sub == 0 && h.done != ticks);
   if (!todo) return;
   ag_mem_fence();  // the front part's stores precede the general part's loads of the same arena
@@ -246,7 +249,7 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
   const int use_q = e->d.P == 1 && !e->no_front;  // the lean front kernel handles single-player arenas' quiet steps
 #define CALL(N, V) for_each_arena_ns<N, V>(e, [&](AgCtx<N, V> &c) { \
     int qd = -1, qb = 0; \
-    if (use_q) { quiet_arena<N, V>(c.gs, c.arena, 0, true, c.act_dxdy, c.act, ticks, with_env != 0, c.slot); qd = c.gs->qinfo[2 * c.arena]; qb = c.gs->qinfo[2 * c.arena + 1]; if (qd == ticks) return; } \
+    if (use_q) { quiet_arena<N, V>(AgHot{c.gs->ar, c.gs->pl, c.gs->cells}, c.gs, c.arena, 0, true, c.act_dxdy, c.act, ticks, with_env != 0, c.slot); qd = c.gs->qinfo[2 * c.arena]; qb = c.gs->qinfo[2 * c.arena + 1]; if (qd == ticks) return; } \
     arena_load(c); env_step(c, ticks, with_env != 0, qd, qb); arena_store(c); })
   AG_DISPATCH_NS(e->ns, CALL);
 #undef CALL
@@ -257,19 +260,22 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
   // step it runs again so that the statistics notice when the arenas have become quiet
   const int use_q = front_ok && !(e->front_off && !e->fused && (e->step_no & 255) != 0);
   if (use_q) e->front_runs++;
+  const AgHot hot{e->s.ar, e->s.pl, e->s.cells};
   if (use_q && e->fused) {
     const unsigned lpw = (unsigned)((e->lds_bytes + 15) & ~(size_t)15);
     const int wg = e->fused_wg, apw = wg / AG_QG;  // threads and arenas per workgroup
-#define CALL(N, V) hipLaunchKernelGGL((k_fused<N, V>), dim3((e->d.A + apw - 1) / apw), dim3(wg), (wg / 64) * lpw, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, (int)lpw)
+#define CALL(N, V) hipLaunchKernelGGL((k_fused<N, V>), dim3((e->d.A + apw - 1) / apw), dim3(wg), (wg / 64) * lpw, e->stream, hot, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, (int)lpw)
     AG_DISPATCH_NS(e->ns, CALL);
 #undef CALL
     HIPCHK(hipGetLastError());
     return 0;
   }
   if (use_q) {
-#define CALL(N, V) hipLaunchKernelGGL((k_quiet<N, V>), dim3((e->d.A + 256 / AG_QG - 1) / (256 / AG_QG)), dim3(256), 0, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, e->parity)
+#define CALLQ(N, V, Q) hipLaunchKernelGGL((k_quiet<N, V, Q>), dim3((e->d.A + 256 / Q - 1) / (256 / Q)), dim3(256), 0, e->stream, hot, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, e->parity)
+#define CALL(N, V) do { switch (e->quiet_qg) { case 1: CALLQ(N, V, 1); break; case 2: CALLQ(N, V, 2); break; case 4: CALLQ(N, V, 4); break; case 8: CALLQ(N, V, 8); break; default: CALLQ(N, V, 16); break; } } while (0)
     AG_DISPATCH_NS(e->ns, CALL);
 #undef CALL
+#undef CALLQ
   }
 #define CALL(N, V) hipLaunchKernelGGL((k_step<N, V>), dim3(e->d.A < 4096 ? e->d.A : 4096), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, use_q, e->parity)
   AG_DISPATCH_NS(e->ns, CALL);
@@ -448,6 +454,13 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   e->fused_fixed = false; e->h_stat = nullptr; e->stat_ev = nullptr; e->stat_pending = false; e->step_no = e->front_runs = e->stat_req_front = e->stat_last_front = 0; e->stat_last_total = 0;
   { const char *fu = getenv("AGARCL_FUSED"); if (fu && (fu[0] == '0' || fu[0] == '1')) { e->fused = fu[0] == '1'; e->fused_fixed = true; } }
   s.qstat = alloc<int32_t>(e, 16);
+  // Lanes per arena of the lean front kernel.  The quiet tick is per-lane code that every lane of an arena's group carries
+  // redundantly and a pellet pass is wave-wide whatever the group size, so the group size only sets how many wavefronts the
+  // arenas make -- and from ~16k arenas on the launch is bound by issued wave-instructions.  Measured (MI355X, C2, us per
+  // step, lanes per arena 16 / 8 / 4 / 2 / 1): 16384: 17.2 / 15.2 / 15.0 / 16.4 / 19.2, 65536: 42.0 / 30.7 / 26.3 / 25.4 /
+  // 27.0, 262144: 137.7 / 90.4 / 71.6 / 66.6 / 64.8: best is ~2048 wavefronts (2 per SIMD) until one lane per arena is reached.
+  e->quiet_qg = 8; while (e->quiet_qg > 1 && (long)d.A * e->quiet_qg > 2048L * 64) e->quiet_qg >>= 1;
+  { const char *w = getenv("AGARCL_QUIET_QG"); if (w) { int v = atoi(w); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) e->quiet_qg = v; } }
   e->fused_wg = 256; { const char *w = getenv("AGARCL_FUSED_WG"); if (w) { int v = atoi(w); if (v == 64 || v == 128 || v == 256) e->fused_wg = v; } }
 #ifndef AGAR_CPU_EMU
   {

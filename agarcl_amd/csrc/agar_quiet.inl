@@ -22,7 +22,7 @@
 // Pellets streamed from HBM / L2.  A pass is a wave-level operation: for every lane group that asks for one, ALL 64
 // lanes read that arena's pellets (NS x 512 B per wave-instruction, every load issued before the first use: one
 // round trip per pass), accumulate lane-private partial results and combine them with DPP reductions.
-template <int NS> struct GrpPel {
+template <int NS, int QG = AG_QG> struct GrpPel {
   AG_GLOBAL float *xy; AG_GLOBAL int32_t *id; int sub;
 #ifdef AGAR_CPU_EMU
   AG_MEM bool lead() const { return true; }
@@ -57,7 +57,7 @@ template <int NS> struct GrpPel {
     const int lane = (int)threadIdx.x & 63;
     while (todo) {
       const int src = (int)__builtin_ctzll(todo);
-      todo &= ~((AG_QG == 64 ? ~0ull : ((1ull << (AG_QG & 63)) - 1ull)) << src);
+      todo &= ~((QG == 64 ? ~0ull : ((1ull << (QG & 63)) - 1ull)) << src);
       PelQuery2 b;
       b.x = u2f(__builtin_amdgcn_readlane(f2u(k.x), src)); b.y = u2f(__builtin_amdgcn_readlane(f2u(k.y), src));
       b.rr1 = u2f(__builtin_amdgcn_readlane(f2u(k.rr1), src)); b.rr2 = u2f(__builtin_amdgcn_readlane(f2u(k.rr2), src));
@@ -68,7 +68,7 @@ template <int NS> struct GrpPel {
       int c2 = 0; unsigned k1 = 0xffffffffu, k2 = 0xffffffffu;
       for (int s = 0; s < NS; s++) { const XY p = gp[s * 64]; pel_accumulate2<AV>(b, p.x, p.y, (unsigned)(s * 64 + lane), c2, k1, k2); }
       pel_reduce2(c2, k1, k2);
-      if ((lane & ~(AG_QG - 1)) == src) { out.cnt2 = c2; out.key1 = k1; out.key2 = k2; }
+      if ((lane & ~(QG - 1)) == src) { out.cnt2 = c2; out.key1 = k1; out.key2 = k2; }
     }
     return out;
   }
@@ -79,7 +79,7 @@ template <int NS> struct GrpPel {
     const int lane = (int)threadIdx.x & 63;
     while (todo) {
       const int src = (int)__builtin_ctzll(todo);  // first lane of the first group that still waits
-      todo &= ~((AG_QG == 64 ? ~0ull : ((1ull << (AG_QG & 63)) - 1ull)) << src);
+      todo &= ~((QG == 64 ? ~0ull : ((1ull << (QG & 63)) - 1ull)) << src);
       PelQuery b;  // that group's query, broadcast to the wave
       b.x = u2f(__builtin_amdgcn_readlane(f2u(k.x), src)); b.y = u2f(__builtin_amdgcn_readlane(f2u(k.y), src));
       b.rr = u2f(__builtin_amdgcn_readlane(f2u(k.rr), src)); b.rr1 = u2f(__builtin_amdgcn_readlane(f2u(k.rr1), src));
@@ -100,7 +100,7 @@ template <int NS> struct GrpPel {
         _Pragma("unroll") for (int s = 0; s < NS; s++) pel_accumulate<AV>(b, p[s].x, p[s].y, (unsigned)(s * 64 + lane), dmin, dsec, c0, c1, first);
         pel_reduce(b.rr, dmin, dsec, c0, c1, first);
       }
-      if ((lane & ~(AG_QG - 1)) == src) { out.dmin2 = u2f((int)dmin); out.dsec2 = u2f((int)dsec); out.cnt = c0; out.cnt1 = c1; out.first = (int)first; }
+      if ((lane & ~(QG - 1)) == src) { out.dmin2 = u2f((int)dmin); out.dsec2 = u2f((int)dsec); out.cnt = c0; out.cnt1 = c1; out.first = (int)first; }
     }
     return out;
   }
@@ -121,12 +121,12 @@ template <int NS> struct GrpPel {
 // Returns the hand-over (per lane, uniform over the group): ticks done (-1: nothing, == ticks: step finished) and the
 // agent's mass before the step.  parity >= 0: also count unfinished arenas in gs->qcount[parity] (two-kernel step).
 struct QHandOver { int done, before; };
-template <int NS, bool AV> AG_DEV QHandOver quiet_arena(const AgState *gs, int arena, int sub, bool valid, const AG_GLOBAL float *act_dxdy, const AG_GLOBAL int32_t *act, int ticks, bool with_env, int slot, int parity = -1) {
-  auto S = (AG_GLOBAL int32_t *)(gs->ar + (size_t)arena * AR_WORDS);
-  auto P = (AG_GLOBAL int32_t *)(gs->pl + (size_t)arena * PL_WORDS);
-  auto C = (AG_GLOBAL uint32_t *)(gs->cells + (size_t)arena * (CF_ALL * AG_CC));   // field f of cell 0 = C[AG_CELL_W(f, 0)]: one 48-byte run
+template <int NS, bool AV, int QG = AG_QG> AG_DEV QHandOver quiet_arena(const AgHot hot, const AgState *gs, int arena, int sub, bool valid, const AG_GLOBAL float *act_dxdy, const AG_GLOBAL int32_t *act, int ticks, bool with_env, int slot, int parity = -1) {
+  auto S = (AG_GLOBAL int32_t *)(hot.ar + (size_t)arena * AR_WORDS);
+  auto P = (AG_GLOBAL int32_t *)(hot.pl + (size_t)arena * PL_WORDS);
+  auto C = (AG_GLOBAL uint32_t *)(hot.cells + (size_t)arena * (CF_ALL * AG_CC));   // field f of cell 0 = C[AG_CELL_W(f, 0)]: one 48-byte run
   auto qi = (AG_GLOBAL int32_t *)(gs->qinfo + (size_t)arena * 2);
-  GrpPel<NS> pel{(AG_GLOBAL float *)(gs->pel_xy + (size_t)arena * 2 * (NS * 64)), (AG_GLOBAL int32_t *)(gs->pel_id + (size_t)arena * (NS * 64)), sub};
+  GrpPel<NS, QG> pel{(AG_GLOBAL float *)(gs->pel_xy + (size_t)arena * 2 * (NS * 64)), (AG_GLOBAL int32_t *)(gs->pel_id + (size_t)arena * (NS * 64)), sub};
   const bool lead = pel.lead() && valid;
 #if defined(AGAR_PROFILE) && !defined(AGAR_CPU_EMU)
   unsigned t0_ = (unsigned)__builtin_readcyclecounter(); unsigned long long w0_ = wall_clock64();

@@ -116,3 +116,6 @@ struct AgState {
   int32_t *qlist;         // [2][A] the arenas k_quiet left unfinished (same parity), in arrival order: k_step's work list
   unsigned long long *prof;  // [16] phase cycle sums (diagnostic builds only; may be null)
 };
+// The three pointers the lean front part needs before it can request an arena's state.  They travel as kernel arguments
+// (preloaded into SGPRs at wave start, see build.py) so that the state loads do not wait for a round trip to the descriptor.
+struct AgHot { int32_t *ar; int32_t *pl; uint32_t *cells; };

@@ -150,6 +150,37 @@ def test_front_kernel_on_off_equivalence(hip_engine_cls, monkeypatch):
         assert np.array_equal(b0, b1)
 
 
+@pytest.mark.parametrize("qg", [1, 2, 4, 8, 16])
+def test_front_kernel_lanes_per_arena(hip_engine_cls, oracle_lib, monkeypatch, qg):
+    """The lean front kernel runs with 1, 2, 4, 8 or 16 lanes per arena (chosen from the arena count; AGARCL_QUIET_QG pins it,
+    AGARCL_FUSED=0 selects the two-kernel step that uses it): 64 / 32 / 16 / 8 / 4 arenas share a wavefront and its pellet
+    passes.  Quiet C2 arenas plus a few big ones, lock-step against the oracle, rewards every step and whole state at the end."""
+    from oracle import blob
+    monkeypatch.setenv("AGARCL_QUIET_QG", str(qg)); monkeypatch.setenv("AGARCL_FUSED", "0")
+    A, steps = 150, 250   # 150 arenas: the last wavefront is ragged for every group size
+    eng = hip_engine_cls(A, **C2)
+    oras = [oracle_lib.OraEnv(**C2) for _ in range(A)]
+    seeds = (31000 + 7 * np.arange(A)).astype(np.uint32)
+    eng.seed(seeds); eng.reset(reset_ids=True)
+    for a, o in enumerate(oras):
+        o.seed(int(seeds[a])); o.reset(True)
+        if a % 37 == 5:   # a big cell: every tick eats, so the front part keeps handing over
+            d = blob.parse(o.dump()); d["players"][0]["cell_mass"][0] = 900
+            b = blob.build(d); o.load(b); eng.load(b, a)
+    rng = np.random.RandomState(qg)
+    for t in range(steps):
+        dxdy = rng.uniform(-1, 1, size=(A, 1, 2)).astype(np.float32); act = np.zeros((A, 1), dtype=np.int32)
+        eng.set_actions(dxdy, act); eng.step()
+        r = eng.rewards()
+        for a in range(A):
+            oras[a].take_actions(dxdy[a], act[a]); ro = oras[a].step()
+            assert r[a, 0] == ro[0], (t, a)
+    for a in range(A):
+        assert blob.diff(oras[a].dump(), eng.dump(a)) is None, a
+    assert not eng.flags().any()
+    eng.close()
+
+
 from snapshot_cases import replay_snapshot_case, snapshot_cases  # noqa: E402
 
 
