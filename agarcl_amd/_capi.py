@@ -54,7 +54,6 @@ SYMBOLS = [
     ("agarcl_rewards_dev", C.c_void_p, [C.c_void_p]),
     ("agarcl_dones_dev", C.c_void_p, [C.c_void_p]),
     ("agarcl_masses_dev", C.c_void_p, [C.c_void_p]),
-    ("agarcl_flags_dev", C.c_void_p, [C.c_void_p]),
     ("agarcl_packed_dev", C.c_void_p, [C.c_void_p, C.c_int32]),
     ("agarcl_last_slot", C.c_int, [C.c_void_p]),
     ("agarcl_get_rewards", C.c_int, [C.c_void_p, C.c_void_p]),
@@ -283,7 +282,7 @@ class BatchedEngine:
 
     def device_ptrs(self):
         return {"rewards": self.L.agarcl_rewards_dev(self.h), "dones": self.L.agarcl_dones_dev(self.h),
-                "masses": self.L.agarcl_masses_dev(self.h), "flags": self.L.agarcl_flags_dev(self.h),
+                "masses": self.L.agarcl_masses_dev(self.h),
                 "packed": self.L.agarcl_packed_dev(self.h, 0)}   # base of the ring of PACKED_SLOTS buffers
 
     def last_slot(self):

@@ -125,12 +125,16 @@ AG_DEV int ub_get(const UBlock &b, int k) { return b.w[k]; }
 AG_DEV void ub_set(UBlock &b, int k, int v) { b.w[k] = v; }
 template <class PT> AG_DEV void ub_load(UBlock &b, PT src, int n) { for (int i = 0; i < 32; i++) b.w[i] = i < n ? src[i] : 0; }
 template <class PT> AG_DEV void ub_store(const UBlock &b, PT dst, int n) { for (int i = 0; i < n; i++) dst[i] = b.w[i]; }
+template <class PT> AG_DEV void ub_load_t(UBlock &b, PT src, int n, int ag_ts_lg) { for (int i = 0; i < 32; i++) b.w[i] = i < n ? src[AG_TW(i)] : 0; }   // tile-transposed source
+template <class PT> AG_DEV void ub_store_t(const UBlock &b, PT dst, int n, int ag_ts_lg) { for (int i = 0; i < n; i++) dst[AG_TW(i)] = b.w[i]; }
 #else
 struct UBlock { int v; };
 AG_DEV int ub_get(const UBlock &b, int k) { return __builtin_amdgcn_readlane(b.v, k); }
 AG_DEV void ub_set(UBlock &b, int k, int v) { b.v = (AG_LANE == k) ? v : b.v; }
 template <class PT> AG_DEV void ub_load(UBlock &b, PT src, int n) { int l = AG_LANE; b.v = l < n ? src[l] : 0; }
 template <class PT> AG_DEV void ub_store(const UBlock &b, PT dst, int n) { int l = AG_LANE; if (l < n) dst[l] = b.v; }
+template <class PT> AG_DEV void ub_load_t(UBlock &b, PT src, int n, int ag_ts_lg) { int l = AG_LANE; b.v = l < n ? src[AG_TW(l)] : 0; }   // tile-transposed source
+template <class PT> AG_DEV void ub_store_t(const UBlock &b, PT dst, int n, int ag_ts_lg) { int l = AG_LANE; if (l < n) dst[AG_TW(l)] = b.v; }
 #endif
 
 // ---- numerics: C++ std::min/max/clamp on floats with their NaN behaviour (R: core/utils.hpp:19-21)
@@ -210,7 +214,7 @@ template <int NS, bool AV> struct AgCtx {
 #endif
   const AgState *gs;
   const AG_GLOBAL float *act_dxdy; const AG_GLOBAL int32_t *act;
-  int arena, P, PC, cells_off, slot;
+  int arena, P, PC, cells_off, slot, ts_lg;
   unsigned char *lds;
   UBlock S;    // arena words (AR_*): register-resident for the whole launch
   UBlock PB;   // current player's words (PL_*): valid inside tick_player only; LDS PLS is its home
@@ -243,10 +247,12 @@ G_SLICE(g_vx, float, vir_x, c.gs->d.VC) G_SLICE(g_vy, float, vir_y, c.gs->d.VC) 
 G_SLICE(g_vm, int32_t, vir_mass, c.gs->d.VC) G_SLICE(g_vh, int32_t, vir_hits, c.gs->d.VC) G_SLICE(g_vid, int32_t, vir_id, c.gs->d.VC)
 G_SLICE(g_fx, float, food_x, c.gs->d.FC) G_SLICE(g_fy, float, food_y, c.gs->d.FC) G_SLICE(g_fvx, float, food_vx, c.gs->d.FC) G_SLICE(g_fvy, float, food_vy, c.gs->d.FC)
 G_SLICE(g_fid, int32_t, food_id, c.gs->d.FC)
-G_SLICE(g_mt, uint64_t, mt, 312) G_SLICE(g_ar, int32_t, ar, AR_WORDS)
-template <int NS, bool AV> AG_DEV AG_GLOBAL int32_t *g_pl(const AgCtx<NS, AV> &c) { return (AG_GLOBAL int32_t *)(c.gs->pl + (size_t)c.arena * c.P * PL_WORDS); }
+G_SLICE(g_mt, uint64_t, mt, 312)
+// tile-transposed arrays (agar_types.h): word w of the returned block is [AG_TW(w)]
+template <int NS, bool AV> AG_DEV AG_GLOBAL int32_t *g_ar(const AgCtx<NS, AV> &c) { const int ag_ts_lg = c.ts_lg; return (AG_GLOBAL int32_t *)(c.gs->ar + AG_TILE_BASE(c.arena, AR_WORDS)); }
+template <int NS, bool AV> AG_DEV AG_GLOBAL int32_t *g_pl(const AgCtx<NS, AV> &c) { const int ag_ts_lg = c.ts_lg; return (AG_GLOBAL int32_t *)(c.gs->pl + AG_TILE_BASE(c.arena, c.P * PL_WORDS)); }
 template <int NS, bool AV> AG_DEV AG_GLOBAL int32_t *g_vt(const AgCtx<NS, AV> &c, int p) { return (AG_GLOBAL int32_t *)(c.gs->vticks + ((size_t)c.arena * c.P + p) * AG_VT_CAP); }
-template <int NS, bool AV> AG_DEV AG_GLOBAL uint32_t *g_cells(const AgCtx<NS, AV> &c, int p) { return (AG_GLOBAL uint32_t *)(c.gs->cells + ((size_t)c.arena * c.P + p) * (CF_ALL * AG_CC)); }
+template <int NS, bool AV> AG_DEV AG_GLOBAL uint32_t *g_cells(const AgCtx<NS, AV> &c, int p) { const int ag_ts_lg = c.ts_lg; return (AG_GLOBAL uint32_t *)(c.gs->cells + AG_TILE_BASE(c.arena, c.P * (CF_ALL * AG_CC)) + AG_TW(p * (CF_ALL * AG_CC))); }
 template <int NS, bool AV> AG_DEV const AG_GLOBAL float *g_lut_r(const AgCtx<NS, AV> &c) { return (const AG_GLOBAL float *)c.gs->lut_r; }
 template <int NS, bool AV> AG_DEV const AG_GLOBAL float *g_lut_ms(const AgCtx<NS, AV> &c) { return (const AG_GLOBAL float *)c.gs->lut_ms; }
 template <int NS, bool AV> AG_DEV const AG_GLOBAL float *g_lut_ss(const AgCtx<NS, AV> &c) { return (const AG_GLOBAL float *)c.gs->lut_ss; }
@@ -335,11 +341,12 @@ template <int NS, bool AV> AG_DEV void arena_load(AgCtx<NS, AV> &c, bool want_pe
   // out of reach of every pellet -- AR_SAFE budget -- never touches them)
   // (want_pellets: the caller knows a general tick is coming -- k_step resuming after k_quiet -- so the pellet loads
   // join the same round trip)
+  const int ag_ts_lg = c.ts_lg;
   c.pel_loaded = false;
   if (want_pellets) { auto gxy = g_pxy(c); AG_PEL_FOR(s, lane, i) { PELX(c, s, lane) = gxy[2 * i]; PELY(c, s, lane) = gxy[2 * i + 1]; } c.pel_loaded = true; }
-  ub_load(c.S, g_ar(c), AR_WORDS);
+  ub_load_t(c.S, g_ar(c), AR_WORDS, ag_ts_lg);
   auto gpl = g_pl(c);
-  AG_LANES(i, c.P * PL_WORDS) PLS(c, 0)[i] = gpl[i];
+  AG_LANES(i, c.P * PL_WORDS) PLS(c, 0)[i] = gpl[AG_TW(i)];
   for (int p = 0; p < c.P; p++) {
     auto g = g_cells(c, p); uint32_t *l = (uint32_t *)(c.lds + c.cells_off + p * CELL_STRIDE);
     AG_LANES(i, AG_CC) {
@@ -362,6 +369,7 @@ template <int NS, bool AV> AG_DEV void ensure_pellets(AgCtx<NS, AV> &c) {
 }
 template <int NS, bool AV> AG_DEV void arena_store(AgCtx<NS, AV> &c) {
   ag_lds_order();
+  const int ag_ts_lg = c.ts_lg;
   int np = SR(c, AR_NPEL);
   if (c.pel_dirty) {  // whole register file incl. sentinels
     auto gxy = g_pxy(c);
@@ -379,7 +387,7 @@ template <int NS, bool AV> AG_DEV void arena_store(AgCtx<NS, AV> &c) {
       for (int f = 0; f < CF_ALL; f++) g[AG_CELL_W(f, i)] = l[f * AG_CC + i];
     }
   }
-  ub_store(c.S, g_ar(c), AR_WORDS);
+  ub_store_t(c.S, g_ar(c), AR_WORDS, ag_ts_lg);
   {  // diagnostics (agarcl_debug_work): pellet-array transfers of this launch; flag watch word (agarcl_poll_flags)
     const int moved = (c.pel_loaded ? 1 : 0) + (c.pel_dirty ? 1 : 0);
     if (moved) { AG_SERIAL { PLS(c, 0)[PL_PASSES] += moved; } ag_lds_order(); }
@@ -387,7 +395,7 @@ template <int NS, bool AV> AG_DEV void arena_store(AgCtx<NS, AV> &c) {
     if (AG_RARE(fl != 0)) { AG_SERIAL { ag_atomic_or(c.gs->qstat + 1, fl); } }
   }
   auto gpl = g_pl(c);
-  AG_LANES(i, c.P * PL_WORDS) gpl[i] = PLS(c, 0)[i];
+  AG_LANES(i, c.P * PL_WORDS) gpl[AG_TW(i)] = PLS(c, 0)[i];
   int nevp = SR(c, AR_NEVP), nevv = SR(c, AR_NEVV);
   if (nevp > 0) { auto ge = (AG_GLOBAL int32_t *)(c.gs->ev_p + (size_t)c.arena * AG_EV_CAP); int lim = nevp < AG_EV_CAP ? nevp : AG_EV_CAP; AG_LANES(i, lim) ge[i] = L_I(c, L_EVP)[i]; }
   if (nevv > 0) { auto ge = (AG_GLOBAL int32_t *)(c.gs->ev_v + (size_t)c.arena * AG_EVV_CAP); int lim = nevv < AG_EVV_CAP ? nevv : AG_EVV_CAP; AG_LANES(i, lim) ge[i] = L_I(c, L_EVV)[i]; }

@@ -31,6 +31,9 @@ static thread_local std::string g_err;
 static int fail(int code, const std::string &m) { g_err = m; return code; }
 extern "C" const char *agarcl_last_error(void) { return g_err.c_str(); }
 
+// host index of word w of arena a in a tile-transposed array with R words per arena (agar_types.h)
+static inline size_t tix(int ag_ts_lg, size_t a, size_t R, size_t w) { return AG_TILE_BASE(a, R) + AG_TW(w); }
+
 // ---- memory / launch abstraction -----------------------------------------------------------------
 #ifdef AGAR_CPU_EMU
 typedef void *ag_stream_t;
@@ -71,7 +74,8 @@ struct agarcl_env {
   bool fused;     // single-launch step (k_fused) instead of k_quiet + k_step: see k_fused
   bool fused_fixed;                // AGARCL_FUSED=0/1 pins the choice
   int fused_wg;                    // threads per workgroup of k_fused (64, 128 or 256)
-  int quiet_qg;                    // lanes per arena of k_quiet (2, 4, 8 or 16): see agarcl_create
+  int quiet_qg;                    // lanes per arena of k_quiet (1, 2, 4, 8 or 16): see agarcl_create
+  uint32_t *d_stage; size_t stage_words;  // staging buffer of pull_t / push_t (one arena's largest transposed block)
   int32_t *h_stat; void *stat_ev;  // pinned copy of {qstat, flag watch word} + the event that says it has arrived
   uint8_t *d_mask;                 // [A] reset mask staging (host masks are copied here, stream-ordered)
   uint32_t flags_seen;             // OR of every flag watch sample so far (agarcl_poll_flags)
@@ -87,7 +91,7 @@ struct agarcl_env {
 template <int NS, bool AV> AG_DEV void ag_ctx_init(AgCtx<NS, AV> &c, const AgState *gs, int arena, unsigned char *lds, const float *act_dxdy, const int32_t *act, int slot = 0) {
   c.slot = slot;
   c.gs = gs; c.arena = arena; c.lds = lds; c.act_dxdy = (const AG_GLOBAL float *)act_dxdy; c.act = (const AG_GLOBAL int32_t *)act;
-  c.P = gs->d.P; c.PC = gs->d.PC;
+  c.P = gs->d.P; c.PC = gs->d.PC; c.ts_lg = gs->d.ts_lg;
   ag_lds_layout(c.P, &c.cells_off);
   c.ncreated = 0; c.pel_dirty = false; c.pel_loaded = false;
 }
@@ -113,20 +117,27 @@ extern __shared__ __align__(16) unsigned char ag_lds[];
 #define AG_KSTEP_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
 #define AG_KERNEL_PROLOGUE AgCtx<NS, AV> c; ag_ctx_init(c, gs, (int)blockIdx.x, ag_lds, act_dxdy, act);
+// Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), and the per-arena word arrays are tile-transposed
+// (agar_types.h): 64 consecutive arenas share their cache lines.  This bijective remap gives every XCD one contiguous range
+// of workgroup indices -- hence of arenas -- so that a tile's lines live in ONE L2 instead of up to eight (speed only).
+__device__ __forceinline__ int ag_xcd_swizzle(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
 
 // One wavefront per arena, grid-stride: the grid is min(A, 4096) single-wave workgroups -- 4 per SIMD is all the register
 // budget admits, so a larger grid would only queue -- and every workgroup walks its share of the arenas.
 // use_q: k_quiet ran in front of this launch and left a work list (qlist / qcount) of the arenas it did not finish; only
 // those are visited, resuming where the front part stopped.  A quiet-dominated step therefore costs this launch one
 // scalar load per workgroup whatever the arena count.
-template <int NS, bool AV> __global__ void __launch_bounds__(64) AG_KSTEP_ATTR k_step(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int use_q, int parity) {
+template <int NS, bool AV, int TSLG> __global__ void __launch_bounds__(64) AG_KSTEP_ATTR k_step(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int use_q, int parity) {
   const int A = gs->d.A;
   int total = A;
   if (use_q) {
     total = gs->qcount[parity];
     if (blockIdx.x == 0 && threadIdx.x == 0) gs->qcount[parity ^ 1] = 0;   // re-arm the other parity's counter for the next step's k_quiet
   }
-  for (int it = (int)blockIdx.x; it < total; it += (int)gridDim.x) {
+  for (int it = TSLG ? ag_xcd_swizzle((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x; it < total; it += (int)gridDim.x) {
     int arena = it, q_done = -1, q_before = 0;
     if (use_q) {
       arena = ((const AG_GLOBAL int32_t *)gs->qlist)[(size_t)parity * A + it];
@@ -134,6 +145,7 @@ template <int NS, bool AV> __global__ void __launch_bounds__(64) AG_KSTEP_ATTR k
       q_done = qi[0]; q_before = qi[1];
     }
     AgCtx<NS, AV> c; ag_ctx_init(c, gs, arena, ag_lds, act_dxdy, act, slot);
+    c.ts_lg = TSLG;   // (== gs->d.ts_lg, as a constant: the array strides fold into the address arithmetic)
 #ifdef AGAR_PROFILE
     for (int i = 0; i < AG_NPROF; i++) c.tacc[i] = 0;
     c.tlast = (unsigned)__builtin_readcyclecounter();
@@ -157,11 +169,11 @@ template <int NS, bool AV> __global__ void __launch_bounds__(64) AG_KSTEP_ATTR k
 #ifndef AG_KQUIET_ATTR
 #define AG_KQUIET_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
-template <int NS, bool AV, int QG> __global__ void __launch_bounds__(256) AG_KQUIET_ATTR k_quiet(const AgHot hot, const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int parity) {
-  int arena = (int)blockIdx.x * (256 / QG) + (int)threadIdx.x / QG;
+template <int NS, bool AV, int QG, int TSLG> __global__ void __launch_bounds__(256) AG_KQUIET_ATTR k_quiet(const AgHot hot, const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int parity) {
+  int arena = (TSLG ? ag_xcd_swizzle((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * (256 / QG) + (int)threadIdx.x / QG;
   const int A = gs->d.A; const bool valid = arena < A;
   if (!valid) arena = A - 1;
-  quiet_arena<NS, AV, QG>(hot, gs, arena, (int)threadIdx.x % QG, valid, (const AG_GLOBAL float *)act_dxdy, (const AG_GLOBAL int32_t *)act, ticks, with_env != 0, slot, parity);
+  quiet_arena<NS, AV, QG, TSLG>(hot, gs, arena, (int)threadIdx.x % QG, valid, (const AG_GLOBAL float *)act_dxdy, (const AG_GLOBAL int32_t *)act, ticks, with_env != 0, slot, parity);
 }
 #ifndef AG_KFUSED_ATTR
 #define AG_KFUSED_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -172,11 +184,11 @@ template <int NS, bool AV, int QG> __global__ void __launch_bounds__(256) AG_KQU
 // scripts/microbench/launch_floor.hip) at the price of serialising a wavefront's unfinished arenas -- the wrong trade
 // when most arenas need the general path every step (mass-1000 modes), where the two-kernel step is used.
 template <int NS, bool AV> __global__ void __launch_bounds__(256) AG_KFUSED_ATTR k_fused(const AgHot hot, const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int lds_per_wave) {
-  int arena = (int)blockIdx.x * ((int)blockDim.x / AG_QG) + (int)threadIdx.x / AG_QG;
+  int arena = (int)blockIdx.x * ((int)blockDim.x / AG_QG) + (int)threadIdx.x / AG_QG;   // (arena-major layout only: ts_lg == 0)
   const int A = gs->d.A; const bool valid = arena < A;
   if (!valid) arena = A - 1;
   const int sub = (int)threadIdx.x % AG_QG;
-  QHandOver h = quiet_arena<NS, AV>(hot, gs, arena, sub, valid, (const AG_GLOBAL float *)act_dxdy, (const AG_GLOBAL int32_t *)act, ticks, with_env != 0, slot, -1);
+  QHandOver h = quiet_arena<NS, AV, AG_QG, 0>(hot, gs, arena, sub, valid, (const AG_GLOBAL float *)act_dxdy, (const AG_GLOBAL int32_t *)act, ticks, with_env != 0, slot, -1);
   unsigned long long todo = __ballot(valid && sub == 0 && h.done != ticks);
   if (!todo) return;
   ag_mem_fence();  // the front part's stores precede the general part's loads of the same arena
@@ -185,6 +197,7 @@ template <int NS, bool AV> __global__ void __launch_bounds__(256) AG_KFUSED_ATTR
     const int src = (int)__builtin_ctzll(todo); todo &= todo - 1ull;
     const int ar = __builtin_amdgcn_readlane(arena, src), qd = __builtin_amdgcn_readlane(h.done, src), qb = __builtin_amdgcn_readlane(h.before, src);
     AgCtx<NS, AV> c; ag_ctx_init(c, gs, ar, lds, act_dxdy, act, slot);
+    c.ts_lg = 0;
     arena_load(c, true);
     env_step(c, ticks, with_env != 0, qd, qb);
     arena_store(c);
@@ -207,11 +220,43 @@ template <int NS, bool AV> __global__ void __launch_bounds__(64) k_respawn(const
   respawn_dead(c);
   arena_store(c);
 }
-__global__ void k_set_word(int32_t *base, int stride, int n, int value) {
+__global__ void k_set_ar_word(int32_t *ar, int ag_ts_lg, int word, int n, int value) {  // one arena word of every arena
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) base[(size_t)i * stride] = value;
+  if (i < n) ar[AG_TILE_BASE(i, AR_WORDS) + AG_TW(word)] = value;
 }
+// one arena's block of a tile-transposed array <-> a contiguous staging buffer (host copies: dumps, snapshots, introspection)
+__global__ void k_tile_gather(const uint32_t *src, uint32_t *dst, int R, int ag_ts_lg) { int w = blockIdx.x * blockDim.x + threadIdx.x; if (w < R) dst[w] = src[AG_TW(w)]; }
+__global__ void k_tile_scatter(uint32_t *dst, const uint32_t *src, int R, int ag_ts_lg) { int w = blockIdx.x * blockDim.x + threadIdx.x; if (w < R) dst[AG_TW(w)] = src[w]; }
 #endif
+// host copy of ONE arena's block of a tile-transposed array (32-bit words): device gather / scatter through a staging buffer
+template <class T> static int pull_t(agarcl_env *e, std::vector<T> &h, const T *dev, size_t a, size_t R) {
+  static_assert(sizeof(T) == 4, "32-bit words");
+  h.resize(R);
+  if (!R) return 0;
+  const int ag_ts_lg = e->d.ts_lg;
+#ifdef AGAR_CPU_EMU
+  for (size_t w = 0; w < R; w++) h[w] = dev[tix(ag_ts_lg, a, R, w)];
+  return 0;
+#else
+  if (R > e->stage_words) return -1;
+  hipLaunchKernelGGL(k_tile_gather, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, e->stream, (const uint32_t *)(dev + AG_TILE_BASE(a, R)), e->d_stage, (int)R, ag_ts_lg);
+  return d2h(h.data(), e->d_stage, R * 4, e->stream);
+#endif
+}
+template <class T> static int push_t(agarcl_env *e, const std::vector<T> &h, T *dev, size_t a) {
+  static_assert(sizeof(T) == 4, "32-bit words");
+  const size_t R = h.size();
+  if (!R) return 0;
+  const int ag_ts_lg = e->d.ts_lg;
+#ifdef AGAR_CPU_EMU
+  for (size_t w = 0; w < R; w++) dev[tix(ag_ts_lg, a, R, w)] = h[w];
+  return 0;
+#else
+  if (R > e->stage_words || h2d(e->d_stage, h.data(), R * 4, e->stream)) return -1;
+  hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, e->stream, (uint32_t *)(dev + AG_TILE_BASE(a, R)), (const uint32_t *)e->d_stage, (int)R, ag_ts_lg);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+#endif
+}
 
 #ifndef AGAR_CPU_EMU
 // Asynchronous statistics.  The kernels keep two running words in HBM (AgState::qstat): [0] the arena-steps the front
@@ -232,7 +277,7 @@ static void poll_stats(agarcl_env *e, bool adapt) {
       const double frac = (double)(uint32_t)(e->h_stat[0] - e->stat_last_total) / ((double)steps * (double)e->d.A);
       // (from 32768 arenas on the two-kernel step is the faster one even when every arena is quiet: the lean front kernel
       // keeps 4 waves per SIMD where the fused kernel, which carries the general engine's registers, keeps 2)
-      if (e->fused && frac > 0.05) e->fused = false; else if (!e->fused && frac < 0.01) e->fused = e->d.A < AG_FUSED_MAX_ARENAS;
+      if (e->fused && frac > 0.05) e->fused = false; else if (!e->fused && frac < 0.01) e->fused = e->d.A < AG_FUSED_MAX_ARENAS && e->d.ts_lg == 0;
       // the two-kernel step's front launch is pure overhead when it finishes (almost) nothing: mass-1000 modes
       e->front_off = !e->fused && frac > 0.99;
     }
@@ -249,7 +294,7 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
   const int use_q = e->d.P == 1 && !e->no_front;  // the lean front kernel handles single-player arenas' quiet steps
 #define CALL(N, V) for_each_arena_ns<N, V>(e, [&](AgCtx<N, V> &c) { \
     int qd = -1, qb = 0; \
-    if (use_q) { quiet_arena<N, V>(AgHot{c.gs->ar, c.gs->pl, c.gs->cells}, c.gs, c.arena, 0, true, c.act_dxdy, c.act, ticks, with_env != 0, c.slot); qd = c.gs->qinfo[2 * c.arena]; qb = c.gs->qinfo[2 * c.arena + 1]; if (qd == ticks) return; } \
+    if (use_q) { const AgHot hot_{c.gs->ar, c.gs->pl, c.gs->cells}; if (c.ts_lg) quiet_arena<N, V, AG_QG, 6>(hot_, c.gs, c.arena, 0, true, c.act_dxdy, c.act, ticks, with_env != 0, c.slot); else quiet_arena<N, V, AG_QG, 0>(hot_, c.gs, c.arena, 0, true, c.act_dxdy, c.act, ticks, with_env != 0, c.slot); qd = c.gs->qinfo[2 * c.arena]; qb = c.gs->qinfo[2 * c.arena + 1]; if (qd == ticks) return; } \
     arena_load(c); env_step(c, ticks, with_env != 0, qd, qb); arena_store(c); })
   AG_DISPATCH_NS(e->ns, CALL);
 #undef CALL
@@ -261,7 +306,8 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
   const int use_q = front_ok && !(e->front_off && !e->fused && (e->step_no & 255) != 0);
   if (use_q) e->front_runs++;
   const AgHot hot{e->s.ar, e->s.pl, e->s.cells};
-  if (use_q && e->fused) {
+  const bool tiled = e->d.ts_lg != 0;   // (0 or 6, agarcl_create)
+  if (use_q && e->fused && !tiled) {   // (k_fused exists for the arena-major layout only)
     const unsigned lpw = (unsigned)((e->lds_bytes + 15) & ~(size_t)15);
     const int wg = e->fused_wg, apw = wg / AG_QG;  // threads and arenas per workgroup
 #define CALL(N, V) hipLaunchKernelGGL((k_fused<N, V>), dim3((e->d.A + apw - 1) / apw), dim3(wg), (wg / 64) * lpw, e->stream, hot, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, (int)lpw)
@@ -271,14 +317,24 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
     return 0;
   }
   if (use_q) {
-#define CALLQ(N, V, Q) hipLaunchKernelGGL((k_quiet<N, V, Q>), dim3((e->d.A + 256 / Q - 1) / (256 / Q)), dim3(256), 0, e->stream, hot, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, e->parity)
+#define CALLQ(N, V, Q) hipLaunchKernelGGL((k_quiet<N, V, Q, T>), dim3((e->d.A + 256 / Q - 1) / (256 / Q)), dim3(256), 0, e->stream, hot, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, e->parity)
 #define CALL(N, V) do { switch (e->quiet_qg) { case 1: CALLQ(N, V, 1); break; case 2: CALLQ(N, V, 2); break; case 4: CALLQ(N, V, 4); break; case 8: CALLQ(N, V, 8); break; default: CALLQ(N, V, 16); break; } } while (0)
-    AG_DISPATCH_NS(e->ns, CALL);
+#define T 6
+    if (tiled) AG_DISPATCH_NS(e->ns, CALL);
+#undef T
+#define T 0
+    if (!tiled) AG_DISPATCH_NS(e->ns, CALL);
+#undef T
 #undef CALL
 #undef CALLQ
   }
-#define CALL(N, V) hipLaunchKernelGGL((k_step<N, V>), dim3(e->d.A < 4096 ? e->d.A : 4096), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, use_q, e->parity)
-  AG_DISPATCH_NS(e->ns, CALL);
+#define CALL(N, V) hipLaunchKernelGGL((k_step<N, V, T>), dim3(e->d.A < 4096 ? e->d.A : 4096), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, use_q, e->parity)
+#define T 6
+  if (tiled) AG_DISPATCH_NS(e->ns, CALL);
+#undef T
+#define T 0
+  if (!tiled) AG_DISPATCH_NS(e->ns, CALL);
+#undef T
 #undef CALL
   if (use_q) e->parity ^= 1;
   HIPCHK(hipGetLastError());
@@ -411,6 +467,10 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   d.PC = ((npel > 0 ? npel : 1) + 63) / 64 * 64;
   d.VC = cfg->cap_viruses > 0 ? cfg->cap_viruses : cfg->num_viruses + 64;
   d.FC = cfg->cap_foods > 0 ? cfg->cap_foods : 256;
+  // layout of the per-arena word arrays (agar_types.h): tiles of 64 arenas where the lean front kernel runs with one to four
+  // lanes per arena (single-player batches from 32768 arenas on), arena-major otherwise.  AGARCL_TILE_LG=0/6 pins it.
+  d.ts_lg = (d.P == 1 && d.A >= 32768) ? 6 : 0;
+  { const char *t = getenv("AGARCL_TILE_LG"); if (t && (t[0] == '0' || t[0] == '6') && !t[1]) d.ts_lg = t[0] - '0'; }
   if (d.P > AG_MAX_PLAYERS) { agarcl_destroy(e); return fail(AGARCL_E_UNSUPPORTED, "too many players per arena"); }
   if (cfg->cap_cells != 0 && cfg->cap_cells != AG_CC) { agarcl_destroy(e); return fail(AGARCL_E_INVALID, "cap_cells is fixed at 32 in this build"); }
   e->d = d; e->g = g;
@@ -428,8 +488,11 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   s.vir_x = alloc<float>(e, A * d.VC); s.vir_y = alloc<float>(e, A * d.VC); s.vir_vx = alloc<float>(e, A * d.VC); s.vir_vy = alloc<float>(e, A * d.VC);
   s.vir_mass = alloc<int32_t>(e, A * d.VC); s.vir_hits = alloc<int32_t>(e, A * d.VC); s.vir_id = alloc<int32_t>(e, A * d.VC);
   s.food_x = alloc<float>(e, A * d.FC); s.food_y = alloc<float>(e, A * d.FC); s.food_vx = alloc<float>(e, A * d.FC); s.food_vy = alloc<float>(e, A * d.FC); s.food_id = alloc<int32_t>(e, A * d.FC);
-  s.cells = alloc<uint32_t>(e, A * d.P * CF_ALL * AG_CC);
-  s.pl = alloc<int32_t>(e, A * d.P * PL_WORDS); s.vticks = alloc<int32_t>(e, A * d.P * AG_VT_CAP); s.ar = alloc<int32_t>(e, A * AR_WORDS);
+  const int ag_ts_lg = d.ts_lg;
+  const size_t At = AG_TILE_ARENAS(A);  // the tile-transposed arrays hold whole tiles
+  e->stage_words = (size_t)d.P * CF_ALL * AG_CC; e->d_stage = alloc<uint32_t>(e, e->stage_words);
+  s.cells = alloc<uint32_t>(e, At * d.P * CF_ALL * AG_CC);
+  s.pl = alloc<int32_t>(e, At * d.P * PL_WORDS); s.vticks = alloc<int32_t>(e, A * d.P * AG_VT_CAP); s.ar = alloc<int32_t>(e, At * AR_WORDS);
   s.mt = alloc<uint64_t>(e, A * 312); s.rnd = alloc<int32_t>(e, A * 35);
   s.scratch = d.P > 1 ? alloc<int32_t>(e, A * (size_t)AGM_WORDS) : nullptr;
   if (d.P > 1 && !s.scratch) { agarcl_destroy(e); return fail(AGARCL_E_NOMEM, "device allocation failed"); }
@@ -447,12 +510,12 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   s.qlist = alloc<int32_t>(e, 2 * (size_t)d.A);
   { const char *nf = getenv("AGARCL_NO_FRONT"); e->no_front = nf && nf[0] == '1'; }
   // modes 0-4 start agents at mass 25 (quiet-dominated); 5 and 6 start at mass 1000 (general path every step)
-  e->fused = d.P == 1 && cfg->mode_number <= 4 && d.A < AG_FUSED_MAX_ARENAS;  // starting point; poll_stats follows what the arenas actually do
+  e->fused = d.P == 1 && cfg->mode_number <= 4 && d.A < AG_FUSED_MAX_ARENAS && d.ts_lg == 0;  // starting point; poll_stats follows what the arenas actually do
   e->front_off = d.P == 1 && cfg->mode_number > 4;
   e->work_step0 = e->work_front0 = 0; e->work_unf0 = 0; e->work_pass0 = 0;
   e->flags_seen = 0; e->d_mask = alloc<uint8_t>(e, (size_t)d.A);
   e->fused_fixed = false; e->h_stat = nullptr; e->stat_ev = nullptr; e->stat_pending = false; e->step_no = e->front_runs = e->stat_req_front = e->stat_last_front = 0; e->stat_last_total = 0;
-  { const char *fu = getenv("AGARCL_FUSED"); if (fu && (fu[0] == '0' || fu[0] == '1')) { e->fused = fu[0] == '1'; e->fused_fixed = true; } }
+  { const char *fu = getenv("AGARCL_FUSED"); if (fu && (fu[0] == '0' || fu[0] == '1')) { e->fused = fu[0] == '1' && d.ts_lg == 0; e->fused_fixed = true; } }
   s.qstat = alloc<int32_t>(e, 16);
   // Lanes per arena of the lean front kernel.  The quiet tick is per-lane code that every lane of an arena's group carries
   // redundantly and a pellet pass is wave-wide whatever the group size, so the group size only sets how many wavefronts the
@@ -493,8 +556,8 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
         h2d(e->lut_ss, ss.data(), ss.size() * 4, e->stream) || h2d(e->lut_anti, an.data(), an.size() * 4, e->stream)) { agarcl_destroy(e); return fail(AGARCL_E_HIP, "LUT upload failed"); }
   }
   {  // initial arena words: id counter 1 (first entity id 2, core/Ball.hpp:18,97), identity player order
-    std::vector<int32_t> ar(A * AR_WORDS, 0);
-    for (size_t a = 0; a < A; a++) { ar[a * AR_WORDS + AR_IDC] = 1; ar[a * AR_WORDS + AR_MTIDX] = 312; for (int p = 0; p < d.P; p++) ar[a * AR_WORDS + AR_ORDER0 + p] = p; }
+    std::vector<int32_t> ar(AG_TILE_ARENAS(A) * AR_WORDS, 0);
+    for (size_t a = 0; a < A; a++) { ar[tix(ag_ts_lg, a, AR_WORDS, AR_IDC)] = 1; ar[tix(ag_ts_lg, a, AR_WORDS, AR_MTIDX)] = 312; for (int p = 0; p < d.P; p++) ar[tix(ag_ts_lg, a, AR_WORDS, AR_ORDER0 + p)] = p; }
     if (h2d(s.ar, ar.data(), ar.size() * 4, e->stream)) { agarcl_destroy(e); return fail(AGARCL_E_HIP, "state upload failed"); }
   }
   *out = e;
@@ -535,10 +598,10 @@ extern "C" int agarcl_seed(agarcl_env *e, const uint32_t *seeds_host, uint32_t b
   for (size_t a = 0; a < A; a++) glibc_srand_host(&rnd[a * 35], seeds_host ? seeds_host[a] : base_seed + (uint32_t)a);
   if (h2d(e->s.rnd, rnd.data(), rnd.size() * 4, e->stream)) return fail(AGARCL_E_HIP, "seed upload failed");
 #ifdef AGAR_CPU_EMU
-  for (size_t a = 0; a < A; a++) e->s.ar[a * AR_WORDS + AR_MTIDX] = 312;
+  for (size_t a = 0; a < A; a++) e->s.ar[tix(e->d.ts_lg, a, AR_WORDS, AR_MTIDX)] = 312;
 #else
   HIPCHK(hipSetDevice(e->device));
-  hipLaunchKernelGGL(k_set_word, dim3((e->d.A + 255) / 256), dim3(256), 0, e->stream, e->s.ar + AR_MTIDX, AR_WORDS, e->d.A, 312);
+  hipLaunchKernelGGL(k_set_ar_word, dim3((e->d.A + 255) / 256), dim3(256), 0, e->stream, e->s.ar, e->d.ts_lg, (int)AR_MTIDX, e->d.A, 312);
   HIPCHK(hipGetLastError());
 #endif
   return AGARCL_OK;
@@ -551,7 +614,7 @@ extern "C" int agarcl_seed_arena(agarcl_env *e, int32_t arena, uint32_t seed) {
   std::vector<int32_t> rnd(35); glibc_srand_host(rnd.data(), seed);
   int32_t idx = 312;
   if (h2d(e->s.mt + (size_t)arena * 312, mt.data(), 312 * 8, e->stream) || h2d(e->s.rnd + (size_t)arena * 35, rnd.data(), 35 * 4, e->stream) ||
-      h2d(e->s.ar + (size_t)arena * AR_WORDS + AR_MTIDX, &idx, 4, e->stream)) return fail(AGARCL_E_HIP, "seed upload failed");
+      h2d(e->s.ar + tix(e->d.ts_lg, (size_t)arena, AR_WORDS, AR_MTIDX), &idx, 4, e->stream)) return fail(AGARCL_E_HIP, "seed upload failed");
   // (BaseEnvironment::seed_ -- what a later save writes as "seed" -- is NOT touched by a load: Engine::seed is called
   // directly, Engine.hpp:347; e->seeds therefore keeps the last agarcl_seed value)
   return AGARCL_OK;
@@ -564,8 +627,9 @@ extern "C" int agarcl_get_seeds(agarcl_env *e, uint32_t *out) {
 // Raw per-arena words (AR_*) and per-player words (PL_*, slot-major): introspection for the snapshot code and tests.
 extern "C" int agarcl_get_arena_words(agarcl_env *e, int32_t arena, int32_t *ar_out, int32_t *pl_out) {
   if (!e || arena < 0 || arena >= e->d.A) return fail(AGARCL_E_INVALID, "agarcl_get_arena_words: bad arguments");
-  if (ar_out && d2h(ar_out, e->s.ar + (size_t)arena * AR_WORDS, AR_WORDS * 4, e->stream)) return fail(AGARCL_E_HIP, "copy failed");
-  if (pl_out && d2h(pl_out, e->s.pl + (size_t)arena * e->d.P * PL_WORDS, (size_t)e->d.P * PL_WORDS * 4, e->stream)) return fail(AGARCL_E_HIP, "copy failed");
+  std::vector<int32_t> t;
+  if (ar_out) { if (pull_t(e, t, e->s.ar, (size_t)arena, AR_WORDS)) return fail(AGARCL_E_HIP, "copy failed"); memcpy(ar_out, t.data(), t.size() * 4); }
+  if (pl_out) { if (pull_t(e, t, e->s.pl, (size_t)arena, (size_t)e->d.P * PL_WORDS)) return fail(AGARCL_E_HIP, "copy failed"); memcpy(pl_out, t.data(), t.size() * 4); }
   return AGARCL_OK;
 }
 
@@ -624,12 +688,14 @@ extern "C" int agarcl_tick(agarcl_env *e, int32_t ticks) {
 
 extern "C" int agarcl_set_targets(agarcl_env *e, const float *txy_host, const int32_t *act_host) {
   if (!e || !txy_host || !act_host) return fail(AGARCL_E_INVALID, "agarcl_set_targets: null pointer");
-  size_t n = (size_t)e->d.A * e->d.P;
-  std::vector<int32_t> pl(n * PL_WORDS);
+  const int ag_ts_lg = e->d.ts_lg;
+  const size_t P = (size_t)e->d.P, n = (size_t)e->d.A * P, R = P * PL_WORDS;
+  std::vector<int32_t> pl(AG_TILE_ARENAS(e->d.A) * R);
   if (d2h(pl.data(), e->s.pl, pl.size() * 4, e->stream)) return fail(AGARCL_E_HIP, "download failed");
   for (size_t i = 0; i < n; i++) {
-    memcpy(&pl[i * PL_WORDS + PL_TX], &txy_host[2 * i], 4); memcpy(&pl[i * PL_WORDS + PL_TY], &txy_host[2 * i + 1], 4);
-    pl[i * PL_WORDS + PL_ACTION] = act_host[i];
+    const size_t a = i / P, w0 = (i % P) * PL_WORDS;
+    memcpy(&pl[tix(ag_ts_lg, a, R, w0 + PL_TX)], &txy_host[2 * i], 4); memcpy(&pl[tix(ag_ts_lg, a, R, w0 + PL_TY)], &txy_host[2 * i + 1], 4);
+    pl[tix(ag_ts_lg, a, R, w0 + PL_ACTION)] = act_host[i];
   }
   if (h2d(e->s.pl, pl.data(), pl.size() * 4, e->stream)) return fail(AGARCL_E_HIP, "upload failed");
   return AGARCL_OK;
@@ -646,7 +712,6 @@ extern "C" int agarcl_respawn_dead(agarcl_env *e) {
 extern "C" const double *agarcl_rewards_dev(agarcl_env *e) { return e ? e->s.rewards : nullptr; }
 extern "C" const uint8_t *agarcl_dones_dev(agarcl_env *e) { return e ? e->s.dones : nullptr; }
 extern "C" const int32_t *agarcl_masses_dev(agarcl_env *e) { return e ? e->s.masses : nullptr; }
-extern "C" const uint32_t *agarcl_flags_dev(agarcl_env *e) { return e ? (const uint32_t *)(e->s.ar + AR_FLAGS) : nullptr; }
 
 #define GETTER(name, field, type, count) \
   extern "C" int name(agarcl_env *e, type *out) { \
@@ -659,9 +724,10 @@ GETTER(agarcl_get_counts, counts, int32_t, e->d.A * 4)
 
 extern "C" int agarcl_get_flags(agarcl_env *e, uint32_t *out) {
   if (!e || !out) return fail(AGARCL_E_INVALID, "agarcl_get_flags: null pointer");
-  std::vector<int32_t> ar((size_t)e->d.A * AR_WORDS);
+  const int ag_ts_lg = e->d.ts_lg;
+  std::vector<int32_t> ar(AG_TILE_ARENAS(e->d.A) * AR_WORDS);
   if (d2h(ar.data(), e->s.ar, ar.size() * 4, e->stream)) return fail(AGARCL_E_HIP, "copy failed");
-  for (int a = 0; a < e->d.A; a++) out[a] = (uint32_t)ar[(size_t)a * AR_WORDS + AR_FLAGS];
+  for (int a = 0; a < e->d.A; a++) out[a] = (uint32_t)ar[tix(ag_ts_lg, (size_t)a, AR_WORDS, AR_FLAGS)];
   return AGARCL_OK;
 }
 
@@ -678,12 +744,12 @@ extern "C" int agarcl_poll_flags(agarcl_env *e, uint32_t *out) {
 
 extern "C" int agarcl_get_events(agarcl_env *e, int32_t *n_events_host, int32_t *pellet_idx_host, int32_t cap, int32_t *virus_idx_host, int32_t cap_v) {
   if (!e || !n_events_host) return fail(AGARCL_E_INVALID, "agarcl_get_events: null pointer");
-  size_t A = (size_t)e->d.A;
-  std::vector<int32_t> ar(A * AR_WORDS), evp(A * AG_EV_CAP), evv(A * AG_EVV_CAP);
+  size_t A = (size_t)e->d.A; const int ag_ts_lg = e->d.ts_lg;
+  std::vector<int32_t> ar(AG_TILE_ARENAS(A) * AR_WORDS), evp(A * AG_EV_CAP), evv(A * AG_EVV_CAP);
   if (d2h(ar.data(), e->s.ar, ar.size() * 4, e->stream) || d2h(evp.data(), e->s.ev_p, evp.size() * 4, e->stream) || d2h(evv.data(), e->s.ev_v, evv.size() * 4, e->stream))
     return fail(AGARCL_E_HIP, "copy failed");
   for (size_t a = 0; a < A; a++) {
-    int np = ar[a * AR_WORDS + AR_NEVP], nv = ar[a * AR_WORDS + AR_NEVV];
+    int np = ar[tix(ag_ts_lg, a, AR_WORDS, AR_NEVP)], nv = ar[tix(ag_ts_lg, a, AR_WORDS, AR_NEVV)];
     n_events_host[2 * a] = np; n_events_host[2 * a + 1] = nv;
     if (pellet_idx_host) for (int i = 0; i < np && i < cap && i < AG_EV_CAP; i++) pellet_idx_host[a * cap + i] = evp[a * AG_EV_CAP + i];
     if (virus_idx_host) for (int i = 0; i < nv && i < cap_v && i < AG_EVV_CAP; i++) virus_idx_host[a * cap_v + i] = evv[a * AG_EVV_CAP + i];
@@ -715,11 +781,12 @@ extern "C" int agarcl_debug_prof_raw(agarcl_env *e, unsigned long long *out) {  
 // general engine, [2] pellet passes (each reads the arena's pellet array once), [3] spare.
 extern "C" int agarcl_debug_work(agarcl_env *e, int64_t *out4, int reset) {
   if (!e || !out4) return AGARCL_E_INVALID;
-  const size_t n = (size_t)e->d.A * e->d.P * PL_WORDS;
+  const int ag_ts_lg = e->d.ts_lg;
+  const size_t R = (size_t)e->d.P * PL_WORDS, n = AG_TILE_ARENAS(e->d.A) * R;
   std::vector<int32_t> pl(n); int32_t st[4];
   if (d2h(pl.data(), e->s.pl, n * 4, e->stream) || d2h(st, e->s.qstat, 16, e->stream)) return AGARCL_E_HIP;
   int64_t passes = 0;
-  for (size_t i = 0; i < (size_t)e->d.A * e->d.P; i++) passes += (uint32_t)pl[i * PL_WORDS + PL_PASSES];
+  for (size_t a = 0; a < (size_t)e->d.A; a++) for (size_t p = 0; p < (size_t)e->d.P; p++) passes += (uint32_t)pl[tix(ag_ts_lg, a, R, p * PL_WORDS + PL_PASSES)];
   const int64_t steps = (int64_t)(e->step_no - e->work_step0) * e->d.A, unfinished = (int64_t)(uint32_t)(st[0] - e->work_unf0) + (int64_t)(e->step_no - e->work_step0 - (e->front_runs - e->work_front0)) * e->d.A;
   out4[0] = steps - unfinished; out4[1] = unfinished; out4[2] = passes - e->work_pass0; out4[3] = 0;
   if (reset) { e->work_step0 = e->step_no; e->work_front0 = e->front_runs; e->work_unf0 = st[0]; e->work_pass0 = passes; }
@@ -746,7 +813,7 @@ template <class T> int push(agarcl_env *e, const std::vector<T> &h, T *dev, size
 extern "C" int agarcl_dump_arena(agarcl_env *e, int32_t arena, uint32_t *buf, int32_t cap) {
   if (!e || !buf || arena < 0 || arena >= e->d.A) return fail(AGARCL_E_INVALID, "agarcl_dump_arena: bad arguments");
   const AgDims &d = e->d; const AgState &s = e->s; size_t a = (size_t)arena; ArenaHost h; int rc = 0;
-  rc |= pull(e, h.ar, s.ar, a * AR_WORDS, AR_WORDS); rc |= pull(e, h.pl, s.pl, a * d.P * PL_WORDS, (size_t)d.P * PL_WORDS); rc |= pull(e, h.vt, s.vticks, a * d.P * AG_VT_CAP, (size_t)d.P * AG_VT_CAP);
+  rc |= pull_t(e, h.ar, s.ar, a, AR_WORDS); rc |= pull_t(e, h.pl, s.pl, a, (size_t)d.P * PL_WORDS); rc |= pull(e, h.vt, s.vticks, a * d.P * AG_VT_CAP, (size_t)d.P * AG_VT_CAP);
   if (rc) return fail(AGARCL_E_HIP, "copy failed");
   size_t np = (size_t)h.ar[AR_NPEL], nv = (size_t)h.ar[AR_NVIR], nf = (size_t)h.ar[AR_NFOOD];
   rc |= pull(e, h.pxy, s.pel_xy, a * d.PC * 2, np * 2); rc |= pull(e, h.pid, s.pel_id, a * d.PC, np);
@@ -754,7 +821,7 @@ extern "C" int agarcl_dump_arena(agarcl_env *e, int32_t arena, uint32_t *buf, in
   rc |= pull(e, h.vm, s.vir_mass, a * d.VC, nv); rc |= pull(e, h.vh, s.vir_hits, a * d.VC, nv); rc |= pull(e, h.vid, s.vir_id, a * d.VC, nv);
   rc |= pull(e, h.fx, s.food_x, a * d.FC, nf); rc |= pull(e, h.fy, s.food_y, a * d.FC, nf); rc |= pull(e, h.fvx, s.food_vx, a * d.FC, nf); rc |= pull(e, h.fvy, s.food_vy, a * d.FC, nf); rc |= pull(e, h.fid, s.food_id, a * d.FC, nf);
   size_t nc = (size_t)d.P * CF_ALL * AG_CC;
-  rc |= pull(e, h.cells, s.cells, a * nc, nc);
+  rc |= pull_t(e, h.cells, s.cells, a, nc);
   if (rc) return fail(AGARCL_E_HIP, "copy failed");
   std::vector<uint32_t> o;
   auto F = [&](float f) { uint32_t u; memcpy(&u, &f, 4); o.push_back(u); };
@@ -777,8 +844,8 @@ extern "C" int agarcl_dump_arena(agarcl_env *e, int32_t arena, uint32_t *buf, in
     for (int i = 0; i < P[PL_NVTICKS]; i++) o.push_back((uint32_t)h.vt[(size_t)p * AG_VT_CAP + i]);
     const uint32_t *C = &h.cells[(size_t)p * CF_ALL * AG_CC];
     for (int i = 0; i < P[PL_NCELLS]; i++) {
-      for (int f = CF_X; f <= CF_ID; f++) o.push_back(C[AG_CELL_W(f, i)]);
-      uint32_t dl = C[AG_CELL_W(CF_DL, i)];
+      for (int f = CF_X; f <= CF_ID; f++) o.push_back(C[AG_CELL_HW(f, i)]);
+      uint32_t dl = C[AG_CELL_HW(CF_DL, i)];
       o.push_back(dl > clock ? dl - clock : 0u);
     }
   }
@@ -800,7 +867,7 @@ static int load_arena_impl(agarcl_env *e, int32_t arena, const uint32_t *b, int3
   // the entity tables and every player's 17 header words must lie inside the blob before anything of them is read
   if ((uint64_t)8 + 3ull * np + 7ull * nv + 5ull * nf + 17ull * npl > (uint64_t)words) return fail(AGARCL_E_INVALID, "agarcl_load_arena: blob length mismatch");
   const uint32_t *const b_end = b + words;
-  if (pull(e, h.ar, s.ar, a * AR_WORDS, AR_WORDS) || pull(e, h.pl, s.pl, a * d.P * PL_WORDS, (size_t)d.P * PL_WORDS)) return fail(AGARCL_E_HIP, "copy failed");
+  if (pull_t(e, h.ar, s.ar, a, AR_WORDS) || pull_t(e, h.pl, s.pl, a, (size_t)d.P * PL_WORDS)) return fail(AGARCL_E_HIP, "copy failed");
   h.vt.assign((size_t)d.P * AG_VT_CAP, 0);
   auto U2F = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
   const uint32_t *p = b + 8;
@@ -843,18 +910,18 @@ static int load_arena_impl(agarcl_env *e, int32_t arena, const uint32_t *b, int3
     p += 17 + nt;
     uint32_t *C = &h.cells[(size_t)slot * CF_ALL * AG_CC];
     for (uint32_t i = 0; i < ncell; i++, p += 9) {
-      for (int f = CF_X; f <= CF_SY; f++) C[AG_CELL_W(f, i)] = p[f];
-      C[AG_CELL_W(CF_M, i)] = p[6] > AG_CELL_MIN_SIZE ? p[6] : AG_CELL_MIN_SIZE; C[AG_CELL_W(CF_ID, i)] = p[7]; C[AG_CELL_W(CF_DL, i)] = clock + p[8];
+      for (int f = CF_X; f <= CF_SY; f++) C[AG_CELL_HW(f, i)] = p[f];
+      C[AG_CELL_HW(CF_M, i)] = p[6] > AG_CELL_MIN_SIZE ? p[6] : AG_CELL_MIN_SIZE; C[AG_CELL_HW(CF_ID, i)] = p[7]; C[AG_CELL_HW(CF_DL, i)] = clock + p[8];
     }
   }
   if (p - b != words) return fail(AGARCL_E_INVALID, "agarcl_load_arena: blob length mismatch");
   int rc = 0;
-  rc |= push(e, h.ar, s.ar, a * AR_WORDS); rc |= push(e, h.pl, s.pl, a * d.P * PL_WORDS); rc |= push(e, h.vt, s.vticks, a * d.P * AG_VT_CAP);
+  rc |= push_t(e, h.ar, s.ar, a); rc |= push_t(e, h.pl, s.pl, a); rc |= push(e, h.vt, s.vticks, a * d.P * AG_VT_CAP);
   rc |= push(e, h.pxy, s.pel_xy, a * d.PC * 2); rc |= push(e, h.pid, s.pel_id, a * d.PC);
   rc |= push(e, h.vx, s.vir_x, a * d.VC); rc |= push(e, h.vy, s.vir_y, a * d.VC); rc |= push(e, h.vvx, s.vir_vx, a * d.VC); rc |= push(e, h.vvy, s.vir_vy, a * d.VC);
   rc |= push(e, h.vm, s.vir_mass, a * d.VC); rc |= push(e, h.vh, s.vir_hits, a * d.VC); rc |= push(e, h.vid, s.vir_id, a * d.VC);
   rc |= push(e, h.fx, s.food_x, a * d.FC); rc |= push(e, h.fy, s.food_y, a * d.FC); rc |= push(e, h.fvx, s.food_vx, a * d.FC); rc |= push(e, h.fvy, s.food_vy, a * d.FC); rc |= push(e, h.fid, s.food_id, a * d.FC);
-  rc |= push(e, h.cells, s.cells, a * nc);
+  rc |= push_t(e, h.cells, s.cells, a);
   return rc ? fail(AGARCL_E_HIP, "upload failed") : AGARCL_OK;
 }
 extern "C" int agarcl_load_arena(agarcl_env *e, int32_t arena, const uint32_t *b, int32_t words) { return load_arena_impl(e, arena, b, words, nullptr, 0, 0); }

@@ -34,23 +34,23 @@ template <class SinkT> AG_DEV int gb_compact(int n, float px, float py, float vi
 
 // one wavefront: player `k` (map iteration order) of `arena`
 AG_DEV void gobigger_player(const AgState *gs, int arena, int k, AgGbCfg o, int32_t *hdr_, float *food_, float *virus_, float *spore_, float *clone_) {
-  const int P = gs->d.P;
-  const AG_GLOBAL int32_t *ar = (const AG_GLOBAL int32_t *)(gs->ar + (size_t)arena * AR_WORDS);
-  const int p = ar[AR_ORDER0 + k];
-  const AG_GLOBAL int32_t *pl = (const AG_GLOBAL int32_t *)(gs->pl + ((size_t)arena * P + p) * PL_WORDS);
-  const AG_GLOBAL uint32_t *C = (const AG_GLOBAL uint32_t *)(gs->cells + ((size_t)arena * P + p) * (CF_ALL * AG_CC));
+  const int P = gs->d.P, ag_ts_lg = gs->d.ts_lg;
+  const AG_GLOBAL int32_t *ar = (const AG_GLOBAL int32_t *)AG_AR_PTR(gs, arena);
+  const int p = ar[AG_TW(AR_ORDER0 + k)];
+  const AG_GLOBAL int32_t *pl = (const AG_GLOBAL int32_t *)AG_PL_PTR(gs, arena, p);
+  const AG_GLOBAL uint32_t *C = (const AG_GLOBAL uint32_t *)AG_CELLS_PTR(gs, arena, p);
   const AG_GLOBAL float *lut_r = (const AG_GLOBAL float *)gs->lut_r;
   const size_t row = (size_t)arena * P + k;
   AG_GLOBAL int32_t *hdr = (AG_GLOBAL int32_t *)hdr_ + row * 8;
   AG_GLOBAL float *food = (AG_GLOBAL float *)food_ + row * o.KF * 4, *virus = (AG_GLOBAL float *)virus_ + row * o.KV * 4;
   AG_GLOBAL float *spore = (AG_GLOBAL float *)spore_ + row * o.KS * 4, *clone = (AG_GLOBAL float *)clone_ + row * o.KC * 7;
   // Player::x / y / mass (core/Player.hpp:102-126): sequential fp32 sums in cell order
-  const int n = pl[PL_NCELLS]; float sx = 0.0f, sy = 0.0f; unsigned tm = 0;
+  const int n = pl[AG_TW(PL_NCELLS)]; float sx = 0.0f, sy = 0.0f; unsigned tm = 0;
   for (int i = 0; i < n; i++) { unsigned m = C[AG_CELL_W(CF_M, i)]; float fm = (float)m; float t = u2f((int)C[AG_CELL_W(CF_X, i)]) * fm; sx += t; t = u2f((int)C[AG_CELL_W(CF_Y, i)]) * fm; sy += t; tm += m; }
   const float px = ag_divf(sx, (float)tm), py = ag_divf(sy, (float)tm);
   const float view = smaxf(sminf((float)(2u * tm), 300.0f), 100.0f);   // clamp<float>(2 * mass, 100, 300), :424-426
   const float centering = (float)o.G / 2.0f;
-  const int np = ar[AR_NPEL], nv = ar[AR_NVIR], nf = ar[AR_NFOOD];
+  const int np = ar[AG_TW(AR_NPEL)], nv = ar[AG_TW(AR_NVIR)], nf = ar[AG_TW(AR_NFOOD)];
   // zero padding first (rows are rewritten below)
   AG_LANES(i, o.KF * 4) food[i] = 0.0f;
   AG_LANES(i, o.KV * 4) virus[i] = 0.0f;
@@ -68,12 +68,12 @@ AG_DEV void gobigger_player(const AgState *gs, int arena, int k, AgGbCfg o, int3
   const AG_GLOBAL float *fx = (const AG_GLOBAL float *)(gs->food_x + (size_t)arena * gs->d.FC), *fy = (const AG_GLOBAL float *)(gs->food_y + (size_t)arena * gs->d.FC);
   const int cs = gb_compact(nf, px, py, view, centering, o.G, o.KS, [&](int i, int r) {
     spore[4 * r] = fx[i] - px; spore[4 * r + 1] = fy[i] - py; spore[4 * r + 2] = r10; spore[4 * r + 3] = (float)AG_FOOD_MASS; }, fx, fy, 1);
-  const AG_GLOBAL float *cx = (const AG_GLOBAL float *)C + CF_X, *cy = (const AG_GLOBAL float *)C + CF_Y;
+  const AG_GLOBAL float *cx = (const AG_GLOBAL float *)C + AG_TW(CF_X), *cy = (const AG_GLOBAL float *)C + AG_TW(CF_Y);  // cell i: [i * AG_TW(CF_ALL)]
   const int cc = gb_compact(n, px, py, view, centering, o.G, o.KC, [&](int i, int r) {
     unsigned m = C[AG_CELL_W(CF_M, i)]; float cvx = u2f((int)C[AG_CELL_W(CF_VX, i)]), cvy = u2f((int)C[AG_CELL_W(CF_VY, i)]);
-    clone[7 * r] = cx[(size_t)i * CF_ALL] - px; clone[7 * r + 1] = cy[(size_t)i * CF_ALL] - py; clone[7 * r + 2] = lut(lut_r, m); clone[7 * r + 3] = (float)m;
-    clone[7 * r + 4] = cvx; clone[7 * r + 5] = cvy; clone[7 * r + 6] = v_direction(cvx, cvy); }, cx, cy, CF_ALL);
+    clone[7 * r] = cx[(size_t)i * AG_TW(CF_ALL)] - px; clone[7 * r + 1] = cy[(size_t)i * AG_TW(CF_ALL)] - py; clone[7 * r + 2] = lut(lut_r, m); clone[7 * r + 3] = (float)m;
+    clone[7 * r + 4] = cvx; clone[7 * r + 5] = cvy; clone[7 * r + 6] = v_direction(cvx, cvy); }, cx, cy, (int)AG_TW(CF_ALL));
   AG_SERIAL {
-    hdr[0] = pl[PL_PID]; hdr[1] = (cv + cf + cs + cc) > 0 ? 1 : 0; hdr[2] = cv; hdr[3] = cf; hdr[4] = cs; hdr[5] = cc; hdr[6] = (int32_t)tm; hdr[7] = p;
+    hdr[0] = pl[AG_TW(PL_PID)]; hdr[1] = (cv + cf + cs + cc) > 0 ? 1 : 0; hdr[2] = cv; hdr[3] = cf; hdr[4] = cs; hdr[5] = cc; hdr[6] = (int32_t)tm; hdr[7] = p;
   }
 }

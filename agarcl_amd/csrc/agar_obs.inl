@@ -41,9 +41,10 @@ OBS_DEV int obs_f2i(float f) { if (!(f > -2147483904.0f && f < 2147483648.0f)) r
 // mass-weighted centroid and total mass of player `p` (Player::x/y/mass, core/Player.hpp:102-126): sequential fp32
 // sums in cell order, evaluated redundantly by every thread
 OBS_DEV void obs_player(const AgState *gs, int arena, int p, float &px, float &py, unsigned &mass) {
-  const int32_t *pl = gs->pl + ((size_t)arena * gs->d.P + p) * PL_WORDS;
-  const uint32_t *C = gs->cells + ((size_t)arena * gs->d.P + p) * (CF_ALL * AG_CC);
-  int n = pl[PL_NCELLS]; float sx = 0.0f, sy = 0.0f; unsigned tm = 0;
+  const int ag_ts_lg = gs->d.ts_lg;
+  const int32_t *pl = AG_PL_PTR(gs, arena, p);
+  const uint32_t *C = AG_CELLS_PTR(gs, arena, p);
+  int n = pl[AG_TW(PL_NCELLS)]; float sx = 0.0f, sy = 0.0f; unsigned tm = 0;
   for (int i = 0; i < n; i++) {
     union { uint32_t u; float f; } x, y; x.u = C[AG_CELL_W(CF_X, i)]; y.u = C[AG_CELL_W(CF_Y, i)];
     unsigned m = C[AG_CELL_W(CF_M, i)]; float fm = (float)m;
@@ -100,9 +101,10 @@ OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o,
     float t2 = (float)G * ddy; t2 = t2 / view; gy = obs_f2i(t2 + centering);
     return 0 <= gx && gx < G && 0 <= gy && gy < G;
   };
+  const int ag_ts_lg = gs->d.ts_lg;
   int ch = 0;
   if (o.pellets) {  // ch+1: "at least one" (= mass 1), ch+2: count
-    const float *pxy = gs->pel_xy + (size_t)arena * gs->d.PC * 2; int np = gs->ar[(size_t)arena * AR_WORDS + AR_NPEL];
+    const float *pxy = gs->pel_xy + (size_t)arena * gs->d.PC * 2; int np = AG_AR_PTR(gs, arena)[AG_TW(AR_NPEL)];
     int32_t *a1 = out + (size_t)(ch + 1) * GG, *a2 = out + (size_t)(ch + 2) * GG;
     OBS_FOR(k, np) { int gx, gy; if (w2g(pxy[2 * k], pxy[2 * k + 1], gx, gy)) { a1[gx * G + gy] = 1; OBS_ATOMIC_ADD(&a2[gx * G + gy], 1); } }
     ch += 2;
@@ -118,8 +120,8 @@ OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o,
 #else
   __shared__ int32_t e_idx[OBS_ECAP], e_mass[OBS_ECAP], e_kind[OBS_ECAP];
 #endif
-  const int32_t *arw = gs->ar + (size_t)arena * AR_WORDS;
-  const int P = gs->d.P, nv = o.viruses ? arw[AR_NVIR] : 0;
+  const int32_t *arw = AG_AR_PTR(gs, arena);
+  const int P = gs->d.P, nv = o.viruses ? arw[AG_TW(AR_NVIR)] : 0;
   int c2 = o.pellets ? 2 : 0;
   int32_t *v1 = out + (size_t)(c2 + 1) * GG, *v2 = out + (size_t)(c2 + 2) * GG; if (o.viruses) c2 += 2;
   int32_t *cown = out + (size_t)(c2 + 1) * GG; if (o.cells) c2 += 1;
@@ -131,11 +133,11 @@ OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o,
   }
   for (int k = -1; k < P; k++) {  // own cells (kind 1), then the other players in the engine's iteration order (kind 2)
     if (k < 0 ? !o.cells : !o.others) continue;
-    const int p = k < 0 ? agent : arw[AR_ORDER0 + k];
+    const int p = k < 0 ? agent : arw[AG_TW(AR_ORDER0 + k)];
     if (k >= 0 && p == agent) continue;
-    const int32_t *pl = gs->pl + ((size_t)arena * P + p) * PL_WORDS;
-    const uint32_t *Cc = gs->cells + ((size_t)arena * P + p) * (CF_ALL * AG_CC);
-    const int n = pl[PL_NCELLS];
+    const int32_t *pl = AG_PL_PTR(gs, arena, p);
+    const uint32_t *Cc = AG_CELLS_PTR(gs, arena, p);
+    const int n = pl[AG_TW(PL_NCELLS)];
     OBS_FOR(i, n) {
       if (E + i < OBS_ECAP) {
         union { uint32_t u; float f; } x, y; x.u = Cc[AG_CELL_W(CF_X, i)]; y.u = Cc[AG_CELL_W(CF_Y, i)];

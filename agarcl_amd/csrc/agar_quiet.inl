@@ -22,6 +22,9 @@
 // Pellets streamed from HBM / L2.  A pass is a wave-level operation: for every lane group that asks for one, ALL 64
 // lanes read that arena's pellets (NS x 512 B per wave-instruction, every load issued before the first use: one
 // round trip per pass), accumulate lane-private partial results and combine them with DPP reductions.
+// word w of one arena's block of a tile-transposed array
+template <class T> struct TileWords { AG_GLOBAL T *p; int ag_ts_lg; AG_MEM AG_GLOBAL T &operator[](int w) const { return p[AG_TW(w)]; } };
+
 template <int NS, int QG = AG_QG> struct GrpPel {
   AG_GLOBAL float *xy; AG_GLOBAL int32_t *id; int sub;
 #ifdef AGAR_CPU_EMU
@@ -121,10 +124,13 @@ template <int NS, int QG = AG_QG> struct GrpPel {
 // Returns the hand-over (per lane, uniform over the group): ticks done (-1: nothing, == ticks: step finished) and the
 // agent's mass before the step.  parity >= 0: also count unfinished arenas in gs->qcount[parity] (two-kernel step).
 struct QHandOver { int done, before; };
-template <int NS, bool AV, int QG = AG_QG> AG_DEV QHandOver quiet_arena(const AgHot hot, const AgState *gs, int arena, int sub, bool valid, const AG_GLOBAL float *act_dxdy, const AG_GLOBAL int32_t *act, int ticks, bool with_env, int slot, int parity = -1) {
-  auto S = (AG_GLOBAL int32_t *)(hot.ar + (size_t)arena * AR_WORDS);
-  auto P = (AG_GLOBAL int32_t *)(hot.pl + (size_t)arena * PL_WORDS);
-  auto C = (AG_GLOBAL uint32_t *)(hot.cells + (size_t)arena * (CF_ALL * AG_CC));   // field f of cell 0 = C[AG_CELL_W(f, 0)]: one 48-byte run
+// TSLG: the env's AgDims::ts_lg as a compile-time constant (a run-time stride costs the front kernel ~190 bytes of scratch per lane)
+template <int NS, bool AV, int QG, int TSLG> AG_DEV QHandOver quiet_arena(const AgHot hot, const AgState *gs, int arena, int sub, bool valid, const AG_GLOBAL float *act_dxdy, const AG_GLOBAL int32_t *act, int ticks, bool with_env, int slot, int parity = -1) {
+  // tile-transposed arrays (agar_types.h): with tiles of 64, consecutive arenas -- consecutive lane groups -- are 4 bytes apart
+  constexpr int ag_ts_lg = TSLG;
+  const TileWords<int32_t> S{(AG_GLOBAL int32_t *)(hot.ar + AG_TILE_BASE(arena, AR_WORDS)), ag_ts_lg};
+  const TileWords<int32_t> P{(AG_GLOBAL int32_t *)(hot.pl + AG_TILE_BASE(arena, PL_WORDS)), ag_ts_lg};    // (one player per arena here)
+  auto C = (AG_GLOBAL uint32_t *)(hot.cells + AG_TILE_BASE(arena, CF_ALL * AG_CC));   // field f of cell 0 = C[AG_CELL_W(f, 0)]
   auto qi = (AG_GLOBAL int32_t *)(gs->qinfo + (size_t)arena * 2);
   GrpPel<NS, QG> pel{(AG_GLOBAL float *)(gs->pel_xy + (size_t)arena * 2 * (NS * 64)), (AG_GLOBAL int32_t *)(gs->pel_id + (size_t)arena * (NS * 64)), sub};
   const bool lead = pel.lead() && valid;

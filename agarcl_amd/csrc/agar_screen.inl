@@ -61,7 +61,8 @@ __global__ void __launch_bounds__(256) k_screen_obs(const AgState *__restrict__ 
   double zd = 100.0 + (double)mass / 10.0; zd = zd < 100.0 ? 100.0 : (zd > 900.0 ? 900.0 : zd);
   const float z = (float)zd, half_h = z * 0.41421356237309504880f, half_w = half_h * ((float)o.W / (float)o.H);
   const float Wd = gs->g.W;
-  const int32_t *ar = gs->ar + (size_t)arena * AR_WORDS;
+  const int ag_ts_lg = gs->d.ts_lg;
+  const int32_t *ar = AG_AR_PTR(gs, arena);
   if (threadIdx.x < 64) {  // ---- wave 0: visible entities in draw order ----
     const int lane = (int)threadIdx.x; const unsigned long long lt = (1ull << lane) - 1ull;
     int count = 0;
@@ -73,7 +74,7 @@ __global__ void __launch_bounds__(256) k_screen_obs(const AgState *__restrict__ 
       count += __popcll(m);
     };
     const float *pxy = gs->pel_xy + (size_t)arena * gs->d.PC * 2; const int32_t *pid = gs->pel_id + (size_t)arena * gs->d.PC;
-    const int np = ar[AR_NPEL], nf = ar[AR_NFOOD], nv = ar[AR_NVIR];
+    const int np = ar[AG_TW(AR_NPEL)], nf = ar[AG_TW(AR_NFOOD)], nv = ar[AG_TW(AR_NVIR)];
     const float r_pel = gs->lut_r[AG_PELLET_MASS], r_food = gs->lut_r[AG_FOOD_MASS];
     const bool av = o.agent_view != 0;
     for (int b = 0; b < np; b += 64) { int i = b + lane; bool v = i < np; emit(v, v ? pxy[2 * i] : 0.f, v ? pxy[2 * i + 1] : 0.f, r_pel, v ? ((av ? 0x0000FFu : scr_palette(pid[i])) | (5u << 24)) : 0u); }
@@ -81,13 +82,13 @@ __global__ void __launch_bounds__(256) k_screen_obs(const AgState *__restrict__ 
       for (int b = 0; b < nf; b += 64) { int i = b + lane; bool v = i < nf; emit(v, v ? gs->food_x[fo + i] : 0.f, v ? gs->food_y[fo + i] : 0.f, r_food, v ? ((av ? 0x0000FFu : scr_palette(gs->food_id[fo + i])) | (7u << 24)) : 0u); } }
     const int main_slot = na - 1;  // state.main_agent_pid: the last agent added
     for (int kk = av ? -1 : 0; kk < P; kk++) {  // players in the engine's iteration order (agent view: the main agent first), cells in vector order
-      const int slot = kk < 0 ? main_slot : ar[AR_ORDER0 + kk];
+      const int slot = kk < 0 ? main_slot : ar[AG_TW(AR_ORDER0 + kk)];
       if (av && kk >= 0 && slot == main_slot) continue;
-      const int32_t *pl = gs->pl + ((size_t)arena * P + slot) * PL_WORDS;
-      const uint32_t *C = gs->cells + ((size_t)arena * P + slot) * (CF_ALL * AG_CC);
-      const int n = pl[PL_NCELLS], kind = pl[PL_KIND];
+      const int32_t *pl = AG_PL_PTR(gs, arena, slot);
+      const uint32_t *C = AG_CELLS_PTR(gs, arena, slot);
+      const int n = pl[AG_TW(PL_NCELLS)], kind = pl[AG_TW(PL_KIND)];
       const unsigned col = (av ? (kk < 0 ? 0x0000E6u /* 0.9 -> 230 */ : 0x00FF00u)
-                               : (kind == 0 ? scr_palette(pl[PL_PID]) : kind == 1 ? scr_palette(4) : kind == 2 ? scr_palette(5) : kind == 3 ? scr_palette(0) : scr_palette(1))) | (50u << 24);
+                               : (kind == 0 ? scr_palette(pl[AG_TW(PL_PID)]) : kind == 1 ? scr_palette(4) : kind == 2 ? scr_palette(5) : kind == 3 ? scr_palette(0) : scr_palette(1))) | (50u << 24);
       bool v = lane < n;
       unsigned m = v ? C[AG_CELL_W(CF_M, lane)] : 0u;
       emit(v, v ? __uint_as_float(C[AG_CELL_W(CF_X, lane)]) : 0.f, v ? __uint_as_float(C[AG_CELL_W(CF_Y, lane)]) : 0.f, v ? gs->lut_r[m < AG_LUT_SIZE ? m : AG_LUT_SIZE - 1] : 0.f, col);

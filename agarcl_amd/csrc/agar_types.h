@@ -52,10 +52,29 @@ enum { CF_X = 0, CF_Y, CF_VX, CF_VY, CF_SX, CF_SY, CF_M, CF_ID, CF_DL, CF_FIELDS
        // derived, persisted so a launch needs no dependent table lookups: radius / max-speed cache of the cell,
        // valid iff CF_CMC == CF_M (agar_core.inl: Cells::cmc/crad/cms)
        CF_CMC = CF_FIELDS, CF_CRAD, CF_CMS, CF_ALL };
-// word index of field f of cell slot i inside a player's HBM cell block: CELL-major, so that one cell's 12 words are one
-// contiguous 48-byte run (a single-cell arena touches one cache line instead of twelve; a lane that stages slot i into LDS
-// reads three 16-byte words).  The LDS copy stays field-major.
-#define AG_CELL_W(f, i) ((i) * CF_ALL + (f))
+// The three per-arena word arrays (ar, pl, cells) are TILE-TRANSPOSED in HBM: arenas are grouped in tiles of TS = 2^ts_lg
+// (AgDims::ts_lg, chosen per env: 0 or 6) and inside a tile the arena index is the fastest one -- word w of arena a of an
+// array with R words per arena lives at
+//     ((a / TS) * R + w) * TS + a % TS.
+// TS = 1 is the plain arena-major layout: an arena's words are contiguous, which is what the general engine (one wavefront
+// per arena) and the 16-lanes-per-arena front part of small batches want -- few cache lines per arena.
+// TS = 64 serves the big batches, where the lean front kernel gives every arena one lane (or two, or four): lane l of a
+// wavefront reads word w of arena 64 t + l, so a wave-instruction moves one contiguous 256-byte run and only the words that
+// are used ever leave HBM (arena-major: every lane touches its own cache lines, 64 lines per load instruction, whole lines
+// for a few words).  Measured on MI355X, C2, us per step, TS 1 / 64: 4096 arenas 9.2 / 9.9, 65536: 26.4 / 22.0, 262144:
+// 65.6 / 45.2; the full-ruleset and multi-player workloads (general engine only) 449 / 457 and 219 / 240.
+// The macros below expect `ag_ts_lg` (the env's AgDims::ts_lg) in scope.
+#define AG_TILE_BASE(a, R) (((((size_t)(a) >> ag_ts_lg) * (size_t)(R)) << ag_ts_lg) + ((size_t)(a) & (((size_t)1 << ag_ts_lg) - 1)))  // offset of word 0 of arena a
+#define AG_TW(w) ((size_t)(w) << ag_ts_lg)                                                        // offset of word w from there
+#define AG_TILE_ARENAS(A) ((((((size_t)(A) ? (size_t)(A) : 1) - 1) >> ag_ts_lg) + 1) << ag_ts_lg)  // arenas allocated
+// one arena's block of each array (gs: AgState pointer); word w of a block is [AG_TW(w)]
+#define AG_AR_PTR(gs, a) ((gs)->ar + AG_TILE_BASE(a, AR_WORDS))
+#define AG_PL_PTR(gs, a, p) ((gs)->pl + AG_TILE_BASE(a, (gs)->d.P * PL_WORDS) + AG_TW((p) * PL_WORDS))
+#define AG_CELLS_PTR(gs, a, p) ((gs)->cells + AG_TILE_BASE(a, (gs)->d.P * (CF_ALL * AG_CC)) + AG_TW((p) * (CF_ALL * AG_CC)))
+// word index of field f of cell slot i inside a player's cell block (cell-major), in tile-transposed HBM and in a
+// contiguous host copy of one arena's block
+#define AG_CELL_HW(f, i) ((i) * CF_ALL + (f))
+#define AG_CELL_W(f, i) AG_TW(AG_CELL_HW(f, i))
 
 struct AgDims {
   int A;         // arenas
@@ -64,6 +83,7 @@ struct AgDims {
   int PC;        // pellet capacity per arena (multiple of 64)
   int VC;        // virus capacity
   int FC;        // food capacity
+  int ts_lg;     // log2 of the tile size of the transposed word arrays (0: arena-major, 6: tiles of 64 arenas)
 };
 
 struct AgParams {
@@ -88,11 +108,11 @@ struct AgState {
   float *vir_x, *vir_y, *vir_vx, *vir_vy; int32_t *vir_mass, *vir_hits, *vir_id;
   // foods [A][FC]
   float *food_x, *food_y, *food_vx, *food_vy; int32_t *food_id;
-  // cells [A][P][AG_CC][CF_ALL] as 32-bit words (AG_CELL_W)
+  // cells [A][P][AG_CC][CF_ALL] as 32-bit words, tile-transposed (AG_TILE_BASE / AG_CELL_W)
   uint32_t *cells;
-  int32_t *pl;      // [A][P][PL_WORDS]
+  int32_t *pl;      // [A][P][PL_WORDS], tile-transposed
   int32_t *vticks;  // [A][P][AG_VT_CAP]
-  int32_t *ar;      // [A][AR_WORDS]
+  int32_t *ar;      // [A][AR_WORDS], tile-transposed
   uint64_t *mt;     // [A][312]
   int32_t *rnd;     // [A][35] glibc rand() ring + position (Player colours, bots' fallbacks)
   int32_t *scratch; // [A][AGM_WORDS] multi-player working memory (null when P == 1)

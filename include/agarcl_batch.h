@@ -107,12 +107,11 @@ int agarcl_set_targets(agarcl_env *env, const float *txy_host, const int32_t *ac
 int agarcl_respawn_dead(agarcl_env *env);
 
 /* results of the last step, HBM-resident: rewards f64[num_arenas][num_agents] (vector<double>,
- * BaseEnvironment.hpp:31,116-121), dones u8[...] (BaseEnvironment.hpp:206), masses i32[...],
- * flags u32[num_arenas] */
+ * BaseEnvironment.hpp:31,116-121), dones u8[...] (BaseEnvironment.hpp:206), masses i32[...]
+ * (capacity flags: agarcl_get_flags / agarcl_poll_flags) */
 const double *agarcl_rewards_dev(agarcl_env *env);
 const uint8_t *agarcl_dones_dev(agarcl_env *env);
 const int32_t *agarcl_masses_dev(agarcl_env *env);
-const uint32_t *agarcl_flags_dev(agarcl_env *env);
 /* (reward, done) as f32 pairs [num_arenas][num_agents][2] in a ring of AGARCL_PACKED_SLOTS contiguous buffers: the
  * k-th agarcl_step of an env writes slot k % 16, so an asynchronous gather (RCCL) of the last 8 steps' results -- one
  * contiguous block -- can overlap the next 8 steps.  agarcl_last_slot = slot of the last step. */

@@ -35,6 +35,20 @@ def test_emulated_kernel_logic_matches_oracle(emu_lib, oracle_lib, case):
     assert ok, "%s: %s" % (cfg, msg)
 
 
+@pytest.mark.parametrize("case", [0, 1, 7, 8])
+def test_emulated_kernel_logic_tile_transposed_layout(emu_lib, oracle_lib, monkeypatch, case):
+    """The per-arena word arrays in tiles of 64 arenas (agar_types.h; chosen for big single-player batches, AGARCL_TILE_LG=6 pins
+    it): same results.  70 arenas = one full tile and a ragged one; quiet, full-ruleset, bots and multi-agent configs."""
+    from agarcl_amd import _capi
+    monkeypatch.setenv("AGARCL_TILE_LG", "6")
+    cfg, steps, sticky = CASES[case]
+    A = 70
+    eng = _capi.BatchedEngine(A, lib=emu_lib, **cfg)
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    ok, msg = run_batched_lockstep(eng, oras, min(steps, 120), seeds=np.arange(411, 411 + A), sticky=sticky, every=10)
+    assert ok, "%s: %s" % (cfg, msg)
+
+
 @pytest.mark.parametrize("cfg", [
     dict(arena_size=1000, num_pellets=1000, num_viruses=0, mode=0),     # BASELINE C2
     dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode=0),    # C3 / mode 0

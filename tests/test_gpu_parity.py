@@ -181,6 +181,21 @@ def test_front_kernel_lanes_per_arena(hip_engine_cls, oracle_lib, monkeypatch, q
     eng.close()
 
 
+@pytest.mark.parametrize("cfg", [C2, dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode=6),
+                                 dict(num_agents=2, arena_size=250, num_pellets=500, num_viruses=10, num_bots=3, mode=0)])
+def test_tile_transposed_layout(hip_engine_cls, oracle_lib, monkeypatch, cfg):
+    """Per-arena word arrays in tiles of 64 arenas (the layout of single-player batches from 32768 arenas on; AGARCL_TILE_LG=6
+    pins it): lock-step against the oracle through the front kernel (4 lanes per arena), the general engine and a multi-player
+    config; 130 arenas = two full tiles and a ragged one."""
+    monkeypatch.setenv("AGARCL_TILE_LG", "6"); monkeypatch.setenv("AGARCL_QUIET_QG", "4"); monkeypatch.setenv("AGARCL_FUSED", "0")
+    A = 130
+    eng = hip_engine_cls(A, **cfg)
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    ok, msg = run_batched_lockstep(eng, oras, 160, seeds=7000 + 3 * np.arange(A), policy_seed=3, sticky=4, every=20)
+    eng.close()
+    assert ok, msg
+
+
 from snapshot_cases import replay_snapshot_case, snapshot_cases  # noqa: E402
 
 
