@@ -57,6 +57,9 @@ static int dsync(ag_stream_t s) { return hipStreamSynchronize(s) == hipSuccess ?
 // measured cross-over of k_fused vs k_quiet + k_step on C2 (us per step, fused / two-kernel with the best lanes-per-arena):
 // 4096: 9.2 / 12.5, 8192: 11.2 / 13.5, 12288: 15.7 / 14.6, 16384: 18.1 / 15.0, 32768: 31.0 / 18.1
 #define AG_FUSED_MAX_ARENAS 10240
+#ifndef AG_KSTEP_SMALL_GRID
+#define AG_KSTEP_SMALL_GRID 256
+#endif
 struct agarcl_env {
   agarcl_config cfg;
   AgDims d; AgParams g; AgState s;   // host copy of the descriptor
@@ -83,6 +86,7 @@ struct agarcl_env {
   bool stat_pending; long step_no, front_runs, stat_req_front, stat_last_front; int32_t stat_last_total;
   int parity;     // launch parity of the k_quiet / k_step pair (selects the unfinished-arena counter)
   bool no_front;  // AGARCL_NO_FRONT=1 in the environment: skip k_quiet (diagnostics / A-B timing only)
+  bool few_unfinished; // adaptive: the front part leaves < 64 arenas per step to k_step (see launch_step)
   bool front_off; // adaptive: the front part finishes (almost) no arena-step, so the two-kernel step runs k_step alone
 };
 
@@ -280,6 +284,7 @@ static void poll_stats(agarcl_env *e, bool adapt) {
       if (e->fused && frac > 0.05) e->fused = false; else if (!e->fused && frac < 0.01) e->fused = e->d.A < AG_FUSED_MAX_ARENAS && e->d.ts_lg == 0;
       // the two-kernel step's front launch is pure overhead when it finishes (almost) nothing: mass-1000 modes
       e->front_off = !e->fused && frac > 0.99;
+      e->few_unfinished = frac * (double)e->d.A < 64.0;   // k_step's work list is short: a small grid dispatches faster
     }
     e->stat_last_total = e->h_stat[0]; e->stat_last_front = e->stat_req_front;
   } else if (e->step_no % 64 == 0) {
@@ -328,7 +333,10 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
 #undef CALL
 #undef CALLQ
   }
-#define CALL(N, V) hipLaunchKernelGGL((k_step<N, V, T>), dim3(e->d.A < 4096 ? e->d.A : 4096), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, use_q, e->parity)
+#define CALL(N, V) hipLaunchKernelGGL((k_step<N, V, T>), dim3(kgrid), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, use_q, e->parity)
+  // grid of k_step: every arena (grid-stride from 4096 workgroups on), or -- working off a list the statistics say is short --
+  // 256 workgroups, which dispatch faster (the loop still visits every listed arena if the list is long after all)
+  const int kfull = e->d.A < 4096 ? e->d.A : 4096, kgrid = use_q && e->few_unfinished && kfull > AG_KSTEP_SMALL_GRID ? AG_KSTEP_SMALL_GRID : kfull;
 #define T 6
   if (tiled) AG_DISPATCH_NS(e->ns, CALL);
 #undef T
@@ -511,7 +519,7 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   { const char *nf = getenv("AGARCL_NO_FRONT"); e->no_front = nf && nf[0] == '1'; }
   // modes 0-4 start agents at mass 25 (quiet-dominated); 5 and 6 start at mass 1000 (general path every step)
   e->fused = d.P == 1 && cfg->mode_number <= 4 && d.A < AG_FUSED_MAX_ARENAS && d.ts_lg == 0;  // starting point; poll_stats follows what the arenas actually do
-  e->front_off = d.P == 1 && cfg->mode_number > 4;
+  e->front_off = d.P == 1 && cfg->mode_number > 4; e->few_unfinished = false;
   e->work_step0 = e->work_front0 = 0; e->work_unf0 = 0; e->work_pass0 = 0;
   e->flags_seen = 0; e->d_mask = alloc<uint8_t>(e, (size_t)d.A);
   e->fused_fixed = false; e->h_stat = nullptr; e->stat_ev = nullptr; e->stat_pending = false; e->step_no = e->front_runs = e->stat_req_front = e->stat_last_front = 0; e->stat_last_total = 0;
