@@ -54,9 +54,11 @@ static int d2h(void *h, const void *d, size_t n, ag_stream_t s) { return hipMemc
 static int dsync(ag_stream_t s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
 #endif
 
-// measured cross-over of k_fused vs k_quiet + k_step on C2 (us per step, fused / two-kernel with the best lanes-per-arena):
-// 4096: 9.2 / 12.5, 8192: 11.2 / 13.5, 12288: 15.7 / 14.6, 16384: 18.1 / 15.0, 32768: 31.0 / 18.1
-#define AG_FUSED_MAX_ARENAS 10240
+// k_fused (one launch) vs k_quiet + k_step on C2, us per step, with 16 lanes per arena in k_fused and the best group size
+// in k_quiet: 4096: 9.2 / 12.5, 8192: 11.2 / 13.5, 12288: 15.7 / 14.6, 16384: 18.1 / 15.0, 32768: 31.0 / 18.1 -- the single
+// launch loses where its batch no longer fits the 2 wavefronts per SIMD it can keep resident.  Its front part therefore gets
+// the lane-group size as a parameter too (the general engine behind it is a real call, shared by all of them).
+#define AG_FUSED_WAVES 2048L   // k_fused keeps 2 wavefronts per SIMD: the single-launch step is used while the batch fits them
 #ifndef AG_KSTEP_SMALL_GRID
 #define AG_KSTEP_SMALL_GRID 256
 #endif
@@ -77,6 +79,7 @@ struct agarcl_env {
   bool fused;     // single-launch step (k_fused) instead of k_quiet + k_step: see k_fused
   bool fused_fixed;                // AGARCL_FUSED=0/1 pins the choice
   int fused_wg;                    // threads per workgroup of k_fused (64, 128 or 256)
+  int fused_qg; bool fused_ok;     // lanes per arena of k_fused (from the arena count) / the batch is one the single launch may serve
   int quiet_qg;                    // lanes per arena of k_quiet (1, 2, 4, 8 or 16): see agarcl_create
   uint32_t *d_stage; size_t stage_words;  // staging buffer of pull_t / push_t (one arena's largest transposed block)
   int32_t *h_stat; void *stat_ev;  // pinned copy of {qstat, flag watch word} + the event that says it has arrived
@@ -179,6 +182,16 @@ template <int NS, bool AV, int QG, int TSLG> __global__ void __launch_bounds__(2
   if (!valid) arena = A - 1;
   quiet_arena<NS, AV, QG, TSLG>(hot, gs, arena, (int)threadIdx.x % QG, valid, (const AG_GLOBAL float *)act_dxdy, (const AG_GLOBAL int32_t *)act, ticks, with_env != 0, slot, parity);
 }
+// The general engine for ONE arena as a real call: k_fused's front part (every lane-group size, both layouts) shares one copy
+// of it per (NS, AV, layout) and keeps its own, small register allocation around the rare call.
+template <int NS, bool AV, int TSLG> __device__ __attribute__((noinline)) void general_arena_step(const AgState *gs, int arena, unsigned char *lds, const float *act_dxdy, const int32_t *act, int slot, int ticks, int with_env, int qd, int qb) {
+  AgCtx<NS, AV> c; ag_ctx_init(c, gs, arena, lds, act_dxdy, act, slot);
+  c.ts_lg = TSLG;
+  arena_load(c, true);
+  env_step(c, ticks, with_env != 0, qd, qb);
+  arena_store(c);
+  ag_lds_order();
+}
 #ifndef AG_KFUSED_ATTR
 #define AG_KFUSED_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
@@ -187,12 +200,12 @@ template <int NS, bool AV, int QG, int TSLG> __global__ void __launch_bounds__(2
 // running the general engine as a wave, one arena after the other.  Saves the second dependent launch (>= 3.4 us:
 // scripts/microbench/launch_floor.hip) at the price of serialising a wavefront's unfinished arenas -- the wrong trade
 // when most arenas need the general path every step (mass-1000 modes), where the two-kernel step is used.
-template <int NS, bool AV> __global__ void __launch_bounds__(256) AG_KFUSED_ATTR k_fused(const AgHot hot, const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int lds_per_wave) {
-  int arena = (int)blockIdx.x * ((int)blockDim.x / AG_QG) + (int)threadIdx.x / AG_QG;   // (arena-major layout only: ts_lg == 0)
+template <int NS, bool AV, int QG, int TSLG> __global__ void __launch_bounds__(256) AG_KFUSED_ATTR k_fused(const AgHot hot, const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int lds_per_wave) {
+  int arena = (TSLG ? ag_xcd_swizzle((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * ((int)blockDim.x / QG) + (int)threadIdx.x / QG;
   const int A = gs->d.A; const bool valid = arena < A;
   if (!valid) arena = A - 1;
-  const int sub = (int)threadIdx.x % AG_QG;
-  QHandOver h = quiet_arena<NS, AV, AG_QG, 0>(hot, gs, arena, sub, valid, (const AG_GLOBAL float *)act_dxdy, (const AG_GLOBAL int32_t *)act, ticks, with_env != 0, slot, -1);
+  const int sub = (int)threadIdx.x % QG;
+  QHandOver h = quiet_arena<NS, AV, QG, TSLG>(hot, gs, arena, sub, valid, (const AG_GLOBAL float *)act_dxdy, (const AG_GLOBAL int32_t *)act, ticks, with_env != 0, slot, -1);
   unsigned long long todo = __ballot(valid && sub == 0 && h.done != ticks);
   if (!todo) return;
   ag_mem_fence();  // the front part's stores precede the general part's loads of the same arena
@@ -200,12 +213,7 @@ template <int NS, bool AV> __global__ void __launch_bounds__(256) AG_KFUSED_ATTR
   while (todo) {
     const int src = (int)__builtin_ctzll(todo); todo &= todo - 1ull;
     const int ar = __builtin_amdgcn_readlane(arena, src), qd = __builtin_amdgcn_readlane(h.done, src), qb = __builtin_amdgcn_readlane(h.before, src);
-    AgCtx<NS, AV> c; ag_ctx_init(c, gs, ar, lds, act_dxdy, act, slot);
-    c.ts_lg = 0;
-    arena_load(c, true);
-    env_step(c, ticks, with_env != 0, qd, qb);
-    arena_store(c);
-    ag_lds_order();
+    general_arena_step<NS, AV, TSLG>(gs, ar, lds, act_dxdy, act, slot, ticks, with_env, qd, qb);
   }
 }
 template <int NS, bool AV> __global__ void __launch_bounds__(64) k_reset(const AgState *__restrict__ gs, const uint8_t *mask, int reset_ids) {
@@ -281,7 +289,7 @@ static void poll_stats(agarcl_env *e, bool adapt) {
       const double frac = (double)(uint32_t)(e->h_stat[0] - e->stat_last_total) / ((double)steps * (double)e->d.A);
       // (from 32768 arenas on the two-kernel step is the faster one even when every arena is quiet: the lean front kernel
       // keeps 4 waves per SIMD where the fused kernel, which carries the general engine's registers, keeps 2)
-      if (e->fused && frac > 0.05) e->fused = false; else if (!e->fused && frac < 0.01) e->fused = e->d.A < AG_FUSED_MAX_ARENAS && e->d.ts_lg == 0;
+      if (e->fused && frac > 0.05) e->fused = false; else if (!e->fused && frac < 0.01) e->fused = e->fused_ok;
       // the two-kernel step's front launch is pure overhead when it finishes (almost) nothing: mass-1000 modes
       e->front_off = !e->fused && frac > 0.99;
       e->few_unfinished = frac * (double)e->d.A < 64.0;   // k_step's work list is short: a small grid dispatches faster
@@ -312,12 +320,19 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
   if (use_q) e->front_runs++;
   const AgHot hot{e->s.ar, e->s.pl, e->s.cells};
   const bool tiled = e->d.ts_lg != 0;   // (0 or 6, agarcl_create)
-  if (use_q && e->fused && !tiled) {   // (k_fused exists for the arena-major layout only)
+  if (use_q && e->fused) {
     const unsigned lpw = (unsigned)((e->lds_bytes + 15) & ~(size_t)15);
-    const int wg = e->fused_wg, apw = wg / AG_QG;  // threads and arenas per workgroup
-#define CALL(N, V) hipLaunchKernelGGL((k_fused<N, V>), dim3((e->d.A + apw - 1) / apw), dim3(wg), (wg / 64) * lpw, e->stream, hot, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, (int)lpw)
-    AG_DISPATCH_NS(e->ns, CALL);
+    const int wg = e->fused_wg, apw = wg / e->fused_qg;  // threads and arenas per workgroup
+#define CALLQ(N, V, Q) hipLaunchKernelGGL((k_fused<N, V, Q, T>), dim3((e->d.A + apw - 1) / apw), dim3(wg), (wg / 64) * lpw, e->stream, hot, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, (int)lpw)
+#define CALL(N, V) do { switch (e->fused_qg) { case 1: CALLQ(N, V, 1); break; case 2: CALLQ(N, V, 2); break; case 4: CALLQ(N, V, 4); break; case 8: CALLQ(N, V, 8); break; default: CALLQ(N, V, 16); break; } } while (0)
+#define T 6
+    if (tiled) AG_DISPATCH_NS(e->ns, CALL);
+#undef T
+#define T 0
+    if (!tiled) AG_DISPATCH_NS(e->ns, CALL);
+#undef T
 #undef CALL
+#undef CALLQ
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -518,12 +533,17 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   s.qlist = alloc<int32_t>(e, 2 * (size_t)d.A);
   { const char *nf = getenv("AGARCL_NO_FRONT"); e->no_front = nf && nf[0] == '1'; }
   // modes 0-4 start agents at mass 25 (quiet-dominated); 5 and 6 start at mass 1000 (general path every step)
-  e->fused = d.P == 1 && cfg->mode_number <= 4 && d.A < AG_FUSED_MAX_ARENAS && d.ts_lg == 0;  // starting point; poll_stats follows what the arenas actually do
+  // single launch (k_fused) wherever the batch fits 2048 wavefronts -- the 2 per SIMD its register footprint admits -- at
+  // some lane-group size: up to 131072 arenas
+  e->fused_qg = 16; while (e->fused_qg > 1 && (long)d.A * e->fused_qg > AG_FUSED_WAVES * 64L) e->fused_qg >>= 1;
+  { const char *w = getenv("AGARCL_FUSED_QG"); if (w) { int v = atoi(w); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) e->fused_qg = v; } }
+  e->fused_ok = d.P == 1 && (long)d.A * e->fused_qg <= AG_FUSED_WAVES * 64L;
+  e->fused = e->fused_ok && cfg->mode_number <= 4;  // starting point; poll_stats follows what the arenas actually do
   e->front_off = d.P == 1 && cfg->mode_number > 4; e->few_unfinished = false;
   e->work_step0 = e->work_front0 = 0; e->work_unf0 = 0; e->work_pass0 = 0;
   e->flags_seen = 0; e->d_mask = alloc<uint8_t>(e, (size_t)d.A);
   e->fused_fixed = false; e->h_stat = nullptr; e->stat_ev = nullptr; e->stat_pending = false; e->step_no = e->front_runs = e->stat_req_front = e->stat_last_front = 0; e->stat_last_total = 0;
-  { const char *fu = getenv("AGARCL_FUSED"); if (fu && (fu[0] == '0' || fu[0] == '1')) { e->fused = fu[0] == '1' && d.ts_lg == 0; e->fused_fixed = true; } }
+  { const char *fu = getenv("AGARCL_FUSED"); if (fu && (fu[0] == '0' || fu[0] == '1')) { e->fused = fu[0] == '1' && d.P == 1; e->fused_fixed = true; } }
   s.qstat = alloc<int32_t>(e, 16);
   // Lanes per arena of the lean front kernel.  The quiet tick is per-lane code that every lane of an arena's group carries
   // redundantly and a pellet pass is wave-wide whatever the group size, so the group size only sets how many wavefronts the

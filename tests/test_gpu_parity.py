@@ -150,13 +150,15 @@ def test_front_kernel_on_off_equivalence(hip_engine_cls, monkeypatch):
         assert np.array_equal(b0, b1)
 
 
-@pytest.mark.parametrize("qg", [1, 2, 4, 8, 16])
-def test_front_kernel_lanes_per_arena(hip_engine_cls, oracle_lib, monkeypatch, qg):
-    """The lean front kernel runs with 1, 2, 4, 8 or 16 lanes per arena (chosen from the arena count; AGARCL_QUIET_QG pins it,
-    AGARCL_FUSED=0 selects the two-kernel step that uses it): 64 / 32 / 16 / 8 / 4 arenas share a wavefront and its pellet
-    passes.  Quiet C2 arenas plus a few big ones, lock-step against the oracle, rewards every step and whole state at the end."""
+@pytest.mark.parametrize("qg,fused,tile", [(1, 0, 0), (2, 0, 0), (4, 0, 0), (8, 0, 0), (16, 0, 0), (1, 1, 6), (2, 1, 0), (4, 1, 6), (8, 1, 0), (2, 0, 6)])
+def test_front_kernel_lanes_per_arena(hip_engine_cls, oracle_lib, monkeypatch, qg, fused, tile):
+    """The lean front part runs with 1, 2, 4, 8 or 16 lanes per arena (chosen from the arena count; AGARCL_QUIET_QG / AGARCL_FUSED_QG
+    pin it, AGARCL_FUSED selects the two-kernel or the single-launch step, AGARCL_TILE_LG the layout of the word arrays): 64 / 32 /
+    16 / 8 / 4 arenas share a wavefront and its pellet passes.  Quiet C2 arenas plus a few big ones, lock-step against the oracle,
+    rewards every step and whole state at the end."""
     from oracle import blob
-    monkeypatch.setenv("AGARCL_QUIET_QG", str(qg)); monkeypatch.setenv("AGARCL_FUSED", "0")
+    monkeypatch.setenv("AGARCL_QUIET_QG", str(qg)); monkeypatch.setenv("AGARCL_FUSED_QG", str(qg))
+    monkeypatch.setenv("AGARCL_FUSED", str(fused)); monkeypatch.setenv("AGARCL_TILE_LG", str(tile))
     A, steps = 150, 250   # 150 arenas: the last wavefront is ragged for every group size
     eng = hip_engine_cls(A, **C2)
     oras = [oracle_lib.OraEnv(**C2) for _ in range(A)]
@@ -167,7 +169,7 @@ def test_front_kernel_lanes_per_arena(hip_engine_cls, oracle_lib, monkeypatch, q
         if a % 37 == 5:   # a big cell: every tick eats, so the front part keeps handing over
             d = blob.parse(o.dump()); d["players"][0]["cell_mass"][0] = 900
             b = blob.build(d); o.load(b); eng.load(b, a)
-    rng = np.random.RandomState(qg)
+    rng = np.random.RandomState(qg + 100 * fused + tile)
     for t in range(steps):
         dxdy = rng.uniform(-1, 1, size=(A, 1, 2)).astype(np.float32); act = np.zeros((A, 1), dtype=np.int32)
         eng.set_actions(dxdy, act); eng.step()
