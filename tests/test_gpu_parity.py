@@ -419,6 +419,36 @@ def test_config4_single_gpu_half_32768_arenas_mode6(hip_engine_cls, oracle_lib):
     eng.close()
 
 
+@pytest.mark.parametrize("A", [65536, 150000])
+def test_big_quiet_batches_default_policy(hip_engine_cls, oracle_lib, A):
+    """North-star batch sizes on ONE GPU with the engine's own choices (65 536 arenas: single launch, 2 lanes per arena, tiled
+    word arrays; 150 000: two kernels, 1 lane per arena, ragged last tile): C2, 60 steps; sampled arenas -- first / last of
+    tiles and wavefronts, the ragged tail -- equal the oracle run alone on the same seed and action stream; no flag anywhere;
+    every arena-step accounted for by the work counters."""
+    from oracle import blob
+    steps = 60
+    eng = hip_engine_cls(A, **C2)
+    eng.seed(None, 52000); eng.reset(reset_ids=True)
+    eng.work(reset=True)
+    sample = sorted({0, 1, 31, 32, 63, 64, 65, 4095, 4096, A // 2 + 7, A - 65, A - 64, A - 2, A - 1})
+    acts = []
+    for t in range(steps):
+        rng = np.random.RandomState(7000 + t // 4)
+        dxdy = rng.uniform(-1, 1, size=(A, 1, 2)).astype(np.float32)
+        a = np.zeros((A, 1), dtype=np.int32)
+        acts.append((dxdy[sample].copy(), a[sample].copy()))
+        eng.set_actions(dxdy, a); eng.step()
+    assert not eng.flags().any()
+    w = eng.work()
+    assert int(w[0]) + int(w[1]) == A * steps and int(w[0]) > 0.99 * A * steps
+    for k, arena in enumerate(sample):
+        o = oracle_lib.OraEnv(**C2); o.seed(52000 + arena); o.reset(True)
+        for dxdy, a in acts:
+            o.take_actions(dxdy[k], a[k]); o.step()
+        assert blob.diff(o.dump(), eng.dump(arena)) is None, "arena %d" % arena
+    eng.close()
+
+
 def test_error_paths(hip_engine_cls):
     from agarcl_amd._capi import AgarclError
     with pytest.raises(AgarclError):
