@@ -324,7 +324,7 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
     const unsigned lpw = (unsigned)((e->lds_bytes + 15) & ~(size_t)15);
     const int wg = e->fused_wg, apw = wg / e->fused_qg;  // threads and arenas per workgroup
 #define CALLQ(N, V, Q) hipLaunchKernelGGL((k_fused<N, V, Q, T>), dim3((e->d.A + apw - 1) / apw), dim3(wg), (wg / 64) * lpw, e->stream, hot, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, (int)lpw)
-#define CALL(N, V) do { switch (e->fused_qg) { case 1: CALLQ(N, V, 1); break; case 2: CALLQ(N, V, 2); break; case 4: CALLQ(N, V, 4); break; case 8: CALLQ(N, V, 8); break; default: CALLQ(N, V, 16); break; } } while (0)
+#define CALL(N, V) do { switch (e->fused_qg) { case 32: CALLQ(N, V, 32); break; case 1: CALLQ(N, V, 1); break; case 2: CALLQ(N, V, 2); break; case 4: CALLQ(N, V, 4); break; case 8: CALLQ(N, V, 8); break; default: CALLQ(N, V, 16); break; } } while (0)
 #define T 6
     if (tiled) AG_DISPATCH_NS(e->ns, CALL);
 #undef T
@@ -535,8 +535,12 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   // modes 0-4 start agents at mass 25 (quiet-dominated); 5 and 6 start at mass 1000 (general path every step)
   // single launch (k_fused) wherever the batch fits 2048 wavefronts -- the 2 per SIMD its register footprint admits -- at
   // some lane-group size: up to 131072 arenas
-  e->fused_qg = 16; while (e->fused_qg > 1 && (long)d.A * e->fused_qg > AG_FUSED_WAVES * 64L) e->fused_qg >>= 1;
-  { const char *w = getenv("AGARCL_FUSED_QG"); if (w) { int v = atoi(w); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) e->fused_qg = v; } }
+  // (measured, C2, us per step by wavefront count: 2048 arenas 512 / 1024 / 2048 wavefronts 8.75 / 8.65 / 9.26; 4096 arenas
+  // 9.47 / 9.23 / 9.81; 8192: 1024 / 2048: 10.23 / 10.63; 16384: 13.52 / 12.11 / 12.30 / 17.96 (512 ... 4096); 32768: 15.97 /
+  // 14.09 / 13.83 / 20.20; 65536: 1024 / 2048 / 4096: 18.97 / 17.70 / 23.93; 131072: 2048 / 4096: 25.57 / 30.92)
+  { const long target = d.A <= 16384 ? 1024L : AG_FUSED_WAVES;   // one wavefront per SIMD for the small batches, two beyond
+    e->fused_qg = 32; while (e->fused_qg > 1 && (long)d.A * e->fused_qg > target * 64L) e->fused_qg >>= 1; }
+  { const char *w = getenv("AGARCL_FUSED_QG"); if (w) { int v = atoi(w); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) e->fused_qg = v; } }
   e->fused_ok = d.P == 1 && (long)d.A * e->fused_qg <= AG_FUSED_WAVES * 64L;
   e->fused = e->fused_ok && cfg->mode_number <= 4;  // starting point; poll_stats follows what the arenas actually do
   e->front_off = d.P == 1 && cfg->mode_number > 4; e->few_unfinished = false;
