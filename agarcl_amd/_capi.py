@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_SO = os.environ.get("AGARCL_HIP_SO") or os.path.join(_HERE, "libagarcl_hip.so")
 
 E_UNSUPPORTED = -3
-PACKED_SLOTS = 16   # include/agarcl_batch.h AGARCL_PACKED_SLOTS
+PACKED_SLOTS = 64   # include/agarcl_batch.h AGARCL_PACKED_SLOTS
 
 
 class AgarclError(RuntimeError):

@@ -38,7 +38,7 @@ enum {
   AR_WORDS = 32
 };
 #define AG_MAX_PLAYERS 16
-#define AG_PACKED_SLOTS 16  // ring of packed (reward, done) result buffers: step k of an env writes slot k % 16
+#define AG_PACKED_SLOTS 64  // ring of packed (reward, done) result buffers: step k of an env writes slot k % 64
 #define AG_CC 32        // cell capacity per player (reference: unbounded vector, nominal limit 14)
 #define AG_EV_CAP 256   // pellet eat events per arena-tick
 #define AG_EVV_CAP 16   // virus eat events per arena-tick (<= players)

@@ -62,7 +62,9 @@ class ResultGatherer:
 
     def gather_packed(self, slot, packed):
         """Zero-copy variant: `packed` is the engine's own ping-pong buffer of step parity `slot` ([A_local, 2] f32,
-        agarcl_packed_dev).  wait_slot(slot) must be called before the engine overwrites that parity again."""
+        agarcl_packed_dev).  wait_slot(slot) must be called before the engine overwrites that parity again.  A gather still
+        in flight on this buffer is waited for first."""
+        self.wait_slot(slot)
         self.work[slot] = self.dist.gather(packed, self.recv[slot] if self.rank == 0 else None, dst=0, group=self.group,
                                            async_op=True)
 

@@ -39,7 +39,7 @@ class VecEnvironment:
         self.dones_u8 = torch.as_tensor(_DevArray(p["dones"], (A, n), "|u1"), device=self.device)
         self.masses = torch.as_tensor(_DevArray(p["masses"], (A, n), "<i4"), device=self.device)
         # (reward, done) f32 pairs in a ring of PACKED_SLOTS buffers: packed[engine.last_slot()] belongs to the last step;
-        # packed_ring[8 * h : 8 * h + 8] is one contiguous block of 8 consecutive steps (what bench.py gathers per collective)
+        # packed_ring[B * h : B * h + B] is one contiguous block of B consecutive steps (what bench.py gathers per collective, B = 32)
         self.packed_ring = torch.as_tensor(_DevArray(p["packed"], (_capi.PACKED_SLOTS, A * n, 2), "<f4"), device=self.device)
         self.packed = [self.packed_ring[k] for k in range(_capi.PACKED_SLOTS)]
         self._act_keep = None

@@ -155,7 +155,7 @@ def spawn_ranks(n):
 
 
 def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, Wm, cfg, rand_act, with_obs, with_screen,
-                 gather_mode, gather_obs):
+                 gather_mode, gather_obs, gather_block=32):
     """Builds the env, runs Wm untimed + K timed steps, returns the measurements of this rank."""
     import torch.distributed as dist
     lo, hi = rank * A, (rank + 1) * A  # weak scaling: every GPU owns `A` arenas
@@ -173,11 +173,14 @@ def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, 
     want_screen = with_screen or (world > 1 and gather_obs == "screen")
     scr = torch.empty((A, 84, 84, 3), dtype=torch.uint8, device=dev) if want_screen else None
     # Multi-GPU result path (the only exchange there is: arenas never interact).
-    #   block: (reward, done) of 8 consecutive steps -- one contiguous block of the engine's 16-slot result ring, zero copy --
-    #          per asynchronous RCCL gather, double-buffered by ring half: for a synthetic policy, where nobody waits for them
+    #   block: (reward, done) of 32 (--gather-block) consecutive steps -- one contiguous block of the engine's 64-slot result
+    #          ring, zero copy -- per asynchronous RCCL gather, double-buffered by ring half: a rollout chunk, as an n-step learner
+    #          consumes them; the collective's host-side launch cost is paid once per block, not once per 9 us step
     #   step : one gather per step straight from the slot the step wrote (what a learner on rank 0 needs; ~20 us of latency each)
     #   --gather-obs screen: additionally every step's uint8 frames [A][84][84][3] go to rank 0 (21 KB per arena)
-    BLK = 8
+    BLK = int(gather_block)
+    SLOTS = 64                                  # agarcl_batch.h AGARCL_PACKED_SLOTS
+    assert SLOTS % (2 * BLK) == 0
     eng = env.engine
     gather = obs_gather = None
     if world > 1:
@@ -188,9 +191,9 @@ def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, 
     def one_step(k):
         eng.set_actions_device(dxdy[k].data_ptr(), act[k].data_ptr())
         if gather is not None and gather_mode == "block":
-            nxt = (eng.last_slot() + 1) % (2 * BLK)
+            nxt = (eng.last_slot() + 1) % SLOTS
             if nxt % BLK == 0:
-                gather.wait_slot(nxt // BLK)    # the engine is about to overwrite this half of the ring
+                gather.wait_slot((nxt // BLK) & 1)   # the engine is about to write this block: the gather that last used its buffer has left
         eng.step(cfg["ticks_per_step"])
         if obs is not None:
             eng.grid_obs(128, True, True, True, True, out_ptr=obs.data_ptr())
@@ -205,16 +208,16 @@ def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, 
             if gather_mode == "step":
                 gather.wait_slot(s_ & 1)
                 gather.gather_packed(s_ & 1, env.packed_ring[s_])
-            elif s_ % BLK == BLK - 1:           # RCCL gather of 8 steps of (reward, done) straight from engine memory
+            elif s_ % BLK == BLK - 1:           # RCCL gather of one block of steps of (reward, done) straight from engine memory
                 h_ = s_ // BLK
-                gather.gather_packed(h_, env.packed_ring[h_ * BLK:(h_ + 1) * BLK].reshape(-1, 2))
+                gather.gather_packed(h_ & 1, env.packed_ring[h_ * BLK:(h_ + 1) * BLK].reshape(-1, 2))
 
     def flush():                                # results of a partial last block still go to rank 0
         s_ = eng.last_slot()
         if gather is not None and gather_mode == "block" and s_ % BLK != BLK - 1:
             h_ = s_ // BLK
-            gather.wait_slot(h_)
-            gather.gather_packed(h_, env.packed_ring[h_ * BLK:(h_ + 1) * BLK].reshape(-1, 2))
+            gather.wait_slot(h_ & 1)
+            gather.gather_packed(h_ & 1, env.packed_ring[h_ * BLK:(h_ + 1) * BLK].reshape(-1, 2))
 
     def drain():
         if gather is not None:
@@ -293,6 +296,7 @@ def main():
     ap.add_argument("--no-large", action="store_true", help="skip the %d-arena roofline_large run" % LARGE_ARENAS)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS), help="C2 = the headline metric's configuration")
     ap.add_argument("--gather", default="block", choices=["block", "step"], help="multi-GPU: how (reward, done) reaches rank 0")
+    ap.add_argument("--gather-block", type=int, default=32, choices=[8, 16, 32], help="multi-GPU, --gather block: steps per collective")
     ap.add_argument("--gather-obs", default="none", choices=["none", "screen"], help="multi-GPU: also gather every step's uint8 frames")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -334,7 +338,7 @@ def main():
     A, K, Wm = args.arenas, args.steps, args.warmup
     ticks = cfg["ticks_per_step"]
     res = run_workload(torch, np, VecEnvironment, agdist, dev, dev_index, rank, world, A, K, Wm, cfg, rand_act, with_obs, with_screen,
-                       args.gather, args.gather_obs)
+                       args.gather, args.gather_obs, args.gather_block)
     value = world * A * ticks * K / res["elapsed"]
     if rank == 0:
         extra = (A * 8 * 128 * 128 * 4 if with_obs else 0) + (A * 84 * 84 * 3 if with_screen else 0)
@@ -350,7 +354,7 @@ def main():
                         "roofline_large for the bandwidth-bound regime")
         if world > 1:
             par = "arena-sharded x%d; every step's (reward, done) gathered to rank 0 %s%s" % (
-                world, "in asynchronous blocks of 8 steps" if args.gather == "block" else "by one collective per step",
+                world, "in asynchronous blocks of %d steps" % args.gather_block if args.gather == "block" else "by one collective per step",
                 ", plus every step's uint8 screen frames" if args.gather_obs == "screen" else "")
         else:
             par = "single GPU"

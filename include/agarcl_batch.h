@@ -113,9 +113,9 @@ const double *agarcl_rewards_dev(agarcl_env *env);
 const uint8_t *agarcl_dones_dev(agarcl_env *env);
 const int32_t *agarcl_masses_dev(agarcl_env *env);
 /* (reward, done) as f32 pairs [num_arenas][num_agents][2] in a ring of AGARCL_PACKED_SLOTS contiguous buffers: the
- * k-th agarcl_step of an env writes slot k % 16, so an asynchronous gather (RCCL) of the last 8 steps' results -- one
- * contiguous block -- can overlap the next 8 steps.  agarcl_last_slot = slot of the last step. */
-#define AGARCL_PACKED_SLOTS 16
+ * k-th agarcl_step of an env writes slot k % 64, so an asynchronous gather (RCCL) of the last 8 / 16 / 32 steps' results -- one
+ * contiguous block -- can overlap the next block of steps.  agarcl_last_slot = slot of the last step. */
+#define AGARCL_PACKED_SLOTS 64
 const float *agarcl_packed_dev(agarcl_env *env, int32_t slot);
 int agarcl_last_slot(agarcl_env *env);
 /* synchronising host copies */

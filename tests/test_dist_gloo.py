@@ -59,40 +59,50 @@ def _worker(rank, world, port, q):
                 ok = ok and torch.equal(got[:, 0], torch.arange(0, world * n_local, dtype=torch.float32) * 2 + (k - 1))
                 ok = ok and bool((got[:, 1] == float((k - 1) % 2)).all())
     g.wait_all()
-    # bench.py's pattern: the engine's 16-slot result ring, one asynchronous gather per block of 8 steps (the ring half the
-    # engine is not writing), and a flush of the partial last block
-    SLOTS, BLK, A = 16, 8, 5
-    ring = torch.zeros((SLOTS, A, 2), dtype=torch.float32)
-    gb = agdist.ResultGatherer(BLK * A, torch.device("cpu"), depth=2)
-    seen = {}
-    last = SLOTS - 1
-    for step in range(21):                       # 21 is not a multiple of 8
-        nxt = (last + 1) % SLOTS
-        if nxt % BLK == 0:
-            gb.wait_slot(nxt // BLK)             # about to overwrite this half
-            if rank == 0 and nxt // BLK in seen:
-                blk0, h = seen.pop(nxt // BLK)
-                got = gb.gathered(h).reshape(world, BLK, A, 2)
-                for r in range(world):
-                    for j in range(BLK):
-                        ok = ok and bool((got[r, j, :, 0] == float(1000 * r + blk0 + j)).all())
-        ring[nxt, :, 0] = float(1000 * rank + step); ring[nxt, :, 1] = 0.0   # "the engine" writes step `step`
-        last = nxt
-        if last % BLK == BLK - 1:
+    # bench.py's pattern: the engine's 64-slot result ring, one asynchronous gather per block of BLK steps into one of two
+    # gather buffers, and a flush of the partial last block (BLK = 32: two blocks = the two ring halves; BLK = 8: eight blocks
+    # share the two buffers)
+    for SLOTS, BLK, A, STEPS in ((64, 32, 5, 75), (64, 8, 3, 101)):
+        ring = torch.zeros((SLOTS, A, 2), dtype=torch.float32)
+        gb = agdist.ResultGatherer(BLK * A, torch.device("cpu"), depth=2)
+        seen = {}
+        last = SLOTS - 1
+        for step in range(STEPS):                    # not a multiple of the block
+            nxt = (last + 1) % SLOTS
+            if nxt % BLK == 0:
+                b = (nxt // BLK) & 1
+                gb.wait_slot(b)                      # the gather that last used this buffer has left (and, BLK = 32, this ring half)
+                if rank == 0 and b in seen:
+                    blk0 = seen.pop(b)
+                    got = gb.gathered(b).reshape(world, BLK, A, 2)
+                    for r in range(world):
+                        for j in range(BLK):
+                            ok = ok and bool((got[r, j, :, 0] == float(1000 * r + blk0 + j)).all())
+            ring[nxt, :, 0] = float(1000 * rank + step); ring[nxt, :, 1] = 0.0   # "the engine" writes step `step`
+            last = nxt
+            if last % BLK == BLK - 1:
+                h = last // BLK
+                if rank == 0 and (h & 1) in seen:    # (BLK < 32: the buffer's previous block is checked before it is reused)
+                    gb.wait_slot(h & 1); blk0 = seen.pop(h & 1)
+                    got = gb.gathered(h & 1).reshape(world, BLK, A, 2)
+                    for r in range(world):
+                        for j in range(BLK):
+                            ok = ok and bool((got[r, j, :, 0] == float(1000 * r + blk0 + j)).all())
+                gb.gather_packed(h & 1, ring[h * BLK:(h + 1) * BLK].reshape(-1, 2))
+                seen[h & 1] = step - BLK + 1
+        if last % BLK != BLK - 1:                    # flush
             h = last // BLK
-            gb.gather_packed(h, ring[h * BLK:(h + 1) * BLK].reshape(-1, 2))
-            seen[h] = (step - BLK + 1, h)
-    if last % BLK != BLK - 1:                    # flush
-        h = last // BLK
-        gb.wait_slot(h); gb.gather_packed(h, ring[h * BLK:(h + 1) * BLK].reshape(-1, 2))
-        gb.wait_slot(h)
-        if rank == 0:
-            got = gb.gathered(h).reshape(world, BLK, A, 2)
-            first = 21 - (last % BLK + 1)
-            for r in range(world):
-                for j in range(last % BLK + 1):
-                    ok = ok and bool((got[r, j, :, 0] == float(1000 * r + first + j)).all())
-    gb.wait_all()
+            gb.wait_slot(h & 1); gb.gather_packed(h & 1, ring[h * BLK:(h + 1) * BLK].reshape(-1, 2))
+            gb.wait_slot(h & 1)
+            if rank == 0:
+                got = gb.gathered(h & 1).reshape(world, BLK, A, 2)
+                first = STEPS - (last % BLK + 1)
+                for r in range(world):
+                    for j in range(last % BLK + 1):
+                        ok = ok and bool((got[r, j, :, 0] == float(1000 * r + first + j)).all())
+        gb.wait_all()
+    SLOTS, A = 64, 5
+    ring = torch.zeros((SLOTS, A, 2), dtype=torch.float32)
     # bench.py --gather step: one collective per step straight from the ring slot the step wrote, parity-buffered
     gs = agdist.ResultGatherer(A, torch.device("cpu"), depth=2)
     for step in range(7):
