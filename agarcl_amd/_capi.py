@@ -48,6 +48,7 @@ SYMBOLS = [
     ("agarcl_reset_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     ("agarcl_set_actions", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     ("agarcl_step", C.c_int, [C.c_void_p, C.c_int32]),
+    ("agarcl_step_actions", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     ("agarcl_tick", C.c_int, [C.c_void_p, C.c_int32]),
     ("agarcl_set_targets", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("agarcl_respawn_dead", C.c_int, [C.c_void_p]),
@@ -188,6 +189,12 @@ class BatchedEngine:
 
     def step(self, ticks=0):
         self._chk(self.L.agarcl_step(self.h, ticks))
+
+    def step_actions(self, dxdy_ptr, act_ptr, ticks=0):
+        """set_actions_device + step in one call (raw HBM pointers as ints)"""
+        rc = self.L.agarcl_step_actions(self.h, dxdy_ptr, act_ptr, ticks)
+        if rc != 0:
+            self._chk(rc)
 
     def tick(self, ticks=1):
         self._chk(self.L.agarcl_tick(self.h, ticks))

@@ -708,6 +708,11 @@ extern "C" int agarcl_step(agarcl_env *e, int32_t ticks) {
   e->slot = (e->slot + 1) % AG_PACKED_SLOTS;
   return rc;
 }
+extern "C" int agarcl_step_actions(agarcl_env *e, const float *dxdy_dev, const int32_t *act_dev, int32_t ticks) {
+  if (!e || !dxdy_dev || !act_dev) return fail(AGARCL_E_INVALID, "agarcl_step_actions: null pointer");
+  e->act_dxdy = dxdy_dev; e->act = act_dev;
+  return agarcl_step(e, ticks);
+}
 extern "C" const float *agarcl_packed_dev(agarcl_env *e, int32_t slot) { return e ? e->s.packed + (size_t)(((slot % AG_PACKED_SLOTS) + AG_PACKED_SLOTS) % AG_PACKED_SLOTS) * e->d.A * e->d.n_agents * 2 : nullptr; }
 extern "C" int agarcl_last_slot(agarcl_env *e) { return e ? (e->slot + AG_PACKED_SLOTS - 1) % AG_PACKED_SLOTS : 0; }
 extern "C" int agarcl_tick(agarcl_env *e, int32_t ticks) {

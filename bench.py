@@ -188,13 +188,19 @@ def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, 
         if gather_obs == "screen":
             obs_gather = agdist.TensorGatherer((A, 84, 84, 3), torch.uint8, dev)
 
+    # raw pointers of the pre-generated policy output, one pair per step (no tensor indexing inside the timed loop)
+    dx_ptr = [dxdy[k].data_ptr() for k in range(K + Wm)]
+    ac_ptr = [act[k].data_ptr() for k in range(K + Wm)]
+    tps = cfg["ticks_per_step"]
+    slot_of = lambda k: (first_slot + k) % SLOTS   # the ring slot step k writes (the engine's slot counter advances by one per step)
+    first_slot = (eng.last_slot() + 1) % SLOTS
+
     def one_step(k):
-        eng.set_actions_device(dxdy[k].data_ptr(), act[k].data_ptr())
         if gather is not None and gather_mode == "block":
-            nxt = (eng.last_slot() + 1) % SLOTS
+            nxt = slot_of(k)
             if nxt % BLK == 0:
                 gather.wait_slot((nxt // BLK) & 1)   # the engine is about to write this block: the gather that last used its buffer has left
-        eng.step(cfg["ticks_per_step"])
+        eng.step_actions(dx_ptr[k], ac_ptr[k], tps)   # take_actions + step: one host call
         if obs is not None:
             eng.grid_obs(128, True, True, True, True, out_ptr=obs.data_ptr())
         if scr is not None:
@@ -204,7 +210,7 @@ def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, 
             if obs_gather is not None:
                 obs_gather.gather(scr)
         if gather is not None:
-            s_ = eng.last_slot()
+            s_ = slot_of(k)
             if gather_mode == "step":
                 gather.wait_slot(s_ & 1)
                 gather.gather_packed(s_ & 1, env.packed_ring[s_])
@@ -229,11 +235,12 @@ def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, 
         one_step(k)
     flush(); drain()
     eng.work(reset=True)                        # (synchronising) the kernels' work counters restart with the timed region
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(); ev1.record()                  # torch creates the HIP events lazily, at their first record(): not inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     for k in range(Wm, Wm + K):
@@ -244,7 +251,7 @@ def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, 
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / K  # HIP events on the launch stream (the engine adopts torch's current stream): avg per step
     if world > 1:

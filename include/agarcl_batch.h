@@ -97,6 +97,9 @@ int agarcl_set_actions(agarcl_env *env, const float *dxdy, const int32_t *act, i
 /* replaces: step() -> list[float], bindings.cpp:132 -> BaseEnvironment::step, BaseEnvironment.hpp:89-122.
  * ticks <= 0 -> ticks_per_step.  Asynchronous on the env's stream. */
 int agarcl_step(agarcl_env *env, int32_t ticks);
+/* agarcl_set_actions(on_device = 1) + agarcl_step in one call: what a vectorised loop whose policy output already lives in
+ * HBM does every step (take_actions + step, bindings.cpp:117-119,132).  One host call per env step instead of two. */
+int agarcl_step_actions(agarcl_env *env, const float *dxdy_dev, const int32_t *act_dev, int32_t ticks);
 /* engine-level tick without the env's action/reward logic (Engine::tick, Engine.hpp:208-240);
  * targets/actions as last set via agarcl_set_targets. */
 int agarcl_tick(agarcl_env *env, int32_t ticks);
