@@ -1568,8 +1568,13 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
         q.mtidx += 2; q.idc += 1;
         pel.append(q.np, px, py, q.idc);
         q.np += 1;
+        // the pellet-free disc shrinks to exclude the new pellet (same margin as a pass leaves: sqrt(d2) - radius - 0.01); it is
+        // NOT given up -- the new pellet falls into it about once in 10^4 times, and a lost disc costs a whole pass
+        float ox = px - q.sx0, oy = py - q.sy0; float d2 = ox * ox, d2b = oy * oy; d2 = d2 + d2b;
+        float sl = ag_sqrtf(d2) - q.r; sl = sl - 0.01f; sl = sl > 0.0f ? sl : 0.0f;
+        if (sl < q.slack) { q.slack = sl; s2 = sl * sl; }
       }
-      q.pel_changed = true; q.slack = 0.0f; s2 = 0.0f;  // a new pellet may lie inside the old pellet-free disc
+      q.pel_changed = true;
     }
   };
 
