@@ -449,6 +449,32 @@ def test_big_quiet_batches_default_policy(hip_engine_cls, oracle_lib, A):
     eng.close()
 
 
+def test_step_actions_is_take_actions_plus_step(hip_engine_cls):
+    """agarcl_step_actions (one host call per env step, policy output already in HBM) == agarcl_set_actions(on_device) + agarcl_step."""
+    import torch
+    A, steps = 96, 40
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    dxdy = (torch.rand((steps, A, 1, 2), generator=g, device=dev) * 2 - 1).contiguous()
+    act = torch.randint(0, 3, (steps, A, 1), generator=g, device=dev, dtype=torch.int32)
+    outs = []
+    for fused_call in (False, True):
+        eng = hip_engine_cls(A, **C3)
+        eng.seed(None, 777); eng.reset(reset_ids=True)
+        rs = []
+        for t in range(steps):
+            if fused_call:
+                eng.step_actions(dxdy[t].data_ptr(), act[t].data_ptr(), 0)
+            else:
+                eng.set_actions_device(dxdy[t].data_ptr(), act[t].data_ptr()); eng.step()
+            rs.append(eng.rewards().copy())
+        outs.append((np.array(rs), [eng.dump(a) for a in range(A)]))
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for b0, b1 in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(b0, b1)
+
+
 def test_error_paths(hip_engine_cls):
     from agarcl_amd._capi import AgarclError
     with pytest.raises(AgarclError):
