@@ -86,3 +86,36 @@ def test_emulated_engine_level_60hz(emu_lib, oracle_lib):
     oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
     ok, msg = run_engine_level_lockstep(eng, oras, 1400, seeds=[5, 6], every=25, respawn=False)
     assert ok, msg
+
+
+def test_emulated_mode3_done_threshold(emu_lib, oracle_lib):
+    """Mode 3 ends an episode when the agent's mass reaches 23 000 (BaseEnvironment.hpp:108-111; pinned against the reference in
+    test_oracle_vs_reference.py): cells loaded just below the threshold cross it by eating -- through the lean front part (arena 0:
+    sparse pellets) and through the general engine (crowded arenas) -- dones, rewards and state against the oracle."""
+    from oracle import blob
+    from agarcl_amd import _capi
+    cfg = dict(num_agents=1, arena_size=300, num_pellets=600, num_viruses=0, mode=3, reward_type=1)
+    A = 4
+    eng = _capi.BatchedEngine(A, lib=emu_lib, **cfg)
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    seeds = np.array([9, 10, 11, 12], dtype=np.uint32)
+    eng.seed(seeds); eng.reset(reset_ids=True)
+    for a, o in enumerate(oras):
+        o.seed(int(seeds[a])); o.reset(True)
+        d = blob.parse(o.dump()); d["players"][0]["cell_mass"][0] = 22999 - 3 * a
+        b = blob.build(d); o.load(b); eng.load(b, a)
+    rng = np.random.RandomState(4)
+    seen = np.zeros(A, bool)
+    for t in range(100):
+        dxdy = rng.uniform(-1, 1, size=(A, 1, 2)).astype(np.float32); act = np.zeros((A, 1), np.int32)
+        eng.set_actions(dxdy, act); eng.step()
+        r, dn = eng.rewards(), eng.dones()
+        for a in range(A):
+            oras[a].take_actions(dxdy[a], act[a]); ro = oras[a].step()
+            assert r[a, 0] == ro[0], (t, a)
+            assert bool(dn[a, 0]) == bool(np.asarray(oras[a].dones())[0]), (t, a)
+        seen |= dn[:, 0].astype(bool)
+    for a in range(A):
+        assert blob.diff(oras[a].dump(), eng.dump(a)) is None, a
+    assert seen.all()
+    eng.close()

@@ -475,6 +475,38 @@ def test_step_actions_is_take_actions_plus_step(hip_engine_cls):
         assert np.array_equal(b0, b1)
 
 
+def test_mode3_done_threshold(hip_engine_cls, oracle_lib):
+    """Mode 3 ends an episode when the agent's mass reaches 23 000 (BaseEnvironment.hpp:108-111; pinned against the reference in
+    test_oracle_vs_reference.py): cells loaded just below the threshold cross it by eating -- through the lean front part (arena 0:
+    sparse pellets) and through the general engine (crowded arenas) -- dones, rewards and state against the oracle."""
+    from oracle import blob
+    cfg = dict(num_agents=1, arena_size=300, num_pellets=600, num_viruses=0, mode=3, reward_type=1)
+    A = 4
+    eng = hip_engine_cls(A, **cfg)
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    seeds = np.array([9, 10, 11, 12], dtype=np.uint32)
+    eng.seed(seeds); eng.reset(reset_ids=True)
+    for a, o in enumerate(oras):
+        o.seed(int(seeds[a])); o.reset(True)
+        d = blob.parse(o.dump()); d["players"][0]["cell_mass"][0] = 22999 - 3 * a
+        b = blob.build(d); o.load(b); eng.load(b, a)
+    rng = np.random.RandomState(4)
+    seen = np.zeros(A, bool)
+    for t in range(100):
+        dxdy = rng.uniform(-1, 1, size=(A, 1, 2)).astype(np.float32); act = np.zeros((A, 1), np.int32)
+        eng.set_actions(dxdy, act); eng.step()
+        r, dn = eng.rewards(), eng.dones()
+        for a in range(A):
+            oras[a].take_actions(dxdy[a], act[a]); ro = oras[a].step()
+            assert r[a, 0] == ro[0], (t, a)
+            assert bool(dn[a, 0]) == bool(np.asarray(oras[a].dones())[0]), (t, a)
+        seen |= dn[:, 0].astype(bool)
+    for a in range(A):
+        assert blob.diff(oras[a].dump(), eng.dump(a)) is None, a
+    assert seen.all()
+    eng.close()
+
+
 def test_error_paths(hip_engine_cls):
     from agarcl_amd._capi import AgarclError
     with pytest.raises(AgarclError):

@@ -84,3 +84,26 @@ def test_screen_respawn_hook_pinned(ref_lib, oracle_lib):
             if t % 10 == 0:
                 assert blob.diff(r.dump(), o.dump()) is None, (cfg, t)
         assert blob.diff(r.dump(), o.dump()) is None
+
+
+def test_mode3_done_threshold_pinned(ref_lib, oracle_lib):
+    """Mode 3 ends an episode when the agent's mass reaches 23 000 (BaseEnvironment.hpp:108-111): a cell loaded at mass 22 990
+    grows across the threshold by eating pellets; rewards, dones and state of the oracle against the real reference."""
+    import numpy as np
+    from oracle import blob
+    cfg = dict(num_agents=1, arena_size=300, num_pellets=600, num_viruses=0, mode=3, reward_type=1)
+    r = ref_lib.RefEnv(**cfg); o = oracle_lib.OraEnv(**cfg)
+    for e in (r, o):
+        e.seed(9); e.reset(True)
+    d = blob.parse(o.dump()); d["players"][0]["cell_mass"][0] = 22990; b = blob.build(d)
+    r.load(b); o.load(b)
+    rng = np.random.RandomState(4)
+    seen_done = False
+    for t in range(120):
+        dxdy = rng.uniform(-1, 1, size=(1, 2)).astype(np.float32); act = np.zeros(1, np.int32)
+        r.take_actions(dxdy, act); o.take_actions(dxdy, act)
+        assert np.array_equal(r.step(), o.step()), t
+        assert np.array_equal(r.dones(), o.dones()), t
+        seen_done = seen_done or bool(np.asarray(r.dones()).any())
+    assert blob.diff(r.dump(), o.dump()) is None
+    assert seen_done, "the threshold was never crossed: the test does not test what it says"
