@@ -253,13 +253,14 @@ class BatchedEngine:
         self._chk(self.L.agarcl_get_events(self.h, _ptr(n), _ptr(pe), cap, _ptr(ve), cap_v))
         return n, pe, ve
 
-    def grid_obs(self, grid_size=128, cells=True, others=True, viruses=True, pellets=True, out_ptr=None):
-        """int32 [A, n_agents, C, G, G] (host copy), or written to the HBM pointer `out_ptr` (returns C)."""
+    def grid_obs(self, grid_size=128, cells=True, others=True, viruses=True, pellets=True, out_ptr=None, persistent=False):
+        """int32 [A, n_agents, C, G, G] (host copy), or written to the HBM pointer `out_ptr` (returns C).  persistent=True: that
+        HBM buffer is rewritten every step and nobody else modifies it -- only what the previous call scattered into it is cleared."""
         ch = C.c_int32(0)
-        self._chk(self.L.agarcl_grid_obs(self.h, grid_size, int(cells), int(others), int(viruses), int(pellets), None, 0, C.byref(ch)))
         if out_ptr is not None:
-            self._chk(self.L.agarcl_grid_obs(self.h, grid_size, int(cells), int(others), int(viruses), int(pellets), C.c_void_p(out_ptr), 1, C.byref(ch)))
+            self._chk(self.L.agarcl_grid_obs(self.h, grid_size, int(cells), int(others), int(viruses), int(pellets), C.c_void_p(out_ptr), 2 if persistent else 1, C.byref(ch)))
             return ch.value
+        self._chk(self.L.agarcl_grid_obs(self.h, grid_size, int(cells), int(others), int(viruses), int(pellets), None, 0, C.byref(ch)))
         out = np.zeros((self.num_arenas, self.num_agents, ch.value, grid_size, grid_size), dtype=np.int32)
         self._chk(self.L.agarcl_grid_obs(self.h, grid_size, int(cells), int(others), int(viruses), int(pellets), _ptr(out), 0, C.byref(ch)))
         return out

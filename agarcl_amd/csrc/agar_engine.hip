@@ -75,6 +75,7 @@ struct agarcl_env {
   float *d_act_dxdy; int32_t *d_act;  // env-owned action buffers (host-copy path)
   float *lut_r, *lut_ms, *lut_ss, *lut_anti;
   int32_t *obs_buf; size_t obs_cap;  // staging for host-side grid observations
+  int32_t *undo_list, *undo_count; const int32_t *undo_out; int undo_key;  // incremental clearing of the grid observation (AgObsUndo)
   std::vector<uint32_t> seeds;  // last seed of every arena (BaseEnvironment::seed_, written into JSON snapshots)
   bool fused;     // single-launch step (k_fused) instead of k_quiet + k_step: see k_fused
   bool fused_fixed;                // AGARCL_FUSED=0/1 pins the choice
@@ -465,7 +466,7 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
 #endif
   agarcl_env *e = new agarcl_env();
   e->cfg = *cfg; e->device = device; e->own_stream = true; e->d_act_dxdy = nullptr; e->d_act = nullptr;
-  e->slot = 0; e->d_state = nullptr; e->act_dxdy = nullptr; e->act = nullptr; e->obs_buf = nullptr; e->obs_cap = 0;
+  e->slot = 0; e->d_state = nullptr; e->act_dxdy = nullptr; e->act = nullptr; e->obs_buf = nullptr; e->obs_cap = 0; e->undo_list = e->undo_count = nullptr; e->undo_out = nullptr; e->undo_key = -1;
 #ifdef AGAR_CPU_EMU
   e->stream = nullptr;
 #else
@@ -974,9 +975,9 @@ extern "C" int64_t agarcl_state_bytes(agarcl_env *e) {
 }
 
 #ifndef AGAR_CPU_EMU
-__global__ void __launch_bounds__(256) k_grid_obs(const AgState *__restrict__ gs, AgObsCfg o, int32_t *out, int zero_fill) {
+__global__ void __launch_bounds__(256) k_grid_obs(const AgState *__restrict__ gs, AgObsCfg o, int32_t *out, int zero_fill, AgObsUndo un) {
   int b = (int)blockIdx.x, na = gs->d.n_agents;
-  grid_obs_agent(gs, b / na, b % na, o, out + (size_t)b * obs_channels(o) * o.G * o.G, zero_fill != 0);
+  grid_obs_agent(gs, b / na, b % na, o, out + (size_t)b * obs_channels(o) * o.G * o.G, zero_fill != 0, un, b);
 }
 // zeros for channels 1 .. C-1 of every frame: a plain streaming fill (grid-stride, 16 bytes per lane), which reaches the
 // write bandwidth of a memset; channel 0 and the entities are written afterwards by k_grid_obs
@@ -1079,9 +1080,21 @@ extern "C" int agarcl_grid_obs(agarcl_env *e, int32_t G, int32_t cells, int32_t 
     dst = e->obs_buf;
   }
   const size_t GG = (size_t)G * G;
-  const bool split = (GG & 3) == 0 && C > 1 && (((size_t)dst) & 15) == 0;
+  // on_device == 2: the caller's buffer still holds this env's previous observation (same grid, same channels): clear only
+  // what was written then.  The first such call (or a different buffer / configuration) clears everything and starts the list.
+  AgObsUndo un{nullptr, nullptr, 0, 0};
+  if ((on_device == 2 || !on_device) && C > 1) {   // (host copies go through the engine's own staging buffer: persistent by construction)
+    const int ucap = OBS_UNDO_CAP(e->d.PC), key = G * 16 + o.cells + 2 * o.others + 4 * o.viruses + 8 * o.pellets;
+    if (!e->undo_list) { e->undo_list = alloc<int32_t>(e, n * (size_t)ucap); e->undo_count = alloc<int32_t>(e, n); }
+    if (e->undo_list && e->undo_count) {
+      un.list = e->undo_list; un.count = e->undo_count; un.cap = ucap;
+      un.clear = e->undo_out == dst && e->undo_key == key;
+      e->undo_out = dst; e->undo_key = key;
+    }
+  }
+  const bool split = !un.clear && (GG & 3) == 0 && C > 1 && (((size_t)dst) & 15) == 0;
   if (split) hipLaunchKernelGGL(k_grid_zero, dim3(8u * (unsigned)n), dim3(256), 0, e->stream, dst, n, (size_t)C * GG / 4, GG / 4);
-  hipLaunchKernelGGL(k_grid_obs, dim3((unsigned)n), dim3(256), 0, e->stream, e->d_state, o, dst, split ? 0 : 1);
+  hipLaunchKernelGGL(k_grid_obs, dim3((unsigned)n), dim3(256), 0, e->stream, e->d_state, o, dst, (split || un.clear) ? 0 : 1, un);
   HIPCHK(hipGetLastError());
   if (!on_device && d2h(out, dst, words * 4, e->stream)) return fail(AGARCL_E_HIP, "agarcl_grid_obs: copy failed");
   return AGARCL_OK;

@@ -36,7 +36,7 @@ WORKLOADS = {
     "C3m6": dict(num_viruses=25, mode_number=6, rand_act=True,
                  desc="C3/mode 6: %d arenas/GPU x 1 agent (mass 1000), 1000x1000, 1000 pellets, 25 viruses, mode 6, 4 ticks/step, random (dx,dy), action ~ U{0,1,2}"),
     "C5": dict(num_viruses=25, mode_number=6, rand_act=True, grid_obs=True,
-               desc="C5: C3/mode 6 + int32 grid observation [%d][8][128][128] written once per step"),
+               desc="C5: C3/mode 6 + int32 grid observation [%d][8][128][128] refreshed once per step (persistent HBM tensor)"),
     "C5s": dict(num_viruses=25, mode_number=6, rand_act=True, screen_obs=True,
                 desc="C5 (screen): C3/mode 6 + uint8 screen observation [%d][84][84][3] written once per step"),
     # BASELINE configs[0] batched: the reference's own bench/main.cpp population (agent + the four bot kinds on the default
@@ -202,7 +202,7 @@ def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, 
                 gather.wait_slot((nxt // BLK) & 1)   # the engine is about to write this block: the gather that last used its buffer has left
         eng.step_actions(dx_ptr[k], ac_ptr[k], tps)   # take_actions + step: one host call
         if obs is not None:
-            eng.grid_obs(128, True, True, True, True, out_ptr=obs.data_ptr())
+            eng.grid_obs(128, True, True, True, True, out_ptr=obs.data_ptr(), persistent=True)   # the same tensor every step
         if scr is not None:
             if obs_gather is not None:
                 obs_gather.wait()               # the previous step's frames have left before they are overwritten
@@ -265,7 +265,7 @@ def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, 
     return res
 
 
-def roofline_block(res, A, K, ticks, cfg, workload, extra_bytes=0.0, kernel=None):
+def roofline_block(res, A, K, ticks, cfg, workload, extra_bytes=0.0, kernel=None, model_extra=None):
     """roofline object for one measured run (see requested_bytes)."""
     n_pel, n_vir, n_food, n_cells = res["counts"]
     P, na = res["players"], cfg["num_agents"]
@@ -273,7 +273,7 @@ def roofline_block(res, A, K, ticks, cfg, workload, extra_bytes=0.0, kernel=None
     t = res["kernel_ms"] * 1e-3
     # SURVEY 8(d) streaming model (every live entity once per tick): 8 N_p + 12 N_v + 72 N_c + 40 N_f + 112 P + 24 A
     b_tick = 8 * n_pel + 12 * n_vir + 72 * n_cells + 40 * n_food + 112 * P + 24 * na
-    model = b_tick * A * ticks + extra_bytes
+    model = b_tick * A * ticks + (extra_bytes if model_extra is None else model_extra)
     traffic = tag = None
     try:  # HBM bytes per step from the PMC counters, recorded separately by scripts/profile_round.sh on THIS kernel source
         tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
@@ -348,11 +348,20 @@ def main():
                        args.gather, args.gather_obs, args.gather_block)
     value = world * A * ticks * K / res["elapsed"]
     if rank == 0:
-        extra = (A * 8 * 128 * 128 * 4 if with_obs else 0) + (A * 84 * 84 * 3 if with_screen else 0)
+        # observation bytes.  Streaming model: the whole tensor is written once per step.  Requested by this
+        # implementation: the grid tensor is persistent (agarcl_grid_obs on_device = 2), so a step rewrites the dense out-of-bounds
+        # channel and, per word scattered, clears the old one and writes the new one plus their undo-list entries (16 B; the
+        # view covers at most (300 / arena)^2 of the arena's pellets and viruses)
+        model_extra = (A * 8 * 128 * 128 * 4 if with_obs else 0) + (A * 84 * 84 * 3 if with_screen else 0)
+        extra = model_extra
+        if with_obs:
+            n_pel, n_vir, n_food, n_cells = res["counts"]
+            vis = min(1.0, (300.0 / cfg["arena_size"]) ** 2)
+            extra = A * (128 * 128 * 4 + 16.0 * (vis * 2 * (n_pel + n_vir) + 3 * n_cells))
         kernel = None
-        if with_obs: kernel = "k_step + k_grid_zero + k_grid_obs"
+        if with_obs: kernel = "k_step + k_grid_obs (persistent tensor: incremental clear)"
         if with_screen: kernel = "k_step + k_screen_obs"
-        roof = roofline_block(res, A, K, ticks, cfg, args.workload, float(extra), kernel)
+        roof = roofline_block(res, A, K, ticks, cfg, args.workload, float(extra), kernel, float(model_extra))
         roof["note"] = ("achieved = HBM bytes one env step moves (PMC FETCH_SIZE x2 + WRITE_SIZE of the same kernel source when profiles/ "
                         "holds them -> `traffic`; otherwise the bytes the kernels request, counted by the kernels themselves) / the step's "
                         "HIP-event time; frac <= 1 by construction.  model_speedup = SURVEY 8(d)'s streaming-model bytes over the same time: "

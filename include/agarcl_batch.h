@@ -142,7 +142,11 @@ int agarcl_get_events(agarcl_env *env, int32_t *n_events_host, int32_t *pellet_i
  * bindings.cpp:104-116,133 -> GridObservation::add_frame, GridEnvironment.hpp:91-123 (one frame: the state
  * after the last step).  Writes i32[num_arenas][num_agents][C][G][G], C = 1 + cells + 2*others + 2*viruses +
  * 2*pellets, into `out` (HBM pointer if on_device != 0, else a host buffer); returns C through *channels.
- * out == NULL only queries C. */
+ * out == NULL only queries C.
+ * on_device == 2: an HBM buffer that still holds THIS env's previous observation of the same configuration, unmodified (a
+ * persistent observation tensor that is rewritten every step): only the words scattered into it last time are cleared instead of
+ * streaming zeros over the whole tensor -- same contents as on_device == 1.  The first such call, and any call with another buffer
+ * or configuration, clears everything. */
 int agarcl_grid_obs(agarcl_env *env, int32_t grid_size, int32_t observe_cells, int32_t observe_others,
                     int32_t observe_viruses, int32_t observe_pellets, int32_t *out, int32_t on_device,
                     int32_t *channels);

@@ -66,3 +66,38 @@ def test_grid_obs_device_buffer_4096(hip_engine_cls):
     assert np.array_equal(out[:8].cpu().numpy(), host[:8])
     assert int(out[:, 0, 5].sum().item()) == 25 * A   # own-cell channel: one cell of mass 25 per agent
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode=6),
+                                 dict(num_agents=2, arena_size=250, num_pellets=500, num_viruses=10, num_bots=3, mode=0)])
+def test_grid_obs_persistent_buffer(hip_engine_cls, cfg):
+    """on_device = 2 (a persistent observation tensor: only what the previous call scattered is cleared) gives the tensor that a
+    full clear gives, step after step -- agents that split, move and shrink their view; also after a switch of configuration and
+    after another buffer was used in between."""
+    import torch
+    A, na = 48, cfg.get("num_agents", 1)
+    eng = hip_engine_cls(A, **cfg)
+    eng.seed(None, 321); eng.reset(reset_ids=True)
+    rng = np.random.RandomState(2)
+    torch.cuda.synchronize()
+    keep = torch.full((A, na, 8, 128, 128), 7, dtype=torch.int32, device="cuda")    # garbage: the first call must clear everything
+    other = torch.full((A, na, 8, 128, 128), 9, dtype=torch.int32, device="cuda")
+    fresh = torch.empty((A, na, 8, 128, 128), dtype=torch.int32, device="cuda")
+    small = torch.full((A, na, 6, 64, 64), 3, dtype=torch.int32, device="cuda")   # 1 + cells + 2 viruses + 2 pellets
+    torch.cuda.synchronize()
+    for t in range(60):
+        eng.set_actions(rng.uniform(-1, 1, size=(A, na, 2)).astype(np.float32), rng.randint(0, 3, size=(A, na)).astype(np.int32))
+        eng.step()
+        eng.grid_obs(128, out_ptr=keep.data_ptr(), persistent=True)
+        eng.grid_obs(128, out_ptr=fresh.data_ptr())
+        eng.sync()    # (the engine has its own stream)
+        assert torch.equal(keep, fresh), t
+        if t == 20:    # another persistent buffer in between: the engine must notice and clear `keep` fully next time
+            eng.grid_obs(128, out_ptr=other.data_ptr(), persistent=True); eng.sync()
+            assert torch.equal(other, fresh)
+        if t == 40:    # another configuration into another buffer
+            eng.grid_obs(64, True, False, True, True, out_ptr=small.data_ptr(), persistent=True)
+            ref = torch.empty_like(small); eng.grid_obs(64, True, False, True, True, out_ptr=ref.data_ptr()); eng.sync()
+            assert torch.equal(small, ref)
+    eng.close()
