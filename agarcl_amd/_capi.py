@@ -49,6 +49,8 @@ SYMBOLS = [
     ("agarcl_set_actions", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     ("agarcl_step", C.c_int, [C.c_void_p, C.c_int32]),
     ("agarcl_step_actions", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    ("agarcl_timer_mark", C.c_int, [C.c_void_p, C.c_int32]),
+    ("agarcl_timer_elapsed_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     ("agarcl_tick", C.c_int, [C.c_void_p, C.c_int32]),
     ("agarcl_set_targets", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("agarcl_respawn_dead", C.c_int, [C.c_void_p]),
@@ -189,6 +191,15 @@ class BatchedEngine:
 
     def step(self, ticks=0):
         self._chk(self.L.agarcl_step(self.h, ticks))
+
+    def timer_mark(self, which):
+        """HIP event on the env's stream: 0 = start, 1 = stop"""
+        self._chk(self.L.agarcl_timer_mark(self.h, which))
+
+    def timer_elapsed_ms(self):
+        ms = C.c_float(0.0)
+        self._chk(self.L.agarcl_timer_elapsed_ms(self.h, C.byref(ms)))
+        return float(ms.value)
 
     def step_actions(self, dxdy_ptr, act_ptr, ticks=0):
         """set_actions_device + step in one call (raw HBM pointers as ints)"""

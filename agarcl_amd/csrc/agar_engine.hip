@@ -74,6 +74,7 @@ struct agarcl_env {
   std::vector<void *> allocs;
   float *d_act_dxdy; int32_t *d_act;  // env-owned action buffers (host-copy path)
   float *lut_r, *lut_ms, *lut_ss, *lut_anti;
+  void *timer_ev[2];               // agarcl_timer_mark / agarcl_timer_elapsed_ms
   int32_t *obs_buf; size_t obs_cap;  // staging for host-side grid observations
   int32_t *undo_list, *undo_count; const int32_t *undo_out; int undo_key;  // incremental clearing of the grid observation (AgObsUndo)
   std::vector<uint32_t> seeds;  // last seed of every arena (BaseEnvironment::seed_, written into JSON snapshots)
@@ -442,6 +443,7 @@ extern "C" int agarcl_destroy(agarcl_env *e) {
   (void)hipStreamSynchronize(e->stream);
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
   if (e->stat_ev) (void)hipEventDestroy((hipEvent_t)e->stat_ev);
+  for (int i = 0; i < 2; i++) if (e->timer_ev[i]) (void)hipEventDestroy((hipEvent_t)e->timer_ev[i]);
   if (e->h_stat) (void)hipHostFree(e->h_stat);
 #endif
   for (void *p : e->allocs) dfree(p);
@@ -466,7 +468,7 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
 #endif
   agarcl_env *e = new agarcl_env();
   e->cfg = *cfg; e->device = device; e->own_stream = true; e->d_act_dxdy = nullptr; e->d_act = nullptr;
-  e->slot = 0; e->d_state = nullptr; e->act_dxdy = nullptr; e->act = nullptr; e->obs_buf = nullptr; e->obs_cap = 0; e->undo_list = e->undo_count = nullptr; e->undo_out = nullptr; e->undo_key = -1;
+  e->slot = 0; e->d_state = nullptr; e->act_dxdy = nullptr; e->act = nullptr; e->timer_ev[0] = e->timer_ev[1] = nullptr; e->obs_buf = nullptr; e->obs_cap = 0; e->undo_list = e->undo_count = nullptr; e->undo_out = nullptr; e->undo_key = -1;
 #ifdef AGAR_CPU_EMU
   e->stream = nullptr;
 #else
@@ -617,6 +619,36 @@ extern "C" int agarcl_set_stream(agarcl_env *e, void *hip_stream) {
 extern "C" int agarcl_sync(agarcl_env *e) {
   if (!e) return fail(AGARCL_E_INVALID, "null env");
   return dsync(e->stream) ? fail(AGARCL_E_HIP, "stream synchronize failed") : AGARCL_OK;
+}
+
+// Two timing events on the env's stream, created once and without the system-scope fence an ordinary event record carries
+// (hipEventDisableSystemFence): mark 0 = start, 1 = stop; elapsed = milliseconds between them (after the stream has passed both).
+extern "C" int agarcl_timer_mark(agarcl_env *e, int32_t which) {
+  if (!e || which < 0 || which > 1) return fail(AGARCL_E_INVALID, "agarcl_timer_mark: bad arguments");
+#ifdef AGAR_CPU_EMU
+  return AGARCL_OK;
+#else
+  HIPCHK(hipSetDevice(e->device));
+  if (!e->timer_ev[0]) {
+    for (int i = 0; i < 2; i++) {
+      hipEvent_t ev = nullptr;
+      if (hipEventCreateWithFlags(&ev, hipEventDisableSystemFence) != hipSuccess) return fail(AGARCL_E_HIP, "agarcl_timer_mark: event creation failed");
+      e->timer_ev[i] = (void *)ev;
+    }
+  }
+  HIPCHK(hipEventRecord((hipEvent_t)e->timer_ev[which], e->stream));
+  return AGARCL_OK;
+#endif
+}
+extern "C" int agarcl_timer_elapsed_ms(agarcl_env *e, float *ms) {
+  if (!e || !ms) return fail(AGARCL_E_INVALID, "agarcl_timer_elapsed_ms: null pointer");
+  *ms = 0.0f;
+#ifndef AGAR_CPU_EMU
+  if (!e->timer_ev[0]) return fail(AGARCL_E_INVALID, "agarcl_timer_elapsed_ms: no marks recorded");
+  HIPCHK(hipEventSynchronize((hipEvent_t)e->timer_ev[1]));
+  HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)e->timer_ev[0], (hipEvent_t)e->timer_ev[1]));
+#endif
+  return AGARCL_OK;
 }
 
 extern "C" int agarcl_seed(agarcl_env *e, const uint32_t *seeds_host, uint32_t base_seed) {

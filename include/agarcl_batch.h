@@ -76,6 +76,10 @@ int agarcl_destroy(agarcl_env *env);
  * stream.  Until called, the env uses a private non-blocking stream. */
 int agarcl_set_stream(agarcl_env *env, void *hip_stream);
 int agarcl_sync(agarcl_env *env);
+/* Timing on the env's own stream (measurement only; nothing in the reference corresponds): two HIP events created without the
+ * system-scope fence of an ordinary event record.  which: 0 = start, 1 = stop.  agarcl_timer_elapsed_ms waits for the stop mark. */
+int agarcl_timer_mark(agarcl_env *env, int32_t which);
+int agarcl_timer_elapsed_ms(agarcl_env *env, float *ms);
 
 /* replaces: seed(int), bindings.cpp:103 -> Engine::seed, Engine.hpp:242-245.  seeds_host[num_arenas];
  * NULL -> arena i gets base_seed + i. */
