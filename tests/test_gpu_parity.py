@@ -475,6 +475,19 @@ def test_step_actions_is_take_actions_plus_step(hip_engine_cls):
         assert np.array_equal(b0, b1)
 
 
+def test_stream_timer(hip_engine_cls):
+    """agarcl_timer_mark / agarcl_timer_elapsed_ms: events on the env's own stream bracket the steps launched between them."""
+    eng = hip_engine_cls(256, **C2)
+    eng.seed(None, 1); eng.reset(reset_ids=True)
+    eng.timer_mark(0)
+    for _ in range(50):
+        eng.step()
+    eng.timer_mark(1)
+    ms = eng.timer_elapsed_ms()
+    assert 0.05 < ms < 50.0, ms          # 50 steps of a few microseconds each
+    eng.close()
+
+
 def test_mode3_done_threshold(hip_engine_cls, oracle_lib):
     """Mode 3 ends an episode when the agent's mass reaches 23 000 (BaseEnvironment.hpp:108-111; pinned against the reference in
     test_oracle_vs_reference.py): cells loaded just below the threshold cross it by eating -- through the lean front part (arena 0:
