@@ -171,10 +171,11 @@ template <int NS, bool AV, int TSLG> __global__ void __launch_bounds__(64) AG_KS
     ag_lds_order();
   }
 }
-// 256 threads = 16 arenas per workgroup, AG_QG lanes each (agar_quiet.inl)
-// k_quiet stands alone only in the two-kernel step, which is chosen where the arena count is large (>= 32768) or the arenas
-// are not quiet.  Capped at 128 VGPRs (4 waves/SIMD instead of 3, 28 bytes of scratch): measured on MI355X, C2, k_quiet +
-// work-list k_step: 65 536 arenas 52.3 -> 49.6 us per step, 262 144 arenas 160.4 -> 148.8 us (the fused launch: 53.0 / 190.6).
+// 256 threads = 256 / QG arenas per workgroup, QG lanes each (agar_quiet.inl)
+// k_quiet stands alone only in the two-kernel step, which is chosen where the batch does not fit k_fused's 2048 wavefronts
+// (> 131072 arenas) or the arenas are not quiet.  Capped at 128 VGPRs (4 waves/SIMD instead of 3, 80 bytes of scratch):
+// measured on MI355X, C2, k_quiet + work-list k_step with 16 lanes per arena: 65 536 arenas 52.3 -> 49.6 us per step,
+// 262 144 arenas 160.4 -> 148.8 us.
 #ifndef AG_KQUIET_ATTR
 #define AG_KQUIET_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
@@ -197,9 +198,9 @@ template <int NS, bool AV, int TSLG> __device__ __attribute__((noinline)) void g
 #ifndef AG_KFUSED_ATTR
 #define AG_KFUSED_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
-// Fused step for quiet-dominated single-player envs: ONE launch.  The front part is k_quiet's; whatever it leaves
-// unfinished (in the C2 workload: 0.02 arenas per 4096-arena step) is completed right here by the same wavefront
-// running the general engine as a wave, one arena after the other.  Saves the second dependent launch (>= 3.4 us:
+// Fused step for quiet-dominated single-player envs: ONE launch.  The front part is k_quiet's (QG lanes per arena, either
+// layout of the word arrays); whatever it leaves unfinished (in the C2 workload: 0.004 arenas per 4096-arena step) is completed
+// right here by the same wavefront calling the general engine (general_arena_step), one arena after the other.  Saves the second dependent launch (>= 3.4 us:
 // scripts/microbench/launch_floor.hip) at the price of serialising a wavefront's unfinished arenas -- the wrong trade
 // when most arenas need the general path every step (mass-1000 modes), where the two-kernel step is used.
 template <int NS, bool AV, int QG, int TSLG> __global__ void __launch_bounds__(256) AG_KFUSED_ATTR k_fused(const AgHot hot, const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int lds_per_wave) {
@@ -289,8 +290,7 @@ static void poll_stats(agarcl_env *e, bool adapt) {
     const long steps = e->stat_req_front - e->stat_last_front;  // steps in which the front part actually ran
     if (adapt && steps > 0) {
       const double frac = (double)(uint32_t)(e->h_stat[0] - e->stat_last_total) / ((double)steps * (double)e->d.A);
-      // (from 32768 arenas on the two-kernel step is the faster one even when every arena is quiet: the lean front kernel
-      // keeps 4 waves per SIMD where the fused kernel, which carries the general engine's registers, keeps 2)
+      // (fused_ok: the batch fits the 2048 wavefronts k_fused keeps resident at its best lane-group size, see agarcl_create)
       if (e->fused && frac > 0.05) e->fused = false; else if (!e->fused && frac < 0.01) e->fused = e->fused_ok;
       // the two-kernel step's front launch is pure overhead when it finishes (almost) nothing: mass-1000 modes
       e->front_off = !e->fused && frac > 0.99;

@@ -1,13 +1,14 @@
-// Lean front kernel body: SIMT style, AG_QG lanes per arena, no LDS, nothing resident -> tiny
-// register footprint, 4 arenas per wavefront.
+// Lean front kernel body: SIMT style, a group of QG lanes per arena (template parameter: 1 ... 32, chosen from the arena count),
+// no LDS, nothing resident -> tiny register footprint, 64 / QG arenas per wavefront.
 //
 // In RL rollouts almost every env step of a single-player arena is "quiet" (see quiet_ticks in agar_core.inl):
 // the whole step touches ~300 bytes of state and now and then scans the pellets.  The quiet tick itself is scalar
 // work per arena; on a machine whose scalar unit has no fp32 it has to run on the vector ALU, where a wave-uniform
 // formulation wastes 63 of 64 lanes and -- at 4096 arenas, 4 waves per SIMD -- is bound by VALU issue.  Here every
-// lane of a 16-lane group carries its arena's scalars redundantly (plain per-lane code, identical fp32 sequence),
-// the group's lanes split the pellet scan 16 ways and combine with a 4-step DPP row all-reduce, and only the
-// group's first lane stores.  4096 arenas = 1024 wavefronts = one per SIMD: latency-, not issue-bound.
+// lane of a group carries its arena's scalars redundantly (plain per-lane code, identical fp32 sequence), a pellet
+// pass is a wave-level operation (all 64 lanes scan the asking arena's pellets), and only the group's first lane
+// stores.  4096 arenas x 16 lanes = 1024 wavefronts = one per SIMD: latency-, not issue-bound; bigger batches take
+// fewer lanes per arena so that the wavefront count stays there (agarcl_create).
 //
 // k_quiet runs first and does the env prologue (take_actions), as many quiet ticks as it can and -- if that was
 // the whole step -- the env epilogue (rewards / dones / packed results).  What it could not finish is left to the
@@ -16,7 +17,7 @@
 // exit on its first load.  Single-player envs only (P == 1); with several players k_quiet is never launched.
 #pragma once
 #ifndef AG_QG
-#define AG_QG 16   // lanes per arena (4 arenas per wavefront)
+#define AG_QG 16   // default lanes per arena (the host emulation's and the tests' choice; the kernels take QG as a parameter)
 #endif
 
 // Pellets streamed from HBM / L2.  A pass is a wave-level operation: for every lane group that asks for one, ALL 64
