@@ -1051,6 +1051,7 @@ extern "C" int agarcl_gobigger_obs(agarcl_env *e, int32_t grid_size, int32_t cap
       e->obs_cap = words;
     }
     unsigned char *q = (unsigned char *)e->obs_buf;
+    e->undo_out = nullptr;   // the shared staging buffer no longer holds a grid observation (agarcl_grid_obs: incremental clearing)
     for (int i = 0; i < 5; i++) { dev[i] = q; q += (nb[i] + 15) / 16 * 16; }
   }
   hipLaunchKernelGGL(k_gobigger_obs, dim3((unsigned)rows), dim3(64), 0, e->stream, e->d_state, o, (int32_t *)dev[0], (float *)dev[1], (float *)dev[2], (float *)dev[3], (float *)dev[4]);
@@ -1078,6 +1079,7 @@ extern "C" int agarcl_screen_obs(agarcl_env *e, int32_t width, int32_t height, i
       e->obs_cap = words;
     }
     dst = (uint8_t *)e->obs_buf;
+    e->undo_out = nullptr;   // (as above)
   }
   AgScreenCfg o; o.W = width; o.H = height; o.agent_view = agent_view != 0;
   hipLaunchKernelGGL(k_screen_obs, dim3((unsigned)n), dim3(256), 0, e->stream, e->d_state, o, dst);
@@ -1107,7 +1109,7 @@ extern "C" int agarcl_grid_obs(agarcl_env *e, int32_t G, int32_t cells, int32_t 
     if (e->obs_cap < words) {
       if (e->obs_buf) { HIPCHK(hipStreamSynchronize(e->stream)); (void)hipFree(e->obs_buf); e->obs_buf = nullptr; e->obs_cap = 0; }
       if (hipMalloc((void **)&e->obs_buf, words * 4) != hipSuccess) return fail(AGARCL_E_NOMEM, "agarcl_grid_obs: staging allocation failed");
-      e->obs_cap = words;
+      e->obs_cap = words; e->undo_out = nullptr;   // a fresh buffer (possibly at the old address): nothing to undo
     }
     dst = e->obs_buf;
   }

@@ -101,3 +101,31 @@ def test_grid_obs_persistent_buffer(hip_engine_cls, cfg):
             ref = torch.empty_like(small); eng.grid_obs(64, True, False, True, True, out_ptr=ref.data_ptr()); eng.sync()
             assert torch.equal(small, ref)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_grid_obs_host_path_repeated(hip_engine_cls, oracle_lib):
+    """The host-copy path goes through the engine's staging buffer, which it treats as persistent (incremental clear) -- unless
+    something else used the buffer in between (screen / GoBigger host copies share it): same config every step, against the oracle."""
+    cfg = dict(arena_size=400, num_pellets=400, num_viruses=6, mode=6)
+    A = 6
+    eng = hip_engine_cls(A, **cfg)
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    seeds = np.arange(70, 70 + A).astype(np.uint32)
+    eng.seed(seeds); eng.reset(reset_ids=True)
+    for o, sd in zip(oras, seeds):
+        o.seed(int(sd)); o.reset(True)
+    rng = np.random.RandomState(8)
+    for t in range(40):
+        dxdy = rng.uniform(-1, 1, size=(A, 1, 2)).astype(np.float32); act = rng.randint(0, 3, size=(A, 1)).astype(np.int32)
+        eng.set_actions(dxdy, act); eng.step()
+        for a in range(A):
+            oras[a].take_actions(dxdy[a], act[a]); oras[a].step()
+        if t % 7 == 3:
+            eng.screen_obs(32, 32)               # another user of the staging buffer
+        if t % 11 == 5:
+            eng.gobigger_obs(64)
+        got = eng.grid_obs(64, True, True, True, True)
+        for a in range(A):
+            assert np.array_equal(got[a, 0], oras[a].grid_obs(0, 64, True, True, True, True)), (t, a)
+    eng.close()
