@@ -1,0 +1,32 @@
+"""One-off soak on the GPU: random configurations x random launch pins (lanes per arena, layout, single / two-kernel step), batched lock-step
+against the oracle.  Prints the first mismatch or a summary.  (A raised capacity flag -- e.g. AGARCL_F_EVENTS_OVERFLOW in an 80 x 80 arena
+with 1300 pellets, where a cell can eat more than 256 pellets in one tick -- is reported like a mismatch: that arena has left the
+reference's unbounded containers by design.)"""
+import os, sys
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np
+from agarcl_amd import _capi
+from oracle import orabind
+from lockstep import run_batched_lockstep
+rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+bad = 0
+for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
+    na = int(rng.choice([1, 1, 1, 1, 2, 3]))
+    mode = int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 6, 7, 8, 9, 10]))
+    nb = int(rng.randint(0, 4)) if mode == 0 and rng.rand() < 0.4 else 0
+    if mode > 6: na = 1
+    cfg = dict(num_agents=na, arena_size=int(rng.choice([80, 150, 250, 400, 1000, 1100])), num_pellets=int(rng.choice([50, 64, 200, 500, 1000, 1300])),
+               num_viruses=int(rng.choice([0, 0, 3, 10, 25])), num_bots=nb, mode=mode, reward_type=int(rng.randint(0, 2)), c_death=int(rng.choice([0, -20])))
+    pins = dict(AGARCL_TILE_LG=str(rng.choice([0, 6])), AGARCL_FUSED=str(rng.choice([0, 1])), AGARCL_FUSED_QG=str(rng.choice([1, 2, 4, 8, 16, 32])), AGARCL_QUIET_QG=str(rng.choice([1, 2, 4, 8, 16])))
+    os.environ.update(pins)
+    A = int(rng.choice([3, 70, 130]))
+    try:
+        eng = _capi.BatchedEngine(A, **cfg)
+    except _capi.AgarclError as e:   # e.g. squared pellets of a big arena exceed the pellet capacity: a loud rejection, not a case
+        print('skipped', cfg, e); continue
+    oras = [orabind.OraEnv(**cfg) for _ in range(A)]
+    ok, msg = run_batched_lockstep(eng, oras, 120, seeds=rng.randint(1, 1 << 30, size=A), policy_seed=int(rng.randint(1, 1000)), sticky=int(rng.choice([1, 4, 8])), every=30)
+    fl = eng.flags(); eng.close()
+    if not ok or fl.any():
+        bad += 1; print("MISMATCH trial", trial, cfg, pins, A, msg, "flags", int(fl.any())); break
+print("soak done:", trial + 1, "trials,", bad, "bad")
