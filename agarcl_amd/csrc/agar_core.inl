@@ -151,6 +151,10 @@ AG_DEV float sqr_dist(float ax, float ay, float bx, float by) { float dx = fabsf
 AG_DEV bool collides(float ax, float ay, float ar, float bx, float by, float br) { float r = smaxf(ar, br); float rr = r * r; return rr >= sqr_dist(ax, ay, bx, by); }
 AG_DEV bool touches(float ax, float ay, float ar, float bx, float by, float br) { float r = ar + br; float rr = r * r; float d = sqr_dist(ax, ay, bx, by) + 0.0f; return rr >= d; }
 AG_DEV bool can_eat_mass(unsigned a, unsigned b) { return (double)a > (double)b * 1.1; }  // R: Ball.hpp:45-47
+// double -> uint32 as the reference's x86-64 build does it (cvttsd2si to 64 bits, low half kept): a NEGATIVE value wraps instead of
+// saturating to 0.  Entities.hpp:199-202: after >= 66 virus meals inside the anti-team window the decay factor 1 - 0.002 * 1.1^k is
+// negative and the reference's cell ends up with mass 2^32 - x; the device's own conversion would give 0.
+AG_DEV unsigned d2u_x86(double v) { return (unsigned)(long long)v; }
 AG_DEV unsigned clamp_mass(unsigned m) { return m > AG_CELL_MIN_SIZE ? m : AG_CELL_MIN_SIZE; }  // R: Entities.hpp:171-177
 
 // ---- LDS layout (bytes).  Everything but the pellet base is a compile-time constant for P == 1 -----
@@ -1012,7 +1016,10 @@ template <int NS, bool AV> AG_DEV int pellets_eat(AgCtx<NS, AV> &c, const Cells 
       float rk = radius_of(c, m + (unsigned)K); rrK = rk * rk;
       pel_launder(c);
       int cK = pel_count(c, [&](float qx, float qy, int) { return hit(qx, qy, rrK); });
-      if (cK == K) break;
+      // (the radius grows with the mass, so cK >= K and the loop ends after at most n_pellets rounds -- unless the mass has wrapped
+      // around 2^32, which the reference's unsigned arithmetic allows (negative decay factor, d2u_x86): then m + K can wrap back to a
+      // tiny mass and the counts would oscillate for ever.  Such an arena is already flagged; the loop must still end.)
+      if (cK <= K) break;
       K = cK;
     }
     if (K > AG_CAND_CAP / 4) { flag(c, 8u); }
@@ -1245,7 +1252,7 @@ template <int NS, bool AV> AG_DEV void decay(AgCtx<NS, AV> &c, const Cells &s, i
     double rate = (double)PRF(c, PL_ANTI_TEAM);
     AG_LANES(i, n) {
       double nm = (double)s.m[i] * (1 - 0.002 * rate);
-      unsigned um = (unsigned)nm;
+      unsigned um = d2u_x86(nm);
       s.m[i] = um > AG_CELL_MIN_SIZE ? um : AG_CELL_MIN_SIZE;
     }
     PW(c, PL_LAST_DECAY, elapsed);
@@ -1553,7 +1560,7 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
     if (q.fcd > 0) q.fcd -= 1; if (q.action == 1 && q.fcd == 0) q.fcd = 10;   // Engine.hpp:1046-1054 (nothing can be ejected: mass < 35)
     if (q.scd > 0) q.scd -= 1; if (q.action == 2 && q.scd == 0) q.scd = 30;   // Engine.hpp:1056-1064 (nothing can split: mass < 50)
     if (AG_RARE(decay_tick && q.elapsed - q.last_decay >= 60)) {             // Engine.hpp:575-584, Entities.hpp:199-203
-      double dm = (double)q.m * (1 - 0.002 * q.rate); unsigned um = (unsigned)dm;
+      double dm = (double)q.m * (1 - 0.002 * q.rate); unsigned um = d2u_x86(dm);
       um = um > AG_CELL_MIN_SIZE ? um : AG_CELL_MIN_SIZE;
       q.last_decay = q.elapsed;
       if (um != q.m) { q.m = um; q.r = lut(lut_r, q.m); q.hi = lut(lut_ms, q.m); rr = q.r * q.r; }  // a smaller radius keeps the disc valid

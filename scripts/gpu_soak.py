@@ -9,7 +9,7 @@ from agarcl_amd import _capi
 from oracle import orabind
 from lockstep import run_batched_lockstep
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
-bad = 0
+bad = flagged = 0
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     na = int(rng.choice([1, 1, 1, 1, 2, 3]))
     mode = int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 6, 7, 8, 9, 10]))
@@ -18,15 +18,22 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     cfg = dict(num_agents=na, arena_size=int(rng.choice([80, 150, 250, 400, 1000, 1100])), num_pellets=int(rng.choice([50, 64, 200, 500, 1000, 1300])),
                num_viruses=int(rng.choice([0, 0, 3, 10, 25])), num_bots=nb, mode=mode, reward_type=int(rng.randint(0, 2)), c_death=int(rng.choice([0, -20])))
     pins = dict(AGARCL_TILE_LG=str(rng.choice([0, 6])), AGARCL_FUSED=str(rng.choice([0, 1])), AGARCL_FUSED_QG=str(rng.choice([1, 2, 4, 8, 16, 32])), AGARCL_QUIET_QG=str(rng.choice([1, 2, 4, 8, 16])))
+    if os.environ.get('SOAK_NOPINS'): pins = {k: '' for k in pins}
+    if os.environ.get('SOAK_TILE') is not None: pins['AGARCL_TILE_LG'] = os.environ['SOAK_TILE']
     os.environ.update(pins)
+    only = int(os.environ.get('SOAK_ONLY', -1))
     A = int(rng.choice([3, 70, 130]))
     try:
-        eng = _capi.BatchedEngine(A, **cfg)
+        eng = _capi.BatchedEngine(A if only < 0 or only == trial else 1, **cfg)
     except _capi.AgarclError as e:   # e.g. squared pellets of a big arena exceed the pellet capacity: a loud rejection, not a case
         print('skipped', cfg, e); continue
+    sd, ps, st = rng.randint(1, 1 << 30, size=A), int(rng.randint(1, 1000)), int(rng.choice([1, 4, 8]))
+    if only >= 0 and only != trial: eng.close(); continue
     oras = [orabind.OraEnv(**cfg) for _ in range(A)]
-    ok, msg = run_batched_lockstep(eng, oras, 120, seeds=rng.randint(1, 1 << 30, size=A), policy_seed=int(rng.randint(1, 1000)), sticky=int(rng.choice([1, 4, 8])), every=30)
+    ok, msg = run_batched_lockstep(eng, oras, 120, seeds=sd, policy_seed=ps, sticky=st, every=int(os.environ.get('SOAK_EVERY', 30)))
     fl = eng.flags(); eng.close()
-    if not ok or fl.any():
-        bad += 1; print("MISMATCH trial", trial, cfg, pins, A, msg, "flags", int(fl.any())); break
-print("soak done:", trial + 1, "trials,", bad, "bad")
+    if fl.any():   # an arena left the reference's unbounded containers / tables: flagged by design, not a parity failure
+        flagged += 1; print("flagged (capacity) trial", trial, cfg, "flags 0x%x" % int(np.bitwise_or.reduce(fl))); continue
+    if not ok:
+        bad += 1; print("MISMATCH trial", trial, cfg, pins, A, msg); break
+print("soak done:", trial + 1, "trials,", bad, "bad,", flagged, "flagged")

@@ -119,3 +119,60 @@ def test_emulated_mode3_done_threshold(emu_lib, oracle_lib):
         assert blob.diff(oras[a].dump(), eng.dump(a)) is None, a
     assert seen.all()
     eng.close()
+
+
+def test_emulated_negative_decay_factor(emu_lib, oracle_lib):
+    """Entities.hpp:199-202 in the reference's x86-64 build: with >= 66 virus meals inside the anti-team window the decay factor
+    1 - 0.002 * 1.1^k is negative and the double -> uint32 conversion wraps (mass 2^32 - x, not 0).  A player loaded with 70 recent
+    virus meals reaches its next decay check: the same wrapped mass as the reference (state equal right after that step), and -- the
+    mass now exceeds the radius / speed tables -- the capacity flag instead of a silent divergence."""
+    from oracle import blob
+    from agarcl_amd import _capi
+    cfg = dict(num_agents=1, arena_size=300, num_pellets=100, num_viruses=0, mode=0, reward_type=1)
+    A = 3
+    eng = _capi.BatchedEngine(A, lib=emu_lib, **cfg)
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    seeds = np.array([3, 4, 5], dtype=np.uint32)
+    eng.seed(seeds); eng.reset(reset_ids=True)
+    for a, o in enumerate(oras):
+        o.seed(int(seeds[a])); o.reset(True)
+        d = blob.parse(o.dump())
+        p = d["players"][0]; p["cell_mass"][0] = 3000 + 100 * a; p["elapsed"] = 500; p["last_decay"] = 470 - a; p["anti_team"] = np.float32(1.1 ** 69)
+        p["virus_ticks"] = np.arange(400, 470, dtype=np.int64)
+        b = blob.build(d); o.load(b); eng.load(b, a)
+    rng = np.random.RandomState(2)
+    wrapped = np.zeros(A, bool)
+    for t in range(40):
+        dxdy = rng.uniform(-1, 1, size=(A, 1, 2)).astype(np.float32); act = np.zeros((A, 1), np.int32)
+        eng.set_actions(dxdy, act); eng.step()
+        r, fl = eng.rewards(), eng.flags()
+        for a in range(A):
+            oras[a].take_actions(dxdy[a], act[a]); ro = oras[a].step()
+            if fl[a]:
+                continue          # a mass beyond the 2^19-entry tables: the arena is flagged as having left the reference (DESIGN 3)
+            assert not wrapped[a], "a wrapped mass must raise AGARCL_F_MASS_LUT_OVERFLOW at its first table look-up, not diverge silently"
+            assert r[a, 0] == ro[0], (t, a)
+            assert blob.diff(oras[a].dump(), eng.dump(a)) is None, (t, a)
+            wrapped[a] = int(blob.parse(oras[a].dump())["players"][0]["cell_mass"][0]) > (1 << 31)
+    assert (eng.flags() & 32).all() and wrapped.all()      # every arena got there: same wrapped mass as the reference, then the flag
+    eng.close()
+
+
+@pytest.mark.timeout(120)
+def test_emulated_wrapped_mass_terminates(emu_lib):
+    """A mass that has wrapped around 2^32 (the reference's unsigned arithmetic allows it: negative decay factor) must not hang the
+    growth closure of the pellet scan (m + K wraps back to a tiny mass and the candidate count would oscillate): the step ends
+    and the arena carries AGARCL_F_MASS_LUT_OVERFLOW."""
+    from oracle import blob
+    from agarcl_amd import _capi
+    cfg = dict(num_agents=1, arena_size=80, num_pellets=64, num_viruses=0, mode=0)
+    A = 2
+    eng = _capi.BatchedEngine(A, lib=emu_lib, **cfg)
+    eng.seed(np.array([5, 6], dtype=np.uint32)); eng.reset(reset_ids=True)
+    for a in range(A):
+        d = blob.parse(eng.dump(a)); d["players"][0]["cell_mass"][0] = (1 << 32) - 3 - a
+        eng.load(blob.build(d), a)
+    for t in range(8):
+        eng.set_actions(np.zeros((A, 1, 2), np.float32), np.zeros((A, 1), np.int32)); eng.step()
+    assert (eng.flags() & 32).all()
+    eng.close()

@@ -107,3 +107,29 @@ def test_mode3_done_threshold_pinned(ref_lib, oracle_lib):
         seen_done = seen_done or bool(np.asarray(r.dones()).any())
     assert blob.diff(r.dump(), o.dump()) is None
     assert seen_done, "the threshold was never crossed: the test does not test what it says"
+
+
+def test_negative_decay_factor_wraps_pinned(ref_lib, oracle_lib):
+    """Entities.hpp:199-202 in the reference's x86-64 build: with >= 66 virus meals inside the anti-team window the decay factor
+    1 - 0.002 * 1.1^k is negative and the double -> uint32 conversion wraps (mass 2^32 - x, not 0).  A player loaded with 70 recent
+    virus meals reaches its next decay check: the wrapped mass, and everything that follows from it, like the reference."""
+    from oracle import blob
+    cfg = dict(num_agents=1, arena_size=300, num_pellets=100, num_viruses=0, mode=0, reward_type=1)
+    import numpy as np
+    r = ref_lib.RefEnv(**cfg); o = oracle_lib.OraEnv(**cfg)
+    for e in (r, o):
+        e.seed(3); e.reset(True)
+    d = blob.parse(o.dump())
+    p = d["players"][0]; p["cell_mass"][0] = 3000; p["elapsed"] = 500; p["last_decay"] = 470; p["anti_team"] = np.float32(1.1 ** 69)
+    p["virus_ticks"] = np.arange(400, 470, dtype=np.int64)
+    b = blob.build(d); r.load(b); o.load(b)
+    rng = np.random.RandomState(2)
+    wrapped = False
+    for t in range(40):
+        dxdy = rng.uniform(-1, 1, size=(1, 2)).astype(np.float32); act = np.zeros(1, np.int32)
+        r.take_actions(dxdy, act); o.take_actions(dxdy, act)
+        assert np.array_equal(r.step(), o.step()), t
+        dd = blob.parse(r.dump())
+        wrapped = wrapped or int(dd["players"][0]["cell_mass"][0]) > (1 << 31)
+        assert blob.diff(r.dump(), o.dump()) is None, t
+    assert wrapped, "the decay never produced a wrapped mass: the test does not test what it says"
