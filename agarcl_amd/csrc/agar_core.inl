@@ -1592,6 +1592,7 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
       if (q.done >= max_ticks) { active = false; break; }
       if (q.m >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0) { active = false; AG_WHY(q, 1); break; }  // eject needs >= 35, split >= 50
       if (q.m >= 111u && q.nv != 0) { active = false; AG_WHY(q, 2); break; }                                  // virus contact needs >= 111
+      if (AG_RARE(q.m >= (unsigned)AG_LUT_SIZE)) { active = false; AG_WHY(q, 2); break; }                      // beyond the tables: the general path flags it
       // regeneration (Engine.hpp:236-239): viruses need the general path; pellets are topped up inline as long as the
       // generator's buffered outputs suffice (2 draws per pellet, one more pellet may be eaten this very tick)
       if (to_regen == 0 && (tgt_v - q.nv > 0 || q.mtidx + 2 * (tgt_p - q.np + 2) > 312)) { active = false; AG_WHY(q, tgt_v - q.nv > 0 ? 3 : 4); break; }   // (up to two pellets may be eaten this very tick)
@@ -1750,6 +1751,14 @@ template <int NS, bool AV> AG_DEV void arena_tick(AgCtx<NS, AV> &c) {
     add_viruses(c, c.gs->g.target_viruses - SR(c, AR_NVIR));
   }
   SW(c, AR_TICKS, ticks + 1); SW(c, AR_CLOCK, SR(c, AR_CLOCK) + 1);
+  // a mass beyond the radius / speed tables (2^19 entries; the reference computes them from the mass, without a limit): every
+  // table look-up clamps, so the arena has left the reference -- say so (AGARCL_F_MASS_LUT_OVERFLOW) instead of diverging silently
+  for (int p = 0; p < c.P; p++) {
+    const int n = ag_uni(PLS(c, p)[PL_NCELLS]);
+    if (n == 0) continue;
+    Cells s = cells_of(c, p);
+    if (AG_RARE(wave_any(n, [&](int i) { return s.m[i] >= (unsigned)AG_LUT_SIZE; }))) flag(c, 32u);
+  }
   AG_T(c, 9);
 }
 

@@ -1,0 +1,48 @@
+"""CPU soak: the kernel source compiled as a host emulation (tests/_build/libagarcl_emu.so) against the oracle on random configurations,
+every trial in its own process under a timeout (a hang is a finding too).   python scripts/cpu_soak.py <seed> <trials>"""
+import multiprocessing as mp, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def trial(args):
+    seed, k = args
+    import ctypes, numpy as np
+    from agarcl_amd import _capi
+    from oracle import orabind
+    from lockstep import run_batched_lockstep
+    rng = np.random.RandomState(seed * 1000 + k)
+    na = int(rng.choice([1, 1, 1, 1, 2, 3]))
+    mode = int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 6, 7, 8, 9, 10]))
+    nb = int(rng.randint(0, 4)) if mode == 0 and rng.rand() < 0.4 else 0
+    if mode > 6: na = 1
+    cfg = dict(num_agents=na, arena_size=int(rng.choice([80, 150, 250, 400, 1000, 1100])), num_pellets=int(rng.choice([50, 64, 200, 500, 1000, 1300])),
+               num_viruses=int(rng.choice([0, 0, 3, 10, 25])), num_bots=nb, mode=mode, reward_type=int(rng.randint(0, 2)), c_death=int(rng.choice([0, -20])))
+    os.environ["AGARCL_TILE_LG"] = str(rng.choice([0, 6]))
+    lib = _capi.bind(ctypes.CDLL(os.path.join(ROOT, "tests", "_build", "libagarcl_emu.so")))
+    A = int(rng.choice([2, 3, 5]))
+    try:
+        eng = _capi.BatchedEngine(A, lib=lib, **cfg)
+    except _capi.AgarclError as e:
+        return ("skipped", cfg, str(e))
+    oras = [orabind.OraEnv(**cfg) for _ in range(A)]
+    ok, msg = run_batched_lockstep(eng, oras, int(rng.choice([120, 300, 600])), seeds=rng.randint(1, 1 << 30, size=A), policy_seed=int(rng.randint(1, 1000)),
+                                   sticky=int(rng.choice([1, 4, 8])), every=10)
+    fl = eng.flags(); eng.close()
+    if fl.any(): return ("flagged", cfg, "0x%x" % int(np.bitwise_or.reduce(fl)))
+    return ("ok", cfg, "") if ok else ("MISMATCH", cfg, msg)
+
+
+if __name__ == "__main__":
+    seed, n = int(sys.argv[1]), int(sys.argv[2])
+    counts = {}
+    with mp.get_context("spawn").Pool(int(os.environ.get("SOAK_PROCS", 6)), maxtasksperchild=1) as pool:
+        results = [pool.apply_async(trial, ((seed, k),)) for k in range(n)]
+        for k, r in enumerate(results):
+            try:
+                kind, cfg, msg = r.get(timeout=600)
+            except mp.TimeoutError:
+                kind, cfg, msg = "HANG", "trial %d" % k, ""
+            counts[kind] = counts.get(kind, 0) + 1
+            if kind in ("MISMATCH", "HANG"): print(kind, "seed", seed, "trial", k, cfg, msg, flush=True)
+    print("cpu soak seed", seed, counts, flush=True)

@@ -148,13 +148,14 @@ def test_emulated_negative_decay_factor(emu_lib, oracle_lib):
         r, fl = eng.rewards(), eng.flags()
         for a in range(A):
             oras[a].take_actions(dxdy[a], act[a]); ro = oras[a].step()
-            if fl[a]:
-                continue          # a mass beyond the 2^19-entry tables: the arena is flagged as having left the reference
-            assert not wrapped[a], "a wrapped mass must raise AGARCL_F_MASS_LUT_OVERFLOW at its first table look-up, not diverge silently"
+            if wrapped[a]:
+                assert fl[a] & 32      # flagged from the wrap on: a mass beyond the 2^19-entry tables has left the reference
+                continue
             assert r[a, 0] == ro[0], (t, a)
-            assert blob.diff(oras[a].dump(), eng.dump(a)) is None, (t, a)
+            assert blob.diff(oras[a].dump(), eng.dump(a)) is None, (t, a)      # (the decay is the step's last tick: still equal, wrapped mass included)
             wrapped[a] = int(blob.parse(oras[a].dump())["players"][0]["cell_mass"][0]) > (1 << 31)
-    assert (eng.flags() & 32).all() and wrapped.all()      # every arena got there: same wrapped mass as the reference, then the flag
+            assert bool(fl[a] & 32) == bool(wrapped[a]), "the flag goes up with the wrapped mass, in the same step, and not before"
+    assert (eng.flags() & 32).all() and wrapped.all()      # every arena got there: same wrapped mass as the reference, and the flag
     eng.close()
 
 
@@ -175,4 +176,24 @@ def test_emulated_wrapped_mass_terminates(emu_lib):
     for t in range(8):
         eng.set_actions(np.zeros((A, 1, 2), np.float32), np.zeros((A, 1), np.int32)); eng.step()
     assert (eng.flags() & 32).all()
+    eng.close()
+
+
+def test_emulated_mass_beyond_tables_is_flagged(emu_lib):
+    """The reference computes radius and speed from the mass without a limit; the tables end at 2^19.  A cell beyond that makes every
+    look-up clamp, so the arena must carry AGARCL_F_MASS_LUT_OVERFLOW after the very next step -- through the lean front part (arena 0:
+    one quiet cell) and through the general engine (arena 1: viruses around, several cells after a split)."""
+    from oracle import blob
+    from agarcl_amd import _capi
+    cfg = dict(num_agents=1, arena_size=400, num_pellets=200, num_viruses=5, mode=0)
+    A = 3
+    eng = _capi.BatchedEngine(A, lib=emu_lib, **cfg)
+    eng.seed(np.array([5, 6, 7], dtype=np.uint32)); eng.reset(reset_ids=True)
+    for a in (0, 1):
+        d = blob.parse(eng.dump(a)); d["players"][0]["cell_mass"][0] = 600000 + a
+        if a == 0: d["virus_x"] = d["virus_x"][:0]; d["virus_y"] = d["virus_y"][:0]; d["virus_vx"] = d["virus_vx"][:0]; d["virus_vy"] = d["virus_vy"][:0]; d["virus_mass"] = d["virus_mass"][:0]; d["virus_hits"] = d["virus_hits"][:0]; d["virus_id"] = d["virus_id"][:0]
+        eng.load(blob.build(d), a)
+    eng.set_actions(np.zeros((A, 1, 2), np.float32), np.array([[0], [2], [0]], np.int32)); eng.step()
+    fl = eng.flags()
+    assert fl[0] & 32 and fl[1] & 32 and fl[2] == 0, fl
     eng.close()
