@@ -18,6 +18,10 @@ def trial(args):
     if mode > 6: na = 1
     cfg = dict(num_agents=na, arena_size=int(rng.choice([80, 150, 250, 400, 1000, 1100])), num_pellets=int(rng.choice([50, 64, 200, 500, 1000, 1300])),
                num_viruses=int(rng.choice([0, 0, 3, 10, 25])), num_bots=nb, mode=mode, reward_type=int(rng.randint(0, 2)), c_death=int(rng.choice([0, -20])))
+    if os.environ.get("SOAK_WIDE"):   # a wider configuration space: other arena sizes, frame skips, tick lengths, no regeneration
+        cfg["arena_size"] = int(rng.choice([60, 120, 200, 300, 600, 1000, 1400])); cfg["ticks_per_step"] = int(rng.choice([1, 2, 4, 8]))
+        rng.rand()   # (dt = 1/60 belongs to the engine-level tick path, tests/lockstep.py run_engine_level_lockstep: BaseEnvironment::step has its own tick length)
+        if rng.rand() < 0.2: cfg["pellet_regen"] = False
     os.environ["AGARCL_TILE_LG"] = str(rng.choice([0, 6]))
     lib = _capi.bind(ctypes.CDLL(os.path.join(ROOT, "tests", "_build", "libagarcl_emu.so")))
     A = int(rng.choice([2, 3, 5]))
@@ -27,7 +31,7 @@ def trial(args):
         return ("skipped", cfg, str(e))
     oras = [orabind.OraEnv(**cfg) for _ in range(A)]
     ok, msg = run_batched_lockstep(eng, oras, int(rng.choice([120, 300, 600])), seeds=rng.randint(1, 1 << 30, size=A), policy_seed=int(rng.randint(1, 1000)),
-                                   sticky=int(rng.choice([1, 4, 8])), every=10)
+                                   sticky=int(rng.choice([1, 4, 8])), every=10, ticks_per_step=cfg.get("ticks_per_step", 4))
     fl = eng.flags(); eng.close()
     if fl.any(): return ("flagged", cfg, "0x%x" % int(np.bitwise_or.reduce(fl)))
     return ("ok", cfg, "") if ok else ("MISMATCH", cfg, msg)
