@@ -22,6 +22,11 @@ def trial(args):
         cfg["arena_size"] = int(rng.choice([60, 120, 200, 300, 600, 1000, 1400])); cfg["ticks_per_step"] = int(rng.choice([1, 2, 4, 8]))
         rng.rand()   # (dt = 1/60 belongs to the engine-level tick path, tests/lockstep.py run_engine_level_lockstep: BaseEnvironment::step has its own tick length)
         if rng.rand() < 0.2: cfg["pellet_regen"] = False
+    if os.environ.get("SOAK_MANY"):   # crowded arenas: up to 6 agents and 6 bots (mode 0)
+        cfg["mode"] = int(rng.choice([0, 0, 0, 4, 6])); cfg["num_agents"] = int(rng.randint(1, 7)); cfg["num_bots"] = int(rng.randint(0, 7)) if cfg["mode"] == 0 else 0
+        cfg["arena_size"] = int(rng.choice([150, 250, 400]))
+    engine_level = bool(os.environ.get("SOAK_ENGINE")) and rng.rand() < 0.7   # bench/main.cpp's path: Engine::tick at dt = 1/60, respawns
+    if engine_level: cfg["dt"] = 1.0 / 60
     os.environ["AGARCL_TILE_LG"] = str(rng.choice([0, 6]))
     lib = _capi.bind(ctypes.CDLL(os.path.join(ROOT, "tests", "_build", "libagarcl_emu.so")))
     A = int(rng.choice([2, 3, 5]))
@@ -30,8 +35,12 @@ def trial(args):
     except _capi.AgarclError as e:
         return ("skipped", cfg, str(e))
     oras = [orabind.OraEnv(**cfg) for _ in range(A)]
-    ok, msg = run_batched_lockstep(eng, oras, int(rng.choice([120, 300, 600])), seeds=rng.randint(1, 1 << 30, size=A), policy_seed=int(rng.randint(1, 1000)),
-                                   sticky=int(rng.choice([1, 4, 8])), every=10, ticks_per_step=cfg.get("ticks_per_step", 4))
+    if engine_level:
+        from lockstep import run_engine_level_lockstep
+        ok, msg = run_engine_level_lockstep(eng, oras, int(rng.choice([400, 1200, 2500])), seeds=rng.randint(1, 1 << 30, size=A), policy_seed=int(rng.randint(1, 1000)), every=20)
+    else:
+      ok, msg = run_batched_lockstep(eng, oras, int(rng.choice([120, 300, 600])), seeds=rng.randint(1, 1 << 30, size=A), policy_seed=int(rng.randint(1, 1000)),
+                                     sticky=int(rng.choice([1, 4, 8])), every=10, ticks_per_step=cfg.get("ticks_per_step", 4))
     fl = eng.flags(); eng.close()
     if fl.any(): return ("flagged", cfg, "0x%x" % int(np.bitwise_or.reduce(fl)))
     return ("ok", cfg, "") if ok else ("MISMATCH", cfg, msg)
