@@ -17,6 +17,13 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     if mode > 6: na = 1
     cfg = dict(num_agents=na, arena_size=int(rng.choice([80, 150, 250, 400, 1000, 1100])), num_pellets=int(rng.choice([50, 64, 200, 500, 1000, 1300])),
                num_viruses=int(rng.choice([0, 0, 3, 10, 25])), num_bots=nb, mode=mode, reward_type=int(rng.randint(0, 2)), c_death=int(rng.choice([0, -20])))
+    tps = 4
+    if os.environ.get("SOAK_WIDE"):   # (as scripts/cpu_soak.py)
+        cfg["arena_size"] = int(rng.choice([60, 120, 200, 300, 600, 1000, 1400])); cfg["ticks_per_step"] = tps = int(rng.choice([1, 2, 4, 8]))
+        if rng.rand() < 0.2: cfg["pellet_regen"] = False
+    if os.environ.get("SOAK_MANY"):
+        cfg["mode"] = int(rng.choice([0, 0, 0, 4, 6])); cfg["num_agents"] = int(rng.randint(1, 7)); cfg["num_bots"] = int(rng.randint(0, 7)) if cfg["mode"] == 0 else 0
+        cfg["arena_size"] = int(rng.choice([150, 250, 400]))
     pins = dict(AGARCL_TILE_LG=str(rng.choice([0, 6])), AGARCL_FUSED=str(rng.choice([0, 1])), AGARCL_FUSED_QG=str(rng.choice([1, 2, 4, 8, 16, 32])), AGARCL_QUIET_QG=str(rng.choice([1, 2, 4, 8, 16])))
     if os.environ.get('SOAK_NOPINS'): pins = {k: '' for k in pins}
     if os.environ.get('SOAK_TILE') is not None: pins['AGARCL_TILE_LG'] = os.environ['SOAK_TILE']
@@ -30,7 +37,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     sd, ps, st = rng.randint(1, 1 << 30, size=A), int(rng.randint(1, 1000)), int(rng.choice([1, 4, 8]))
     if only >= 0 and only != trial: eng.close(); continue
     oras = [orabind.OraEnv(**cfg) for _ in range(A)]
-    ok, msg = run_batched_lockstep(eng, oras, 120, seeds=sd, policy_seed=ps, sticky=st, every=int(os.environ.get('SOAK_EVERY', 30)))
+    ok, msg = run_batched_lockstep(eng, oras, 120, seeds=sd, policy_seed=ps, sticky=st, every=int(os.environ.get('SOAK_EVERY', 30)), ticks_per_step=tps)
     fl = eng.flags(); eng.close()
     if fl.any():   # an arena left the reference's unbounded containers / tables: flagged by design, not a parity failure
         flagged += 1; print("flagged (capacity) trial", trial, cfg, "flags 0x%x" % int(np.bitwise_or.reduce(fl))); continue
