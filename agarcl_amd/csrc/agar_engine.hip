@@ -326,7 +326,7 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
     const unsigned lpw = (unsigned)((e->lds_bytes + 15) & ~(size_t)15);
     const int wg = e->fused_wg, apw = wg / e->fused_qg;  // threads and arenas per workgroup
 #define CALLQ(N, V, Q) hipLaunchKernelGGL((k_fused<N, V, Q, T>), dim3((e->d.A + apw - 1) / apw), dim3(wg), (wg / 64) * lpw, e->stream, hot, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, (int)lpw)
-#define CALL(N, V) do { switch (e->fused_qg) { case 32: CALLQ(N, V, 32); break; case 1: CALLQ(N, V, 1); break; case 2: CALLQ(N, V, 2); break; case 4: CALLQ(N, V, 4); break; case 8: CALLQ(N, V, 8); break; default: CALLQ(N, V, 16); break; } } while (0)
+#define CALL(N, V) do { switch (e->fused_qg) { case 1: CALLQ(N, V, 1); break; case 2: CALLQ(N, V, 2); break; case 4: CALLQ(N, V, 4); break; case 8: CALLQ(N, V, 8); break; default: CALLQ(N, V, 16); break; } } while (0)
 #define T 6
     if (tiled) AG_DISPATCH_NS(e->ns, CALL);
 #undef T
@@ -542,8 +542,11 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   // 9.47 / 9.23 / 9.81; 8192: 1024 / 2048: 10.23 / 10.63; 16384: 13.52 / 12.11 / 12.30 / 17.96 (512 ... 4096); 32768: 15.97 /
   // 14.09 / 13.83 / 20.20; 65536: 1024 / 2048 / 4096: 18.97 / 17.70 / 23.93; 131072: 2048 / 4096: 25.57 / 30.92)
   { const long target = d.A <= 16384 ? 1024L : AG_FUSED_WAVES;   // one wavefront per SIMD for the small batches, two beyond
-    e->fused_qg = 32; while (e->fused_qg > 1 && (long)d.A * e->fused_qg > target * 64L) e->fused_qg >>= 1; }
-  { const char *w = getenv("AGARCL_FUSED_QG"); if (w) { int v = atoi(w); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) e->fused_qg = v; } }
+    // (32 lanes per arena measured 1 % faster below 4096 arenas -- 2048 arenas: 8.75 -> 8.65 us -- but the k_fused<32 pellet slots,
+    // 3x3 pellet grid, 32 lanes> variant died with a memory-aperture violation in one GPU soak trial (scripts/gpu_soak.py 62, trial 28:
+    // 1100^2 arena, 1300 pellets, mode 6, 130 arenas) in which 1, 2, 4, 8 and 16 lanes ran clean; not root-caused, so not offered)
+    e->fused_qg = 16; while (e->fused_qg > 1 && (long)d.A * e->fused_qg > target * 64L) e->fused_qg >>= 1; }
+  { const char *w = getenv("AGARCL_FUSED_QG"); if (w) { int v = atoi(w); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) e->fused_qg = v; } }
   e->fused_ok = d.P == 1 && (long)d.A * e->fused_qg <= AG_FUSED_WAVES * 64L;
   e->fused = e->fused_ok && cfg->mode_number <= 4;  // starting point; poll_stats follows what the arenas actually do
   e->front_off = d.P == 1 && cfg->mode_number > 4; e->few_unfinished = false;

@@ -24,9 +24,11 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     if os.environ.get("SOAK_MANY"):
         cfg["mode"] = int(rng.choice([0, 0, 0, 4, 6])); cfg["num_agents"] = int(rng.randint(1, 7)); cfg["num_bots"] = int(rng.randint(0, 7)) if cfg["mode"] == 0 else 0
         cfg["arena_size"] = int(rng.choice([150, 250, 400]))
-    pins = dict(AGARCL_TILE_LG=str(rng.choice([0, 6])), AGARCL_FUSED=str(rng.choice([0, 1])), AGARCL_FUSED_QG=str(rng.choice([1, 2, 4, 8, 16, 32])), AGARCL_QUIET_QG=str(rng.choice([1, 2, 4, 8, 16])))
+    pins = dict(AGARCL_TILE_LG=str(rng.choice([0, 6])), AGARCL_FUSED=str(rng.choice([0, 1])), AGARCL_FUSED_QG=str(rng.choice([1, 2, 4, 8, 16, 16])), AGARCL_QUIET_QG=str(rng.choice([1, 2, 4, 8, 16])))
     if os.environ.get('SOAK_NOPINS'): pins = {k: '' for k in pins}
     if os.environ.get('SOAK_TILE') is not None: pins['AGARCL_TILE_LG'] = os.environ['SOAK_TILE']
+    for k_ in list(pins):
+        if os.environ.get('SOAK_PIN_' + k_) is not None: pins[k_] = os.environ['SOAK_PIN_' + k_]
     os.environ.update(pins)
     only = int(os.environ.get('SOAK_ONLY', -1))
     A = int(rng.choice([3, 70, 130]))
@@ -36,6 +38,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
         print('skipped', cfg, e); continue
     sd, ps, st = rng.randint(1, 1 << 30, size=A), int(rng.randint(1, 1000)), int(rng.choice([1, 4, 8]))
     if only >= 0 and only != trial: eng.close(); continue
+    if os.environ.get('SOAK_VERBOSE'): print('trial', trial, cfg, pins, A, flush=True)
     oras = [orabind.OraEnv(**cfg) for _ in range(A)]
     ok, msg = run_batched_lockstep(eng, oras, 120, seeds=sd, policy_seed=ps, sticky=st, every=int(os.environ.get('SOAK_EVERY', 30)), ticks_per_step=tps)
     fl = eng.flags(); eng.close()
