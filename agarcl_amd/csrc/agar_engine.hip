@@ -542,18 +542,20 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   // 9.47 / 9.23 / 9.81; 8192: 1024 / 2048: 10.23 / 10.63; 16384: 13.52 / 12.11 / 12.30 / 17.96 (512 ... 4096); 32768: 15.97 /
   // 14.09 / 13.83 / 20.20; 65536: 1024 / 2048 / 4096: 18.97 / 17.70 / 23.93; 131072: 2048 / 4096: 25.57 / 30.92)
   { const long target = d.A <= 16384 ? 1024L : AG_FUSED_WAVES;   // one wavefront per SIMD for the small batches, two beyond
-    // (32 lanes per arena measured 1 % faster below 4096 arenas -- 2048 arenas: 8.75 -> 8.65 us -- but the k_fused<32 pellet slots,
-    // 3x3 pellet grid, 32 lanes> variant died with a memory-aperture violation in one GPU soak trial (scripts/gpu_soak.py 62, trial 28:
-    // 1100^2 arena, 1300 pellets, mode 6, 130 arenas) in which 1, 2, 4, 8 and 16 lanes ran clean; not root-caused, so not offered)
+    // (32 lanes per arena measured 1 % faster below 4096 arenas -- 2048 arenas: 8.75 -> 8.65 us; withdrawn together with the finding at fused_ok)
     e->fused_qg = 16; while (e->fused_qg > 1 && (long)d.A * e->fused_qg > target * 64L) e->fused_qg >>= 1; }
   { const char *w = getenv("AGARCL_FUSED_QG"); if (w) { int v = atoi(w); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) e->fused_qg = v; } }
-  e->fused_ok = d.P == 1 && (long)d.A * e->fused_qg <= AG_FUSED_WAVES * 64L;
+  // NOT for envs with 32 pellet slots per lane (> 1024 pellets) or a 3x3 pellet grid (arena > 1020): the k_fused<32, false, ...>
+  // variants died with a memory-aperture violation in GPU soak trials that sent every arena through the general tail (scripts/
+  // gpu_soak.py 62 / 28 and 91 / 7: 1100^2 arena, 1300 pellets, mode 6) -- not root-caused; such envs take the two-kernel step,
+  // whose kernels ran the same trials clean
+  e->fused_ok = d.P == 1 && (long)d.A * e->fused_qg <= AG_FUSED_WAVES * 64L && e->ns < 32 && e->all_vis;
   e->fused = e->fused_ok && cfg->mode_number <= 4;  // starting point; poll_stats follows what the arenas actually do
   e->front_off = d.P == 1 && cfg->mode_number > 4; e->few_unfinished = false;
   e->work_step0 = e->work_front0 = 0; e->work_unf0 = 0; e->work_pass0 = 0;
   e->flags_seen = 0; e->d_mask = alloc<uint8_t>(e, (size_t)d.A);
   e->fused_fixed = false; e->h_stat = nullptr; e->stat_ev = nullptr; e->stat_pending = false; e->step_no = e->front_runs = e->stat_req_front = e->stat_last_front = 0; e->stat_last_total = 0;
-  { const char *fu = getenv("AGARCL_FUSED"); if (fu && (fu[0] == '0' || fu[0] == '1')) { e->fused = fu[0] == '1' && d.P == 1; e->fused_fixed = true; } }
+  { const char *fu = getenv("AGARCL_FUSED"); if (fu && (fu[0] == '0' || fu[0] == '1')) { e->fused = fu[0] == '1' && e->fused_ok; e->fused_fixed = true; } }
   s.qstat = alloc<int32_t>(e, 16);
   // Lanes per arena of the lean front kernel.  The quiet tick is per-lane code that every lane of an arena's group carries
   // redundantly and a pellet pass is wave-wide whatever the group size, so the group size only sets how many wavefronts the
