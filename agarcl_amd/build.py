@@ -33,7 +33,8 @@ def needs_build():
 
 
 def build(force=False, verbose=False, extra=(), out=OUT):
-    """extra/out: diagnostic variants only (e.g. -DAGAR_PROFILE -> libagarcl_hip_prof.so, used by scripts/)."""
+    """extra/out: diagnostic variants only (e.g. -DAGAR_PROFILE -> build_variants/lib_PROF.so, used by scripts/; build_variants/ is
+    git-ignored and travels to the GPU box only while it exists -- delete it when the measurements are done)."""
     if not force and not needs_build() and out == OUT:
         return OUT
     cmd = [hipcc()] + FLAGS + list(extra) + ["-o", out, SRC]
@@ -64,7 +65,8 @@ def build_pybind(force=False):
 
 if __name__ == "__main__":
     if "--profile" in sys.argv:
-        print(build(True, "-v" in sys.argv, ["-DAGAR_PROFILE"], os.path.join(HERE, "libagarcl_hip_prof.so")))
+        os.makedirs(os.path.join(HERE, "..", "build_variants"), exist_ok=True)
+        print(build(True, "-v" in sys.argv, ["-DAGAR_PROFILE"], os.path.join(HERE, "..", "build_variants", "lib_PROF.so")))
     elif "--pybind" in sys.argv:
         print(build_pybind(True))
     else:

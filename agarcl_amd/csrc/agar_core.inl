@@ -57,7 +57,7 @@ AG_DEV void ag_lds_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront
 // which ROCm's headers map to the approximate __ocml_native_sqrt_f32.
 AG_DEV float ag_sqrtf(float x) { return __builtin_sqrtf(x); }
 AG_DEV float ag_divf(float a, float b) { return a / b; }
-AG_DEV void ag_atomic_or(int32_t *p, int v) { atomicOr(p, v); }
+AG_DEV void ag_atomic_or(int32_t *p, int v) { (void)__hip_atomic_fetch_or((__attribute__((address_space(1))) int32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // (p is HBM: a global, not a flat, atomic)
 AG_DEV bool ag_any(bool p) { return __ballot(p) != 0ull; }   // does any ACTIVE lane of the wave want it?
 #endif
 
@@ -1246,7 +1246,7 @@ template <int NS, bool AV> AG_DEV void decay(AgCtx<NS, AV> &c, const Cells &s, i
     ag_mem_fence();
     int w = ag_uni(T[0]);
     PW(c, PL_NVTICKS, w);
-    if (w != 0) PW(c, PL_ANTI_TEAM, f2u(c.gs->lut_anti[w - 1 < AG_ANTI_LUT ? w - 1 : AG_ANTI_LUT - 1]));
+    if (w != 0) PW(c, PL_ANTI_TEAM, f2u(((const AG_GLOBAL float *)c.gs->lut_anti)[w - 1 < AG_ANTI_LUT ? w - 1 : AG_ANTI_LUT - 1]));
   }
   if (elapsed - PR(c, PL_LAST_DECAY) >= 60) {
     double rate = (double)PRF(c, PL_ANTI_TEAM);

@@ -88,7 +88,8 @@ struct agarcl_env {
   uint8_t *d_mask;                 // [A] reset mask staging (host masks are copied here, stream-ordered)
   uint32_t flags_seen;             // OR of every flag watch sample so far (agarcl_poll_flags)
   long work_step0, work_front0; int32_t work_unf0; int64_t work_pass0;  // agarcl_debug_work baselines
-  bool stat_pending; long step_no, front_runs, stat_req_front, stat_last_front; int32_t stat_last_total;
+  bool stat_pending, stat_stale_flags;   // a sample is in flight / it was requested before the last reset: its flag word is void
+  long step_no, front_runs, stat_req_front, stat_last_front; int32_t stat_last_total;
   int parity;     // launch parity of the k_quiet / k_step pair (selects the unfinished-arena counter)
   bool no_front;  // AGARCL_NO_FRONT=1 in the environment: skip k_quiet (diagnostics / A-B timing only)
   bool few_unfinished; // adaptive: the front part leaves < 64 arenas per step to k_step (see launch_step)
@@ -143,8 +144,9 @@ template <int NS, bool AV, int TSLG> __global__ void __launch_bounds__(64) AG_KS
   const int A = gs->d.A;
   int total = A;
   if (use_q) {
-    total = gs->qcount[parity];
-    if (blockIdx.x == 0 && threadIdx.x == 0) gs->qcount[parity ^ 1] = 0;   // re-arm the other parity's counter for the next step's k_quiet
+    auto qc = (AG_GLOBAL int32_t *)gs->qcount;
+    total = qc[parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) qc[parity ^ 1] = 0;   // re-arm the other parity's counter for the next step's k_quiet
   }
   for (int it = TSLG ? ag_xcd_swizzle((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x; it < total; it += (int)gridDim.x) {
     int arena = it, q_done = -1, q_before = 0;
@@ -187,8 +189,16 @@ template <int NS, bool AV, int QG, int TSLG> __global__ void __launch_bounds__(2
 }
 // The general engine for ONE arena as a real call: k_fused's front part (every lane-group size, both layouts) shares one copy
 // of it per (NS, AV, layout) and keeps its own, small register allocation around the rare call.
-template <int NS, bool AV, int TSLG> __device__ __attribute__((noinline)) void general_arena_step(const AgState *gs, int arena, unsigned char *lds, const float *act_dxdy, const int32_t *act, int slot, int ticks, int with_env, int qd, int qb) {
-  AgCtx<NS, AV> c; ag_ctx_init(c, gs, arena, lds, act_dxdy, act, slot);
+// The wave's LDS block travels as a BYTE OFFSET into ag_lds, not as a pointer: a pointer parameter is a generic (flat) address to the
+// compiler, every LDS access of the callee becomes a flat_* instruction, and the hardware picks the aperture of a flat access from the
+// address REGISTER alone -- the instruction's immediate offset is added afterwards.  hipcc folds constant parts of an index into that
+// immediate, so `cand[4 * b + 4]` with b == -1 (the insertion sort of pellets_eat placing a record at the front) became
+// flat_store(vaddr = lds + L_CAND*0 - 16, offset: L_CAND + 16): for the workgroup's first wavefront, whose block starts at LDS offset 0,
+// vaddr lies 16 bytes BELOW the LDS aperture and the queue dies with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION (found by the GPU soak,
+// located with rocgdb: profiles/r03_fused_fault_rocgdb.txt).  `ag_lds + offset` formed inside the callee keeps the LDS
+// address space: ds_* instructions, whose 32-bit address arithmetic has no aperture to leave (tests/test_isa_lds_access.py keeps it so).
+template <int NS, bool AV, int TSLG> __device__ __attribute__((noinline)) void general_arena_step(const AgState *gs, int arena, int lds_off, const float *act_dxdy, const int32_t *act, int slot, int ticks, int with_env, int qd, int qb) {
+  AgCtx<NS, AV> c; ag_ctx_init(c, gs, arena, ag_lds + lds_off, act_dxdy, act, slot);
   c.ts_lg = TSLG;
   arena_load(c, true);
   env_step(c, ticks, with_env != 0, qd, qb);
@@ -212,7 +222,7 @@ template <int NS, bool AV, int QG, int TSLG> __global__ void __launch_bounds__(2
   unsigned long long todo = __ballot(valid && sub == 0 && h.done != ticks);
   if (!todo) return;
   ag_mem_fence();  // the front part's stores precede the general part's loads of the same arena
-  unsigned char *lds = ag_lds + ((int)threadIdx.x >> 6) * lds_per_wave;
+  const int lds = ((int)threadIdx.x >> 6) * lds_per_wave;   // (a byte offset into ag_lds: see general_arena_step)
   while (todo) {
     const int src = (int)__builtin_ctzll(todo); todo &= todo - 1ull;
     const int ar = __builtin_amdgcn_readlane(arena, src), qd = __builtin_amdgcn_readlane(h.done, src), qb = __builtin_amdgcn_readlane(h.before, src);
@@ -220,7 +230,12 @@ template <int NS, bool AV, int QG, int TSLG> __global__ void __launch_bounds__(2
   }
 }
 template <int NS, bool AV> __global__ void __launch_bounds__(64) k_reset(const AgState *__restrict__ gs, const uint8_t *mask, int reset_ids) {
-  if (mask && !mask[blockIdx.x]) return;
+  if (mask && !mask[blockIdx.x]) {
+    // the flag watch word (qstat[1]) was zeroed in front of this launch (agarcl_reset / agarcl_reset_device): arenas that are NOT reset
+    // put their flags back, so the watch becomes the OR over the arenas that are still flagged after the masked reset
+    if (threadIdx.x == 0) { const int ag_ts_lg = gs->d.ts_lg; const int fl = ((const AG_GLOBAL int32_t *)gs->ar)[AG_TILE_BASE(blockIdx.x, AR_WORDS) + AG_TW(AR_FLAGS)]; if (fl) ag_atomic_or(gs->qstat + 1, fl); }
+    return;
+  }
   const float *act_dxdy = nullptr; const int32_t *act = nullptr;
   AG_KERNEL_PROLOGUE
   arena_load(c);
@@ -286,7 +301,8 @@ static void poll_stats(agarcl_env *e, bool adapt) {
   if (e->stat_pending) {
     if (hipEventQuery((hipEvent_t)e->stat_ev) != hipSuccess) return;
     e->stat_pending = false;
-    e->flags_seen |= (uint32_t)e->h_stat[1];
+    if (!e->stat_stale_flags) e->flags_seen |= (uint32_t)e->h_stat[1];
+    e->stat_stale_flags = false;
     const long steps = e->stat_req_front - e->stat_last_front;  // steps in which the front part actually ran
     if (adapt && steps > 0) {
       const double frac = (double)(uint32_t)(e->h_stat[0] - e->stat_last_total) / ((double)steps * (double)e->d.A);
@@ -369,7 +385,8 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
 static int launch_reset(agarcl_env *e, const uint8_t *mask_dev, const uint8_t *mask_host, int reset_ids) {
 #ifdef AGAR_CPU_EMU
   (void)mask_dev;
-#define CALL(N, V) for_each_arena_ns<N, V>(e, [&](AgCtx<N, V> &c) { if (mask_host && !mask_host[c.arena]) return; arena_load(c); env_reset(c, reset_ids); c.pel_dirty = true; arena_store(c); })
+  e->s.qstat[1] = 0;
+#define CALL(N, V) for_each_arena_ns<N, V>(e, [&](AgCtx<N, V> &c) { if (mask_host && !mask_host[c.arena]) { e->s.qstat[1] |= e->s.ar[tix(e->d.ts_lg, (size_t)c.arena, AR_WORDS, AR_FLAGS)]; return; } arena_load(c); env_reset(c, reset_ids); c.pel_dirty = true; arena_store(c); })
   AG_DISPATCH_NS(e->ns, CALL);
 #undef CALL
 #else
@@ -542,19 +559,15 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   // 9.47 / 9.23 / 9.81; 8192: 1024 / 2048: 10.23 / 10.63; 16384: 13.52 / 12.11 / 12.30 / 17.96 (512 ... 4096); 32768: 15.97 /
   // 14.09 / 13.83 / 20.20; 65536: 1024 / 2048 / 4096: 18.97 / 17.70 / 23.93; 131072: 2048 / 4096: 25.57 / 30.92)
   { const long target = d.A <= 16384 ? 1024L : AG_FUSED_WAVES;   // one wavefront per SIMD for the small batches, two beyond
-    // (32 lanes per arena measured 1 % faster below 4096 arenas -- 2048 arenas: 8.75 -> 8.65 us; withdrawn together with the finding at fused_ok)
+    // (32 lanes per arena measured 1 % faster below 4096 arenas -- 2048 arenas: 8.75 -> 8.65 us -- not worth 16 more instantiations)
     e->fused_qg = 16; while (e->fused_qg > 1 && (long)d.A * e->fused_qg > target * 64L) e->fused_qg >>= 1; }
   { const char *w = getenv("AGARCL_FUSED_QG"); if (w) { int v = atoi(w); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) e->fused_qg = v; } }
-  // NOT for envs with 32 pellet slots per lane (> 1024 pellets) or a 3x3 pellet grid (arena > 1020): the k_fused<32, false, ...>
-  // variants died with a memory-aperture violation in GPU soak trials that sent every arena through the general tail (scripts/
-  // gpu_soak.py 62 / 28 and 91 / 7: 1100^2 arena, 1300 pellets, mode 6) -- not root-caused; such envs take the two-kernel step,
-  // whose kernels ran the same trials clean
-  e->fused_ok = d.P == 1 && (long)d.A * e->fused_qg <= AG_FUSED_WAVES * 64L && e->ns < 32 && e->all_vis;
+  e->fused_ok = d.P == 1 && (long)d.A * e->fused_qg <= AG_FUSED_WAVES * 64L;
   e->fused = e->fused_ok && cfg->mode_number <= 4;  // starting point; poll_stats follows what the arenas actually do
   e->front_off = d.P == 1 && cfg->mode_number > 4; e->few_unfinished = false;
   e->work_step0 = e->work_front0 = 0; e->work_unf0 = 0; e->work_pass0 = 0;
   e->flags_seen = 0; e->d_mask = alloc<uint8_t>(e, (size_t)d.A);
-  e->fused_fixed = false; e->h_stat = nullptr; e->stat_ev = nullptr; e->stat_pending = false; e->step_no = e->front_runs = e->stat_req_front = e->stat_last_front = 0; e->stat_last_total = 0;
+  e->fused_fixed = false; e->h_stat = nullptr; e->stat_ev = nullptr; e->stat_pending = e->stat_stale_flags = false; e->step_no = e->front_runs = e->stat_req_front = e->stat_last_front = 0; e->stat_last_total = 0;
   { const char *fu = getenv("AGARCL_FUSED"); if (fu && (fu[0] == '0' || fu[0] == '1')) { e->fused = fu[0] == '1' && e->fused_ok; e->fused_fixed = true; } }
   s.qstat = alloc<int32_t>(e, 16);
   // Lanes per arena of the lean front kernel.  The quiet tick is per-lane code that every lane of an arena's group carries
@@ -703,6 +716,16 @@ extern "C" int agarcl_get_arena_words(agarcl_env *e, int32_t arena, int32_t *ar_
   return AGARCL_OK;
 }
 
+#ifndef AGAR_CPU_EMU
+// Every reset restarts the flag watch (agarcl_poll_flags): the device word is zeroed in front of k_reset, whose not-reset arenas OR their
+// flags back in (a full reset leaves none), the host's accumulated view is dropped, and a statistics sample that is still in flight --
+// taken before this reset -- must not bring the old flags back.
+static int restart_flag_watch(agarcl_env *e) {
+  if (hipMemsetAsync(e->s.qstat + 1, 0, 4, e->stream) != hipSuccess) return fail(AGARCL_E_HIP, "flag watch reset failed");
+  e->flags_seen = 0; e->stat_stale_flags = e->stat_pending;
+  return 0;
+}
+#endif
 extern "C" int agarcl_reset(agarcl_env *e, const uint8_t *mask_host, int32_t reset_ids) {
   if (!e) return fail(AGARCL_E_INVALID, "null env");
   uint8_t *mask_dev = nullptr;
@@ -711,10 +734,8 @@ extern "C" int agarcl_reset(agarcl_env *e, const uint8_t *mask_host, int32_t res
   if (mask_host) {  // stream-ordered upload into the env's own mask buffer: no allocation, no device-wide sync
     mask_dev = e->d_mask;
     HIPCHK(hipMemcpyAsync(mask_dev, mask_host, (size_t)e->d.A, hipMemcpyHostToDevice, e->stream));
-  } else {
-    e->flags_seen = 0;
-    HIPCHK(hipMemsetAsync(e->s.qstat + 1, 0, 4, e->stream));  // a full reset clears every arena's flags: restart the watch
   }
+  if (restart_flag_watch(e)) return AGARCL_E_HIP;
 #endif
   return launch_reset(e, mask_dev, mask_host, reset_ids);
 }
@@ -724,6 +745,7 @@ extern "C" int agarcl_reset_device(agarcl_env *e, const uint8_t *mask_dev, int32
   return launch_reset(e, nullptr, mask_dev, reset_ids);  // (test-only host build: "device" memory is host memory)
 #else
   HIPCHK(hipSetDevice(e->device));
+  if (restart_flag_watch(e)) return AGARCL_E_HIP;
   return launch_reset(e, mask_dev, nullptr, reset_ids);
 #endif
 }
@@ -811,7 +833,7 @@ extern "C" int agarcl_poll_flags(agarcl_env *e, uint32_t *out) {
 #ifdef AGAR_CPU_EMU
   *out = (uint32_t)e->s.qstat[1];
 #else
-  if (e->stat_pending && hipEventQuery((hipEvent_t)e->stat_ev) == hipSuccess) e->flags_seen |= (uint32_t)e->h_stat[1];
+  if (e->stat_pending && !e->stat_stale_flags && hipEventQuery((hipEvent_t)e->stat_ev) == hipSuccess) e->flags_seen |= (uint32_t)e->h_stat[1];
   *out = e->flags_seen;
 #endif
   return AGARCL_OK;
@@ -1118,6 +1140,7 @@ extern "C" int agarcl_grid_obs(agarcl_env *e, int32_t G, int32_t cells, int32_t 
     }
     dst = e->obs_buf;
   }
+  if (on_device == 1 && dst == e->undo_out) e->undo_out = nullptr;   // a plain call into the persistent buffer: its undo list no longer describes what the buffer holds
   const size_t GG = (size_t)G * G;
   // on_device == 2: the caller's buffer still holds this env's previous observation (same grid, same channels): clear only
   // what was written then.  The first such call (or a different buffer / configuration) clears everything and starts the list.

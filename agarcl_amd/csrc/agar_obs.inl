@@ -36,7 +36,14 @@ struct AgObsCfg { int G, cells, others, viruses, pellets; };
 // kernel zeroes exactly the words it wrote last time -- it keeps their offsets in a per-frame undo list -- and records the
 // new ones.  undo == nullptr: off.  clear: the list of the previous call is valid for this buffer.
 struct AgObsUndo { int32_t *list; int32_t *count; int cap; int clear; };
-#define OBS_UNDO_CAP(PC) (2 * (PC) + 2 * 1024)   // every pellet writes two words, every staged entity at most two (OBS_ECAP = 1024)
+#define OBS_ECAP 1024  // viruses + cells of all players staged per frame (16 players x 32 cell slots = 512 cells at most; entities
+                       // beyond the cap -- more than ~500 viruses -- are not drawn)
+#define OBS_PELLET_WORDS 2   // words a pellet writes (channels "at least one" and "count")
+#define OBS_ENTITY_WORDS 2   // words a staged entity writes at most (virus: last mass + sum; other cell: min + max; own cell: 1)
+#define OBS_UNDO_CAP(PC) (OBS_PELLET_WORDS * (PC) + OBS_ENTITY_WORDS * OBS_ECAP)
+// a frame whose recorded writes overflowed the list (cannot happen while the two constants above describe the kernel; kept as a net):
+// the stored count is -1 and the next call zero-fills that frame instead of undoing it
+#define OBS_UNDO_OVERFLOW (-1)
 
 OBS_DEV int obs_channels(const AgObsCfg &o) { return 1 + o.cells + 2 * o.others + 2 * o.viruses + 2 * o.pellets; }
 
@@ -68,7 +75,10 @@ OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o,
   __shared__ int un_cnt;
   int32_t *ul = un.list ? un.list + (size_t)frame * un.cap : nullptr;
   if (ul) {
-    if (un.clear) { const int n_prev = un.count[frame]; OBS_FOR(k, n_prev) out[ul[k]] = 0; }   // undo the previous observation's scattered writes
+    if (un.clear) {   // undo the previous observation's scattered writes
+      const int n_prev = un.count[frame];   // (block-uniform)
+      if (n_prev == OBS_UNDO_OVERFLOW) zero_fill = true; else OBS_FOR(k, n_prev) out[ul[k]] = 0;
+    }
     if (threadIdx.x == 0) un_cnt = 0;
   }
   auto rec = [&](int off) { if (ul) { const int p_ = atomicAdd(&un_cnt, 1); if (p_ < un.cap) ul[p_] = off; } };
@@ -131,8 +141,6 @@ OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o,
   // keeps the LAST writer, the other channel ops are sum / min / max).  Here every entity is a thread: the entities are
   // staged in LDS (grid cell or -1, mass, kind), and for each grid cell the FIRST entity of a kind that maps to it writes
   // the combined value of all of them with a plain store -- no read-modify-write chain, same result.
-#define OBS_ECAP 1024  // viruses + cells of all players staged per frame (16 players x 32 cell slots = 512 cells at most; entities
-                       // beyond the cap -- more than ~500 viruses -- are not drawn)
 #ifdef AGAR_CPU_EMU
   std::vector<int32_t> e_idx_v(OBS_ECAP), e_mass_v(OBS_ECAP), e_kind_v(OBS_ECAP); int32_t *e_idx = e_idx_v.data(), *e_mass = e_mass_v.data(), *e_kind = e_kind_v.data();
 #else
@@ -183,6 +191,6 @@ OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o,
     else { omin[idx] = mn; omax[idx] = mx; rec((int)(omin - out) + idx); rec((int)(omax - out) + idx); }
   }
 #ifndef AGAR_CPU_EMU
-  if (ul) { OBS_BARRIER(); if (threadIdx.x == 0) un.count[frame] = un_cnt < un.cap ? un_cnt : un.cap; }
+  if (ul) { OBS_BARRIER(); if (threadIdx.x == 0) un.count[frame] = un_cnt <= un.cap ? un_cnt : OBS_UNDO_OVERFLOW; }
 #endif
 }

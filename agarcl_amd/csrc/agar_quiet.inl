@@ -54,7 +54,10 @@ template <int NS, int QG = AG_QG> struct GrpPel {
   AG_MEM unsigned cap() const { return (unsigned)(NS * 64); }
   AG_MEM bool any(bool p) const { return __ballot(p) != 0ull; }
   // the rare second pass (agar_core.inl PelScan2), wave-level like scan(): noinline keeps its registers out of the hot loop's budget
-  template <bool AV> __attribute__((noinline)) AG_MEM_NOINLINE PelScan2 scan2(bool need, const PelQuery2 &k) {
+  // (the query and the pellet pointer travel by value: a reference / `this` would be a generic pointer into the caller's scratch frame,
+  // read with flat_* instructions)
+  template <bool AV> AG_MEM PelScan2 scan2(bool need, const PelQuery2 &k) { return scan2_call<AV>(xy, need, k); }
+  template <bool AV> static __attribute__((noinline)) AG_MEM_NOINLINE PelScan2 scan2_call(AG_GLOBAL float *xy, bool need, const PelQuery2 k) {
     PelScan2 out{0, 0xffffffffu, 0xffffffffu};
     unsigned long long todo = __ballot(need);
     if (todo) ag_mem_fence();
@@ -179,10 +182,11 @@ template <int NS, bool AV, int QG, int TSLG> AG_DEV QHandOver quiet_arena(const 
   if (lead && !ok) { qi[0] = -1; qi[1] = 0; }
 #ifndef AGAR_CPU_EMU
   if (lead && !(ok && finished)) {
-    if (parity >= 0) { const int at = atomicAdd(gs->qcount + parity, 1); gs->qlist[(size_t)parity * gs->d.A + at] = arena; }  // k_step's work list
-    atomicAdd(gs->qstat, 1);                              // statistics for the host's fused / two-kernel choice
+    // (HBM words behind descriptor pointers: cast to the global address space, so that these are global_*, not flat_*, instructions)
+    if (parity >= 0) { const int at = __hip_atomic_fetch_add((AG_GLOBAL int32_t *)gs->qcount + parity, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ((AG_GLOBAL int32_t *)gs->qlist)[(size_t)parity * gs->d.A + at] = arena; }  // k_step's work list
+    (void)__hip_atomic_fetch_add((AG_GLOBAL int32_t *)gs->qstat, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // statistics for the host's fused / two-kernel choice
 #ifdef AGAR_PROFILE_REASONS
-    atomicAdd(gs->qstat + 4 + (ok ? (q.why & 7) : 0), 1);   // [4] not a single-cell / food-free arena, [5..11] AG_WHY
+    (void)__hip_atomic_fetch_add((AG_GLOBAL int32_t *)gs->qstat + 4 + (ok ? (q.why & 7) : 0), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // [4] not a single-cell / food-free arena, [5..11] AG_WHY
 #endif
   }
 #endif

@@ -29,6 +29,7 @@ class VecEnvironment:
         self.num_arenas, self.num_agents, self.ticks_per_step = num_arenas, num_agents, ticks_per_step
         self.engine = _capi.BatchedEngine(num_arenas, num_agents, ticks_per_step, arena_size, pellet_regen, num_pellets,
                                           num_viruses, num_bots, reward_type, c_death, mode_number, dt, device, **caps)
+        self._torch_stream = bool(use_torch_stream)
         if use_torch_stream:
             # launch on torch's current stream so torch events / collectives order against the engine
             with torch.cuda.device(self.device):
@@ -52,13 +53,18 @@ class VecEnvironment:
 
     def reset(self, mask=None, reset_ids=False):
         """mask: None (all arenas), a host uint8/bool array, or a CUDA uint8 tensor [A] such as self.dones_u8[:, 0] made
-        contiguous -- the device form is a pure stream-ordered launch (no copy, no synchronisation)."""
+        contiguous -- the device form is a pure stream-ordered launch (no copy, no synchronisation) when the engine runs on torch's
+        stream (use_torch_stream=True, the default).  With an engine-owned stream the mask's producer (torch's current stream) is
+        waited for first: nothing else orders the cast below against the reset kernel.
+        Every reset also restarts the capacity-flag watch (strict_flags): after reset(mask) only arenas that are still flagged count."""
         torch = self.torch
         if isinstance(mask, torch.Tensor) and mask.is_cuda:
             m = mask.to(torch.uint8).contiguous().reshape(-1)
             if m.numel() != self.num_arenas:
                 raise ValueError("mask must have one entry per arena")
             self._mask_keep = m
+            if not self._torch_stream:
+                torch.cuda.current_stream(self.device).synchronize()
             self.engine.reset_device(m.data_ptr(), reset_ids)
         else:
             self.engine.reset(None if mask is None else np.asarray(mask), reset_ids)

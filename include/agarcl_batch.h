@@ -133,7 +133,8 @@ int agarcl_get_flags(agarcl_env *env, uint32_t *out_host);
 /* Cheap watch on the flags: every kernel ORs the flags it raises into one device word, which the engine fetches
  * asynchronously (pinned memory, never waited for) every few steps.  Returns through *or_of_flags the OR of all
  * flags seen so far (0 = none); never blocks; may lag the device by up to ~64 steps.  agarcl_get_flags is the exact,
- * synchronising query; agarcl_reset (unmasked) clears the watch word. */
+ * synchronising query.  Every reset restarts the watch: after agarcl_reset / agarcl_reset_device it reports the OR over the arenas that
+ * are still flagged -- none after an unmasked reset, and none once a masked reset has covered every flagged arena. */
 int agarcl_poll_flags(agarcl_env *env, uint32_t *or_of_flags);
 /* live entity counts of the last step: i32[num_arenas][4] = pellets, viruses, foods, cells(all players) */
 int agarcl_get_counts(agarcl_env *env, int32_t *out_host);
@@ -150,7 +151,11 @@ int agarcl_get_events(agarcl_env *env, int32_t *n_events_host, int32_t *pellet_i
  * on_device == 2: an HBM buffer that still holds THIS env's previous observation of the same configuration, unmodified (a
  * persistent observation tensor that is rewritten every step): only the words scattered into it last time are cleared instead of
  * streaming zeros over the whole tensor -- same contents as on_device == 1.  The first such call, and any call with another buffer
- * or configuration, clears everything. */
+ * or configuration, clears everything.  The buffer is owned by that sequence of calls: a plain (on_device == 1) call of this env into
+ * the same buffer voids the record and the next on_device == 2 call clears everything again; anything ELSE that writes into the buffer
+ * between two on_device == 2 calls (another env, the caller) leaves words the incremental clear does not know about.
+ * Which one a consumer gets: on_device == 1 is the stateless default (full clear, 2.1 GB of stores at 4096 x 8 x 128 x 128: ~395 us);
+ * on_device == 2 is the opt-in fast path for a tensor that is rewritten every step (~115 us). */
 int agarcl_grid_obs(agarcl_env *env, int32_t grid_size, int32_t observe_cells, int32_t observe_others,
                     int32_t observe_viruses, int32_t observe_pellets, int32_t *out, int32_t on_device,
                     int32_t *channels);

@@ -3,7 +3,7 @@ import sys, time, ctypes as C
 sys.path.insert(0, '.')
 import numpy as np
 from agarcl_amd import _capi
-lib = _capi.bind(C.CDLL('agarcl_amd/libagarcl_hip_prof.so'))
+lib = _capi.bind(C.CDLL('build_variants/lib_PROF.so'))
 names = ['load', 'tick_pre', 'pl_load/bots', 'kinematics', 'virus', 'pellets', 'stats/food', 'emit/split/add', 'recomb/decay/store', 'regen/end', 'env_post', 'store', 'selfcol(+rendezvous)', 'remove', 'sort', 'plcol/foods']
 def run(A, K=100, ticks=4, **cfg):
     eng = _capi.BatchedEngine(A, lib=lib, **cfg)

@@ -3,7 +3,7 @@ import sys, ctypes as C
 sys.path.insert(0, '.')
 import numpy as np
 from agarcl_amd import _capi
-lib = _capi.bind(C.CDLL('agarcl_amd/libagarcl_hip_prof.so'))
+lib = _capi.bind(C.CDLL('build_variants/lib_PROF.so'))
 names = ['load', 'tick_pre(+quiet run)', 'pl_load/bots', 'selfcol', 'virus', 'pellets', 'stats/food', 'emit/split/add', 'recomb/decay/store', 'regen/end', 'env_post', 'store', 'kinematics', 'remove', 'sort', 'plcol/foods']
 A, K = 4096, 200
 eng = _capi.BatchedEngine(A, lib=lib, arena_size=1000, num_pellets=1000, num_viruses=0, mode=0)

@@ -4,7 +4,7 @@ sys.path.insert(0, '.')
 import numpy as np
 from agarcl_amd import _capi
 from oracle import blob
-lib = _capi.bind(C.CDLL('agarcl_amd/libagarcl_hip_prof.so'))
+lib = _capi.bind(C.CDLL('build_variants/lib_PROF.so'))
 names = ['load', 'tick_pre', 'pl_load/bots', 'selfcol', 'virus', 'pellets', 'stats/food', 'emit/split/add', 'recomb/decay/store', 'regen/end', 'env_post', 'store', 'kinematics', 'remove', 'sort', 'plcol/foods']
 A, K = 4096, 200
 eng = _capi.BatchedEngine(A, lib=lib, arena_size=1000, num_pellets=1000, num_viruses=25, mode=0)

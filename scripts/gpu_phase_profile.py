@@ -2,7 +2,7 @@ import sys, time, ctypes as C
 sys.path.insert(0, '.')
 import numpy as np
 from agarcl_amd import _capi
-lib = _capi.bind(C.CDLL('agarcl_amd/libagarcl_hip_prof.so'))
+lib = _capi.bind(C.CDLL('build_variants/lib_PROF.so'))
 lib.agarcl_debug_prof.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 names = ['load', 'tick_pre', 'pl_load', 'selfcol', 'virus', 'pellets', 'stats/food', 'emit/split/add', 'recomb/decay/store', 'regen/end', 'env_post', 'store', 'kinematics', 'remove', 'sort', 'plcol/foods']
 def run(A, K=100, ticks=4, rand_act=False, **cfg):

@@ -4,7 +4,7 @@ import sys, time, ctypes as C
 sys.path.insert(0, '.')
 import numpy as np
 from agarcl_amd import _capi
-lib = _capi.bind(C.CDLL('agarcl_amd/libagarcl_hip_prof.so'))
+lib = _capi.bind(C.CDLL('build_variants/lib_PROF.so'))
 lib.agarcl_debug_prof.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 def run(A, move, ticks, K=300):
     eng = _capi.BatchedEngine(A, arena_size=1000, num_pellets=1000, num_viruses=0, mode=1, lib=lib)  # mode 1: no regen, no decay

@@ -258,3 +258,20 @@ def run_engine_level_lockstep(engine, oracles, ticks, seeds, policy_seed=7, ever
                 if d:
                     return False, "tick %d: arena %d: %s" % (t, a, d)
     return True, "ok"
+
+
+def soak_trial(seed, trial):
+    """The draws scripts/gpu_soak.py makes (default distribution) up to and including `trial` of stream `seed`:
+    (cfg, launch pins, arenas, arena seeds, policy seed, sticky) of that trial -- so that a recorded soak finding can be replayed."""
+    rng = np.random.RandomState(seed)
+    for _ in range(trial + 1):
+        na = int(rng.choice([1, 1, 1, 1, 2, 3])); mode = int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 6, 7, 8, 9, 10]))
+        nb = int(rng.randint(0, 4)) if mode == 0 and rng.rand() < 0.4 else 0
+        if mode > 6: na = 1
+        cfg = dict(num_agents=na, arena_size=int(rng.choice([80, 150, 250, 400, 1000, 1100])), num_pellets=int(rng.choice([50, 64, 200, 500, 1000, 1300])),
+                   num_viruses=int(rng.choice([0, 0, 3, 10, 25])), num_bots=nb, mode=mode, reward_type=int(rng.randint(0, 2)), c_death=int(rng.choice([0, -20])))
+        pins = dict(AGARCL_TILE_LG=str(rng.choice([0, 6])), AGARCL_FUSED=str(rng.choice([0, 1])), AGARCL_FUSED_QG=str(rng.choice([1, 2, 4, 8, 16, 16])), AGARCL_QUIET_QG=str(rng.choice([1, 2, 4, 8, 16])))
+        A = int(rng.choice([3, 70, 130]))
+        if mode in (1, 2, 5) and (cfg["arena_size"] // 2) * 4 > 2048: continue   # squared pellets beyond the pellet capacity: agarcl_create rejects, the soak skips
+        sd, ps, st = rng.randint(1, 1 << 30, size=A), int(rng.randint(1, 1000)), int(rng.choice([1, 4, 8]))
+    return cfg, pins, A, sd, ps, st

@@ -645,6 +645,89 @@ def test_vec_environment_device_reset_and_flag_watch(oracle_lib):
     env.close()
 
 
+def test_flag_watch_restarts_on_masked_reset():
+    """The normal RL auto-reset path: an arena raises a capacity flag, step() reports it (strict_flags), the caller resets exactly the
+    flagged arenas with a device mask -- and the watch must be clean again: 130 further steps without an error, poll_flags() == 0.
+    A masked reset that leaves a flagged arena alone keeps reporting it."""
+    import torch
+    from agarcl_amd.vec_env import VecEnvironment
+    from agarcl_amd._capi import AgarclError
+    A = 8
+    env = VecEnvironment(A, arena_size=200, num_pellets=100, mode_number=6, cap_foods=4)     # 4 food slots: feeding overflows
+    env.seed(base_seed=3); env.reset(reset_ids=True)
+    feed = torch.full((A, 1, 2), 0.5, device=env.device), torch.ones((A, 1), dtype=torch.int32, device=env.device)
+    idle = torch.zeros((A, 1, 2), device=env.device), torch.zeros((A, 1), dtype=torch.int32, device=env.device)
+    with pytest.raises(AgarclError):
+        for t in range(400):
+            env.take_actions(*feed); env.step()
+            if t % 50 == 49:
+                env.sync()
+    env.sync()
+    flagged = env.engine.flags() != 0
+    assert flagged.any()
+    # (1) a masked reset that misses one flagged arena: the watch still reports
+    first = int(np.flatnonzero(flagged)[0])
+    part = flagged.copy(); part[first] = False
+    env.reset(torch.as_tensor(part.astype(np.uint8), device=env.device))
+    env.sync()
+    assert (env.engine.flags() != 0).tolist() == [a == first for a in range(A)]
+    with pytest.raises(AgarclError):
+        for t in range(200):
+            env.take_actions(*idle); env.step()
+            if t % 50 == 49:
+                env.sync()
+    # (2) the reset the error message asks for: every flagged arena
+    env.sync()
+    env.reset(torch.as_tensor((env.engine.flags() != 0).astype(np.uint8), device=env.device))
+    for t in range(130):
+        env.take_actions(*idle); env.step()     # raises if the watch is sticky
+        if t % 40 == 39:
+            env.sync()
+    env.sync()
+    assert env.engine.poll_flags() == 0 and not env.engine.flags().any()
+    # (3) the same with a host mask
+    with pytest.raises(AgarclError):
+        for t in range(400):
+            env.take_actions(*feed); env.step()
+            if t % 50 == 49:
+                env.sync()
+    env.sync()
+    env.reset((env.engine.flags() != 0).astype(np.uint8))
+    for t in range(130):
+        env.take_actions(*idle); env.step()
+        if t % 40 == 39:
+            env.sync()
+    env.sync()
+    assert env.engine.poll_flags() == 0
+    env.close()
+
+
+def test_grid_obs_plain_call_voids_the_undo_list(hip_engine_cls):
+    """agarcl_grid_obs(on_device=2, buf), (on_device=1, buf), (on_device=2, buf): the middle call's scattered words are not in the undo
+    list of the first, so the third must clear everything -- its contents equal a fresh full-clear observation."""
+    import torch
+    A, G = 6, 32
+    eng = hip_engine_cls(A, **C3M6)
+    eng.seed(None, 9); eng.reset(reset_ids=True)
+    rng = np.random.RandomState(4)
+    dev = torch.device("cuda", 0)
+    C = 8   # 1 + cells + 2 others + 2 viruses + 2 pellets
+    buf = torch.full((A, 1, C, G, G), 7, dtype=torch.int32, device=dev); ref = torch.empty_like(buf)
+    def step(n):
+        for _ in range(n):
+            eng.set_actions(rng.uniform(-1, 1, size=(A, 1, 2)).astype(np.float32), rng.randint(0, 3, size=(A, 1)).astype(np.int32)); eng.step()
+    def obs(t, mode):
+        assert eng.grid_obs(G, out_ptr=t.data_ptr(), persistent=(mode == 2)) == C
+        eng.sync()
+    step(5); obs(buf, 2)
+    step(5); obs(buf, 1)
+    step(5); obs(buf, 2); obs(ref, 1)
+    assert torch.equal(buf, ref)
+    step(5); obs(buf, 2); obs(ref, 1)           # and the incremental path proper still agrees
+    assert torch.equal(buf, ref)
+    eng.close()
+
+
 def test_work_counters_account_for_every_arena_step(hip_engine_cls):
     """agarcl_debug_work (what bench.py's requested-bytes figure is built on): every arena-step is counted exactly once, as
     finished by the lean front part or as having gone through the general engine; pellet-array transfers are counted."""
@@ -666,3 +749,26 @@ def test_work_counters_account_for_every_arena_step(hip_engine_cls):
         else:
             assert w[1] > 0.9 * A * steps and w[2] >= A * steps    # mass-1000 agents: the general engine every step, pellets read every launch
         eng.close()
+
+
+@pytest.mark.parametrize("trial", [(91, 7), (62, 28), None], ids=["soak91_7", "soak62_28", "c3m6"])
+@pytest.mark.parametrize("qg", [16, 4])
+def test_fused_general_tail_regression(hip_engine_cls, oracle_lib, monkeypatch, trial, qg):
+    """k_fused pinned, tiled layout, 130 arenas in a mass-1000 mode: every arena-step runs general_arena_step behind the front part,
+    several arenas per wavefront one after the other, incl. the workgroup's first wavefront (LDS block at offset 0).
+    (91, 7) and (62, 28) are the scripts/gpu_soak.py trials that killed the queue in round 2 (memory-aperture violation: flat_* LDS access
+    whose folded offset left the address register below the aperture base, DESIGN.md section 2), replayed with their own seeds and policy;
+    the third case is the shipped default shape (16 pellet slots, 2 x 2 pellet grid)."""
+    from lockstep import soak_trial
+    if trial is None:
+        cfg, A, seeds, ps, st = dict(C3M6), 130, np.arange(4242, 4242 + 130), 5, 4
+    else:
+        cfg, _, A, seeds, ps, st = soak_trial(*trial)
+        assert (cfg["arena_size"], cfg["num_pellets"], cfg["mode"], A) == (1100, 1300, 6, 130)
+    monkeypatch.setenv("AGARCL_FUSED", "1"); monkeypatch.setenv("AGARCL_TILE_LG", "6"); monkeypatch.setenv("AGARCL_FUSED_QG", str(qg))
+    eng = hip_engine_cls(A, **cfg)
+    assert eng.L.agarcl_debug_fused(eng.h) == 1, "the single-launch step must serve this env (no fence on pellet slots / pellet grid)"
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    ok, msg = run_batched_lockstep(eng, oras, 120, seeds=np.asarray(seeds, dtype=np.uint32), policy_seed=ps, sticky=st, every=30)
+    eng.close()
+    assert ok, msg
