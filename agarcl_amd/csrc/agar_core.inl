@@ -81,6 +81,7 @@ template <class F> AG_DEV int wave_count(int n, F f) { int s = 0; for (int i = 0
 template <class F> AG_DEV unsigned wave_max(int n, F f) { unsigned s = 0; for (int i = 0; i < n; i++) { unsigned v = f(i); if (v > s) s = v; } return s; }
 template <class F> AG_DEV unsigned wave_min(int n, F f) { unsigned s = UINT_MAX; for (int i = 0; i < n; i++) { unsigned v = f(i); if (v < s) s = v; } return s; }
 template <class F> AG_DEV bool wave_any(int n, F f) { bool a = false; for (int i = 0; i < n; i++) a = a | (bool)f(i); return a; }
+template <class F> AG_DEV unsigned wave_or(int n, F f) { unsigned s = 0; for (int i = 0; i < n; i++) s |= f(i); return s; }
 template <class P, class S> AG_DEV int wave_compact(int n, P pred, S sink) { int c = 0; for (int i = 0; i < n; i++) if (pred(i)) { sink(i, c); c++; } return c; }
 #else
 // DPP scan (row_shr 1,2,4,8 + row_bcast15/31): lane 63 ends up with the reduction of all 64 lanes.
@@ -91,9 +92,12 @@ template <class P, class S> AG_DEV int wave_compact(int n, P pred, S sink) { int
 #define AG_OP_ADD(a, b) ((a) + (b))
 #define AG_OP_UMAX(a, b) ((unsigned)(a) > (unsigned)(b) ? (a) : (b))
 #define AG_OP_UMIN(a, b) ((unsigned)(a) < (unsigned)(b) ? (a) : (b))
+#define AG_OP_OR(a, b) ((a) | (b))
 AG_DEV int wred_add(int v) { AG_DPP_REDUCE(v, 0, AG_OP_ADD) return __builtin_amdgcn_readlane(v, 63); }
 AG_DEV unsigned wred_max(unsigned u) { int v = (int)u; AG_DPP_REDUCE(v, 0, AG_OP_UMAX) return (unsigned)__builtin_amdgcn_readlane(v, 63); }
 AG_DEV unsigned wred_min(unsigned u) { int v = (int)u; AG_DPP_REDUCE(v, -1, AG_OP_UMIN) return (unsigned)__builtin_amdgcn_readlane(v, 63); }
+AG_DEV unsigned wred_or(unsigned u) { int v = (int)u; AG_DPP_REDUCE(v, 0, AG_OP_OR) return (unsigned)__builtin_amdgcn_readlane(v, 63); }
+template <class F> AG_DEV unsigned wave_or(int n, F f) { unsigned s = 0; for (int i = AG_LANE; i < n; i += 64) s |= f(i); return wred_or(s); }
 template <class F> AG_DEV int wave_sum(int n, F f) { int s = 0; for (int i = AG_LANE; i < n; i += 64) s += f(i); return wred_add(s); }
 template <class F> AG_DEV int wave_count(int n, F f) {
   int c = 0;
@@ -192,21 +196,29 @@ struct Cells {  // LDS arrays of one player
 // pellets live in registers: lane l, slot s holds pellet s*64+l; unused entries hold a far-away sentinel
 // so the scan needs no bounds test.  (test-only host build: plain arrays)
 #define AG_PEL_SENTINEL 3.0e38f
+// `dirty`: bit s set <=> this lane's slot s differs from HBM (arena_store writes back only those: one eaten pellet is two 8-byte
+// stores, not the whole array)
 template <int NS> struct Pel {
 #ifdef AGAR_CPU_EMU
-  float x[NS][64], y[NS][64];
+  float x[NS][64], y[NS][64]; unsigned dirty[64];
 #else
-  float x[NS], y[NS];
+  float x[NS], y[NS]; unsigned dirty;
 #endif
 };
 #ifdef AGAR_CPU_EMU
 #define AG_PEL_FOR(s, lane, i) for (int s = 0; s < NS; s++) for (int lane = 0, i = s * 64; lane < 64; lane++, i++)
 #define PELX(c, s, lane) (c).pel.x[s][lane]
 #define PELY(c, s, lane) (c).pel.y[s][lane]
+#define PEL_MARK(c, s, lane) ((c).pel.dirty[lane] |= 1u << (s))
+#define PEL_DIRTY(c, s, lane) (((c).pel.dirty[lane] >> (s)) & 1u)
+#define PEL_CLEAN(c) do { for (int l_ = 0; l_ < 64; l_++) (c).pel.dirty[l_] = 0u; } while (0)
 #else
 #define AG_PEL_FOR(s, lane, i) _Pragma("unroll") for (int s = 0; s < NS; s++) for (int lane = AG_LANE, i = s * 64 + AG_LANE, once_ = 1; once_; once_ = 0)
 #define PELX(c, s, lane) (c).pel.x[s]
 #define PELY(c, s, lane) (c).pel.y[s]
+#define PEL_MARK(c, s, lane) ((c).pel.dirty |= 1u << (s))
+#define PEL_DIRTY(c, s, lane) (((c).pel.dirty >> (s)) & 1u)
+#define PEL_CLEAN(c) ((c).pel.dirty = 0u)
 #endif
 
 // AV ("all visible"): the pellet grid is at most 2x2 buckets (arena <= 1020), so every bucket is within +-1 of
@@ -223,7 +235,8 @@ template <int NS, bool AV> struct AgCtx {
   UBlock S;    // arena words (AR_*): register-resident for the whole launch
   UBlock PB;   // current player's words (PL_*): valid inside tick_player only; LDS PLS is its home
   int ncreated;
-  bool pel_dirty, pel_loaded;
+  bool pel_dirty, pel_loaded;   // pel_dirty: some slot is marked in pel.dirty
+  bool pel_all;                 // every slot is dirty (reset): the store skips the per-slot tests
 };
 
 template <int NS, bool AV> AG_DEV int *L_I(const AgCtx<NS, AV> &c, int off) { return (int *)(c.lds + off); }
@@ -320,10 +333,11 @@ template <int NS, bool AV> AG_DEV void pel_launder(AgCtx<NS, AV> &c) {
 template <int NS, bool AV> AG_DEV void pel_move(AgCtx<NS, AV> &c, int dst, int src) {
 #ifdef AGAR_CPU_EMU
   c.pel.x[dst >> 6][dst & 63] = c.pel.x[src >> 6][src & 63]; c.pel.y[dst >> 6][dst & 63] = c.pel.y[src >> 6][src & 63];
+  PEL_MARK(c, dst >> 6, dst & 63);
 #else
   int ss = src >> 6, sl = src & 63, ds = dst >> 6, dl = dst & 63; float vx = 0.0f, vy = 0.0f;
   _Pragma("unroll") for (int s = 0; s < NS; s++) if (s == ss) { vx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.pel.x[s]), sl)); vy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.pel.y[s]), sl)); }
-  _Pragma("unroll") for (int s = 0; s < NS; s++) if (s == ds && AG_LANE == dl) { c.pel.x[s] = vx; c.pel.y[s] = vy; }
+  _Pragma("unroll") for (int s = 0; s < NS; s++) if (s == ds && AG_LANE == dl) { c.pel.x[s] = vx; c.pel.y[s] = vy; PEL_MARK(c, s, 0); }
 #endif
 }
 // uniform read of pellet i
@@ -360,7 +374,7 @@ template <int NS, bool AV> AG_DEV void arena_load(AgCtx<NS, AV> &c, bool want_pe
       for (int f = 0; f < CF_ALL; f++) l[f * AG_CC + i] = g[AG_CELL_W(f, i)];
     }
   }
-  c.pel_dirty = false; c.ncreated = 0;
+  c.pel_dirty = false; c.pel_all = false; PEL_CLEAN(c); c.ncreated = 0;
   ag_lds_order();
 }
 // Pellet capacity is exactly NS*64 and HBM keeps the sentinel at every index >= n_pellets, so the load is NS
@@ -375,9 +389,10 @@ template <int NS, bool AV> AG_DEV void arena_store(AgCtx<NS, AV> &c) {
   ag_lds_order();
   const int ag_ts_lg = c.ts_lg;
   int np = SR(c, AR_NPEL);
-  if (c.pel_dirty) {  // whole register file incl. sentinels
+  if (c.pel_dirty) {  // the slots that changed (after a reset: the whole register file incl. sentinels)
     auto gxy = g_pxy(c);
-    AG_PEL_FOR(s, lane, i) { gxy[2 * i] = PELX(c, s, lane); gxy[2 * i + 1] = PELY(c, s, lane); }
+    if (c.pel_all) { AG_PEL_FOR(s, lane, i) { gxy[2 * i] = PELX(c, s, lane); gxy[2 * i + 1] = PELY(c, s, lane); } }
+    else { AG_PEL_FOR(s, lane, i) { if (PEL_DIRTY(c, s, lane)) { gxy[2 * i] = PELX(c, s, lane); gxy[2 * i + 1] = PELY(c, s, lane); } } }
   }
   int total_cells = 0;
   for (int p = 0; p < c.P; p++) {
@@ -393,7 +408,7 @@ template <int NS, bool AV> AG_DEV void arena_store(AgCtx<NS, AV> &c) {
   }
   ub_store_t(c.S, g_ar(c), AR_WORDS, ag_ts_lg);
   {  // diagnostics (agarcl_debug_work): pellet-array transfers of this launch; flag watch word (agarcl_poll_flags)
-    const int moved = (c.pel_loaded ? 1 : 0) + (c.pel_dirty ? 1 : 0);
+    const int moved = (c.pel_loaded ? 1 : 0) + (c.pel_dirty && c.pel_all ? 1 : 0);   // (dirty-slot stores are a few 8-byte words: not counted as a transfer)
     if (moved) { AG_SERIAL { PLS(c, 0)[PL_PASSES] += moved; } ag_lds_order(); }
     const int fl = SR(c, AR_FLAGS);
     if (AG_RARE(fl != 0)) { AG_SERIAL { ag_atomic_or(c.gs->qstat + 1, fl); } }
@@ -505,7 +520,7 @@ template <int NS, bool AV> AG_DEV void add_pellets(AgCtx<NS, AV> &c, int n) {
       gid[base + j] = idc + 1 + done + j;
     }
     ag_lds_order();
-    AG_PEL_FOR(s, lane, i) { if (i >= base && i < base + b) { PELX(c, s, lane) = stage[2 * (i - base)]; PELY(c, s, lane) = stage[2 * (i - base) + 1]; } }
+    AG_PEL_FOR(s, lane, i) { if (i >= base && i < base + b) { PELX(c, s, lane) = stage[2 * (i - base)]; PELY(c, s, lane) = stage[2 * (i - base) + 1]; PEL_MARK(c, s, lane); } }
     ag_lds_order();
   }
   SW(c, AR_NPEL, np + n); SW(c, AR_IDC, idc + n);
@@ -539,7 +554,7 @@ template <int NS, bool AV> AG_DEV void create_squared_pellets(AgCtx<NS, AV> &c) 
       else if (side == 1) { x = cx + half; y = (cx - half) + t; }
       else if (side == 2) { x = (cx + half) - t; y = cx + half; }
       else { x = cx - half; y = (cx + half) - t; }
-      PELX(c, s, lane) = x; PELY(c, s, lane) = y; gid[k] = idc + 1 + k;
+      PELX(c, s, lane) = x; PELY(c, s, lane) = y; PEL_MARK(c, s, lane); gid[k] = idc + 1 + k;
     }
   }
   SW(c, AR_NPEL, total); SW(c, AR_IDC, idc + total);
@@ -799,67 +814,114 @@ AG_DEV void q_visit(const QuadK &q, bool t0, bool stat, float r, float ro, unsig
 // level never holds more than n / 2 pairs.  A sweep started before its predecessor is known to have found an overlap is
 // harmless: if the predecessor finds none, no cell has moved and every later visit is a no-op (both prevent_overlap and
 // avoid_static_overlap act on touching pairs only); the loop still ends at the first completed sweep without a hit.
+// Level skipping: a level whose pairs all fail the touch test is a no-op (both prevent_overlap and avoid_static_overlap act on touching
+// pairs only), and 52 of the 72 levels of a mode-6 tick are such.  So the touch test of ALL pairs is made in one pass -- one lane per pair,
+// the result OR-reduced into one bit per local level L = a + b ("some pair of level L touches at the current positions") -- and repeated
+// only after a level that moved a cell.  The walk over the levels then goes straight from one level with a set bit to the next (a shift
+// and a count-trailing-zeros on the 64-bit mask): the levels in between are never iterated.  (Measured on MI355X: iterating them with a
+// cheap scalar test per level was 45 % SLOWER than the old loop although it executed fewer vector instructions -- every skipped level was
+// a handful of taken branches between small blocks of a 150 KB kernel, each an instruction-fetch stall; the walk below has none.)
+// Phases: sweep sN starts when sweep sN - 1 reaches its local level D + 1, so phase sN holds the levels LN = 1 .. D of sweep sN together
+// with LO = LN + D of sweep sN - 1 (phase 5, the static sweep, runs on to LN = LL).
 template <int NS, bool AV> AG_DEV void self_collisions(AgCtx<NS, AV> &c, const Cells &s, int n, float tx, float ty) {
   // (move_player has just refreshed every cell's radius cache, so s.crad[] is valid for all n cells)
-  // wave-parallel any-touch test; when no pair touches the reference's first sweep is a no-op
-  bool any = wave_any(n * n, [&](int k) { int a = k / n, b = k - a * n; return a < b && touches(s.x[a], s.y[a], s.crad[a], s.x[b], s.y[b], s.crad[b]); });
-  if (!any) return;
-  const float dt = c.gs->g.dt, W = c.gs->g.W;
-  const int LL = 2 * n - 3, D = n < LL ? n : LL, total = 5 * D + LL;
-  bool hit_even = false, hit_odd = false;   // "a pair touched" of the (at most two, consecutive) sweeps in flight, by sweep parity
-  int sN = 0, LN = 0;                       // newest sweep that has started and its local level (a + b)
-  for (int lev = 1; lev <= total; lev++) {
-    LN++;
-    if (sN < 5 && LN > D) { sN++; LN -= D; if (sN & 1) hit_odd = false; else hit_even = false; }
-    const int sO = sN - 1, LO = LN + D;
-    const bool validO = sO >= 0 && LO <= LL, validN = LN <= LL;
-    // pairs of a local level L: a = a0 .. (L - 1) / 2, b = L - a
-    const int a0O = LO - (n - 1) > 0 ? LO - (n - 1) : 0, wO = validO ? (LO - 1) / 2 - a0O + 1 : 0;
-    const int a0N = LN - (n - 1) > 0 ? LN - (n - 1) : 0, wN = validN ? (LN - 1) / 2 - a0N + 1 : 0;
-    // lane j: a pair of the older sweep first, then of the newer one; only x, y, r are read before the pair is known to touch
-    auto visit = [&](int j, int &sw) -> bool {
-      int a, b;
-      if (j < wO) { a = a0O + j; b = LO - a; sw = sO; } else { a = a0N + (j - wO); b = LN - a; sw = sN; }
-      CellR A, B;
-      A.x = s.x[a]; A.y = s.y[a]; A.r = s.crad[a]; B.x = s.x[b]; B.y = s.y[b]; B.r = s.crad[b];
-      if (!touches(A.x, A.y, A.r, B.x, B.y, B.r)) return false;
-      A.vx = s.vx[a]; A.vy = s.vy[a]; A.sx = s.sx[a]; A.sy = s.sy[a]; A.m = s.m[a];
-      B.vx = s.vx[b]; B.vy = s.vy[b]; B.sx = s.sx[b]; B.sy = s.sy[b]; B.m = s.m[b];
-      if (sw < 5) prevent_overlap(A, B, dt, tx, ty, W); else avoid_static_overlap(A, B, W);
-      cellr_store(s, a, A); cellr_store(s, b, B);
-      return true;
-    };
-    bool he = false, ho = false;
+  const int NP = n * (n - 1) / 2;   // pairs (a, b), a < b, numbered row-major: k = a n - a (a + 1) / 2 + b - a - 1
+  auto decode = [&](int k, int &a, int &b) { a = 0; int row = n - 1, rem = k; while (row > 0 && rem >= row) { rem -= row; a++; row--; } b = a + 1 + rem; };
 #ifdef AGAR_CPU_EMU
-    for (int j = 0; j < wO + wN; j++) { int sw = 0; if (visit(j, sw)) { if (sw & 1) ho = true; else he = true; } }
+  auto pair_of = [&](int k, int &a, int &b) { decode(k, a, b); };
 #else
-    {  // four lanes per pair (q_visit): lane = 4 * pair + 2 * cell + component
-      const int lane = AG_LANE, j = lane >> 2; int sw = 0; bool t0 = false;
-      if (j < wO + wN) {
+  // this lane's pairs of the first 128 (all of them up to 16 cells), decoded once per call -- NOT once per pass: arenas with 12+ cells,
+  // whose second round decoded on the fly, ran 1.5x longer than the others, and a launch lasts as long as its slowest arena
+  int a_l, b_l, a_l2 = 0, b_l2 = 0; decode(AG_LANE, a_l, b_l);
+  if (NP > 64) decode(AG_LANE + 64, a_l2, b_l2);
+  auto pair_of = [&](int k, int &a, int &b) { if (k < 64) { a = a_l; b = b_l; } else if (k < 128) { a = a_l2; b = b_l2; } else decode(k, a, b); };
+#endif
+  const int LL = 2 * n - 3;                  // local levels 1 .. LL (<= 61 at 32 cells)
+  unsigned long long H = 0ull;               // bit L: some pair with a + b == L touches at the current positions
+  auto level_hits = [&]() {
+    const unsigned lo = wave_or(NP, [&](int k) -> unsigned { int a, b; pair_of(k, a, b); const int L = a + b; return (L < 32 && touches(s.x[a], s.y[a], s.crad[a], s.x[b], s.y[b], s.crad[b])) ? 1u << L : 0u; });
+    const unsigned hi = LL < 32 ? 0u : wave_or(NP, [&](int k) -> unsigned { int a, b; pair_of(k, a, b); const int L = a + b; return (L >= 32 && touches(s.x[a], s.y[a], s.crad[a], s.x[b], s.y[b], s.crad[b])) ? 1u << (L - 32) : 0u; });
+    H = ((unsigned long long)hi << 32) | lo;
+#if defined(AGAR_PROFILE_LEVELS) && !defined(AGAR_CPU_EMU)
+    AG_SERIAL { atomicAdd(c.gs->qstat + 12, 1); }
+#endif
+  };
+  level_hits();
+  if (H == 0ull) return;   // no pair touches: the reference's first sweep is a no-op
+  const float dt = c.gs->g.dt, W = c.gs->g.W;
+  const int D = n < LL ? n : LL;
+  auto levels_1_to = [](int k) -> unsigned long long { return ((1ull << (k + 1)) - 1ull) & ~1ull; };   // bits 1 .. k (k <= 62)
+  unsigned touched = 0u;   // bit s: sweep s has visited a touching pair
+  for (int sN = 0; sN <= 5; sN++) {
+    const int sO = sN - 1, plen = sN < 5 ? D : LL;
+    const int eo = sN >= 1 ? LL - D : 0;   // the level of this phase at which the older sweep completes (0: it has no level here)
+    bool done = false;
+    for (int LN = 0;;) {
+      // levels of this phase after LN at which something touches: the newer sweep's LN, the older sweep's LN + D
+      const unsigned long long M = (H & levels_1_to(plen)) | (eo >= 1 ? (H >> D) & levels_1_to(eo) : 0ull);
+      const unsigned long long R = M >> (LN + 1);
+      const int Lhit = R ? LN + 1 + (int)__builtin_ctzll(R) : 1000;
+      if (eo > LN && eo < Lhit) {   // the older sweep completes before anything else touches
+        if (!((touched >> sO) & 1u)) { done = true; break; }
+        LN = eo; continue;
+      }
+      if (Lhit > plen) break;
+      LN = Lhit;
+      const int LO = LN + D;
+      const bool validO = sN >= 1 && LO <= LL;
+      // pairs of a local level L: a = a0 .. (L - 1) / 2, b = L - a
+      const int a0O = LO - (n - 1) > 0 ? LO - (n - 1) : 0, wO = validO ? (LO - 1) / 2 - a0O + 1 : 0;
+      const int a0N = LN - (n - 1) > 0 ? LN - (n - 1) : 0, wN = (LN - 1) / 2 - a0N + 1;
+      bool he = false, ho = false;
+#ifdef AGAR_CPU_EMU
+      // lane j: a pair of the older sweep first, then of the newer one; only x, y, r are read before the pair is known to touch
+      auto visit = [&](int j, int &sw) -> bool {
         int a, b;
         if (j < wO) { a = a0O + j; b = LO - a; sw = sO; } else { a = a0N + (j - wO); b = LN - a; sw = sN; }
-        QuadK q; q.cB = (lane & 2) != 0; q.kY = (lane & 1) != 0; q.W = W; q.dt = dt; q.tk = q.kY ? ty : tx;
-        const int self = q.cB ? b : a;
-        float *pp = (q.kY ? s.y : s.x) + self, *vp = (q.kY ? s.vy : s.vx) + self;
-        float p = *pp; const float r = s.crad[self], ro = q_cell(r);
-        { const float dk = fabsf(p - q_cell(p)), s2 = dk * dk; const float rs = r + ro, rr = rs * rs; t0 = rr >= (s2 + q_comp(s2)) + 0.0f; }
-        if (ag_any(t0)) {
-          float v = *vp; const float sv = (q.kY ? s.sy : s.sx)[self]; const unsigned m = s.m[self], mo = q_cellu(m);
-          q_visit(q, t0, sw >= 5, r, ro, m, mo, sv, p, v);
-          if (t0) { *pp = p; *vp = v; }
+        CellR A, B;
+        A.x = s.x[a]; A.y = s.y[a]; A.r = s.crad[a]; B.x = s.x[b]; B.y = s.y[b]; B.r = s.crad[b];
+        if (!touches(A.x, A.y, A.r, B.x, B.y, B.r)) return false;
+        A.vx = s.vx[a]; A.vy = s.vy[a]; A.sx = s.sx[a]; A.sy = s.sy[a]; A.m = s.m[a];
+        B.vx = s.vx[b]; B.vy = s.vy[b]; B.sx = s.sx[b]; B.sy = s.sy[b]; B.m = s.m[b];
+        if (sw < 5) prevent_overlap(A, B, dt, tx, ty, W); else avoid_static_overlap(A, B, W);
+        cellr_store(s, a, A); cellr_store(s, b, B);
+        return true;
+      };
+      for (int j = 0; j < wO + wN; j++) { int sw = 0; if (visit(j, sw)) { if (sw & 1) ho = true; else he = true; } }
+#else
+      {  // four lanes per pair (q_visit): lane = 4 * pair + 2 * cell + component
+        const int lane = AG_LANE, j = lane >> 2; int sw = 0; bool t0 = false;
+        if (j < wO + wN) {
+          int a, b;
+          if (j < wO) { a = a0O + j; b = LO - a; sw = sO; } else { a = a0N + (j - wO); b = LN - a; sw = sN; }
+          QuadK q; q.cB = (lane & 2) != 0; q.kY = (lane & 1) != 0; q.W = W; q.dt = dt; q.tk = q.kY ? ty : tx;
+          const int self = q.cB ? b : a;
+          float *pp = (q.kY ? s.y : s.x) + self, *vp = (q.kY ? s.vy : s.vx) + self;
+          float p = *pp; const float r = s.crad[self], ro = q_cell(r);
+          { const float dk = fabsf(p - q_cell(p)), s2 = dk * dk; const float rs = r + ro, rr = rs * rs; t0 = rr >= (s2 + q_comp(s2)) + 0.0f; }
+          if (ag_any(t0)) {
+            float v = *vp; const float sv = (q.kY ? s.sy : s.sx)[self]; const unsigned m = s.m[self], mo = q_cellu(m);
+            q_visit(q, t0, sw >= 5, r, ro, m, mo, sv, p, v);
+            if (t0) { *pp = p; *vp = v; }
+          }
         }
+        he = __ballot(t0 && !(sw & 1)) != 0ull; ho = __ballot(t0 && (sw & 1)) != 0ull;
       }
-      he = __ballot(t0 && !(sw & 1)) != 0ull; ho = __ballot(t0 && (sw & 1)) != 0ull;
-    }
 #endif
-    hit_even = hit_even || he; hit_odd = hit_odd || ho;
+      ag_lds_order();
 #if defined(AGAR_PROFILE_LEVELS) && !defined(AGAR_CPU_EMU)
-    AG_SERIAL { atomicAdd(c.gs->qstat + 2, 1); if (he || ho) atomicAdd(c.gs->qstat + 3, 1); }   // diagnostic build: levels walked / levels with a touching pair
+      AG_SERIAL { atomicAdd(c.gs->qstat + 2, 1); if (he || ho) atomicAdd(c.gs->qstat + 3, 1); }   // diagnostic build: levels visited / with a touching pair
 #endif
-    ag_lds_order();
-    // a sweep that has completed without a single touching pair ends the relaxation
-    if (validO && LO == LL && !((sO & 1) ? hit_odd : hit_even)) break;
-    if (validN && LN == LL && !((sN & 1) ? hit_odd : hit_even)) break;
+      if (he || ho) {
+        const bool hn = (sN & 1) ? ho : he, hold = (sN & 1) ? he : ho;   // he / ho are by sweep parity: the newer sweep's, the older sweep's
+        touched |= (hn ? 1u << sN : 0u) | ((hold && sN >= 1) ? 1u << sO : 0u);
+        level_hits();   // cells have moved: the touch bits are taken again
+      }
+      // a sweep that has completed without a single touching pair ends the relaxation
+      if (LN == eo && !((touched >> sO) & 1u)) { done = true; break; }
+    }
+    if (done) break;
+    if (plen == LL && !((touched >> sN) & 1u)) break;   // (the newer sweep completes inside its own phase only up to 3 cells, and in the last phase)
   }
 }
 // Kinematics of ONE cell for one tick (Engine::move_player's loop body, Engine.hpp:616-626).  Shared by the
@@ -1372,7 +1434,7 @@ template <int NS, bool AV> AG_DEV void remove_pellets(AgCtx<NS, AV> &c) {
   }
   // keep the padding invariant: everything at index >= n is a sentinel again
   int n0 = SR(c, AR_NPEL);
-  AG_PEL_FOR(s, lane, i) { if (i >= n && i < n0) { PELX(c, s, lane) = AG_PEL_SENTINEL; PELY(c, s, lane) = AG_PEL_SENTINEL; } }
+  AG_PEL_FOR(s, lane, i) { if (i >= n && i < n0) { PELX(c, s, lane) = AG_PEL_SENTINEL; PELY(c, s, lane) = AG_PEL_SENTINEL; PEL_MARK(c, s, lane); } }
   SW(c, AR_NPEL, n);
   c.pel_dirty = true;
 }
@@ -1678,14 +1740,14 @@ template <int NS, bool AV> struct RegPel {
   }
   AG_MEM void append(int idx, float x, float y, int id) {  // pellets.emplace_back
     ensure_pellets(c);
-    AG_PEL_FOR(s, lane, i) { if (i == idx) { PELX(c, s, lane) = x; PELY(c, s, lane) = y; } }
+    AG_PEL_FOR(s, lane, i) { if (i == idx) { PELX(c, s, lane) = x; PELY(c, s, lane) = y; PEL_MARK(c, s, lane); } }
     auto gid = g_pid(c); AG_SERIAL { gid[idx] = id; }
     c.pel_dirty = true;
   }
   AG_MEM void swap_pop(int ev, int np) {
     if (np > 1 && ev < np - 1) { pel_move(c, ev, np - 1); auto gid = g_pid(c); AG_SERIAL { gid[ev] = gid[np - 1]; } }
     int lastp = np - 1;
-    AG_PEL_FOR(sl_, lane, i) { if (i == lastp) { PELX(c, sl_, lane) = AG_PEL_SENTINEL; PELY(c, sl_, lane) = AG_PEL_SENTINEL; } }
+    AG_PEL_FOR(sl_, lane, i) { if (i == lastp) { PELX(c, sl_, lane) = AG_PEL_SENTINEL; PELY(c, sl_, lane) = AG_PEL_SENTINEL; PEL_MARK(c, sl_, lane); } }
     c.pel_dirty = true;
   }
 };
@@ -1729,7 +1791,20 @@ template <int NS, bool AV> AG_DEV int quiet_run(AgCtx<NS, AV> &c, int max_ticks)
 }
 
 // ---- Engine::tick.  R: Engine.hpp:208-240 --------------------------------------------------------------------
+// Issue priority of this wavefront among the (up to four) wavefronts of its SIMD, from the arena's cell count.  A launch lasts as long as
+// its slowest arena, the arenas with 12 - 16 cells (120 pairs, 109 relaxation levels) are the slowest by far -- the mean wavefront is
+// done at 0.6 of the launch (SQ_WAVE_CYCLES vs SQ_BUSY_CYCLES) -- and the wavefronts sharing their SIMD have slack: let the big ones go first.
+AG_DEV void ag_set_priority(int cells) {
+#ifndef AGAR_CPU_EMU
+#ifndef AG_NO_PRIO
+  if (cells >= 14) __builtin_amdgcn_s_setprio(3); else if (cells >= 12) __builtin_amdgcn_s_setprio(2); else if (cells >= 9) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
+#else
+  (void)cells;
+#endif
+}
 template <int NS, bool AV> AG_DEV void arena_tick(AgCtx<NS, AV> &c) {
+  { int big = 0; for (int p = 0; p < c.P; p++) { const int n_ = ag_uni(PLS(c, p)[PL_NCELLS]); big = n_ > big ? n_ : big; } ag_set_priority(c.P == 1 ? big : big + c.P / 2); }
   ensure_pellets(c);
   SW(c, AR_SAFE, 0);  // the out-of-reach budget is only maintained by quiet_run
   SW(c, AR_NEVP, 0); SW(c, AR_NEVV, 0);
@@ -1821,6 +1896,7 @@ template <int NS, bool AV> AG_DEV void env_step(AgCtx<NS, AV> &c, int ticks, boo
 #endif
     arena_tick(c); t++;
   }
+  ag_set_priority(0);
   if (with_env) {
     if (c.gs->g.screen_respawn) {  // R: ScreenEnvironment.hpp:233-243 via BaseEnvironment.hpp:96-97: per agent, after the ticks
       for (int i = 0; i < na; i++) if (ag_uni(PLS(c, i)[PL_NCELLS]) == 0) { respawn(c, i); SW(c, AR_RESPAWNED, 1); }
@@ -1848,7 +1924,7 @@ template <int NS, bool AV> AG_DEV void env_reset(AgCtx<NS, AV> &c, int reset_ids
   SW(c, AR_NPEL, 0); SW(c, AR_NVIR, 0); SW(c, AR_NFOOD, 0); SW(c, AR_TICKS, 0); SW(c, AR_FLAGS, 0);
   SW(c, AR_NEVP, 0); SW(c, AR_NEVV, 0); SW(c, AR_DONE, 0); SW(c, AR_RESPAWNED, 0);
   AG_PEL_FOR(s, lane, i) { PELX(c, s, lane) = AG_PEL_SENTINEL; PELY(c, s, lane) = AG_PEL_SENTINEL; }
-  c.pel_loaded = true; SW(c, AR_SAFE, 0);
+  c.pel_loaded = true; c.pel_dirty = true; c.pel_all = true; SW(c, AR_SAFE, 0);
   if (c.gs->g.squared) create_squared_pellets(c); else add_pellets(c, c.gs->g.target_pellets);
   add_viruses(c, c.gs->g.target_viruses);
   int na = c.gs->d.n_agents, mode = c.gs->g.mode, nb = c.P - na;

@@ -103,7 +103,7 @@ template <int NS, bool AV> AG_DEV void ag_ctx_init(AgCtx<NS, AV> &c, const AgSta
   c.gs = gs; c.arena = arena; c.lds = lds; c.act_dxdy = (const AG_GLOBAL float *)act_dxdy; c.act = (const AG_GLOBAL int32_t *)act;
   c.P = gs->d.P; c.PC = gs->d.PC; c.ts_lg = gs->d.ts_lg;
   ag_lds_layout(c.P, &c.cells_off);
-  c.ncreated = 0; c.pel_dirty = false; c.pel_loaded = false;
+  c.ncreated = 0; c.pel_dirty = false; c.pel_loaded = false; c.pel_all = false; PEL_CLEAN(c);
 }
 #define AG_DISPATCH_NS(ns, CALL) do { if (e->all_vis) { switch (ns) { case 4: CALL(4, true); break; case 8: CALL(8, true); break; case 16: CALL(16, true); break; default: CALL(32, true); break; } } \
   else { switch (ns) { case 4: CALL(4, false); break; case 8: CALL(8, false); break; case 16: CALL(16, false); break; default: CALL(32, false); break; } } } while (0)
@@ -239,8 +239,7 @@ template <int NS, bool AV> __global__ void __launch_bounds__(64) k_reset(const A
   const float *act_dxdy = nullptr; const int32_t *act = nullptr;
   AG_KERNEL_PROLOGUE
   arena_load(c);
-  env_reset(c, reset_ids);
-  c.pel_dirty = true;
+  env_reset(c, reset_ids);   // (marks every pellet slot dirty)
   arena_store(c);
 }
 template <int NS, bool AV> __global__ void __launch_bounds__(64) k_respawn(const AgState *__restrict__ gs) {
@@ -386,7 +385,7 @@ static int launch_reset(agarcl_env *e, const uint8_t *mask_dev, const uint8_t *m
 #ifdef AGAR_CPU_EMU
   (void)mask_dev;
   e->s.qstat[1] = 0;
-#define CALL(N, V) for_each_arena_ns<N, V>(e, [&](AgCtx<N, V> &c) { if (mask_host && !mask_host[c.arena]) { e->s.qstat[1] |= e->s.ar[tix(e->d.ts_lg, (size_t)c.arena, AR_WORDS, AR_FLAGS)]; return; } arena_load(c); env_reset(c, reset_ids); c.pel_dirty = true; arena_store(c); })
+#define CALL(N, V) for_each_arena_ns<N, V>(e, [&](AgCtx<N, V> &c) { if (mask_host && !mask_host[c.arena]) { e->s.qstat[1] |= e->s.ar[tix(e->d.ts_lg, (size_t)c.arena, AR_WORDS, AR_FLAGS)]; return; } arena_load(c); env_reset(c, reset_ids); arena_store(c); })
   AG_DISPATCH_NS(e->ns, CALL);
 #undef CALL
 #else

@@ -39,11 +39,15 @@ WORKLOADS = {
                desc="C5: C3/mode 6 + int32 grid observation [%d][8][128][128] refreshed once per step (persistent HBM tensor)"),
     "C5s": dict(num_viruses=25, mode_number=6, rand_act=True, screen_obs=True,
                 desc="C5 (screen): C3/mode 6 + uint8 screen observation [%d][84][84][3] written once per step"),
+    # between the quiet headline and the mass-1000 extreme: what a learning agent's mid-game costs
+    "mid": dict(num_viruses=25, rand_act=True, start_mass=150,
+                desc="mid-game: %d arenas/GPU x 1 agent grown to mass 150 (ejects / splits fire, ejected food lies around), 1000x1000, 1000 pellets, 25 viruses, mode 0, 4 ticks/step, action ~ U{0,1,2}"),
     # BASELINE configs[0] batched: the reference's own bench/main.cpp population (agent + the four bot kinds on the default
     # 250x250 arena, Engine::tick at dt = 1/60 s), 4 ticks per launch
     "C1": dict(arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, dt=1.0 / 60, rand_act=True,
                desc="C1 batched: %d arenas/GPU x (1 agent + 4 bots), 250x250, 500 pellets, 10 viruses, mode 0, dt 1/60 s, 4 ticks/step"),
 }
+TRAFFIC_FILE = "r03_pmc_traffic.json"   # PMC FETCH_SIZE / WRITE_SIZE per step of the bench workloads, recorded by scripts/profile_round.sh
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
 
 
@@ -73,7 +77,7 @@ def requested_bytes(work, counts, P, n_agents, ticks, pellet_cap):
     return front * front_steps + general * general_steps + pellet_moves * pellet_cap * 8.0
 
 
-def cpu_baseline(seconds_budget=12.0):
+def cpu_baseline(seconds_budget=12.0, c3_budget=6.0):
     """The same per-arena workload on the host cores, timed on a bounded sample.
     kind "reference": oracle/_ref/libagar_ref.so = the unmodified reference engine (prebuilt from
     /root/reference); otherwise kind "port": the plain-C restatement."""
@@ -135,7 +139,33 @@ def cpu_baseline(seconds_budget=12.0):
     for t in th: t.join()
     el = time.perf_counter() - t0
     total = sum(done)
+    # the full rule set beside it (BASELINE configs[2] = C3, mode 6: agent mass 1000, 25 viruses, action ~ U{0,1,2}): same engine, all cores,
+    # a bounded 6 s
+    mk6 = lambda: Env(num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True, num_pellets=1000,
+                      num_viruses=25, num_bots=0, reward_type=1, c_death=0, mode=6)
+    done6 = [0] * cores
+    deadline6 = time.perf_counter() + c3_budget
+
+    def worker6(w):
+        j = 0
+        while time.perf_counter() < deadline6:
+            with mk_lock:
+                env = mk6()
+            env.seed(10000 + w * 64 + j); env.reset(True)
+            for _ in range(20):
+                done6[w] += env.run_random(400, policy_seed=w * 64 + j + 1, allow_actions=True)
+                if time.perf_counter() >= deadline6:
+                    break
+            env.close(); j += 1
+    th = [threading.Thread(target=worker6, args=(w,)) for w in range(cores)]
+    t0 = time.perf_counter()
+    for t in th: t.start()
+    for t in th: t.join()
+    el6 = time.perf_counter() - t0
     return {"value": total / el, "unit": "env-steps/s", "cores": cores, "kind": kind,
+            "c3m6_value": sum(done6) / el6, "c3m6_cores": cores,
+            "c3m6_sample": "%.0f s of C3 / mode 6 (1000x1000, 1000 pellets, 25 viruses, agent mass 1000, random dx/dy, action ~ U{0,1,2}), one engine per host "
+                           "thread, %d threads, %d arena-ticks in total" % (c3_budget, cores, sum(done6)),
             "sample": "%.0f s of the C2 workload (1000x1000, 1000 pellets, 1 agent, random dx/dy, action none), one engine "
                       "per host thread, %d threads, %d arena-ticks in total; single-thread rate %.0f ticks/s"
                       % (seconds_budget, cores, total, rate1),
@@ -155,13 +185,22 @@ def spawn_ranks(n):
 
 
 def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, Wm, cfg, rand_act, with_obs, with_screen,
-                 gather_mode, gather_obs, gather_block=32):
+                 gather_mode, gather_obs, gather_block=32, start_mass=0):
     """Builds the env, runs Wm untimed + K timed steps, returns the measurements of this rank."""
     import torch.distributed as dist
     lo, hi = rank * A, (rank + 1) * A  # weak scaling: every GPU owns `A` arenas
     env = env_cls(A, device=dev_index, strict_flags=False, **cfg)
     env.seed(agdist.arena_seeds(10000, lo, hi))
     env.reset(reset_ids=True)
+    if start_mass:   # grown agents, through the product's own snapshot path (the reference's JSON wire format, agarcl_amd/snapshot.py)
+        from agarcl_amd import snapshot
+        sn = snapshot.save_arena(env.engine, 0, cfg)   # one start state for every arena (seeds and actions differ): enough for a timing
+        for pl in sn["players"]:
+            for cell in pl["cells"]:
+                cell["mass"] = int(start_mass)
+        for a in range(A):
+            sn["seed"] = 10000 + lo + a
+            snapshot.load_arena(env.engine, a, sn, reset_ids=True)
     # synthetic random policy, resident in HBM before the timed region: counter-based per (arena, step)
     g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
     na = cfg["num_agents"]
@@ -277,7 +316,7 @@ def roofline_block(res, A, K, ticks, cfg, workload, extra_bytes=0.0, kernel=None
     model = b_tick * A * ticks + (extra_bytes if model_extra is None else model_extra)
     traffic = tag = None
     try:  # HBM bytes per step from the PMC counters, recorded separately by scripts/profile_round.sh on THIS kernel source
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
         ent = tj["runs"].get("%s@%d" % (workload, A))
         if ent and tj.get("source_sha") == source_sha():
             traffic, tag = ent["traffic_bytes_per_step"], "%s, source %s" % (tj.get("recorded", "?"), tj["source_sha"])
@@ -285,7 +324,9 @@ def roofline_block(res, A, K, ticks, cfg, workload, extra_bytes=0.0, kernel=None
         pass
     moved = traffic if traffic else req
     out = {"bound": "hbm", "achieved": moved / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved / t / 1e9 / HBM_PEAK_GBS,
-           "traffic": traffic, "traffic_source": tag, "requested_bytes_per_step": req, "kernel_ms": res["kernel_ms"],
+           "traffic": traffic, "traffic_source": tag, "requested_bytes_per_step": req, "algorithmic_bytes_per_step": req,
+           # how much of what leaves HBM the kernels asked for (1 = no wasted re-reads / partial lines / spills); None without PMC data
+           "frac_of_requested": (req / traffic) if traffic else None, "kernel_ms": res["kernel_ms"],
            "kernel": kernel or ("k_fused (one launch per env step)" if res["fused"] and P == 1 else ("k_quiet + k_step" if P == 1 else "k_step")),
            "arenas": A, "streaming_model_bytes_per_step": model, "streaming_model_bytes_per_arena_tick": b_tick,
            "model_speedup": model / t / 1e9 / HBM_PEAK_GBS,
@@ -302,6 +343,7 @@ def main():
     ap.add_argument("--arenas", type=int, default=ARENAS_PER_GPU, help="arenas per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large", action="store_true", help="skip the %d-arena roofline_large run" % LARGE_ARENAS)
+    ap.add_argument("--no-full", action="store_true", help="skip the roofline_full runs (C3 / mode 6 and the mid-game workload)")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS), help="C2 = the headline metric's configuration")
     ap.add_argument("--gather", default="block", choices=["block", "step"], help="multi-GPU: how (reward, done) reaches rank 0")
     ap.add_argument("--gather-block", type=int, default=32, choices=[8, 16, 32], help="multi-GPU, --gather block: steps per collective")
@@ -314,6 +356,7 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: the number of rank processes must equal --gpus" % (args.gpus, world))
     wl = dict(WORKLOADS[args.workload])
     desc, rand_act, with_obs, with_screen = wl.pop("desc"), wl.pop("rand_act", False), wl.pop("grid_obs", False), wl.pop("screen_obs", False)
+    start_mass = wl.pop("start_mass", 0)
     cfg = dict(CFG); cfg.update(wl)
 
     import torch
@@ -346,7 +389,12 @@ def main():
     A, K, Wm = args.arenas, args.steps, args.warmup
     ticks = cfg["ticks_per_step"]
     res = run_workload(torch, np, VecEnvironment, agdist, dev, dev_index, rank, world, A, K, Wm, cfg, rand_act, with_obs, with_screen,
-                       args.gather, args.gather_obs, args.gather_block)
+                       args.gather, args.gather_obs, args.gather_block, start_mass)
+    devs = [None] * world   # which device every rank ran on: lets the driver see "RCCL saw N ranks on N GPUs"
+    if world > 1:
+        dist.all_gather_object(devs, "%s:%d" % (os.uname().nodename, dev_index))
+    else:
+        devs = ["%s:%d" % (os.uname().nodename, dev_index)]
     value = world * A * ticks * K / res["elapsed"]
     if rank == 0:
         # observation bytes.  Streaming model: the whole tensor is written once per step.  Requested by this
@@ -381,6 +429,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc % A, "arenas_total": world * A, "ticks_per_step": ticks, "parallelism": par},
             "gym_steps_per_s": value / ticks,
+            "world_size": world, "backend": (backend if world > 1 else None), "rank_devices": devs,
             "roofline": roof,
             "capacity_flags_raised": int((res["flags"] != 0).sum()),
         }
@@ -394,6 +443,22 @@ def main():
                 out["roofline_large"] = rl
             except Exception as ex:  # the headline line must not depend on it
                 out["roofline_large"] = {"error": str(ex)}
+        if world == 1 and not args.no_full and args.workload == "C2":
+            # the other two regimes in the same run: the full rule set at mass 1000 (BASELINE configs[2]) and a learning agent's mid-game
+            full = {}
+            for name, fk, fw in (("C3m6", 100, 20), ("mid", 150, 400)):
+                try:
+                    w2 = dict(WORKLOADS[name]); w2.pop("desc"); ra = w2.pop("rand_act", False); sm = w2.pop("start_mass", 0)
+                    c2 = dict(CFG); c2.update(w2)
+                    r2 = run_workload(torch, np, VecEnvironment, agdist, dev, dev_index, 0, 1, A, fk, fw, c2, ra, False, False, "block", "none", 32, sm)
+                    rf = roofline_block(r2, A, fk, ticks, c2, name)
+                    rf["value_env_steps_per_s"] = A * ticks * fk / r2["elapsed"]; rf["ms_per_step"] = r2["elapsed"] / fk * 1e3
+                    rf["mean_counts_pellets_viruses_foods_cells"] = [float(x) for x in r2["counts"]]
+                    rf["workload"] = WORKLOADS[name]["desc"] % A
+                    full["%s@%d" % (name, A)] = rf
+                except Exception as ex:
+                    full["%s@%d" % (name, A)] = {"error": str(ex)}
+            out["roofline_full"] = full
         if world == 1:  # measured roofline next to the nominal one: device stream copy and fill of 1 GiB
             try:
                 src = torch.empty(1 << 28, dtype=torch.int32, device=dev); dst = torch.empty_like(src)
@@ -408,7 +473,7 @@ def main():
                 copy_gbs = _bw(lambda: dst.copy_(src), 2 * src.numel() * 4)
                 fill_gbs = _bw(lambda: dst.fill_(1), src.numel() * 4)
                 del src, dst
-                for r in (out["roofline"], out.get("roofline_large")):
+                for r in [out["roofline"], out.get("roofline_large")] + list(out.get("roofline_full", {}).values()):
                     if r and "achieved" in r:
                         r["measured_copy_GBs"] = copy_gbs; r["measured_fill_GBs"] = fill_gbs
                         r["frac_of_measured_copy"] = r["achieved"] / copy_gbs

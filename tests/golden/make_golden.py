@@ -32,9 +32,14 @@ def crc(b):
     return zlib.crc32(c.tobytes()) & 0xFFFFFFFF
 
 
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]   # name prefixes: regenerate only those fixtures (default: all)
+
+
 def record(name, cfg, steps, seed=None, init=None, actions=None, policy_seed=1, sticky=4, allow_actions=True,
            checkpoints=None, note=""):
     """Env-level trace: take_actions + step (cfg['ticks_per_step'] ticks per step)."""
+    if ONLY and not any(name.startswith(p) for p in ONLY):
+        return
     env = refbind.RefEnv(**cfg)
     if seed is not None:
         env.seed(seed)
@@ -130,6 +135,28 @@ def main():
     record("roll_multi3_mode6_s5", dict(num_agents=3, ticks_per_step=4, arena_size=250, num_pellets=500, num_viruses=10, mode=6),
            400, seed=5, sticky=8, checkpoints=[0, 399])
     record("roll_mode9_bot_s2", dict(num_agents=1, ticks_per_step=4, arena_size=200, num_pellets=500, num_viruses=5, num_bots=1, mode=9), 300, seed=2, sticky=8)
+
+    # ---- F1: reset / spawn as standalone vectors: seeds {0, 1, 42} x the four (W, N_p, N_v) shapes -> every position and id
+    for W, n_p, n_v in ((250, 500, 10), (1000, 1000, 0), (1000, 1000, 25), (350, 500, 0)):
+        for sd in (0, 1, 42):
+            record("f1_spawn_w%d_p%d_v%d_s%d" % (W, n_p, n_v, sd), dict(num_agents=1, ticks_per_step=4, arena_size=W, num_pellets=n_p, num_viruses=n_v, mode=0),
+                   1, seed=sd, allow_actions=False, note="blob0 = the state right after seed + reset (Engine.hpp:98-148, BaseEnvironment.hpp:179-204)")
+    # ---- F2: kinematics of one cell: scripted directions (incl. none, and into the walls of a small arena), 200 ticks, state CRC every
+    # tick and the full state every 20th
+    def f2_actions(t):
+        k = t // 10
+        dirs = [(1.0, 0.0), (0.0, 1.0), (-1.0, -1.0), (0.0, 0.0), (0.3, -0.7), (-1.0, 0.0), (-1.0, 0.0), (-1.0, 0.0), (0.0, -1.0), (0.0, -1.0),
+                (1.0, 1.0), (1.0, 1.0), (1.0, 1.0), (1.0, 1.0), (1e-3, -1e-3), (0.0, 0.0), (-0.5, 0.9), (1.0, -1.0), (1.0, -1.0), (0.2, 0.2)]
+        d = dirs[k % len(dirs)]
+        return [[d[0], d[1], 0]]
+    record("f2_kinematics_200", dict(num_agents=1, ticks_per_step=1, arena_size=60, num_pellets=0, num_viruses=0, mode=3, pellet_regen=False),
+           200, seed=12, actions=f2_actions, checkpoints=list(range(0, 200, 20)), note="one cell, no pellets: Engine.hpp:609-630, core/types.hpp:176-223")
+    # ---- F10 at the survey's length: single-arena rollouts of 4000 ticks (1000 steps), C2 x 8 seeds and C3 in modes 0 / 4 / 6
+    for sd in range(8):
+        record("roll4k_c2_s%d" % (20000 + sd), C2, 1000, seed=20000 + sd, allow_actions=False, checkpoints=[0, 499, 999])
+    record("roll4k_c3_mode0_s11", C3, 1000, seed=11, checkpoints=[0, 499, 999])
+    record("roll4k_c3_mode4_s12", dict(C3, mode=4), 1000, seed=12, checkpoints=[0, 499, 999])
+    record("roll4k_c3_mode6_s13", C3m6, 1000, seed=13, sticky=8, checkpoints=[0, 499, 999])
 
     small = dict(num_agents=1, arena_size=200, num_pellets=40, num_viruses=0, mode=3, **T1)  # mode 3: no decay
 

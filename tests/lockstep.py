@@ -129,6 +129,23 @@ class EngineAsEnv:
     def flags(self):
         return int(self.e.flags()[0])
 
+    # engine-level driving (Engine::tick without BaseEnvironment::step around it), as RefEnv / OraEnv offer it
+    def pids(self):
+        ar, pl = self.e.arena_words(0)
+        return [int(pl[int(ar[13 + k]), 15]) for k in range(self.e.players) if int(pl[int(ar[13 + k]), 16]) == 0]   # AR_ORDER0, PL_PID, PL_KIND
+
+    def set_player(self, pid, tx, ty, action):
+        _, pl = self.e.arena_words(0)
+        txy = np.zeros((1, self.e.players, 2), np.float32); act = np.zeros((1, self.e.players), np.int32)
+        for slot in range(self.e.players):
+            txy[0, slot] = pl[slot, 2:4].view(np.float32); act[0, slot] = pl[slot, 1]
+            if int(pl[slot, 15]) == pid:
+                txy[0, slot] = (tx, ty); act[0, slot] = action
+        self.e.set_targets(txy, act)
+
+    def tick(self):
+        self.e.tick(1)
+
 
 def golden_crc(b):
     import zlib

@@ -54,3 +54,4 @@ def test_two_rank_shards_equal_one_rank_run_emulated(emu_lib):
     total, steps = 10, 60
     parts = run_two_ranks("emu", total, steps)
     check_against_single_process("emu", parts, total, steps)
+
