@@ -68,6 +68,7 @@ SYMBOLS = [
     ("agarcl_get_events", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     ("agarcl_grid_obs", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     ("agarcl_screen_obs", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    ("agarcl_ram_obs", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     ("agarcl_gobigger_obs", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     ("agarcl_dump_arena", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     ("agarcl_load_arena", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
@@ -283,6 +284,17 @@ class BatchedEngine:
             return None
         out = np.zeros((self.num_arenas, self.num_agents, height, width, 4 if agent_view else 3), dtype=np.uint8)
         self._chk(self.L.agarcl_screen_obs(self.h, width, height, int(bool(agent_view)), _ptr(out), 0))
+        return out
+
+    def ram_obs(self, k_cells=16, k_pellets=16, k_viruses=8, k_others=16, out_ptr=None):
+        """float32 [A, n_agents, D] (host copy), or written to the HBM pointer `out_ptr` (returns D): include/agarcl_batch.h agarcl_ram_obs"""
+        d = C.c_int32(0)
+        if out_ptr is not None:
+            self._chk(self.L.agarcl_ram_obs(self.h, k_cells, k_pellets, k_viruses, k_others, C.c_void_p(out_ptr), 1, C.byref(d)))
+            return d.value
+        self._chk(self.L.agarcl_ram_obs(self.h, k_cells, k_pellets, k_viruses, k_others, None, 0, C.byref(d)))
+        out = np.zeros((self.num_arenas, self.num_agents, d.value), dtype=np.float32)
+        self._chk(self.L.agarcl_ram_obs(self.h, k_cells, k_pellets, k_viruses, k_others, _ptr(out), 0, C.byref(d)))
         return out
 
     def gobigger_obs(self, grid_size=128, cap_food=256, cap_virus=64, cap_spore=64, cap_clone=32, out_ptrs=None):

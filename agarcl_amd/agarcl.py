@@ -80,6 +80,29 @@ class _Environment:
         self._loaded = True
 
 
+class RamEnvironment(_Environment):
+    """NOT in the reference's module (obs_type "ram" is named by gym_agario/AgarioEnv.py:52 and by BASELINE configs[0], but the reference
+    has no ram environment: AgarioEnv.py:211 raises, environment/test/ram-env-test.hpp is empty).  Same surface as the other classes;
+    get_state() returns one float32 vector per agent in the layout of include/agarcl_batch.h agarcl_ram_obs."""
+
+    def __init__(self, num_agents, ticks_per_step, arena_size, pellet_regen, num_pellets, num_viruses, num_bots,
+                 reward_type=0, c_death=0, mode_number=0):
+        super().__init__(num_agents, ticks_per_step, arena_size, pellet_regen, num_pellets, num_viruses, num_bots, reward_type, c_death, mode_number)
+        self._k = dict(k_cells=16, k_pellets=16, k_viruses=8, k_others=16)
+
+    def configure_observation(self, config):
+        for k in self._k:
+            if k in config:
+                self._k[k] = int(config[k])
+
+    def observation_shape(self):
+        return (4 + 3 * self._k["k_cells"] + 2 * self._k["k_pellets"] + 3 * self._k["k_viruses"] + 3 * self._k["k_others"],)
+
+    def get_state(self):
+        obs = self._engine.ram_obs(**self._k)
+        return [obs[0, i].copy() for i in range(self._num_agents)]
+
+
 class GridEnvironment(_Environment):
     """agarcl.GridEnvironment (bindings.cpp:99-135)."""
 

@@ -814,6 +814,25 @@ AG_DEV void q_visit(const QuadK &q, bool t0, bool stat, float r, float ro, unsig
 // level never holds more than n / 2 pairs.  A sweep started before its predecessor is known to have found an overlap is
 // harmless: if the predecessor finds none, no cell has moved and every later visit is a no-op (both prevent_overlap and
 // avoid_static_overlap act on touching pairs only); the loop still ends at the first completed sweep without a hit.
+// Issue priority of this wavefront among the (up to four) wavefronts of its SIMD, from the relaxation work in front of it.  A launch lasts
+// as long as its slowest arena, and the slowest are not the ones with many cells (41 % of the mode-6 arenas have all 14) but the ones whose
+// cells sit in one dense clump: every level touches, 1.1 M cycles of relaxation per step against a mean of 0.4 M (scripts/
+// gpu_arena_spread.py: max / mean arena-step = 2.4, the same arenas step after step).  The wavefronts sharing their SIMD have slack, so the
+// loaded ones go first: priority from the number of local levels with a touching pair.
+#ifndef AG_PRIO_T3
+#define AG_PRIO_T3 20
+#define AG_PRIO_T2 14
+#define AG_PRIO_T1 8
+#endif
+AG_DEV void ag_set_priority(int load) {
+#ifndef AGAR_CPU_EMU
+#ifndef AG_NO_PRIO
+  if (load >= AG_PRIO_T3) __builtin_amdgcn_s_setprio(3); else if (load >= AG_PRIO_T2) __builtin_amdgcn_s_setprio(2); else if (load >= AG_PRIO_T1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
+#else
+  (void)load;
+#endif
+}
 // Level skipping: a level whose pairs all fail the touch test is a no-op (both prevent_overlap and avoid_static_overlap act on touching
 // pairs only), and 52 of the 72 levels of a mode-6 tick are such.  So the touch test of ALL pairs is made in one pass -- one lane per pair,
 // the result OR-reduced into one bit per local level L = a + b ("some pair of level L touches at the current positions") -- and repeated
@@ -847,6 +866,7 @@ template <int NS, bool AV> AG_DEV void self_collisions(AgCtx<NS, AV> &c, const C
 #endif
   };
   level_hits();
+  ag_set_priority((int)__builtin_popcountll(H));
   if (H == 0ull) return;   // no pair touches: the reference's first sweep is a no-op
   const float dt = c.gs->g.dt, W = c.gs->g.W;
   const int D = n < LL ? n : LL;
@@ -1791,20 +1811,7 @@ template <int NS, bool AV> AG_DEV int quiet_run(AgCtx<NS, AV> &c, int max_ticks)
 }
 
 // ---- Engine::tick.  R: Engine.hpp:208-240 --------------------------------------------------------------------
-// Issue priority of this wavefront among the (up to four) wavefronts of its SIMD, from the arena's cell count.  A launch lasts as long as
-// its slowest arena, the arenas with 12 - 16 cells (120 pairs, 109 relaxation levels) are the slowest by far -- the mean wavefront is
-// done at 0.6 of the launch (SQ_WAVE_CYCLES vs SQ_BUSY_CYCLES) -- and the wavefronts sharing their SIMD have slack: let the big ones go first.
-AG_DEV void ag_set_priority(int cells) {
-#ifndef AGAR_CPU_EMU
-#ifndef AG_NO_PRIO
-  if (cells >= 14) __builtin_amdgcn_s_setprio(3); else if (cells >= 12) __builtin_amdgcn_s_setprio(2); else if (cells >= 9) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
-#else
-  (void)cells;
-#endif
-}
 template <int NS, bool AV> AG_DEV void arena_tick(AgCtx<NS, AV> &c) {
-  { int big = 0; for (int p = 0; p < c.P; p++) { const int n_ = ag_uni(PLS(c, p)[PL_NCELLS]); big = n_ > big ? n_ : big; } ag_set_priority(c.P == 1 ? big : big + c.P / 2); }
   ensure_pellets(c);
   SW(c, AR_SAFE, 0);  // the out-of-reach budget is only maintained by quiet_run
   SW(c, AR_NEVP, 0); SW(c, AR_NEVV, 0);

@@ -25,6 +25,7 @@
 #include "agar_obs.inl"
 #include "agar_screen.inl"
 #include "agar_gobigger.inl"
+#include "agar_ram.inl"
 
 // ---- thread-local error string -------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -88,6 +89,7 @@ struct agarcl_env {
   uint8_t *d_mask;                 // [A] reset mask staging (host masks are copied here, stream-ordered)
   uint32_t flags_seen;             // OR of every flag watch sample so far (agarcl_poll_flags)
   long work_step0, work_front0; int32_t work_unf0; int64_t work_pass0;  // agarcl_debug_work baselines
+  long next_poll; int poll_gap;          // when the next statistics sample is requested (poll_stats)
   bool stat_pending, stat_stale_flags;   // a sample is in flight / it was requested before the last reset: its flag word is void
   long step_no, front_runs, stat_req_front, stat_last_front; int32_t stat_last_total;
   int parity;     // launch parity of the k_quiet / k_step pair (selects the unfinished-arena counter)
@@ -312,10 +314,14 @@ static void poll_stats(agarcl_env *e, bool adapt) {
       e->few_unfinished = frac * (double)e->d.A < 64.0;   // k_step's work list is short: a small grid dispatches faster
     }
     e->stat_last_total = e->h_stat[0]; e->stat_last_front = e->stat_req_front;
-  } else if (e->step_no % 64 == 0) {
+  } else if (e->step_no >= e->next_poll) {
+    // every 64 steps -- but 2, 8 and 32 steps after a reset or a state load, whose arenas may behave quite unlike what the starting form
+    // was chosen for (grown agents under the single launch: every arena-step through its serialising general tail, 3x the two-kernel time)
     if (hipMemcpyAsync(e->h_stat, e->s.qstat, 8, hipMemcpyDeviceToHost, e->stream) != hipSuccess) return;
     if (hipEventRecord((hipEvent_t)e->stat_ev, e->stream) != hipSuccess) return;
     e->stat_pending = true; e->stat_req_front = e->front_runs;
+    e->poll_gap = e->poll_gap < 64 ? e->poll_gap * 4 : 64; if (e->poll_gap > 64) e->poll_gap = 64;
+    e->next_poll = e->step_no + e->poll_gap;
   }
 }
 #endif
@@ -566,7 +572,7 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   e->front_off = d.P == 1 && cfg->mode_number > 4; e->few_unfinished = false;
   e->work_step0 = e->work_front0 = 0; e->work_unf0 = 0; e->work_pass0 = 0;
   e->flags_seen = 0; e->d_mask = alloc<uint8_t>(e, (size_t)d.A);
-  e->fused_fixed = false; e->h_stat = nullptr; e->stat_ev = nullptr; e->stat_pending = e->stat_stale_flags = false; e->step_no = e->front_runs = e->stat_req_front = e->stat_last_front = 0; e->stat_last_total = 0;
+  e->fused_fixed = false; e->h_stat = nullptr; e->stat_ev = nullptr; e->next_poll = 2; e->poll_gap = 2; e->stat_pending = e->stat_stale_flags = false; e->step_no = e->front_runs = e->stat_req_front = e->stat_last_front = 0; e->stat_last_total = 0;
   { const char *fu = getenv("AGARCL_FUSED"); if (fu && (fu[0] == '0' || fu[0] == '1')) { e->fused = fu[0] == '1' && e->fused_ok; e->fused_fixed = true; } }
   s.qstat = alloc<int32_t>(e, 16);
   // Lanes per arena of the lean front kernel.  The quiet tick is per-lane code that every lane of an arena's group carries
@@ -722,6 +728,7 @@ extern "C" int agarcl_get_arena_words(agarcl_env *e, int32_t arena, int32_t *ar_
 static int restart_flag_watch(agarcl_env *e) {
   if (hipMemsetAsync(e->s.qstat + 1, 0, 4, e->stream) != hipSuccess) return fail(AGARCL_E_HIP, "flag watch reset failed");
   e->flags_seen = 0; e->stat_stale_flags = e->stat_pending;
+  e->poll_gap = 2; e->next_poll = e->step_no + 2;   // and the step-form statistics are sampled soon again
   return 0;
 }
 #endif
@@ -1018,6 +1025,7 @@ static int load_arena_impl(agarcl_env *e, int32_t arena, const uint32_t *b, int3
   rc |= push(e, h.vm, s.vir_mass, a * d.VC); rc |= push(e, h.vh, s.vir_hits, a * d.VC); rc |= push(e, h.vid, s.vir_id, a * d.VC);
   rc |= push(e, h.fx, s.food_x, a * d.FC); rc |= push(e, h.fy, s.food_y, a * d.FC); rc |= push(e, h.fvx, s.food_vx, a * d.FC); rc |= push(e, h.fvy, s.food_vy, a * d.FC); rc |= push(e, h.fid, s.food_id, a * d.FC);
   rc |= push_t(e, h.cells, s.cells, a);
+  e->poll_gap = 2; e->next_poll = e->step_no + 2;   // a loaded state may need the other step form: sample the statistics soon
   return rc ? fail(AGARCL_E_HIP, "upload failed") : AGARCL_OK;
 }
 extern "C" int agarcl_load_arena(agarcl_env *e, int32_t arena, const uint32_t *b, int32_t words) { return load_arena_impl(e, arena, b, words, nullptr, 0, 0); }
@@ -1083,6 +1091,43 @@ extern "C" int agarcl_gobigger_obs(agarcl_env *e, int32_t grid_size, int32_t cap
   hipLaunchKernelGGL(k_gobigger_obs, dim3((unsigned)rows), dim3(64), 0, e->stream, e->d_state, o, (int32_t *)dev[0], (float *)dev[1], (float *)dev[2], (float *)dev[3], (float *)dev[4]);
   HIPCHK(hipGetLastError());
   if (!on_device) for (int i = 0; i < 5; i++) if (d2h(host[i], dev[i], nb[i], e->stream)) return fail(AGARCL_E_HIP, "agarcl_gobigger_obs: copy failed");
+  return AGARCL_OK;
+#endif
+}
+
+#ifndef AGAR_CPU_EMU
+__global__ void __launch_bounds__(64) k_ram_obs(const AgState *__restrict__ gs, AgRamCfg o, float *out) {
+  const int na = gs->d.n_agents, b = (int)blockIdx.x;
+  ram_obs_agent(gs, b / na, b % na, o, out);
+}
+#endif
+extern "C" int agarcl_ram_obs(agarcl_env *e, int32_t k_cells, int32_t k_pellets, int32_t k_viruses, int32_t k_others, float *out, int32_t on_device, int32_t *dim) {
+  if (!e) return fail(AGARCL_E_INVALID, "null env");
+  if (k_cells < 0 || k_pellets < 0 || k_viruses < 0 || k_others < 0 || k_cells > AG_CC || k_pellets > 2048 || k_viruses > 1024 || k_others > 512)
+    return fail(AGARCL_E_INVALID, "agarcl_ram_obs: row counts out of range");
+  AgRamCfg o; o.KC = k_cells; o.KP = k_pellets; o.KV = k_viruses; o.KO = k_others;
+  const int D = ag_ram_dim(o);
+  if (dim) *dim = D;
+  if (!out) return AGARCL_OK;
+#ifdef AGAR_CPU_EMU
+  (void)on_device;
+  return fail(AGARCL_E_UNSUPPORTED, "agarcl_ram_obs: the ram observation exists only as a HIP kernel");
+#else
+  HIPCHK(hipSetDevice(e->device));
+  const size_t n = (size_t)e->d.A * e->d.n_agents, words = n * (size_t)D;
+  float *dst = out;
+  if (!on_device) {
+    if (e->obs_cap < words) {
+      if (e->obs_buf) { HIPCHK(hipStreamSynchronize(e->stream)); (void)hipFree(e->obs_buf); e->obs_buf = nullptr; e->obs_cap = 0; }
+      if (hipMalloc((void **)&e->obs_buf, words * 4) != hipSuccess) return fail(AGARCL_E_NOMEM, "agarcl_ram_obs: staging allocation failed");
+      e->obs_cap = words;
+    }
+    dst = (float *)e->obs_buf;
+    e->undo_out = nullptr;   // the shared staging buffer no longer holds a grid observation
+  }
+  hipLaunchKernelGGL(k_ram_obs, dim3((unsigned)n), dim3(64), 0, e->stream, e->d_state, o, dst);
+  HIPCHK(hipGetLastError());
+  if (!on_device && d2h(out, dst, words * 4, e->stream)) return fail(AGARCL_E_HIP, "agarcl_ram_obs: copy failed");
   return AGARCL_OK;
 #endif
 }

@@ -1,0 +1,83 @@
+// "ram" observation: a flat fp32 vector per (arena, agent) -- the agent's own cells and its K nearest pellets / viruses / other players'
+// cells, relative to the agent's centre.  BASELINE configs[0] names a ram observation, but the reference has none to match: "ram" is
+// accepted by gym_agario/AgarioEnv.py:52 and rejected at :211, agario-ram-v0 is never registered, environment/test/ram-env-test.hpp is
+// empty ("the build's own flat fp32 dump ... excluded from parity and included only in timing").  So the layout is this
+// repository's own (include/agarcl_batch.h: agarcl_ram_obs), checked on the GPU against the host restatement oracle/ram_oracle.py:
+//
+//   [0..3]                         px, py (Player::x / y: mass-weighted centre, sequential fp32 sums in cell order), total mass, cell count
+//   [4 ..)  KC x (dx, dy, mass)    own cells in cell order
+//   then    KP x (dx, dy)          the KP pellets nearest to (px, py), nearest first (ties: lower index)
+//   then    KV x (dx, dy, mass)    the KV nearest viruses
+//   then    KO x (dx, dy, mass)    the KO nearest cells of the other players (players in slot order, cells in cell order)
+// dx = x - px, dy = y - py in fp32; rows beyond the number of entities are zero.  One wavefront per (arena, agent); selection = K rounds of
+// "smallest (squared distance, index) key above the previous one": a lane-private scan of the lane's entities + two wave minima.
+#pragma once
+
+struct AgRamCfg { int KC, KP, KV, KO; };
+#ifdef AGAR_CPU_EMU
+static inline
+#else
+__host__ __device__ inline
+#endif
+int ag_ram_dim(const AgRamCfg &o) { return 4 + 3 * o.KC + 2 * o.KP + 3 * o.KV + 3 * o.KO; }
+
+#ifndef AGAR_CPU_EMU
+// K nearest of n entities: pos(i, x, y) gives entity i's position; emit(rank, i, dx, dy) writes a selected one
+template <class PosT, class EmitT> AG_DEV void ram_nearest(int n, int K, float px, float py, PosT pos, EmitT emit) {
+  unsigned last_d = 0u, last_i = 0u; bool first = true;
+  const int rounds = K < n ? K : n;
+  for (int r = 0; r < rounds; r++) {
+    unsigned best_d = 0xffffffffu, best_i = 0xffffffffu;
+    for (int i = AG_LANE; i < n; i += 64) {
+      float x, y; pos(i, x, y);
+      const float dx = x - px, dy = y - py; const float a = dx * dx, b = dy * dy;
+      const unsigned d = (unsigned)f2u(a + b);   // (>= 0, or NaN: its bits order above every distance)
+      const bool above = first || d > last_d || (d == last_d && (unsigned)i > last_i);
+      if (above && (d < best_d || (d == best_d && (unsigned)i < best_i))) { best_d = d; best_i = (unsigned)i; }
+    }
+    const unsigned md = wred_min(best_d);
+    const unsigned mi = wred_min(best_d == md ? best_i : 0xffffffffu);
+    if (mi == 0xffffffffu) break;
+    last_d = md; last_i = mi; first = false;
+    AG_SERIAL { float x, y; pos((int)mi, x, y); emit(r, (int)mi, x - px, y - py); }
+  }
+}
+
+AG_DEV void ram_obs_agent(const AgState *gs, int arena, int agent, AgRamCfg o, float *out_) {
+  const int P = gs->d.P, ag_ts_lg = gs->d.ts_lg, dim = ag_ram_dim(o);
+  AG_GLOBAL float *out = (AG_GLOBAL float *)out_ + ((size_t)arena * gs->d.n_agents + agent) * dim;
+  const AG_GLOBAL int32_t *ar = (const AG_GLOBAL int32_t *)AG_AR_PTR(gs, arena);
+  const AG_GLOBAL int32_t *pl = (const AG_GLOBAL int32_t *)AG_PL_PTR(gs, arena, agent);   // agent i == player slot i
+  const AG_GLOBAL uint32_t *C = (const AG_GLOBAL uint32_t *)AG_CELLS_PTR(gs, arena, agent);
+  AG_LANES(i, dim) out[i] = 0.0f;
+  ag_mem_fence();
+  const int n = pl[AG_TW(PL_NCELLS)]; float sx = 0.0f, sy = 0.0f; unsigned tm = 0;
+  for (int i = 0; i < n; i++) { unsigned m = C[AG_CELL_W(CF_M, i)]; float fm = (float)m; float t = u2f((int)C[AG_CELL_W(CF_X, i)]) * fm; sx += t; t = u2f((int)C[AG_CELL_W(CF_Y, i)]) * fm; sy += t; tm += m; }
+  const float px = ag_divf(sx, (float)tm), py = ag_divf(sy, (float)tm);   // (a dead agent: 0 / 0 = NaN, as Player::x() gives)
+  AG_SERIAL { out[0] = px; out[1] = py; out[2] = (float)tm; out[3] = (float)n; }
+  AG_GLOBAL float *oc = out + 4, *op = oc + 3 * o.KC, *ov = op + 2 * o.KP, *oo = ov + 3 * o.KV;
+  AG_LANES(i, n < o.KC ? n : o.KC) { oc[3 * i] = u2f((int)C[AG_CELL_W(CF_X, i)]) - px; oc[3 * i + 1] = u2f((int)C[AG_CELL_W(CF_Y, i)]) - py; oc[3 * i + 2] = (float)C[AG_CELL_W(CF_M, i)]; }
+  const int np = ar[AG_TW(AR_NPEL)], nv = ar[AG_TW(AR_NVIR)];
+  const AG_GLOBAL float *pxy = (const AG_GLOBAL float *)(gs->pel_xy + (size_t)arena * gs->d.PC * 2);
+  ram_nearest(np, o.KP, px, py, [&](int i, float &x, float &y) { x = pxy[2 * i]; y = pxy[2 * i + 1]; },
+              [&](int r, int, float dx, float dy) { op[2 * r] = dx; op[2 * r + 1] = dy; });
+  const AG_GLOBAL float *vx = (const AG_GLOBAL float *)(gs->vir_x + (size_t)arena * gs->d.VC), *vy = (const AG_GLOBAL float *)(gs->vir_y + (size_t)arena * gs->d.VC);
+  const AG_GLOBAL int32_t *vm = (const AG_GLOBAL int32_t *)(gs->vir_mass + (size_t)arena * gs->d.VC);
+  ram_nearest(nv, o.KV, px, py, [&](int i, float &x, float &y) { x = vx[i]; y = vy[i]; },
+              [&](int r, int i, float dx, float dy) { ov[3 * r] = dx; ov[3 * r + 1] = dy; ov[3 * r + 2] = (float)vm[i]; });
+  // other players' cells: entity index = slot * AG_CC + cell (slots in ascending order, the agent's own slot skipped)
+  if (P > 1 && o.KO > 0) {
+    const AG_GLOBAL uint32_t *C0 = (const AG_GLOBAL uint32_t *)AG_CELLS_PTR(gs, arena, 0);
+    const AG_GLOBAL int32_t *pl0 = (const AG_GLOBAL int32_t *)AG_PL_PTR(gs, arena, 0);
+    auto cell = [&](int e, float &x, float &y, float &m) {   // entity e: NaN position (never selected before real ones) for holes
+      const int s = e / AG_CC, i = e - s * AG_CC;
+      const bool live = s != agent && i < pl0[AG_TW(s * PL_WORDS + PL_NCELLS)];
+      const AG_GLOBAL uint32_t *Cs = C0 + AG_TW(s * (CF_ALL * AG_CC));
+      x = live ? u2f((int)Cs[AG_CELL_W(CF_X, i)]) : u2f(0x7fc00000); y = live ? u2f((int)Cs[AG_CELL_W(CF_Y, i)]) : u2f(0x7fc00000); m = live ? (float)Cs[AG_CELL_W(CF_M, i)] : 0.0f;
+    };
+    int live_total = 0; for (int s = 0; s < P; s++) if (s != agent) live_total += pl0[AG_TW(s * PL_WORDS + PL_NCELLS)];
+    ram_nearest(P * AG_CC, o.KO < live_total ? o.KO : live_total, px, py, [&](int e, float &x, float &y) { float m; cell(e, x, y, m); },
+                [&](int r, int e, float dx, float dy) { float x, y, m; cell(e, x, y, m); oo[3 * r] = dx; oo[3 * r + 1] = dy; oo[3 * r + 2] = m; });
+  }
+}
+#endif

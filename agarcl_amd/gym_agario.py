@@ -5,9 +5,16 @@ Same constructor keywords ("difficulty" presets + overrides, AgarioEnv.py:298-36
 reset() -> (obs, {}), step(a) -> (obs, reward, done, truncated=False, {'steps', 'untransformed_rewards'}),
 single-agent unwrapping (AgarioEnv.py:114-118), episodic cut-off after `number_steps` (AgarioEnv.py:111-112).
 gymnasium is optional: when it is importable the class derives from gymnasium.Env and exposes real spaces.
-Video recording (cv2) and OpenGL rendering are outside the hot path and not provided.
+render() and the video recorder (AgarioEnv.py:134-181, 366-404) are provided on top of the engine's rule-based rasteriser: "rgb_array"
+returns the screen observation or a 512 x 512 frame (get_frame), recorded frames are painted as the reference paints them and
+generate_video writes the same Motion-JPEG container (cv2 when importable, else agarcl_amd/video.py).  There is no OpenGL window: render
+mode "human" has nothing to show on a GPU server and returns None.
 """
+import os
+
 import numpy as np
+
+from .agar_utils import Color, get_color_array
 
 
 def _binding():
@@ -51,6 +58,8 @@ class AgarioEnv(_Base):
         self.steps = None
         self.obs_type = obs_type
         self.render_mode = render_mode
+        self.video_recorder = []
+        self.video_recorder_enabled = False
         self.agent_view = kwargs.get("agent_view", False)
         self.add_noise = kwargs.get("add_noise", True)
         self.number_of_steps = kwargs.get("number_steps", 500)
@@ -63,6 +72,8 @@ class AgarioEnv(_Base):
                 self.observation_space = _spaces.Box(-1, np.iinfo(np.int32).max, self.observation_shape, dtype=np.int32)
             elif obs_type == "screen":
                 self.observation_space = _spaces.Box(low=0, high=255, shape=self.observation_shape, dtype=np.uint8)
+            elif obs_type == "ram":
+                self.observation_space = _spaces.Box(low=-np.inf, high=np.inf, shape=self.observation_shape, dtype=np.float32)
             else:
                 self.observation_space = _spaces.Box(low=0, high=255, shape=self.observation_shape, dtype=np.float32)
 
@@ -111,7 +122,15 @@ class AgarioEnv(_Base):
             full_args = (kwargs.get("map_width", 512), kwargs.get("map_height", 512), kwargs.get("frame_limit", 1000)) + base_args + (kwargs.get("agent_view", False),)
             env = agarcl.GoBiggerEnvironment(*full_args)
             return env, tuple(env.observation_shape())
-        raise ValueError("obs_type %r is not provided by the HIP engine (the reference rejects \"ram\" too, AgarioEnv.py:211)" % obs_type)
+        if obs_type == "ram":
+            # an extension: the reference names "ram" (AgarioEnv.py:52, BASELINE configs[0]) and then raises for it (AgarioEnv.py:211).
+            # Here it is a flat float32 vector per agent (include/agarcl_batch.h agarcl_ram_obs); always through the ctypes classes,
+            # the compiled module keeps exactly the reference's class list
+            from . import agarcl as mirror
+            env = mirror.RamEnvironment(*base_args[:10])
+            env.configure_observation({k: kwargs[k] for k in ("k_cells", "k_pellets", "k_viruses", "k_others") if k in kwargs})
+            return env, tuple(env.observation_shape())
+        raise ValueError(obs_type)
 
     # -- AgarioEnv.py:270-296 (validation; the reference samples noise and then discards it) --------------
     def _sanitize_actions(self, actions):
@@ -142,6 +161,8 @@ class AgarioEnv(_Base):
         rewards = self._env.step()
         assert len(rewards) == self.num_agents
         self.observations = self._make_observations()
+        if self.video_recorder_enabled:   # (one agent, as in the reference: AgarioEnv.py:99-101)
+            self.video_recorder.append(self._make_video_observation(self.observations[0]))
         dones = self._env.dones()
         truncations = [False] * len(dones)
         if self.steps >= self.number_of_steps and self.env_type == 0:
@@ -163,8 +184,60 @@ class AgarioEnv(_Base):
             self._env.seed(seed)
             return [self._seed]
 
-    def render(self):
+    def render(self):                       # AgarioEnv.py:134-147
+        if self.render_mode == "human":
+            self._env.render()              # (no window exists on a GPU server: a no-op, like the reference built without a display)
+        if self.render_mode == "rgb_array":
+            if self.obs_type == "screen":
+                return getattr(self, "observations", None)
+            if self.obs_type in ("grid", "gobigger"):
+                return self._env.get_frame()
         return None
+
+    def _make_video_observation(self, observation):   # AgarioEnv.py:159-181
+        if self.obs_type in ("grid", "gobigger"):
+            return self._env.get_frame()[0]
+        if not self.agent_view:
+            return observation
+        observation = observation[0]
+        rgb = np.zeros_like(observation[..., :3])
+        rgb[..., 0].fill(255)
+        pellets_mask = observation[..., 0] != 255
+        bots_mask = observation[..., 1] == 255
+        virus_mask = observation[..., 2] == 255
+        main_agent_mask = (observation[..., 3] <= 230) & (observation[..., 3] > 30)
+        grid_lines_mask = observation[..., 3] <= 30
+        rgb[pellets_mask] = get_color_array(Color.WHITE)
+        rgb[bots_mask] = get_color_array(Color.PURPLE)
+        rgb[virus_mask] = get_color_array(Color.GREEN)
+        rgb[main_agent_mask] = get_color_array(Color.BLUE)
+        rgb[grid_lines_mask] = [26, 0, 0]
+        return rgb
+
+    def enable_video_recorder(self):        # AgarioEnv.py:372-376
+        self.video_recorder_enabled = True
+
+    def disable_video_recorder(self):
+        self.video_recorder_enabled = False
+
+    def generate_video(self, path, video_name):   # AgarioEnv.py:379-404: Motion-JPEG, 60 frames per second
+        if not os.path.exists(path):
+            os.makedirs(path, exist_ok=True)
+        full_path = os.path.join(path, video_name)
+        if not self.video_recorder_enabled:
+            print("Video recorder is not enabled. Please enable it before generating video")
+            return None
+        if len(self.video_recorder) == 0:
+            print("No frames to generate video")
+            return None
+        from .video import write_mjpeg_avi
+        frames = []
+        for frame in self.video_recorder:
+            if not isinstance(frame, np.ndarray):
+                raise TypeError("Error: A frame is not a numpy array.")
+            frames.append(frame[0] if frame.ndim == 4 else frame)   # the plain screen observation is (1, W, H, 3)
+        write_mjpeg_avi(full_path, frames, fps=60.0)
+        return full_path
 
     def close(self):
         self._env.close()

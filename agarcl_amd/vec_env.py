@@ -100,6 +100,16 @@ class VecEnvironment:
                                             "unbounded containers): read engine.flags() and reset those arenas" % fl)
         return self.rewards
 
+    def ram_obs(self, out=None, k_cells=16, k_pellets=16, k_viruses=8, k_others=16):
+        """float32 CUDA tensor [A, n_agents, D] of the "ram" observation (include/agarcl_batch.h agarcl_ram_obs), written by one launch on
+        the env's stream; pass the previous tensor as `out` to reuse it."""
+        torch = self.torch
+        D = 4 + 3 * k_cells + 2 * k_pellets + 3 * k_viruses + 3 * k_others
+        if out is None:
+            out = torch.empty((self.num_arenas, self.num_agents, D), dtype=torch.float32, device=self.device)
+        self.engine.ram_obs(k_cells, k_pellets, k_viruses, k_others, out_ptr=out.data_ptr())
+        return out
+
     def dones(self):
         return self.dones_u8.bool()
 

@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 ARENAS_PER_GPU = 4096
 LARGE_ARENAS = 65536        # the "roofline_large" block: north star ">= 50k parallel arenas"
+XLARGE_ARENAS = 262144      # "roofline_xlarge": the same kernels where they are bandwidth-bound (two-kernel step, one lane per arena)
 CFG = dict(num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True, num_pellets=1000, num_viruses=0,
            num_bots=0, reward_type=1, c_death=0, mode_number=0)
 # The headline line is C2.  The other SURVEY 8(d) workloads are selectable for DESIGN.md's measurement table only.
@@ -46,6 +47,8 @@ WORKLOADS = {
     # 250x250 arena, Engine::tick at dt = 1/60 s), 4 ticks per launch
     "C1": dict(arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, dt=1.0 / 60, rand_act=True,
                desc="C1 batched: %d arenas/GPU x (1 agent + 4 bots), 250x250, 500 pellets, 10 viruses, mode 0, dt 1/60 s, 4 ticks/step"),
+    "C1r": dict(arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, dt=1.0 / 60, rand_act=True, ram_obs=True,
+                desc="C1 batched + ram observation: %d arenas/GPU x (1 agent + 4 bots), 250x250, 500 pellets, 10 viruses, mode 0, dt 1/60 s, 4 ticks/step, f32 [A][1][152] written once per step"),
 }
 TRAFFIC_FILE = "r03_pmc_traffic.json"   # PMC FETCH_SIZE / WRITE_SIZE per step of the bench workloads, recorded by scripts/profile_round.sh
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
@@ -185,7 +188,7 @@ def spawn_ranks(n):
 
 
 def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, Wm, cfg, rand_act, with_obs, with_screen,
-                 gather_mode, gather_obs, gather_block=32, start_mass=0):
+                 gather_mode, gather_obs, gather_block=32, start_mass=0, with_ram=False):
     """Builds the env, runs Wm untimed + K timed steps, returns the measurements of this rank."""
     import torch.distributed as dist
     lo, hi = rank * A, (rank + 1) * A  # weak scaling: every GPU owns `A` arenas
@@ -211,6 +214,7 @@ def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, 
     obs = torch.empty((A, 8, 128, 128), dtype=torch.int32, device=dev) if with_obs else None
     want_screen = with_screen or (world > 1 and gather_obs == "screen")
     scr = torch.empty((A, 84, 84, 3), dtype=torch.uint8, device=dev) if want_screen else None
+    ram = torch.empty((A, na, 152), dtype=torch.float32, device=dev) if with_ram else None
     # Multi-GPU result path (the only exchange there is: arenas never interact).
     #   block: (reward, done) of 32 (--gather-block) consecutive steps -- one contiguous block of the engine's 64-slot result
     #          ring, zero copy -- per asynchronous RCCL gather, double-buffered by ring half: a rollout chunk, as an n-step learner
@@ -242,6 +246,8 @@ def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, 
         eng.step_actions(dx_ptr[k], ac_ptr[k], tps)   # take_actions + step: one host call
         if obs is not None:
             eng.grid_obs(128, True, True, True, True, out_ptr=obs.data_ptr(), persistent=True)   # the same tensor every step
+        if ram is not None:
+            eng.ram_obs(16, 16, 8, 16, out_ptr=ram.data_ptr())
         if scr is not None:
             if obs_gather is not None:
                 obs_gather.wait()               # the previous step's frames have left before they are overwritten
@@ -357,6 +363,7 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     desc, rand_act, with_obs, with_screen = wl.pop("desc"), wl.pop("rand_act", False), wl.pop("grid_obs", False), wl.pop("screen_obs", False)
     start_mass = wl.pop("start_mass", 0)
+    with_ram = wl.pop("ram_obs", False)
     cfg = dict(CFG); cfg.update(wl)
 
     import torch
@@ -389,7 +396,7 @@ def main():
     A, K, Wm = args.arenas, args.steps, args.warmup
     ticks = cfg["ticks_per_step"]
     res = run_workload(torch, np, VecEnvironment, agdist, dev, dev_index, rank, world, A, K, Wm, cfg, rand_act, with_obs, with_screen,
-                       args.gather, args.gather_obs, args.gather_block, start_mass)
+                       args.gather, args.gather_obs, args.gather_block, start_mass, with_ram)
     devs = [None] * world   # which device every rank ran on: lets the driver see "RCCL saw N ranks on N GPUs"
     if world > 1:
         dist.all_gather_object(devs, "%s:%d" % (os.uname().nodename, dev_index))
@@ -401,7 +408,7 @@ def main():
         # implementation: the grid tensor is persistent (agarcl_grid_obs on_device = 2), so a step rewrites the dense out-of-bounds
         # channel and, per word scattered, clears the old one and writes the new one plus their undo-list entries (16 B; the
         # view covers at most (300 / arena)^2 of the arena's pellets and viruses)
-        model_extra = (A * 8 * 128 * 128 * 4 if with_obs else 0) + (A * 84 * 84 * 3 if with_screen else 0)
+        model_extra = (A * 8 * 128 * 128 * 4 if with_obs else 0) + (A * 84 * 84 * 3 if with_screen else 0) + (A * cfg["num_agents"] * 152 * 4 if with_ram else 0)
         extra = model_extra
         if with_obs:
             n_pel, n_vir, n_food, n_cells = res["counts"]
@@ -410,6 +417,7 @@ def main():
         kernel = None
         if with_obs: kernel = "k_step + k_grid_obs (persistent tensor: incremental clear)"
         if with_screen: kernel = "k_step + k_screen_obs"
+        if with_ram: kernel = "k_step + k_ram_obs"
         roof = roofline_block(res, A, K, ticks, cfg, args.workload, float(extra), kernel, float(model_extra))
         roof["note"] = ("achieved = HBM bytes one env step moves (PMC FETCH_SIZE x2 + WRITE_SIZE of the same kernel source when profiles/ "
                         "holds them -> `traffic`; otherwise the bytes the kernels request, counted by the kernels themselves) / the step's "
@@ -443,6 +451,14 @@ def main():
                 out["roofline_large"] = rl
             except Exception as ex:  # the headline line must not depend on it
                 out["roofline_large"] = {"error": str(ex)}
+            try:
+                xl = run_workload(torch, np, VecEnvironment, agdist, dev, dev_index, 0, 1, XLARGE_ARENAS, 100, 20, cfg, rand_act, False, False, "block", "none")
+                rx = roofline_block(xl, XLARGE_ARENAS, 100, ticks, cfg, args.workload)
+                rx["value_env_steps_per_s"] = XLARGE_ARENAS * ticks * 100 / xl["elapsed"]
+                rx["ms_per_step"] = xl["elapsed"] / 100 * 1e3
+                out["roofline_xlarge"] = rx
+            except Exception as ex:
+                out["roofline_xlarge"] = {"error": str(ex)}
         if world == 1 and not args.no_full and args.workload == "C2":
             # the other two regimes in the same run: the full rule set at mass 1000 (BASELINE configs[2]) and a learning agent's mid-game
             full = {}
@@ -473,7 +489,7 @@ def main():
                 copy_gbs = _bw(lambda: dst.copy_(src), 2 * src.numel() * 4)
                 fill_gbs = _bw(lambda: dst.fill_(1), src.numel() * 4)
                 del src, dst
-                for r in [out["roofline"], out.get("roofline_large")] + list(out.get("roofline_full", {}).values()):
+                for r in [out["roofline"], out.get("roofline_large"), out.get("roofline_xlarge")] + list(out.get("roofline_full", {}).values()):
                     if r and "achieved" in r:
                         r["measured_copy_GBs"] = copy_gbs; r["measured_fill_GBs"] = fill_gbs
                         r["frac_of_measured_copy"] = r["achieved"] / copy_gbs

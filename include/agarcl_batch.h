@@ -169,6 +169,15 @@ int agarcl_grid_obs(agarcl_env *env, int32_t grid_size, int32_t observe_cells, i
  * (ScreenEnvironment.hpp:48-88), u8[...][height][width][4].  `out` is an HBM pointer if on_device != 0, else a host buffer. */
 int agarcl_screen_obs(agarcl_env *env, int32_t width, int32_t height, int32_t agent_view, uint8_t *out, int32_t on_device);
 
+/* "ram" observation (BASELINE configs[0]).  The reference has NO counterpart to replace: obs_type "ram" passes the check at
+ * gym_agario/AgarioEnv.py:52 and is rejected at :211, agario-ram-v0 is never registered (gym_agario/__init__.py:9-23) and
+ * environment/test/ram-env-test.hpp is empty -- so the layout is this library's own.  Writes f32[num_arenas][num_agents][D],
+ * D = 4 + 3 k_cells + 2 k_pellets + 3 k_viruses + 3 k_others, returned through *dim (out == NULL only queries D):
+ *   px, py, total mass, cell count | k_cells x (dx, dy, mass) own cells in cell order | k_pellets x (dx, dy) nearest pellets, nearest first
+ *   (ties: lower index) | k_viruses x (dx, dy, mass) nearest viruses | k_others x (dx, dy, mass) nearest cells of the other players;
+ * dx = x - px, dy = y - py; absent rows are zero.  `out` is an HBM pointer if on_device != 0, else a host buffer. */
+int agarcl_ram_obs(agarcl_env *env, int32_t k_cells, int32_t k_pellets, int32_t k_viruses, int32_t k_others, float *out, int32_t on_device, int32_t *dim);
+
 /* replaces: GoBiggerEnvironment::get_state() (bindings.cpp:28-47,353) -> GoBiggerObservation::add_frame
  * (environment/envs/GoBiggerEnvironment.hpp:446-541), as padded tensors for EVERY player of every arena (row k of the
  * player axis = the k-th player in the engine's map iteration order; P = agarcl_players_per_arena):

@@ -4,7 +4,7 @@
 #   gpurun_out/<tag>/bench_default.json, bench_driver20.json (scripts/gpu_round.sh)       -> profiles/<round>_bench_*_unprofiled.json
 # and, with --resources, rebuilds the kernel resource table (hipcc -Rpass-analysis=kernel-resource-usage, ~2.5 min).
 set -e
-TAG=$1; ROUND=${2:-r02}; ROOT=$(cd "$(dirname "$0")/.." && pwd); cd $ROOT
+TAG=$1; ROUND=${2:-r03}; ROOT=$(cd "$(dirname "$0")/.." && pwd); cd $ROOT
 for f in gpurun_out/profiles_$TAG/${TAG}_*; do cp $f profiles/${ROUND}_${f#gpurun_out/profiles_$TAG/${TAG}_}; done
 for n in default driver20; do
   [ -f gpurun_out/$TAG/bench_$n.json ] && grep '^{' gpurun_out/$TAG/bench_$n.json | tail -1 > profiles/${ROUND}_bench_${n}_unprofiled.json

@@ -1,13 +1,13 @@
 #!/bin/bash
 # One GPU session of the round: parity tests, headline + driver-style + side-workload bench lines.  scripts/gpu_round.sh <tag>
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/$TAG; mkdir -p $O
 cd $ROOT
 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -5 $O/pytest.log
 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 2500 $O/bench_default.json
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-large > $O/bench_driver20.json 2>> $O/bench_default.err
-for w in C3m0 C3m6 C5 C5s C1; do python bench.py --workload $w --steps 200 --warmup 40 --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err; done
+python bench.py --steps 20 --warmup 5 > $O/bench_driver20.json 2>> $O/bench_default.err
+for w in C3m0 C3m6 mid C5 C5s C1; do python bench.py --workload $w --steps 200 --warmup $([ $w = mid ] && echo 400 || echo 40) --no-cpu-baseline --no-full > $O/bench_$w.json 2> $O/bench_$w.err; done
 for a in 1024 16384 65536 262144; do python bench.py --arenas $a --steps 200 --warmup 40 --no-cpu-baseline --no-large > $O/bench_C2_$a.json 2> $O/bench_C2_$a.err; done
 python - <<PY
 import json,glob,os

@@ -134,8 +134,16 @@ def test_gym_wrapper_all_three_observation_types():
         else:
             assert set(obs) == {"global_state", "player_states"}
         g.close()
+    # "ram": accepted by the reference's first check and rejected when the env is built (AgarioEnv.py:52,211); here it is an extension -- a flat
+    # float32 vector per agent (include/agarcl_batch.h agarcl_ram_obs)
+    g = AgarioEnv(obs_type="ram", num_viruses=5, k_pellets=8)
+    g.seed(3); obs, _ = g.reset()
+    assert obs.shape == (4 + 48 + 16 + 24 + 48,) and obs.dtype == np.float32 and obs[2] == 25 and obs[3] == 1
+    obs, rew, done, trunc, info = g.step(((0.5, 0.5), 0))
+    assert obs.shape == (140,) and isinstance(rew, float)
+    g.close()
     with pytest.raises(ValueError):
-        AgarioEnv(obs_type="ram")             # accepted by the reference's first check, rejected when the env is built (AgarioEnv.py:52,211)
+        AgarioEnv(obs_type="pixels")
 
 
 def test_registration_with_a_stand_in_gymnasium(monkeypatch):
