@@ -22,14 +22,14 @@ __host__ __device__ inline
 int ag_ram_dim(const AgRamCfg &o) { return 4 + 3 * o.KC + 2 * o.KP + 3 * o.KV + 3 * o.KO; }
 
 #ifndef AGAR_CPU_EMU
-// K nearest of n entities: pos(i, x, y) gives entity i's position; emit(rank, i, dx, dy) writes a selected one
+// K nearest of n entities: pos(i, x, y) gives entity i's position (false: no such entity); emit(rank, i, dx, dy) writes a selected one
 template <class PosT, class EmitT> AG_DEV void ram_nearest(int n, int K, float px, float py, PosT pos, EmitT emit) {
   unsigned last_d = 0u, last_i = 0u; bool first = true;
   const int rounds = K < n ? K : n;
   for (int r = 0; r < rounds; r++) {
     unsigned best_d = 0xffffffffu, best_i = 0xffffffffu;
     for (int i = AG_LANE; i < n; i += 64) {
-      float x, y; pos(i, x, y);
+      float x, y; if (!pos(i, x, y)) continue;   // (a hole of a fixed-capacity table: never a candidate, whatever the centre is)
       const float dx = x - px, dy = y - py; const float a = dx * dx, b = dy * dy;
       const unsigned d = (unsigned)f2u(a + b);   // (>= 0, or NaN: its bits order above every distance)
       const bool above = first || d > last_d || (d == last_d && (unsigned)i > last_i);
@@ -39,7 +39,7 @@ template <class PosT, class EmitT> AG_DEV void ram_nearest(int n, int K, float p
     const unsigned mi = wred_min(best_d == md ? best_i : 0xffffffffu);
     if (mi == 0xffffffffu) break;
     last_d = md; last_i = mi; first = false;
-    AG_SERIAL { float x, y; pos((int)mi, x, y); emit(r, (int)mi, x - px, y - py); }
+    AG_SERIAL { float x, y; (void)pos((int)mi, x, y); emit(r, (int)mi, x - px, y - py); }
   }
 }
 
@@ -59,24 +59,25 @@ AG_DEV void ram_obs_agent(const AgState *gs, int arena, int agent, AgRamCfg o, f
   AG_LANES(i, n < o.KC ? n : o.KC) { oc[3 * i] = u2f((int)C[AG_CELL_W(CF_X, i)]) - px; oc[3 * i + 1] = u2f((int)C[AG_CELL_W(CF_Y, i)]) - py; oc[3 * i + 2] = (float)C[AG_CELL_W(CF_M, i)]; }
   const int np = ar[AG_TW(AR_NPEL)], nv = ar[AG_TW(AR_NVIR)];
   const AG_GLOBAL float *pxy = (const AG_GLOBAL float *)(gs->pel_xy + (size_t)arena * gs->d.PC * 2);
-  ram_nearest(np, o.KP, px, py, [&](int i, float &x, float &y) { x = pxy[2 * i]; y = pxy[2 * i + 1]; },
+  ram_nearest(np, o.KP, px, py, [&](int i, float &x, float &y) { x = pxy[2 * i]; y = pxy[2 * i + 1]; return true; },
               [&](int r, int, float dx, float dy) { op[2 * r] = dx; op[2 * r + 1] = dy; });
   const AG_GLOBAL float *vx = (const AG_GLOBAL float *)(gs->vir_x + (size_t)arena * gs->d.VC), *vy = (const AG_GLOBAL float *)(gs->vir_y + (size_t)arena * gs->d.VC);
   const AG_GLOBAL int32_t *vm = (const AG_GLOBAL int32_t *)(gs->vir_mass + (size_t)arena * gs->d.VC);
-  ram_nearest(nv, o.KV, px, py, [&](int i, float &x, float &y) { x = vx[i]; y = vy[i]; },
+  ram_nearest(nv, o.KV, px, py, [&](int i, float &x, float &y) { x = vx[i]; y = vy[i]; return true; },
               [&](int r, int i, float dx, float dy) { ov[3 * r] = dx; ov[3 * r + 1] = dy; ov[3 * r + 2] = (float)vm[i]; });
   // other players' cells: entity index = slot * AG_CC + cell (slots in ascending order, the agent's own slot skipped)
   if (P > 1 && o.KO > 0) {
     const AG_GLOBAL uint32_t *C0 = (const AG_GLOBAL uint32_t *)AG_CELLS_PTR(gs, arena, 0);
     const AG_GLOBAL int32_t *pl0 = (const AG_GLOBAL int32_t *)AG_PL_PTR(gs, arena, 0);
-    auto cell = [&](int e, float &x, float &y, float &m) {   // entity e: NaN position (never selected before real ones) for holes
+    auto cell = [&](int e, float &x, float &y, float &m) -> bool {   // entity e = (slot, cell); false for the agent's own slot and empty cell slots
       const int s = e / AG_CC, i = e - s * AG_CC;
       const bool live = s != agent && i < pl0[AG_TW(s * PL_WORDS + PL_NCELLS)];
       const AG_GLOBAL uint32_t *Cs = C0 + AG_TW(s * (CF_ALL * AG_CC));
-      x = live ? u2f((int)Cs[AG_CELL_W(CF_X, i)]) : u2f(0x7fc00000); y = live ? u2f((int)Cs[AG_CELL_W(CF_Y, i)]) : u2f(0x7fc00000); m = live ? (float)Cs[AG_CELL_W(CF_M, i)] : 0.0f;
+      x = live ? u2f((int)Cs[AG_CELL_W(CF_X, i)]) : 0.0f; y = live ? u2f((int)Cs[AG_CELL_W(CF_Y, i)]) : 0.0f; m = live ? (float)Cs[AG_CELL_W(CF_M, i)] : 0.0f;
+      return live;
     };
     int live_total = 0; for (int s = 0; s < P; s++) if (s != agent) live_total += pl0[AG_TW(s * PL_WORDS + PL_NCELLS)];
-    ram_nearest(P * AG_CC, o.KO < live_total ? o.KO : live_total, px, py, [&](int e, float &x, float &y) { float m; cell(e, x, y, m); },
+    ram_nearest(P * AG_CC, o.KO < live_total ? o.KO : live_total, px, py, [&](int e, float &x, float &y) { float m; return cell(e, x, y, m); },
                 [&](int r, int e, float dx, float dy) { float x, y, m; cell(e, x, y, m); oo[3 * r] = dx; oo[3 * r + 1] = dy; oo[3 * r + 2] = m; });
   }
 }

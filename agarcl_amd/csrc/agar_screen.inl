@@ -24,7 +24,12 @@
 // the flat buffer, row boundaries included).  "Main agent" = state.main_agent_pid = the last agent added (BaseEnvironment.hpp:189).
 //
 // One 256-thread workgroup per (arena, agent): wave 0 compacts the entities that can touch the view into an LDS list in
-// draw order (ordered ballot compaction); then every thread shades pixels, walking the list and keeping the last hit.
+// draw order (ordered ballot compaction).  k_screen_obs then PAINTS them, in that order, into an LDS frame buffer: a band of rows at a
+// time (<= 8192 pixels, the whole frame at 84 x 84), every wavefront owning a quarter of the band's rows and testing only the pixels
+// of an entity's bounding box -- ~1200 inside-tests per 84 x 84 frame instead of 7056 pixels x ~40 entities -- the grid lines come
+// from per-column / per-row flags, and the band leaves LDS as one coalesced byte stream.  Same per-pixel rules and the same fp32
+// expressions as the pixel-wise kernel (k_screen_obs_pixelwise: every thread shades pixels, walking the whole list), which is kept as the
+// cross-check (AGARCL_SCREEN_PIXELWISE=1; tests/test_screen_obs.py compares the two byte for byte).
 #pragma once
 #include "agar_types.h"
 
@@ -49,7 +54,19 @@ __device__ __forceinline__ bool scr_inside(float dx, float dy, float r, int nsid
   return dx * cosf(phi) + dy * sinf(phi) <= apo;
 }
 
-__global__ void __launch_bounds__(256) k_screen_obs(const AgState *__restrict__ gs, AgScreenCfg o, uint8_t *out) {
+// the same test with the apothem r * cos(pi / nsides) handed in (computed once per entity by the band kernel)
+__device__ __forceinline__ bool scr_inside_apo(float dx, float dy, float r, float apo, int nsides) {
+  float d2 = dx * dx + dy * dy;
+  if (d2 > r * r) return false;
+  if (d2 <= apo * apo) return true;
+  const float step = 6.28318530717958647692f / (float)nsides;
+  float th = atan2f(dy, dx); if (th < 0.0f) th += 6.28318530717958647692f;
+  float k = floorf(th / step);
+  float phi = (k + 0.5f) * step;
+  return dx * cosf(phi) + dy * sinf(phi) <= apo;
+}
+
+__global__ void __launch_bounds__(256) k_screen_obs_pixelwise(const AgState *__restrict__ gs, AgScreenCfg o, uint8_t *out) {
   __shared__ float ex[AG_SCR_CAP], ey[AG_SCR_CAP], er[AG_SCR_CAP];
   __shared__ unsigned ec[AG_SCR_CAP];  // 0x00BBGGRR | nsides << 24
   __shared__ int n_list;
@@ -138,6 +155,205 @@ __global__ void __launch_bounds__(256) k_screen_obs(const AgState *__restrict__ 
         a2 = a1; a1 = alpha;
       }
     }
+  }
+}
+#define AG_SCR_BAND 7168   // pixels of one LDS band (28 KiB of packed RGBA): a whole 84 x 84 frame
+__global__ void __launch_bounds__(256) k_screen_obs(const AgState *__restrict__ gs, AgScreenCfg o, uint8_t *out) {
+  __shared__ float ex[AG_SCR_CAP], ey[AG_SCR_CAP], er[AG_SCR_CAP];
+  __shared__ unsigned ec[AG_SCR_CAP];  // 0x00BBGGRR | nsides << 24
+  __shared__ unsigned fb[AG_SCR_BAND];  // 0xAABBGGRR of the band's pixels
+  __shared__ uint8_t colflag[1024], rowflag[1024];   // bit 0: a grid line falls into this pixel column / row; bit 1: the column / row lies inside the arena
+  __shared__ float colx[1024], rowy[1024];           // world coordinate of every pixel column's / row's centre
+  __shared__ float eapo[AG_SCR_CAP];                 // apothem of an entity's polygon
+  __shared__ unsigned ebx[AG_SCR_CAP], eby[AG_SCR_CAP];   // pixel box of an entity: first | last << 16 column / row (one pixel of margin; empty: first > last)
+  __shared__ int n_list;
+  const int na = gs->d.n_agents, arena = (int)blockIdx.x / na, agent = (int)blockIdx.x % na, P = gs->d.P;
+  const int CH = o.agent_view ? 4 : 3;
+  uint8_t *dst = out + (size_t)blockIdx.x * o.W * o.H * CH;
+  float px, py; unsigned mass;
+  obs_player(gs, arena, agent, px, py, mass);
+  double zd = 100.0 + (double)mass / 10.0; zd = zd < 100.0 ? 100.0 : (zd > 900.0 ? 900.0 : zd);
+  const float z = (float)zd, half_h = z * 0.41421356237309504880f, half_w = half_h * ((float)o.W / (float)o.H);
+  const float Wd = gs->g.W;
+  const int ag_ts_lg = gs->d.ts_lg;
+  const int32_t *ar = AG_AR_PTR(gs, arena);
+  if (threadIdx.x < 64) {  // ---- wave 0: visible entities in draw order ----
+    const int lane = (int)threadIdx.x; const unsigned long long lt = (1ull << lane) - 1ull;
+    int count = 0;
+    auto emit = [&](bool valid, float x, float y, float r, unsigned col) {
+      bool vis = valid && fabsf(x - px) <= half_w + r && fabsf(y - py) <= half_h + r;
+      unsigned long long m = __ballot(vis);
+      int slot = count + __popcll(m & lt);
+      if (vis && slot < AG_SCR_CAP) { ex[slot] = x; ey[slot] = y; er[slot] = r; ec[slot] = col; }
+      count += __popcll(m);
+    };
+    const float *pxy = gs->pel_xy + (size_t)arena * gs->d.PC * 2; const int32_t *pid = gs->pel_id + (size_t)arena * gs->d.PC;
+    const int np = ar[AG_TW(AR_NPEL)], nf = ar[AG_TW(AR_NFOOD)], nv = ar[AG_TW(AR_NVIR)];
+    const float r_pel = gs->lut_r[AG_PELLET_MASS], r_food = gs->lut_r[AG_FOOD_MASS];
+    const bool av = o.agent_view != 0;
+    for (int b0 = 0; b0 < np; b0 += 16 * 64) {   // 16 chunks of pellets at a time: every load is issued before the first ballot (one round trip, not 16)
+      float xs[16], ys[16]; int ids[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) { const int i = b0 + j * 64 + lane; const bool v = i < np; xs[j] = v ? pxy[2 * i] : 0.f; ys[j] = v ? pxy[2 * i + 1] : 0.f; ids[j] = (v && !av) ? pid[i] : 0; }
+#pragma unroll
+      for (int j = 0; j < 16; j++) { const int i = b0 + j * 64 + lane; const bool v = i < np; if (b0 + j * 64 < np) emit(v, xs[j], ys[j], r_pel, v ? ((av ? 0x0000FFu : scr_palette(ids[j])) | (5u << 24)) : 0u); }
+    }
+    { size_t fo = (size_t)arena * gs->d.FC;
+      for (int b = 0; b < nf; b += 64) { int i = b + lane; bool v = i < nf; emit(v, v ? gs->food_x[fo + i] : 0.f, v ? gs->food_y[fo + i] : 0.f, r_food, v ? ((av ? 0x0000FFu : scr_palette(gs->food_id[fo + i])) | (7u << 24)) : 0u); } }
+    const int main_slot = na - 1;  // state.main_agent_pid: the last agent added
+    for (int kk = av ? -1 : 0; kk < P; kk++) {  // players in the engine's iteration order (agent view: the main agent first), cells in vector order
+      const int slot = kk < 0 ? main_slot : ar[AG_TW(AR_ORDER0 + kk)];
+      if (av && kk >= 0 && slot == main_slot) continue;
+      const int32_t *pl = AG_PL_PTR(gs, arena, slot);
+      const uint32_t *C = AG_CELLS_PTR(gs, arena, slot);
+      const int n = pl[AG_TW(PL_NCELLS)], kind = pl[AG_TW(PL_KIND)];
+      const unsigned col = (av ? (kk < 0 ? 0x0000E6u /* 0.9 -> 230 */ : 0x00FF00u)
+                               : (kind == 0 ? scr_palette(pl[AG_TW(PL_PID)]) : kind == 1 ? scr_palette(4) : kind == 2 ? scr_palette(5) : kind == 3 ? scr_palette(0) : scr_palette(1))) | (50u << 24);
+      bool v = lane < n;
+      unsigned m = v ? C[AG_CELL_W(CF_M, lane)] : 0u;
+      emit(v, v ? __uint_as_float(C[AG_CELL_W(CF_X, lane)]) : 0.f, v ? __uint_as_float(C[AG_CELL_W(CF_Y, lane)]) : 0.f, v ? gs->lut_r[m < AG_LUT_SIZE ? m : AG_LUT_SIZE - 1] : 0.f, col);
+    }
+    { size_t vo = (size_t)arena * gs->d.VC;
+      for (int b = 0; b < nv; b += 64) { int i = b + lane; bool v = i < nv; unsigned m = v ? (unsigned)gs->vir_mass[vo + i] : 0u;
+        emit(v, v ? gs->vir_x[vo + i] : 0.f, v ? gs->vir_y[vo + i] : 0.f, v ? gs->lut_r[m < AG_LUT_SIZE ? m : AG_LUT_SIZE - 1] : 0.f, (av ? 0xFF0000u : scr_palette(3)) | (150u << 24)); } }
+    if (lane == 0) n_list = count < AG_SCR_CAP ? count : AG_SCR_CAP;
+  }
+  // grid lines: the pixel column / row a line falls into (one pixel wide), and which columns / rows lie inside the arena
+  const float sx_scale = (float)o.W * 0.5f / half_w, sy_scale = (float)o.H * 0.5f / half_h, spacing = Wd / 7.0f;
+  for (int k = (int)threadIdx.x; k < o.W; k += 256) {
+    const float wx = px + (((float)k + 0.5f) / (float)o.W * 2.0f - 1.0f) * half_w;
+    uint8_t f = (wx >= 0.0f && wx <= Wd) ? 2 : 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { float g = (float)i * spacing; if ((int)floorf((g - px) * sx_scale + (float)o.W * 0.5f) == k) f |= 1; }
+    colflag[k] = f; colx[k] = wx;
+  }
+  for (int k = (int)threadIdx.x; k < o.H; k += 256) {
+    const float wy = py + (((float)k + 0.5f) / (float)o.H * 2.0f - 1.0f) * half_h;
+    uint8_t f = (wy >= 0.0f && wy <= Wd) ? 2 : 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { float g = (float)i * spacing; if ((int)floorf((g - py) * sy_scale + (float)o.H * 0.5f) == k) f |= 1; }
+    rowflag[k] = f; rowy[k] = wy;
+  }
+  __syncthreads();
+  for (int k = (int)threadIdx.x; k < n_list; k += 256) {   // conservative pixel box of every listed entity (one pixel of margin: the inside test decides)
+    const float x = ex[k], y = ey[k], r = er[k];
+    int c0 = (int)floorf(((x - r - px) / half_w + 1.0f) * 0.5f * (float)o.W - 0.5f) - 1, c1 = (int)floorf(((x + r - px) / half_w + 1.0f) * 0.5f * (float)o.W - 0.5f) + 2;
+    int r0 = (int)floorf(((y - r - py) / half_h + 1.0f) * 0.5f * (float)o.H - 0.5f) - 1, r1 = (int)floorf(((y + r - py) / half_h + 1.0f) * 0.5f * (float)o.H - 0.5f) + 2;
+    c0 = c0 < 0 ? 0 : c0; c1 = c1 > o.W - 1 ? o.W - 1 : c1; r0 = r0 < 0 ? 0 : r0; r1 = r1 > o.H - 1 ? o.H - 1 : r1;
+    if (c0 > c1 || r0 > r1) { c0 = 1; c1 = 0; r0 = 1; r1 = 0; }
+    ebx[k] = (unsigned)c0 | ((unsigned)c1 << 16); eby[k] = (unsigned)r0 | ((unsigned)r1 << 16);
+    { const float step = 6.28318530717958647692f / (float)(int)(ec[k] >> 24); eapo[k] = r * cosf(0.5f * step); }
+  }
+  __syncthreads();
+  const int n = n_list, wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  const int band_rows = AG_SCR_BAND / o.W > 0 ? (AG_SCR_BAND / o.W < o.H ? AG_SCR_BAND / o.W : o.H) : 1;
+  int a1 = 255, a2 = 255;   // agent view: final alphas of the two previous pixels (thread 0 carries them from band to band)
+  for (int row0 = 0; row0 < o.H; row0 += band_rows) {   // row 0 = bottom (glReadPixels)
+    const int rows = o.H - row0 < band_rows ? o.H - row0 : band_rows, npix = rows * o.W;
+    // background + grid
+    const int step_r = 256 / o.W, step_c = 256 - step_r * o.W;   // (one division: the loop below walks rows and columns by addition)
+    for (int q = (int)threadIdx.x, r = (int)threadIdx.x / o.W, cidx = (int)threadIdx.x - r * o.W; q < npix; q += 256, r += step_r, cidx += step_c) {
+      if (cidx >= o.W) { cidx -= o.W; r += 1; }
+      const uint8_t cf = colflag[cidx], rf = rowflag[row0 + r];
+      const bool grid = ((cf & 1) && (rf & 2)) || ((rf & 1) && (cf & 2));
+      fb[q] = grid ? 0xFF00001Au : (o.agent_view ? 0u : 0x00FFFFFFu);   // (0.1, 0, 0) -> 26; alpha byte: a fragment was written
+    }
+    __syncthreads();
+    // entities in draw order; a wavefront paints only its own rows, so later entities overwrite earlier ones without any exchange
+    const int rpw = (rows + 3) >> 2, wr0 = row0 + wave * rpw, wr1 = (wr0 + rpw < row0 + rows ? wr0 + rpw : row0 + rows) - 1;
+    if (wr0 <= wr1) for (int k = 0; k < n; k++) {
+      const unsigned bx = ebx[k], by = eby[k];
+      const int c0 = (int)(bx & 0xFFFFu), c1 = (int)(bx >> 16);
+      int r0 = (int)(by & 0xFFFFu), r1 = (int)(by >> 16);
+      r0 = r0 < wr0 ? wr0 : r0; r1 = r1 > wr1 ? wr1 : r1;
+      if (c0 > c1 || r0 > r1) continue;   // (wave-uniform)
+      const float x = ex[k], y = ey[k], r = er[k], apo = eapo[k]; const unsigned e = ec[k];
+      for (int ty = r0; ty <= r1; ty += 8) for (int tx = c0; tx <= c1; tx += 8) {   // 8 x 8 pixel tiles of the box, a lane per pixel
+        const int rr = ty + (lane >> 3), cc = tx + (lane & 7);
+        if (rr <= r1 && cc <= c1 && scr_inside_apo(colx[cc] - x, rowy[rr] - y, r, apo, (int)(e >> 24))) fb[(rr - row0) * o.W + cc] = (e & 0xFFFFFFu) | 0xFF000000u;
+      }
+    }
+    __syncthreads();
+    if (CH == 4) {  // ScreenObservation::post_processing_frame_data (ScreenEnvironment.hpp:48-88): a sequential pass over the flat buffer
+      // With the colours this kernel paints (one non-zero channel per pixel: 26 grid, 230 main agent, 255 pellets / others / viruses) the
+      // pass has a closed form.  A pixel whose channel is <= 230 moves it into alpha: no dependence.  A 255-pixel keeps alpha 255 unless
+      // the two previous FINAL alphas are both <= 30, then it takes the previous one; so a run of consecutive 255-pixels takes ONE value,
+      // decided at its first pixel -- 255, or the alpha in front of the run -- and only run starts are sequential: a dozen per frame instead
+      // of 7056 pixels.  (Any other pixel -- none can occur -- sends the band through the literal loop below.)
+      __shared__ int pp_irregular, pp_carry[2];
+      if (threadIdx.x == 0) { pp_irregular = 0; }
+      __syncthreads();
+      for (int q = (int)threadIdx.x; q < npix; q += 256) {   // phase 1: everything that does not depend on a neighbour
+        const unsigned w = fb[q]; const unsigned r_ = w & 0xFFu, g_ = (w >> 8) & 0xFFu, b_ = (w >> 16) & 0xFFu, al = w >> 24;
+        const int nz = (r_ != 0) + (g_ != 0) + (b_ != 0); const unsigned v = r_ | g_ | b_;
+        if (nz == 0) continue;                                  // background: alpha stays what it is
+        if (nz > 1 || (v > 230u && (v != 255u || al != 255u))) { pp_irregular = 1; continue; }
+        if (v <= 230u) fb[q] = v << 24;                         // the value moves into alpha, the channel is cleared
+      }
+      __syncthreads();
+      if (pp_irregular == 0) {
+        if (threadIdx.x < 64) {   // phase 2 (one wavefront, in pixel order): runs of 255-pixels
+          int run_val = -1;       // value of the run that reaches into the current chunk from the left (-1: none)
+          for (int c0_ = 0; c0_ < npix; c0_ += 64) {
+            const int q = c0_ + lane; const bool in = q < npix;
+            const unsigned w = in ? fb[q] : 0u;
+            const bool X = in && (w & 0xFFFFFFu) != 0u;            // after phase 1 only 255-pixels still carry a colour
+            unsigned long long xm = __ballot(X);
+            // final alphas of the two pixels in front of every lane's pixel, as far as they are NOT 255-pixels (those are resolved below)
+            unsigned long long done = 0ull;                       // 255-pixels of this chunk whose alpha has been decided
+            unsigned long long todo = xm;
+            int carry_val = run_val;
+            while (todo) {
+              const int s_ = (int)__builtin_ctzll(todo);           // first undecided 255-pixel: a run start, or the continuation of the left run
+              // length of the run inside this chunk
+              const unsigned long long from = xm >> s_; const int len = (~from) ? (int)__builtin_ctzll(~from) : 64 - s_;
+              int val;
+              if (s_ == 0 && carry_val >= 0) val = carry_val;     // the run started in an earlier chunk
+              else {
+                const int p = row0 * o.W + c0_ + s_;              // flat pixel index of the run start
+                int f1, f2;                                        // final alphas of pixels p - 1 and p - 2
+                if (c0_ + s_ >= 1) f1 = (int)(fb[c0_ + s_ - 1] >> 24); else f1 = a1;
+                if (c0_ + s_ >= 2) f2 = (int)(fb[c0_ + s_ - 2] >> 24); else f2 = (c0_ + s_ == 1) ? a1 : a2;
+                val = (p >= 2 && f2 <= 30 && f1 <= 30) ? f1 : 255;
+              }
+              if (lane >= s_ && lane < s_ + len) fb[q] = (w & 0xFFFFFFu) | ((unsigned)val << 24);
+              ag_lds_order();
+              const unsigned long long runmask = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << s_;
+              todo &= ~runmask; done |= runmask;
+              carry_val = -1;
+              run_val = (s_ + len == 64) ? val : -1;               // the run touches the chunk's right edge: it may continue
+            }
+            if (!(xm >> 63)) run_val = -1;
+          }
+          // the band's last two final alphas, for the next band
+          ag_lds_order();
+          if (lane == 0) { const int l1 = (int)(fb[npix - 1] >> 24), l2 = npix >= 2 ? (int)(fb[npix - 2] >> 24) : a1; pp_carry[0] = l1; pp_carry[1] = l2; }
+        }
+        __syncthreads();
+        a2 = pp_carry[1]; a1 = pp_carry[0];
+      } else if (threadIdx.x == 0) {
+        for (int q = 0; q < npix; q++) {
+          unsigned w = fb[q]; int alpha = (int)(w >> 24); unsigned rgb = w & 0xFFFFFFu;
+          const int p = row0 * o.W + q;
+          for (int ch = 0; ch < 3; ch++) {
+            const int v = (int)((rgb >> (8 * ch)) & 0xFFu);
+            if (v == 0) continue;
+            if (v <= 230) { alpha = v; rgb &= ~(0xFFu << (8 * ch)); }
+            else if (p >= 2 && a2 <= 30 && a1 <= 30) alpha = a1;
+          }
+          fb[q] = rgb | ((unsigned)alpha << 24);
+          a2 = a1; a1 = alpha;
+        }
+        pp_carry[0] = a1; pp_carry[1] = a2;
+      }
+      __syncthreads();
+      if (pp_irregular != 0) { a1 = pp_carry[0]; a2 = pp_carry[1]; }
+    }
+    // the band leaves LDS as one coalesced byte stream
+    uint8_t *bd = dst + (size_t)row0 * o.W * CH; const int nbytes = npix * CH;
+    if (CH == 4) { for (int b = (int)threadIdx.x; b < nbytes; b += 256) bd[b] = (uint8_t)((fb[b >> 2] >> (8 * (b & 3))) & 0xFFu); }
+    else { for (int b = (int)threadIdx.x; b < nbytes; b += 256) { const int q = b / 3, ch = b - q * 3; bd[b] = (uint8_t)((fb[q] >> (8 * ch)) & 0xFFu); } }
+    __syncthreads();
   }
 }
 #endif

@@ -7,7 +7,7 @@
 # those into profiles/ and commit them.
 set -u
 TAG=${1:-r03}; shift
-RUNS=${@:-"C2:4096:400 C2:65536:200 C2:262144:100 C3m6:4096:200 mid:4096:200 C5:4096:100 C1:4096:200"}
+RUNS=${@:-"C2:4096:400 C2:65536:200 C2:262144:100 C3m6:4096:200 mid:4096:200 C5:4096:100 C5s:4096:100 C1:4096:200 C1r:4096:200"}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -120,3 +120,70 @@ def test_gym_wrapper_screen_observation():
         obs, rew, done, trunc, info = g.step(((0.2, -0.4), 0))
         assert obs.shape == (1, 64, 64, 3) and obs.dtype == np.uint8 and isinstance(rew, float) and trunc is False
     g.close()
+
+
+@pytest.mark.gpu
+def test_screen_obs_device_buffer_4096(hip_engine_cls):
+    """BASELINE config 5's other half at its full size: uint8 [4096][1][84][84][3] written straight into a torch HBM tensor, on the
+    full rule set after 40 steps (agents split, eject, pop on viruses).  A sample of arenas is compared with the host restatement of the
+    rasterisation rules (tolerance on polygon edges, as above); ALL frames through size-independent properties."""
+    import torch
+    from oracle import screen_oracle
+    A, W, H = 4096, 84, 84
+    cfg = dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode=6)
+    eng = hip_engine_cls(A, **cfg)
+    eng.seed(None, 10000); eng.reset(reset_ids=True)
+    rng = np.random.RandomState(3)
+    acts = [rng.randint(0, 3, size=(A, 1)).astype(np.int32) for _ in range(8)]
+    mv = [rng.uniform(-1, 1, size=(A, 1, 2)).astype(np.float32) for _ in range(8)]
+    for t in range(40):
+        eng.set_actions(mv[t % 8], acts[t % 8]); eng.step()
+    out = torch.full((A, 1, H, W, 3), 7, dtype=torch.uint8, device="cuda")
+    eng.screen_obs(W, H, out_ptr=out.data_ptr()); eng.sync()
+    f = out.cpu().numpy()
+    again = torch.empty_like(out); eng.screen_obs(W, H, out_ptr=again.data_ptr()); eng.sync()
+    assert torch.equal(out, again)                                              # deterministic
+    assert np.array_equal(f[:16], eng.screen_obs(W, H)[:16])                    # the host path returns the same frames
+    for a in list(range(0, A, 293)) + [A - 1]:                                  # 15 arenas against the rule restatement
+        ar, pl = eng.arena_words(a)
+        ref = screen_oracle.render(eng.dump(a), cfg["arena_size"], int(pl[0, 15]), [0], W, H)
+        diff = (ref != f[a, 0]).any(axis=2).mean()
+        assert diff <= 0.004, "arena %d: %.2f%% of the pixels differ" % (a, 100 * diff)
+    flat = f.reshape(A, H * W, 3)
+    white = (flat == 255).all(axis=2).mean(axis=1)
+    assert (flat.max(axis=(1, 2)) == 255).all()                                 # every frame has background
+    assert white.min() > 0.05 and white.mean() > 0.3                            # ... and it dominates on average (a mass-1000 agent's cells cover the view centre)
+    centre = f[:, 0, H // 2 - 1:H // 2 + 1, W // 2 - 1:W // 2 + 1].reshape(A, -1, 3)
+    assert (~(centre == 255).all(axis=2)).any(axis=1).mean() > 0.95             # the camera sits on the agent: something is drawn at the centre
+    # agent view (N4) at the full size: three binary channels + the main agent in the fourth
+    av = torch.empty((A, 1, H, W, 4), dtype=torch.uint8, device="cuda")
+    eng.screen_obs(W, H, out_ptr=av.data_ptr(), agent_view=True); eng.sync()
+    g = av.cpu().numpy()
+    assert set(np.unique(g[..., :3])) <= {0, 255}
+    assert ((g[..., 3] == 230).reshape(A, -1).any(axis=1)).mean() > 0.95
+    eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,steps", [
+    (dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode=6), 40),
+    (dict(num_agents=2, arena_size=200, num_pellets=300, num_viruses=5, num_bots=3, mode=0), 60),
+    (dict(arena_size=60, num_pellets=100, num_viruses=2, mode=0), 10),
+])
+def test_band_rasteriser_equals_the_pixelwise_kernel(hip_engine_cls, monkeypatch, cfg, steps):
+    """k_screen_obs paints bounding boxes into an LDS band; k_screen_obs_pixelwise shades every pixel against every entity: the same rules,
+    so the same bytes -- at the training size, a non-square size, the 512 x 512 frame of get_frame() (several bands) and in agent view."""
+    A = 5
+    na = cfg.get("num_agents", 1)
+    eng = hip_engine_cls(A, **cfg)
+    eng.seed(None, 91); eng.reset(reset_ids=True)
+    rng = np.random.RandomState(6)
+    for t in range(steps):
+        eng.set_actions(rng.uniform(-1, 1, size=(A, na, 2)).astype(np.float32), rng.randint(0, 3, size=(A, na)).astype(np.int32)); eng.step()
+    for (W, H, av) in ((84, 84, False), (96, 64, False), (512, 512, False), (84, 84, True), (200, 120, True), (1024, 33, False)):
+        monkeypatch.delenv("AGARCL_SCREEN_PIXELWISE", raising=False)
+        new = eng.screen_obs(W, H, agent_view=av)
+        monkeypatch.setenv("AGARCL_SCREEN_PIXELWISE", "1")
+        old = eng.screen_obs(W, H, agent_view=av)
+        assert np.array_equal(new, old), (W, H, av, float((new != old).mean()))
+    eng.close()
