@@ -1011,6 +1011,19 @@ template <int NS, bool AV> AG_DEV bool virus_collisions(AgCtx<NS, AV> &c, const 
   if (maxm < 111u) return false;  // virus mass >= 100 and can_eat needs mass > 1.1 * virus mass
   auto vx_ = g_vx(c); auto vy_ = g_vy(c); auto vm_ = g_vm(c);
   int vgw = c.gs->g.vgw, vgh = c.gs->g.vgh; unsigned VC = (unsigned)c.gs->d.VC;
+  // One pass, a lane per virus against all cells, proves the common case -- no cell reaches a virus it can eat -- in two round trips to
+  // HBM (the viruses, then their radii) instead of two per cell: with 14 cells of 111+ mass the per-cell scans below were 28 dependent
+  // round trips a tick.  Same predicate as the scan, so a miss here is a miss there; nothing has changed in between.
+  if (!wave_any(nv, [&](int vi) {
+        float vx = vx_[vi], vy = vy_[vi]; unsigned vmass = (unsigned)vm_[vi]; float vr = radius_of(c, vmass);
+        int bx = f2i(vx) / AG_VIRUS_GRID, by = f2i(vy) / AG_VIRUS_GRID; bool h = bx >= 0 && bx < vgw && by >= 0 && by < vgh, any = false;
+        for (int k = 0; k < n; k++) {
+          unsigned m = s.m[k]; float x = s.x[k], y = s.y[k];
+          int ddx = bx - f2i(x) / AG_VIRUS_GRID, ddy = by - f2i(y) / AG_VIRUS_GRID;
+          any = any | (m >= 111u && ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1 && can_eat_mass(m, vmass) && collides(x, y, cell_rad(c, s, k), vx, vy, vr));
+        }
+        return h && any;
+      })) return false;
   for (int k = 0; k < n; k++) {
     unsigned m = ag_uniu(s.m[k]);
     if (m < 111u) continue;
@@ -1227,13 +1240,14 @@ template <int NS, bool AV> AG_DEV void move_foods(AgCtx<NS, AV> &c) {
   auto vx = g_vx(c); auto vy = g_vy(c); auto vvx = g_vvx(c); auto vvy = g_vvy(c); auto vm = g_vm(c); auto vh = g_vh(c); auto vid = g_vid(c);
   auto advance = [&](float &x, float &y, float &ux, float &uy) { v_decelerate(ux, uy, AG_FOOD_DECEL, dt); float t = ux * dt; x += t; t = uy * dt; y += t; boundary(W, x, y, fr); };
   // does any moving food reach a virus after its move?  (virus radii only grow by being fed)
-  bool hits = nv > 0 && wave_any(nf, [&](int i) {
-    float x = fx[i], y = fy[i], ux = fvx[i], uy = fvy[i];
+  // (a lane per (food, virus) pair: all loads of a pass are in flight together -- a loop over the viruses inside a lane was two dependent
+  // round trips to HBM per virus, 50 a tick in every arena with a moving food)
+  bool hits = nv > 0 && wave_any(nf * nv, [&](int k) {
+    int i = k / nv, v = k - i * nv;
+    float x = fx[i], y = fy[i], ux = fvx[i], uy = fvy[i], wx = vx[v], wy = vy[v], wr = radius_of(c, (unsigned)vm[v]);
     if (vmag(ux, uy) == 0) return false;
     advance(x, y, ux, uy);
-    bool h = false;
-    for (int v = 0; v < nv; v++) h = h || collides(x, y, fr, vx[v], vy[v], radius_of(c, (unsigned)vm[v]));
-    return h;
+    return collides(x, y, fr, wx, wy, wr);
   });
   if (!hits) {
     AG_LANES(i, nf) {
@@ -1360,7 +1374,11 @@ template <int NS, bool AV> AG_DEV void tick_player(AgCtx<NS, AV> &c, int p) {
   c.ncreated = 0;
   int create_limit = AG_PLAYER_CELL_LIMIT - n;
   bool can_eat_virus = n >= AG_PLAYER_CELL_LIMIT;
+#ifdef AG_ABL_VIRUS
+  if (false) {
+#else
   if (virus_collisions(c, s, n, create_limit, can_eat_virus)) {
+#endif
     int nt = PR(c, PL_NVTICKS), el = PR(c, PL_ELAPSED);
     if (nt < AG_VT_CAP) { auto vt = g_vt(c, p); AG_SERIAL { vt[nt] = el; } PW(c, PL_NVTICKS, nt + 1); ag_mem_fence(); } else flag(c, 16u);
     PW(c, PL_VIRUSES_EATEN, PR(c, PL_VIRUSES_EATEN) + 1);
@@ -1378,6 +1396,7 @@ template <int NS, bool AV> AG_DEV void tick_player(AgCtx<NS, AV> &c, int p) {
   // per-cell: auto split (mass >= 22500) then eat ejected food.  R: Engine.hpp:520-525, 592-601
   bool big = total >= AG_MAX_MASS && wave_any(n, [&](int i) { return s.m[i] >= AG_MAX_MASS; });
   bool food_work = big;
+#ifndef AG_ABL_FOODTEST
   if (!big && SR(c, AR_NFOOD) > 0) {
     // one pass over the foods (a lane each) against all cells proves the common case -- nobody touches any food --
     // instead of one HBM round trip per cell; without an auto-split no mass changes between here and a cell's own turn
@@ -1388,6 +1407,7 @@ template <int NS, bool AV> AG_DEV void tick_player(AgCtx<NS, AV> &c, int p) {
       return h;
     });
   }
+#endif
   if (food_work) {
     float tx = PRF(c, PL_TX), ty = PRF(c, PL_TY);
     int fe_total = 0;
@@ -1409,8 +1429,10 @@ template <int NS, bool AV> AG_DEV void tick_player(AgCtx<NS, AV> &c, int p) {
   }
   AG_T(c, 6);
   create_limit -= c.ncreated;
+#ifndef AG_ABL_EMITSPLIT
   maybe_emit_food(c, s, n);
   maybe_split(c, s, n, create_limit);
+#endif
   // add created cells.  R: core/Player.hpp:195-201
   int ncr = c.ncreated;
   if (ncr > 0) {
@@ -1427,7 +1449,9 @@ template <int NS, bool AV> AG_DEV void tick_player(AgCtx<NS, AV> &c, int p) {
     ag_lds_order();
   }
   AG_T(c, 7);
+#ifndef AG_ABL_RECOMB
   n = recombine_cells(c, s, n);
+#endif
   PW(c, PL_NCELLS, n);
   decay(c, s, p, n);
   ub_store(c.PB, PLS(c, p), PL_WORDS);
@@ -1820,12 +1844,16 @@ template <int NS, bool AV> AG_DEV void arena_tick(AgCtx<NS, AV> &c) {
   remove_pellets(c);
   remove_viruses(c);
   AG_T(c, 13);
+#ifndef AG_ABL_SORT
   for (int k = 0; k < c.P; k++) sort_cells_by_id(c, SR(c, AR_ORDER0 + k));
+#endif
   AG_T(c, 14);
   // PrecisionCollisionDetection::solve: with one player every strip scan breaks on an own cell
   // (utils/collision_detection.hpp:51) => no eats.
   players_collision(c);
+#ifndef AG_ABL_FOODMOVE
   move_foods(c);
+#endif
   AG_T(c, 15);
   int ticks = SR(c, AR_TICKS);
   if (c.gs->g.regen && ticks % 120 == 0) {
