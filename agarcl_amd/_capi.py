@@ -76,6 +76,7 @@ SYMBOLS = [
     ("agarcl_seed_arena", C.c_int, [C.c_void_p, C.c_int32, C.c_uint32]),
     ("agarcl_get_seeds", C.c_int, [C.c_void_p, C.c_void_p]),
     ("agarcl_get_arena_words", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    ("agarcl_player_words", C.c_int, []),
     ("agarcl_num_arenas", C.c_int, [C.c_void_p]),
     ("agarcl_players_per_arena", C.c_int, [C.c_void_p]),
     ("agarcl_state_bytes", C.c_int64, [C.c_void_p]),
@@ -333,9 +334,9 @@ class BatchedEngine:
         return out
 
     def arena_words(self, arena):
-        """(ar i32[32], pl i32[players][20]) raw words of one arena (agar_types.h AR_* / PL_*)."""
+        """(ar i32[32], pl i32[players][agarcl_player_words()]) raw words of one arena (agar_types.h AR_* / PL_*)."""
         P = int(self.L.agarcl_players_per_arena(self.h))
-        ar = np.zeros(32, dtype=np.int32); pl = np.zeros((P, 20), dtype=np.int32)
+        ar = np.zeros(32, dtype=np.int32); pl = np.zeros((P, int(self.L.agarcl_player_words())), dtype=np.int32)
         self._chk(self.L.agarcl_get_arena_words(self.h, arena, _ptr(ar), _ptr(pl)))
         return ar, pl
 

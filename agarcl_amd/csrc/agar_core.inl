@@ -1540,6 +1540,12 @@ template <int NS, bool AV> AG_DEV void sort_cells_by_id(AgCtx<NS, AV> &c, int p)
 //     S = dmin - radius - 0.01 of p0 nothing can be inside its radius: no scan, and a launch that stays in the disc
 //     never reads the pellets from HBM at all.  (A random walk leaves the disc far later than its path length would
 //     suggest.  Only with AV: otherwise buckets change visibility as the cell moves.)
+//   * Tracked pellet (PL_CAND_*): the pass also names the nearest pellet itself and the distance dsec to the SECOND nearest.  The disc
+//     then reaches to the second nearest -- S = dsec - radius(mass + 1) - 0.01: inside it no OTHER pellet lies within the radius the cell
+//     has now or after one eat -- and the tracked pellet is tested by itself every tick (the pass's own fp32 distance).  When it comes
+//     within the radius it is the only one, also for the grown radius: a plain eat WITHOUT a pass; the disc stands (it was measured for
+//     the radius after this very eat).  A third of the passes were eats, and the larger disc is left far later: far fewer passes, and a
+//     pass is the one thing in a quiet step that waits for HBM.
 //   * A plain eat (exactly one pellet inside the radius, still exactly one inside the grown radius, not a regen
 //     tick) is performed inline: mass + 1, swap-pop removal, event record -- identical to the general path's result.
 // The run stops BEFORE the first tick that needs anything else (nothing of that tick has been written) and the
@@ -1562,33 +1568,47 @@ struct QState {  // per arena: wave-uniform in k_step, uniform over the arena's 
   int why;
 #endif
   float x, y, svx, svy, vx, vy, r, hi, tx, ty, slack, sx0, sy0;  // slack = S, (sx0, sy0) = centre of the pellet-free disc
+  float cx, cy; int cidx;  // the tracked pellet (PL_CAND_*): the one pellet the disc does not exclude; cidx < 0: none
   double rate;
   bool pel_changed;
 };
 // One fused pass over an arena's pellets as seen from (x, y): squared distance to the nearest one, how many lie
 // within rr and within rr1 (the radius after eating one), and the index of the first one within rr.
-struct PelScan { float dmin2, dsec2; int cnt, cnt1, first; };  // dsec2: squared distance to the SECOND nearest pellet
+// dsec2: squared distance to the SECOND nearest pellet; near / nx / ny: the nearest pellet itself (lowest index among equally near ones; -1: none
+// visible, or somebody is in reach -- then the caller has no use for it)
+struct PelScan { float dmin2, dsec2; int cnt, cnt1, first; int near; float nx, ny; };
 struct PelQuery { float x, y, rr, rr1; int gx, gy; };  // gx, gy: the cell's pellet bucket (used only without AV)
 template <bool AV> AG_DEV bool pel_visible(const PelQuery &k, float qx, float qy) {  // R: Engine.hpp:976-990 (3x3 bucket walk)
   if constexpr (AV) return true;
   else { int ddx = f2i(qx) / AG_PELLET_GRID - k.gx, ddy = f2i(qy) / AG_PELLET_GRID - k.gy; return ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1; }
 }
 // lane-level accumulation of one pellet into the partial results (dmin as float bits: orders like the value for d2 >= 0)
-template <bool AV> AG_DEV void pel_accumulate(const PelQuery &k, float qx, float qy, unsigned idx, unsigned &dmin, unsigned &dsec, int &c0, int &c1, unsigned &first) {
+template <bool AV> AG_DEV void pel_accumulate(const PelQuery &k, float qx, float qy, unsigned idx, unsigned &dmin, unsigned &dsec, int &c0, int &c1, unsigned &first, unsigned &ni, float &nx, float &ny) {
   if (!pel_visible<AV>(k, qx, qy)) return;
   float d2 = sqr_dist(k.x, k.y, qx, qy);
   unsigned b = (unsigned)f2u(d2);
+  if (b < dmin) { ni = idx; nx = qx; ny = qy; }   // (callers feed ascending indices: the first of equally near pellets stays)
   unsigned hi = b > dmin ? b : dmin; dsec = hi < dsec ? hi : dsec; dmin = b < dmin ? b : dmin;  // two smallest, lane-private
   if (k.rr >= d2) { c0 += 1; first = idx < first ? idx : first; }
   if (k.rr1 >= d2) c1 += 1;
 }
 
 #ifndef AGAR_CPU_EMU
+// nobody in reach: the nearest pellet itself (lowest index among equally near ones; index = slot * 64 + lane, so its low six bits name the
+// lane that holds it) and the wave-wide second smallest distance (the owner offers its own second, every other lane its minimum)
+AG_DEV void pel_reduce_near(unsigned lane_min, unsigned dmin, unsigned &dsec, unsigned &ni, float &nx, float &ny) {
+  ni = wred_min(lane_min == dmin ? ni : 0xffffffffu);
+  const int owner = (int)(ni & 63u);
+  dsec = wred_min(AG_LANE == owner ? dsec : lane_min);
+  nx = u2f(__builtin_amdgcn_readlane(f2u(nx), owner)); ny = u2f(__builtin_amdgcn_readlane(f2u(ny), owner));
+}
 // wave-wide combination of the lane-private partials of one pass (all 64 lanes active)
-AG_DEV void pel_reduce(float rr, unsigned &dmin, unsigned &dsec, int &c0, int &c1, unsigned &first) {
+AG_DEV void pel_reduce(float rr, unsigned &dmin, unsigned &dsec, int &c0, int &c1, unsigned &first, unsigned &ni, float &nx, float &ny) {
   const unsigned lane_min = dmin;
   dmin = wred_min(dmin);
-  if (rr >= u2f((int)dmin)) {  // (uniform branch) only when somebody is in reach
+  if (!(rr >= u2f((int)dmin))) { pel_reduce_near(lane_min, dmin, dsec, ni, nx, ny); return; }
+  ni = 0xffffffffu;
+  {  // (uniform branch) only when somebody is in reach
     c0 = wred_add(c0); c1 = wred_add(c1); first = wred_min(first);
     // second smallest overall: the lane that owns the minimum offers its own second, every other lane its minimum
     // (two lanes holding the same minimal value would mean two pellets at that distance: c0 >= 2, no inline eat)
@@ -1641,11 +1661,12 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
   int to_regen = regen ? (120 - q.ticks % 120) % 120 : -1, to_decay = decay ? 59 - q.elapsed % 60 : -1;
   // the pending tick of phase B: where the cell moved to, what it would weigh after one pellet
   float nx = q.x, ny = q.y, nvx = 0.0f, nvy = 0.0f, nsx = q.svx, nsy = q.svy;
-  unsigned nm = q.m; float rr1_pending = 0.0f;
+  unsigned nm = q.m; float rr1_pending = 0.0f, r1_pending = 0.0f;
   bool need = false; float dsec_pending = 0.0f;
 
   // everything of a tick after the pellets have been dealt with (ev: index of the eaten pellet or -1; ev2: a second one, eaten after it)
-  auto finish_tick = [&](int ev, int ev2, bool rescanned, float nslack) {
+  // (tracked: ev is the tracked pellet, eaten without a pass -- the disc stands)
+  auto finish_tick = [&](int ev, int ev2, bool rescanned, float nslack, bool tracked = false) {
     const bool regen_tick = to_regen == 0, decay_tick = to_decay == 0;
     q.m_move = q.m;
     q.x = nx; q.y = ny; q.vx = nvx; q.vy = nvy; q.svx = nsx; q.svy = nsy;
@@ -1659,8 +1680,11 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
       q.pel_changed = true;
       // one pellet eaten: it was the nearest one and the pass also saw the second nearest, which bounds the new pellet-free disc
       // around this very position -- no second pass on the next tick.  Two eaten: no bound is known, the next tick looks.
-      float sl = ag_sqrtf(dsec_pending) - q.r; sl = sl - 0.01f; sl = (ev2 < 0 && sl > 0.0f) ? sl : 0.0f;
-      q.slack = sl; s2 = sl * sl;
+      q.cidx = -1;
+      if (!tracked) {
+        float sl = ag_sqrtf(dsec_pending) - q.r; sl = sl - 0.01f; sl = (ev2 < 0 && sl > 0.0f) ? sl : 0.0f;
+        q.slack = sl; s2 = sl * sl;
+      }
     }
     if ((unsigned)q.hm < q.m) q.hm = (int)q.m;
     if (q.fcd > 0) q.fcd -= 1; if (q.action == 1 && q.fcd == 0) q.fcd = 10;   // Engine.hpp:1046-1054 (nothing can be ejected: mass < 35)
@@ -1675,6 +1699,8 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
     to_regen = to_regen == 0 ? 119 : to_regen - 1; to_decay = to_decay == 0 ? 59 : to_decay - 1;
     if (AG_RARE(regen_tick && tgt_p - q.np > 0)) {  // add_pellets(target - n): random_location(r) per pellet, Engine.hpp:418-424, 236-239
       const int n_new = tgt_p - q.np;
+      // (a disc with a tracked pellet keeps every OTHER pellet out of the radius after one eat)
+      const float reach = q.cidx >= 0 ? lut(lut_r, clamp_mass(q.m + AG_PELLET_MASS)) : q.r;
       for (int j = 0; j < n_new; j++) {
         float px = mt_to_float(mt_temper(mt[q.mtidx]), pel_span) + pel_r;
         float py = mt_to_float(mt_temper(mt[q.mtidx + 1]), pel_span) + pel_r;
@@ -1684,7 +1710,7 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
         // the pellet-free disc shrinks to exclude the new pellet (same margin as a pass leaves: sqrt(d2) - radius - 0.01); it is
         // NOT given up -- the new pellet falls into it about once in 10^4 times, and a lost disc costs a whole pass
         float ox = px - q.sx0, oy = py - q.sy0; float d2 = ox * ox, d2b = oy * oy; d2 = d2 + d2b;
-        float sl = ag_sqrtf(d2) - q.r; sl = sl - 0.01f; sl = sl > 0.0f ? sl : 0.0f;
+        float sl = ag_sqrtf(d2) - reach; sl = sl - 0.01f; sl = sl > 0.0f ? sl : 0.0f;
         if (sl < q.slack) { q.slack = sl; s2 = sl * sl; }
       }
       q.pel_changed = true;
@@ -1710,7 +1736,14 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
         if (AG_RARE(!(AV && o2 < s2))) {  // left the pellet-free disc (or none known): look at the pellets
           need = true;
           nm = clamp_mass(q.m + AG_PELLET_MASS);
-          float r1 = lut(lut_r, nm); rr1_pending = r1 * r1;
+          float r1 = lut(lut_r, nm); rr1_pending = r1 * r1; r1_pending = r1;
+          break;
+        }
+        // inside the disc only the tracked pellet can be within the radius, now or after one eat
+        if (q.cidx >= 0 && AG_RARE(rr >= sqr_dist(nx, ny, q.cx, q.cy))) {
+          nm = clamp_mass(q.m + AG_PELLET_MASS);
+          if (nm >= AG_CELL_MIN_SIZE + AG_FOOD_MASS && q.action != 0) { active = false; AG_WHY(q, 1); break; }   // (as after a pass: an eject / split may follow the eat)
+          finish_tick(q.cidx, -1, false, 0.0f, true);
           break;
         }
       }
@@ -1746,8 +1779,14 @@ template <bool AV, class PelT, class LutT, class MtT> AG_DEV void quiet_ticks(QS
         }
         else { active = false; AG_WHY(q, sc.cnt != 1 ? 6 : sc.cnt1 != 1 ? 7 : 1); }  // (nothing of this tick is committed)
       } else {
-        float sl = ag_sqrtf(sc.dmin2) - q.r; sl = sl - 0.01f;
-        nslack = sl > 0.0f ? sl : 0.0f;
+        // nobody in reach: the disc up to the second nearest pellet with the nearest one tracked, or -- should that leave no room -- the
+        // plain disc up to the nearest
+        float sl2 = ag_sqrtf(sc.dsec2) - r1_pending; sl2 = sl2 - 0.01f;
+#ifdef AG_NO_TRACK   // (measurement switch: the plain disc only)
+        sl2 = 0.0f;
+#endif
+        if (AV && sc.near >= 0 && sl2 > 0.0f) { nslack = sl2; q.cidx = sc.near; q.cx = sc.nx; q.cy = sc.ny; }
+        else { float sl = ag_sqrtf(sc.dmin2) - q.r; sl = sl - 0.01f; nslack = sl > 0.0f ? sl : 0.0f; q.cidx = -1; }
       }
       if (active) finish_tick(ev, ev2, true, nslack);
     }
@@ -1771,15 +1810,16 @@ template <int NS, bool AV> struct RegPel {
     return out;
   }
   template <bool AV2> AG_MEM PelScan scan(bool need, const PelQuery &k) {
-    PelScan out{3.0e38f, 3.0e38f, 0, 0, -1};
+    PelScan out{3.0e38f, 3.0e38f, 0, 0, -1, -1, 0.0f, 0.0f};
     if (!need) return out;
     ensure_pellets(c); pel_launder(c);
-    unsigned dmin = 0x7f800000u, dsec = 0x7f800000u, first = 0xffffffffu; int c0 = 0, c1 = 0;
-    AG_PEL_FOR(s, lane, i) { pel_accumulate<AV>(k, PELX(c, s, lane), PELY(c, s, lane), (unsigned)i, dmin, dsec, c0, c1, first); }
+    unsigned dmin = 0x7f800000u, dsec = 0x7f800000u, first = 0xffffffffu, ni = 0xffffffffu; int c0 = 0, c1 = 0; float nx = 0.0f, ny = 0.0f;
+    AG_PEL_FOR(s, lane, i) { pel_accumulate<AV>(k, PELX(c, s, lane), PELY(c, s, lane), (unsigned)i, dmin, dsec, c0, c1, first, ni, nx, ny); }
 #ifndef AGAR_CPU_EMU
-    pel_reduce(k.rr, dmin, dsec, c0, c1, first);
+    pel_reduce(k.rr, dmin, dsec, c0, c1, first, ni, nx, ny);
 #endif
     out.dmin2 = u2f((int)dmin); out.dsec2 = u2f((int)dsec); out.cnt = c0; out.cnt1 = c1; out.first = (int)first;
+    out.near = (int)ni; out.nx = nx; out.ny = ny;
     return out;
   }
   AG_MEM void append(int idx, float x, float y, int id) {  // pellets.emplace_back
@@ -1814,6 +1854,7 @@ template <int NS, bool AV> AG_DEV int quiet_run(AgCtx<NS, AV> &c, int max_ticks)
   q.last_decay = PR(c, PL_LAST_DECAY); q.nvt = PR(c, PL_NVTICKS); q.food_eaten = PR(c, PL_FOOD_EATEN); q.hm = PR(c, PL_HIGHEST_MASS);
   q.rate = (double)PRF(c, PL_ANTI_TEAM); q.slack = u2f(SR(c, AR_SAFE)); q.sx0 = PRF(c, PL_SAFE_X); q.sy0 = PRF(c, PL_SAFE_Y);
   q.mtidx = SR(c, AR_MTIDX); q.idc = SR(c, AR_IDC); q.passes = 0;
+  q.cx = PRF(c, PL_CAND_X); q.cy = PRF(c, PL_CAND_Y); q.cidx = PR(c, PL_CAND_IDX);
   RegPel<NS, AV> pel{c};
   quiet_ticks<AV>(q, c.gs->g, g_lut_r(c), g_lut_ms(c), (const AG_GLOBAL uint64_t *)g_mt(c), pel, max_ticks);
   if (q.done == 0) return 0;
@@ -1823,6 +1864,7 @@ template <int NS, bool AV> AG_DEV int quiet_run(AgCtx<NS, AV> &c, int max_ticks)
     s.m[0] = q.m; s.cmc[0] = q.m; s.crad[0] = q.r; s.cms[0] = q.hi;
     P[PL_ELAPSED] = q.elapsed; P[PL_MIN_MASS] = (int)q.m_move; P[PL_HIGHEST_MASS] = q.hm; P[PL_FEED_CD] = q.fcd; P[PL_SPLIT_CD] = q.scd;
     P[PL_FOOD_EATEN] = q.food_eaten; P[PL_LAST_DECAY] = q.last_decay; P[PL_SAFE_X] = f2u(q.sx0); P[PL_SAFE_Y] = f2u(q.sy0);
+    P[PL_CAND_X] = f2u(q.cx); P[PL_CAND_Y] = f2u(q.cy); P[PL_CAND_IDX] = q.cidx;
     if (q.last_ev >= 0) evp[0] = q.last_ev;
     if (q.last_ev2 >= 0) evp[1] = q.last_ev2;
   }

@@ -713,6 +713,8 @@ extern "C" int agarcl_get_seeds(agarcl_env *e, uint32_t *out) {
   return AGARCL_OK;
 }
 // Raw per-arena words (AR_*) and per-player words (PL_*, slot-major): introspection for the snapshot code and tests.
+static_assert(AR_WORDS == AGARCL_ARENA_WORDS && PL_WORDS == AGARCL_PLAYER_WORDS, "include/agarcl_batch.h must state the word counts of agar_types.h");
+extern "C" int agarcl_player_words(void) { return PL_WORDS; }
 extern "C" int agarcl_get_arena_words(agarcl_env *e, int32_t arena, int32_t *ar_out, int32_t *pl_out) {
   if (!e || arena < 0 || arena >= e->d.A) return fail(AGARCL_E_INVALID, "agarcl_get_arena_words: bad arguments");
   std::vector<int32_t> t;

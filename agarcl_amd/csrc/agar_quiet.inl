@@ -40,11 +40,12 @@ template <int NS, int QG = AG_QG> struct GrpPel {
     return out;
   }
   template <bool AV> AG_MEM PelScan scan(bool need, const PelQuery &k) {
-    PelScan out{3.0e38f, 3.0e38f, 0, 0, -1};
+    PelScan out{3.0e38f, 3.0e38f, 0, 0, -1, -1, 0.0f, 0.0f};
     if (!need) return out;
-    unsigned dmin = 0x7f800000u, dsec = 0x7f800000u, first = 0xffffffffu; int c0 = 0, c1 = 0;
-    for (int i = 0; i < NS * 64; i++) pel_accumulate<AV>(k, xy[2 * i], xy[2 * i + 1], (unsigned)i, dmin, dsec, c0, c1, first);
+    unsigned dmin = 0x7f800000u, dsec = 0x7f800000u, first = 0xffffffffu, ni = 0xffffffffu; int c0 = 0, c1 = 0; float nx = 0.0f, ny = 0.0f;
+    for (int i = 0; i < NS * 64; i++) pel_accumulate<AV>(k, xy[2 * i], xy[2 * i + 1], (unsigned)i, dmin, dsec, c0, c1, first, ni, nx, ny);
     out.dmin2 = u2f((int)dmin); out.dsec2 = u2f((int)dsec); out.cnt = c0; out.cnt1 = c1; out.first = (int)first;
+    if (!(k.rr >= out.dmin2)) { out.near = (int)ni; out.nx = nx; out.ny = ny; }
     return out;
   }
 #else
@@ -80,7 +81,7 @@ template <int NS, int QG = AG_QG> struct GrpPel {
     return out;
   }
   template <bool AV> AG_MEM PelScan scan(bool need, const PelQuery &k) {
-    PelScan out{3.0e38f, 3.0e38f, 0, 0, -1};
+    PelScan out{3.0e38f, 3.0e38f, 0, 0, -1, -1, 0.0f, 0.0f};
     unsigned long long todo = __ballot(need);
     if (todo) ag_mem_fence();  // pellets this wave wrote earlier (swap-pop, regeneration) must be visible to the pass
     const int lane = (int)threadIdx.x & 63;
@@ -96,18 +97,23 @@ template <int NS, int QG = AG_QG> struct GrpPel {
       auto gp = (const AG_GLOBAL XY *)(((unsigned long long)hi << 32) | lo) + lane;
       XY p[NS];
       _Pragma("unroll") for (int s = 0; s < NS; s++) p[s] = gp[s * 64];
-      // the usual outcome is "nothing in reach": a lean minimum first, the full accumulation only when something is
-      unsigned dmin = 0x7f800000u, dsec = 0x7f800000u, first = 0xffffffffu; int c0 = 0, c1 = 0;
+      // the usual outcome is "nothing in reach": the two smallest distances and the nearest pellet first, the counts only when something is
+      unsigned dmin = 0x7f800000u, dsec = 0x7f800000u, first = 0xffffffffu, ni = 0xffffffffu; int c0 = 0, c1 = 0; float nx = 0.0f, ny = 0.0f;
       _Pragma("unroll") for (int s = 0; s < NS; s++) {
-        if (pel_visible<AV>(b, p[s].x, p[s].y)) { unsigned v = (unsigned)f2u(sqr_dist(b.x, b.y, p[s].x, p[s].y)); dmin = v < dmin ? v : dmin; }
+        if (pel_visible<AV>(b, p[s].x, p[s].y)) {
+          const unsigned v = (unsigned)f2u(sqr_dist(b.x, b.y, p[s].x, p[s].y));
+          if (v < dmin) { ni = (unsigned)(s * 64 + lane); nx = p[s].x; ny = p[s].y; }
+          const unsigned hi = v > dmin ? v : dmin; dsec = hi < dsec ? hi : dsec; dmin = v < dmin ? v : dmin;
+        }
       }
+      const unsigned lane_min = dmin;
       dmin = wred_min(dmin);
       if (b.rr >= u2f((int)dmin)) {  // (uniform branch)
-        dmin = 0x7f800000u;
-        _Pragma("unroll") for (int s = 0; s < NS; s++) pel_accumulate<AV>(b, p[s].x, p[s].y, (unsigned)(s * 64 + lane), dmin, dsec, c0, c1, first);
-        pel_reduce(b.rr, dmin, dsec, c0, c1, first);
-      }
-      if ((lane & ~(QG - 1)) == src) { out.dmin2 = u2f((int)dmin); out.dsec2 = u2f((int)dsec); out.cnt = c0; out.cnt1 = c1; out.first = (int)first; }
+        dmin = 0x7f800000u; dsec = 0x7f800000u; ni = 0xffffffffu;
+        _Pragma("unroll") for (int s = 0; s < NS; s++) pel_accumulate<AV>(b, p[s].x, p[s].y, (unsigned)(s * 64 + lane), dmin, dsec, c0, c1, first, ni, nx, ny);
+        pel_reduce(b.rr, dmin, dsec, c0, c1, first, ni, nx, ny);
+      } else pel_reduce_near(lane_min, dmin, dsec, ni, nx, ny);
+      if ((lane & ~(QG - 1)) == src) { out.dmin2 = u2f((int)dmin); out.dsec2 = u2f((int)dsec); out.cnt = c0; out.cnt1 = c1; out.first = (int)first; out.near = (int)ni; out.nx = nx; out.ny = ny; }
     }
     return out;
   }
@@ -153,6 +159,7 @@ template <int NS, bool AV, int QG, int TSLG> AG_DEV QHandOver quiet_arena(const 
   q.action = P[PL_ACTION]; q.tx = u2f(P[PL_TX]); q.ty = u2f(P[PL_TY]);
   q.elapsed = P[PL_ELAPSED]; q.fcd = P[PL_FEED_CD]; q.scd = P[PL_SPLIT_CD]; q.last_decay = P[PL_LAST_DECAY]; q.nvt = P[PL_NVTICKS];
   q.food_eaten = P[PL_FOOD_EATEN]; q.hm = P[PL_HIGHEST_MASS]; q.rate = (double)u2f(P[PL_ANTI_TEAM]); q.sx0 = u2f(P[PL_SAFE_X]); q.sy0 = u2f(P[PL_SAFE_Y]); q.passes = P[PL_PASSES];
+  q.cx = u2f(P[PL_CAND_X]); q.cy = u2f(P[PL_CAND_Y]); q.cidx = P[PL_CAND_IDX];
   q.nv = S[AR_NVIR]; q.np = S[AR_NPEL]; q.ticks = S[AR_TICKS]; q.slack = u2f(S[AR_SAFE]); q.mtidx = S[AR_MTIDX]; q.idc = S[AR_IDC];
   int clock = S[AR_CLOCK], done_flag = S[AR_DONE];
   float dx = 0.0f, dy = 0.0f; int action = 0;
@@ -190,6 +197,18 @@ template <int NS, bool AV, int QG, int TSLG> AG_DEV QHandOver quiet_arena(const 
 #endif
   }
 #endif
+  {
+#ifndef AGAR_CPU_EMU
+  // The stores below go to the words the prologue loaded.  Left to itself the compiler keeps every one of those 64-bit addresses alive
+  // across the whole tick loop -- 128 registers do not hold them: 176-192 bytes of scratch per lane, 50 MB of spill traffic a step at
+  // 262 144 arenas.  An arena index the optimiser cannot see through makes it form the addresses again here: one register lives on.
+  int arena_w = arena; asm volatile("" : "+v"(arena_w));
+  const TileWords<int32_t> S{(AG_GLOBAL int32_t *)(hot.ar + AG_TILE_BASE(arena_w, AR_WORDS)), ag_ts_lg};
+  const TileWords<int32_t> P{(AG_GLOBAL int32_t *)(hot.pl + AG_TILE_BASE(arena_w, PL_WORDS)), ag_ts_lg};
+  auto C = (AG_GLOBAL uint32_t *)(hot.cells + AG_TILE_BASE(arena_w, CF_ALL * AG_CC));
+  auto qi = (AG_GLOBAL int32_t *)(gs->qinfo + (size_t)arena_w * 2);
+  arena = arena_w;
+#endif
   if (lead && ok) {
     if (q.done > 0) {
       C[AG_CELL_W(CF_X, 0)] = (uint32_t)f2u(q.x); C[AG_CELL_W(CF_Y, 0)] = (uint32_t)f2u(q.y); C[AG_CELL_W(CF_VX, 0)] = (uint32_t)f2u(q.vx); C[AG_CELL_W(CF_VY, 0)] = (uint32_t)f2u(q.vy);
@@ -197,6 +216,7 @@ template <int NS, bool AV, int QG, int TSLG> AG_DEV QHandOver quiet_arena(const 
       C[AG_CELL_W(CF_CMC, 0)] = q.m; C[AG_CELL_W(CF_CRAD, 0)] = (uint32_t)f2u(q.r); C[AG_CELL_W(CF_CMS, 0)] = (uint32_t)f2u(q.hi);
       P[PL_ELAPSED] = q.elapsed; P[PL_MIN_MASS] = (int)q.m_move; P[PL_HIGHEST_MASS] = q.hm; P[PL_FEED_CD] = q.fcd; P[PL_SPLIT_CD] = q.scd;
       P[PL_FOOD_EATEN] = q.food_eaten; P[PL_LAST_DECAY] = q.last_decay; P[PL_SAFE_X] = f2u(q.sx0); P[PL_SAFE_Y] = f2u(q.sy0); P[PL_PASSES] = q.passes;
+      P[PL_CAND_X] = f2u(q.cx); P[PL_CAND_Y] = f2u(q.cy); P[PL_CAND_IDX] = q.cidx;
       S[AR_NEVP] = (q.last_ev >= 0 ? 1 : 0) + (q.last_ev2 >= 0 ? 1 : 0); S[AR_NEVV] = 0; S[AR_NPEL] = q.np; S[AR_TICKS] = q.ticks; S[AR_CLOCK] = clock + q.done; S[AR_SAFE] = f2u(q.slack); S[AR_MTIDX] = q.mtidx; S[AR_IDC] = q.idc;
       if (q.last_ev >= 0) { auto ge = (AG_GLOBAL int32_t *)(gs->ev_p + (size_t)arena * AG_EV_CAP); ge[0] = q.last_ev; if (q.last_ev2 >= 0) ge[1] = q.last_ev2; }
       auto cn = (AG_GLOBAL int32_t *)(gs->counts + (size_t)arena * 4);
@@ -207,6 +227,7 @@ template <int NS, bool AV, int QG, int TSLG> AG_DEV QHandOver quiet_arena(const 
     // epilogue of BaseEnvironment::step for a live single player: no respawn in any mode
     if (finished && with_env) emit_agent_result(gs, slot, arena, 1, 0, q.m, before, 0, done_flag);
     qi[0] = q.done; qi[1] = (int)before;
+  }
   }
   QHandOver h; h.done = ok ? q.done : -1; h.before = (int)before;
   return h;

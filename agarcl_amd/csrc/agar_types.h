@@ -27,7 +27,10 @@ enum {
   PL_FOOD_EATEN, PL_HIGHEST_MASS, PL_CELLS_EATEN, PL_VIRUSES_EATEN, PL_MIN_MASS, PL_NVTICKS, PL_PID, PL_KIND,
   PL_SAFE_X, PL_SAFE_Y,  // single-player arenas: where the pellet-free disc of radius AR_SAFE was measured (agar_core.inl quiet_ticks)
   PL_PASSES,             // diagnostics: how often this arena's pellet array has been read from memory (slot 0 only; never part of a blob)
-  PL_WORDS = 20
+  // single-player arenas: the ONE pellet the disc does not exclude -- the nearest one at the time of the pass (position as f32 bits, index;
+  // index < 0: none).  With it the disc reaches to the SECOND nearest pellet, and eating the tracked one needs no pass (quiet_ticks)
+  PL_CAND_X, PL_CAND_Y, PL_CAND_IDX, PL_SPARE,
+  PL_WORDS = 24
 };
 // per-arena int32 words ([A][AR_WORDS])
 enum {

@@ -47,7 +47,7 @@ struct EngineProxy {
     return out;
   }
   py::tuple arena_words(int arena) {
-    py::array_t<int32_t> ar(32), pl({(py::ssize_t)players(), (py::ssize_t)20});
+    py::array_t<int32_t> ar(AGARCL_ARENA_WORDS), pl({(py::ssize_t)players(), (py::ssize_t)AGARCL_PLAYER_WORDS});
     check(agarcl_get_arena_words(h, arena, ar.mutable_data(), pl.mutable_data()));
     return py::make_tuple(ar, pl);
   }

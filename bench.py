@@ -71,12 +71,12 @@ def requested_bytes(work, counts, P, n_agents, ticks, pellet_cap):
     agar_core.inl arena_load / arena_store (general engine); the shared mass tables stay in L2 and are not counted."""
     front_steps, general_steps, pellet_moves = (float(x) for x in work[:3])
     n_pel, n_vir, n_food, n_cells = counts
-    # front part, per arena-step: loads cell 0 (48) + 15 player words (60) + 9 arena words (36) + action (12);
-    # stores cell (40) + player (52) + arena (40) + counts (16) + results f64/i32/u8/packed (21) + hand-over (8)
-    front = 156.0 + 177.0
-    # general engine, per arena-step: arena words r+w (256), player words r+w (160 P), all 32 cell slots read (1536 P) +
+    # front part, per arena-step: loads cell 0 (48) + 18 player words (72) + 9 arena words (36) + action (12);
+    # stores cell (40) + player (64) + arena (40) + counts (16) + results f64/i32/u8/packed (21) + hand-over (8)
+    front = 168.0 + 189.0
+    # general engine, per arena-step: arena words r+w (256), player words r+w (192 P), all 32 cell slots read (1536 P) +
     # live cells written (48 N_c), results (29 A) + counts (16); per tick: viruses x/y/mass (12 N_v) and foods (20 N_f) read
-    general = 256.0 + 160.0 * P + 1536.0 * P + 48.0 * n_cells + 29.0 * n_agents + 16.0 + ticks * (12.0 * n_vir + 20.0 * n_food)
+    general = 256.0 + 192.0 * P + 1536.0 * P + 48.0 * n_cells + 29.0 * n_agents + 16.0 + ticks * (12.0 * n_vir + 20.0 * n_food)
     return front * front_steps + general * general_steps + pellet_moves * pellet_cap * 8.0
 
 

@@ -212,8 +212,13 @@ int agarcl_adopt_arena(agarcl_env *env, int32_t arena, const uint32_t *blob_host
 int agarcl_seed_arena(agarcl_env *env, int32_t arena, uint32_t seed);
 /* last seed of every arena, u32[num_arenas] (BaseEnvironment::seed_, the "seed" field of a snapshot, :225) */
 int agarcl_get_seeds(agarcl_env *env, uint32_t *out_host);
-/* raw words of one arena: ar_out i32[32] (agar_types.h AR_*), pl_out i32[players][20] (PL_*, slot-major); either may be NULL */
+/* raw words of one arena: ar_out i32[AGARCL_ARENA_WORDS] (agar_types.h AR_*), pl_out i32[players][AGARCL_PLAYER_WORDS] (PL_*, slot-major);
+ * either may be NULL.  agarcl_player_words() returns AGARCL_PLAYER_WORDS of the library that is loaded (callers without the header size
+ * their buffer by it). */
+#define AGARCL_ARENA_WORDS 32
+#define AGARCL_PLAYER_WORDS 24
 int agarcl_get_arena_words(agarcl_env *env, int32_t arena, int32_t *ar_out, int32_t *pl_out);
+int agarcl_player_words(void);
 
 /* introspection */
 int agarcl_num_arenas(agarcl_env *env);
