@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 ARENAS_PER_GPU = 4096
 LARGE_ARENAS = 65536        # the "roofline_large" block: north star ">= 50k parallel arenas"
 XLARGE_ARENAS = 262144      # "roofline_xlarge": the same kernels where they are bandwidth-bound (two-kernel step, one lane per arena)
+SWEEP_ARENAS = (16384, 131072)   # "roofline_sweep": two more sizes around roofline_large
 CFG = dict(num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True, num_pellets=1000, num_viruses=0,
            num_bots=0, reward_type=1, c_death=0, mode_number=0)
 # The headline line is C2.  The other SURVEY 8(d) workloads are selectable for DESIGN.md's measurement table only.
@@ -459,6 +460,17 @@ def main():
                 out["roofline_xlarge"] = rx
             except Exception as ex:
                 out["roofline_xlarge"] = {"error": str(ex)}
+            # between and beside them: where the step turns from latency- to bandwidth-bound (compact entries, same accounting)
+            sweep = []
+            for a_ in SWEEP_ARENAS:
+                try:
+                    r_ = run_workload(torch, np, VecEnvironment, agdist, dev, dev_index, 0, 1, a_, 100, 20, cfg, rand_act, False, False, "block", "none")
+                    b_ = roofline_block(r_, a_, 100, ticks, cfg, args.workload)
+                    sweep.append({"arenas": a_, "ms_per_step": r_["elapsed"] / 100 * 1e3, "value_env_steps_per_s": a_ * ticks * 100 / r_["elapsed"],
+                                  "achieved": b_["achieved"], "frac": b_["frac"], "unit": b_["unit"]})
+                except Exception as ex:
+                    sweep.append({"arenas": a_, "error": str(ex)})
+            out["roofline_sweep"] = sweep
         if world == 1 and not args.no_full and args.workload == "C2":
             # the other two regimes in the same run: the full rule set at mass 1000 (BASELINE configs[2]) and a learning agent's mid-game
             full = {}
