@@ -177,11 +177,14 @@ template <int NS, bool AV, int TSLG> __global__ void __launch_bounds__(64) AG_KS
 }
 // 256 threads = 256 / QG arenas per workgroup, QG lanes each (agar_quiet.inl)
 // k_quiet stands alone only in the two-kernel step, which is chosen where the batch does not fit k_fused's 2048 wavefronts
-// (> 131072 arenas) or the arenas are not quiet.  Capped at 128 VGPRs (4 waves/SIMD instead of 3, 80 bytes of scratch):
-// measured on MI355X, C2, k_quiet + work-list k_step with 16 lanes per arena: 65 536 arenas 52.3 -> 49.6 us per step,
-// 262 144 arenas 160.4 -> 148.8 us.
+// (> 131072 arenas) or the arenas are not quiet.  Register budget of 3 waves per SIMD (168 VGPRs).  Round 2 capped it at 128 (4 waves: 80
+// bytes of scratch then, and 65 536 arenas 52.3 -> 49.6 us); with the tracked pellet in the tick loop's state the 16-slot variants need
+// 156-159 registers, and at 128 every launch pushed 112-192 bytes per lane through scratch -- at 262 144 arenas 66 of the 198 MB a step
+// moved.  Measured with the budget of 3 waves (no scratch; the 4- and 8-slot variants still fit 128 registers and keep 4 waves): 262 144
+// arenas 45.8 -> 36.6 us per step, 524 288: 81.6 -> 55.0, the two-kernel step at 4096 / 65 536 / 131 072 arenas 15.3 -> 11.0 /
+// 25.0 -> 18.2 / 33.1 -> 24.2 us (the single launch k_fused still wins up to 131 072: 16.7 and 22.6 us at 65 536 and 131 072).
 #ifndef AG_KQUIET_ATTR
-#define AG_KQUIET_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#define AG_KQUIET_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
 #endif
 template <int NS, bool AV, int QG, int TSLG> __global__ void __launch_bounds__(256) AG_KQUIET_ATTR k_quiet(const AgHot hot, const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int parity) {
   int arena = (TSLG ? ag_xcd_swizzle((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * (256 / QG) + (int)threadIdx.x / QG;
