@@ -157,7 +157,13 @@ __global__ void __launch_bounds__(256) k_screen_obs_pixelwise(const AgState *__r
     }
   }
 }
-#define AG_SCR_BAND 7168   // pixels of one LDS band (28 KiB of packed RGBA): a whole 84 x 84 frame
+// pixels of one LDS band (14 KiB of packed RGBA): half an 84 x 84 frame.  With the whole frame in one band (7168 pixels, 28 KiB) the kernel
+// holds 52 KB of LDS and three workgroups share a compute unit; with two bands of 42 rows it holds 38 KB and four do -- the second pass over
+// the entity boxes costs less than the fourth workgroup brings: 4096 frames 215.8 -> 196.4 us, agent view 285.8 -> 254.8 (four bands of 21
+// rows, five workgroups: 214.2 / 269.9)
+#ifndef AG_SCR_BAND
+#define AG_SCR_BAND 3584
+#endif
 __global__ void __launch_bounds__(256) k_screen_obs(const AgState *__restrict__ gs, AgScreenCfg o, uint8_t *out) {
   __shared__ float ex[AG_SCR_CAP], ey[AG_SCR_CAP], er[AG_SCR_CAP];
   __shared__ unsigned ec[AG_SCR_CAP];  // 0x00BBGGRR | nsides << 24
