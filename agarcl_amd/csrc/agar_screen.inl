@@ -164,12 +164,14 @@ __global__ void __launch_bounds__(256) k_screen_obs_pixelwise(const AgState *__r
 #ifndef AG_SCR_BAND
 #define AG_SCR_BAND 3584
 #endif
-__global__ void __launch_bounds__(256) k_screen_obs(const AgState *__restrict__ gs, AgScreenCfg o, uint8_t *out) {
+// TAB: capacity of the per-column / per-row tables (256 for frames up to 256 x 256 -- with it the kernel holds 31 KB of LDS and FIVE workgroups
+// share a compute unit --, 1024 beyond)
+template <int TAB> __global__ void __launch_bounds__(256) k_screen_obs(const AgState *__restrict__ gs, AgScreenCfg o, uint8_t *out) {
   __shared__ float ex[AG_SCR_CAP], ey[AG_SCR_CAP], er[AG_SCR_CAP];
   __shared__ unsigned ec[AG_SCR_CAP];  // 0x00BBGGRR | nsides << 24
   __shared__ unsigned fb[AG_SCR_BAND];  // 0xAABBGGRR of the band's pixels
-  __shared__ uint8_t colflag[1024], rowflag[1024];   // bit 0: a grid line falls into this pixel column / row; bit 1: the column / row lies inside the arena
-  __shared__ float colx[1024], rowy[1024];           // world coordinate of every pixel column's / row's centre
+  __shared__ uint8_t colflag[TAB], rowflag[TAB];   // bit 0: a grid line falls into this pixel column / row; bit 1: the column / row lies inside the arena
+  __shared__ float colx[TAB], rowy[TAB];           // world coordinate of every pixel column's / row's centre
   __shared__ float eapo[AG_SCR_CAP];                 // apothem of an entity's polygon
   __shared__ unsigned ebx[AG_SCR_CAP], eby[AG_SCR_CAP];   // pixel box of an entity: first | last << 16 column / row (one pixel of margin; empty: first > last)
   __shared__ int n_list;
