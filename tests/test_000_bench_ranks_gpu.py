@@ -68,6 +68,7 @@ def test_bench_line_as_the_driver_runs_it_gpu():
     c = b["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["c3m6_value"] > 0 and c["unit"] == "env-steps/s" and c["sample"]
     assert b["roofline_large"]["arenas"] == 65536 and b["roofline_xlarge"]["arenas"] == 262144
+    assert [e["arenas"] for e in b["roofline_sweep"]] == [16384, 131072] and all("error" not in e and e["ms_per_step"] > 0 and 0 < e["frac"] <= 1 for e in b["roofline_sweep"])
     full = b["roofline_full"]
     assert set(full) == {"C3m6@4096", "mid@4096"}
     for v in full.values():
