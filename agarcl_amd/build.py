@@ -32,16 +32,39 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force=False, verbose=False, extra=(), out=OUT):
-    """extra/out: diagnostic variants only (e.g. -DAGAR_PROFILE -> build_variants/lib_PROF.so, used by scripts/; build_variants/ is
+PARTS = [(ns, av) for ns in (4, 8, 16, 32) for av in (1, 0)]   # (pellet slots per lane, all buckets visible): one translation unit each
+
+
+def _compile(args):
+    subprocess.check_call(args)
+    return args[-1]
+
+
+def build(force=False, verbose=False, extra=(), out=OUT, single=False, jobs=None):
+    """Nine translation units compiled in parallel -- the main unit (-DAG_SPLIT_BUILD: host code, C ABI, observation kernels) and one
+    part unit per (NS, AV) pair (-DAG_PART_NS / -DAG_PART_AV: the step / reset kernels of that pair, agar_engine.hip "split build") --
+    linked into one shared library.  single=True compiles the same source as one unit (3-4 minutes instead of < 1).
+    extra/out: diagnostic variants only (e.g. -DAGAR_PROFILE -> build_variants/lib_PROF.so, used by scripts/; build_variants/ is
     git-ignored and travels to the GPU box only while it exists -- delete it when the measurements are done)."""
     if not force and not needs_build() and out == OUT:
         return OUT
-    cmd = [hipcc()] + FLAGS + list(extra) + ["-o", out, SRC]
+    base = [hipcc()] + FLAGS + list(extra)
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd)
-    return OUT
+        base.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    if single or os.environ.get("AGARCL_BUILD_SINGLE") == "1":
+        subprocess.check_call(base + ["-o", out, SRC])
+        return out
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    comp = [f for f in base if f != "-shared"]
+    with tempfile.TemporaryDirectory(prefix="agarcl_build_") as tmp:
+        units = [comp + ["-DAG_SPLIT_BUILD", "-c", SRC, "-o", os.path.join(tmp, "main.o")]]
+        for ns, av in PARTS:
+            units.append(comp + ["-DAG_PART_NS=%d" % ns, "-DAG_PART_AV=%d" % av, "-c", SRC, "-o", os.path.join(tmp, "part_%d_%d.o" % (ns, av))])
+        with ThreadPoolExecutor(max_workers=jobs or min(len(units), os.cpu_count() or 1)) as pool:
+            objs = list(pool.map(_compile, units))
+        subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
 
 
 def pybind_out():
@@ -70,4 +93,4 @@ if __name__ == "__main__":
     elif "--pybind" in sys.argv:
         print(build_pybind(True))
     else:
-        print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+        print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, single="--single" in sys.argv))

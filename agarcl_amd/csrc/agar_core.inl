@@ -1829,6 +1829,7 @@ template <int NS, bool AV> struct RegPel {
     c.pel_dirty = true;
   }
   AG_MEM void swap_pop(int ev, int np) {
+    ensure_pellets(c);   // the tracked pellet is eaten without a pass: on a launch that has not read the pellets yet the registers hold nothing to swap
     if (np > 1 && ev < np - 1) { pel_move(c, ev, np - 1); auto gid = g_pid(c); AG_SERIAL { gid[ev] = gid[np - 1]; } }
     int lastp = np - 1;
     AG_PEL_FOR(sl_, lane, i) { if (i == lastp) { PELX(c, sl_, lane) = AG_PEL_SENTINEL; PELY(c, sl_, lane) = AG_PEL_SENTINEL; PEL_MARK(c, sl_, lane); } }
@@ -1880,6 +1881,7 @@ template <int NS, bool AV> AG_DEV int quiet_run(AgCtx<NS, AV> &c, int max_ticks)
 template <int NS, bool AV> AG_DEV void arena_tick(AgCtx<NS, AV> &c) {
   ensure_pellets(c);
   SW(c, AR_SAFE, 0);  // the out-of-reach budget is only maintained by quiet_run
+  if (c.P == 1) { AG_SERIAL { PLS(c, 0)[PL_CAND_IDX] = -1; } ag_lds_order(); }   // ... and the tracked pellet goes with the disc (no stale index may outlive it)
   SW(c, AR_NEVP, 0); SW(c, AR_NEVV, 0);
   AG_T(c, 1);
   for (int k = 0; k < c.P; k++) tick_player(c, SR(c, AR_ORDER0 + k));
@@ -2014,7 +2016,7 @@ template <int NS, bool AV> AG_DEV void env_reset(AgCtx<NS, AV> &c, int reset_ids
     if (i >= na) { int b = mode > 6 ? mode - 7 : (i - na) % nb; kind = b == 0 ? AG_KIND_HUNGRY : b == 1 ? AG_KIND_HUNGRY_SHY : b == 2 ? AG_KIND_AGGRESSIVE : b == 3 ? AG_KIND_AGGRESSIVE_SHY : AG_KIND_HUNGRY; }
     int *P = PLS(c, i);
     AG_SERIAL {
-      P[PL_PID] = pid; P[PL_KIND] = kind; P[PL_ACTION] = 0; P[PL_TX] = 0; P[PL_TY] = 0;
+      P[PL_PID] = pid; P[PL_KIND] = kind; P[PL_ACTION] = 0; P[PL_TX] = 0; P[PL_TY] = 0; P[PL_CAND_IDX] = -1;   // (AR_SAFE is zeroed above: no tracked pellet either)
       P[PL_FOOD_EATEN] = 0; P[PL_HIGHEST_MASS] = (int)AG_CELL_MIN_SIZE; P[PL_CELLS_EATEN] = 0; P[PL_VIRUSES_EATEN] = 0;
       if (kind == 0) (void)ag_rand_next(rnd);  // Player(pid, name) draws random_color(): core/Player.hpp:53, color.hpp:14-16
     }

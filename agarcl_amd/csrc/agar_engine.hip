@@ -22,15 +22,19 @@
 #include "../../include/agarcl_batch.h"
 #include "agar_core.inl"
 #include "agar_quiet.inl"
+#ifndef AG_PART_NS   // (split build: the observation kernels live in the main unit only)
 #include "agar_obs.inl"
 #include "agar_screen.inl"
 #include "agar_gobigger.inl"
 #include "agar_ram.inl"
+#endif
 
 // ---- thread-local error string -------------------------------------------------------------------
 static thread_local std::string g_err;
 static int fail(int code, const std::string &m) { g_err = m; return code; }
+#ifndef AG_PART_NS   // (split build: the C ABI lives in the main unit only)
 extern "C" const char *agarcl_last_error(void) { return g_err.c_str(); }
+#endif
 
 // host index of word w of arena a in a tile-transposed array with R words per arena (agar_types.h)
 static inline size_t tix(int ag_ts_lg, size_t a, size_t R, size_t w) { return AG_TILE_BASE(a, R) + AG_TW(w); }
@@ -254,6 +258,7 @@ template <int NS, bool AV> __global__ void __launch_bounds__(64) k_respawn(const
   respawn_dead(c);
   arena_store(c);
 }
+#ifndef AG_PART_NS   // (split build: plain kernels live in the main unit only)
 __global__ void k_set_ar_word(int32_t *ar, int ag_ts_lg, int word, int n, int value) {  // one arena word of every arena
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) ar[AG_TILE_BASE(i, AR_WORDS) + AG_TW(word)] = value;
@@ -262,6 +267,31 @@ __global__ void k_set_ar_word(int32_t *ar, int ag_ts_lg, int word, int n, int va
 __global__ void k_tile_gather(const uint32_t *src, uint32_t *dst, int R, int ag_ts_lg) { int w = blockIdx.x * blockDim.x + threadIdx.x; if (w < R) dst[w] = src[AG_TW(w)]; }
 __global__ void k_tile_scatter(uint32_t *dst, const uint32_t *src, int R, int ag_ts_lg) { int w = blockIdx.x * blockDim.x + threadIdx.x; if (w < R) dst[AG_TW(w)] = src[w]; }
 #endif
+#endif
+
+// ---- split build (build.py): the step / reset kernels of ONE (NS, AV) pair per translation unit -----------------------------------------
+// The 8 (pellet slots, all-visible) pairs x (2 layouts x 5 lane-group sizes) instantiations of the step kernels are what makes this file
+// slow to compile (3 m 47 s in one piece).  build.py therefore compiles it nine times in parallel: eight "part" units (-DAG_PART_NS=<4|8|16|32>
+// -DAG_PART_AV=<0|1>: only the kernel templates above and their explicit instantiations for that pair; the rest of the file is skipped) and the
+// main unit (-DAG_SPLIT_BUILD: everything else, with the step kernels declared `extern template`), linked into one libagarcl_hip.so.  The
+// same source without either macro still builds as a single unit.
+#if !defined(AGAR_CPU_EMU) && (defined(AG_PART_NS) || defined(AG_SPLIT_BUILD))
+#define AG_INST_STEP(X, N, V, T) X template __global__ void k_step<N, V, T>(const AgState *__restrict__, const float *, const int32_t *, int, int, int, int, int);
+#define AG_INST_FRONT(X, N, V, Q, T) \
+  X template __global__ void k_quiet<N, V, Q, T>(const AgHot, const AgState *__restrict__, const float *, const int32_t *, int, int, int, int); \
+  X template __global__ void k_fused<N, V, Q, T>(const AgHot, const AgState *__restrict__, const float *, const int32_t *, int, int, int, int);
+#define AG_INST_LAYOUT(X, N, V, T) AG_INST_STEP(X, N, V, T) AG_INST_FRONT(X, N, V, 1, T) AG_INST_FRONT(X, N, V, 2, T) AG_INST_FRONT(X, N, V, 4, T) AG_INST_FRONT(X, N, V, 8, T) AG_INST_FRONT(X, N, V, 16, T)
+#define AG_INST_PAIR(X, N, V) AG_INST_LAYOUT(X, N, V, 0) AG_INST_LAYOUT(X, N, V, 6) \
+  X template __global__ void k_reset<N, V>(const AgState *__restrict__, const uint8_t *, int); \
+  X template __global__ void k_respawn<N, V>(const AgState *__restrict__);
+#ifdef AG_PART_NS
+AG_INST_PAIR(, AG_PART_NS, (AG_PART_AV != 0))
+#else
+#define AG_INST_ALL(N) AG_INST_PAIR(extern, N, true) AG_INST_PAIR(extern, N, false)
+AG_INST_ALL(4) AG_INST_ALL(8) AG_INST_ALL(16) AG_INST_ALL(32)
+#endif
+#endif
+#ifndef AG_PART_NS   // (a part unit ends here)
 // host copy of ONE arena's block of a tile-transposed array (32-bit words): device gather / scatter through a staging buffer
 template <class T> static int pull_t(agarcl_env *e, std::vector<T> &h, const T *dev, size_t a, size_t R) {
   static_assert(sizeof(T) == 4, "32-bit words");
@@ -730,10 +760,14 @@ extern "C" int agarcl_get_arena_words(agarcl_env *e, int32_t arena, int32_t *ar_
 // Every reset restarts the flag watch (agarcl_poll_flags): the device word is zeroed in front of k_reset, whose not-reset arenas OR their
 // flags back in (a full reset leaves none), the host's accumulated view is dropped, and a statistics sample that is still in flight --
 // taken before this reset -- must not bring the old flags back.
-static int restart_flag_watch(agarcl_env *e) {
+// `resample`: the reset covers every arena (or a state was loaded), so the arenas may behave quite unlike what the step form was chosen for:
+// the step-form statistics are sampled 2, 8 and 32 steps later.  A MASKED reset leaves the sampling cadence alone -- a learner that calls
+// reset(mask = dones) after every step would otherwise pay a copy and an event record every other step for ever, and feed the fused /
+// two-kernel choice from 2-step windows.
+static int restart_flag_watch(agarcl_env *e, bool resample) {
   if (hipMemsetAsync(e->s.qstat + 1, 0, 4, e->stream) != hipSuccess) return fail(AGARCL_E_HIP, "flag watch reset failed");
   e->flags_seen = 0; e->stat_stale_flags = e->stat_pending;
-  e->poll_gap = 2; e->next_poll = e->step_no + 2;   // and the step-form statistics are sampled soon again
+  if (resample) { e->poll_gap = 2; e->next_poll = e->step_no + 2; }
   return 0;
 }
 #endif
@@ -746,7 +780,9 @@ extern "C" int agarcl_reset(agarcl_env *e, const uint8_t *mask_host, int32_t res
     mask_dev = e->d_mask;
     HIPCHK(hipMemcpyAsync(mask_dev, mask_host, (size_t)e->d.A, hipMemcpyHostToDevice, e->stream));
   }
-  if (restart_flag_watch(e)) return AGARCL_E_HIP;
+  bool most = !mask_host;   // an unmasked reset, or a mask that covers at least a quarter of the arenas, changes what the batch looks like
+  if (mask_host) { size_t n = 0; for (int a = 0; a < e->d.A; a++) n += mask_host[a] != 0; most = 4 * n >= (size_t)e->d.A; }
+  if (restart_flag_watch(e, most)) return AGARCL_E_HIP;
 #endif
   return launch_reset(e, mask_dev, mask_host, reset_ids);
 }
@@ -756,7 +792,7 @@ extern "C" int agarcl_reset_device(agarcl_env *e, const uint8_t *mask_dev, int32
   return launch_reset(e, nullptr, mask_dev, reset_ids);  // (test-only host build: "device" memory is host memory)
 #else
   HIPCHK(hipSetDevice(e->device));
-  if (restart_flag_watch(e)) return AGARCL_E_HIP;
+  if (restart_flag_watch(e, false)) return AGARCL_E_HIP;   // (a device mask is the auto-reset loop's: the sampling cadence stays)
   return launch_reset(e, mask_dev, nullptr, reset_ids);
 #endif
 }
@@ -1013,7 +1049,7 @@ static int load_arena_impl(agarcl_env *e, int32_t arena, const uint32_t *b, int3
     uint32_t nt = p[16];
     if (nt > AG_VT_CAP) return fail(AGARCL_E_CAPACITY, "agarcl_load_arena: too many virus ticks");
     if (p + 17 + nt + 9ull * ncell > b_end) return fail(AGARCL_E_INVALID, "agarcl_load_arena: blob length mismatch");
-    P[PL_NVTICKS] = (int32_t)nt;
+    P[PL_NVTICKS] = (int32_t)nt; P[PL_CAND_IDX] = -1;   // (AR_SAFE = 0 above: a loaded state has neither a pellet-free disc nor a tracked pellet)
     for (uint32_t i = 0; i < nt; i++) h.vt[(size_t)slot * AG_VT_CAP + i] = (int32_t)p[17 + i];
     p += 17 + nt;
     uint32_t *C = &h.cells[(size_t)slot * CF_ALL * AG_CC];
@@ -1214,3 +1250,4 @@ extern "C" int agarcl_grid_obs(agarcl_env *e, int32_t G, int32_t cells, int32_t 
   return AGARCL_OK;
 #endif
 }
+#endif  // AG_PART_NS

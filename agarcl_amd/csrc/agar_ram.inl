@@ -53,7 +53,10 @@ AG_DEV void ram_obs_agent(const AgState *gs, int arena, int agent, AgRamCfg o, f
   ag_mem_fence();
   const int n = pl[AG_TW(PL_NCELLS)]; float sx = 0.0f, sy = 0.0f; unsigned tm = 0;
   for (int i = 0; i < n; i++) { unsigned m = C[AG_CELL_W(CF_M, i)]; float fm = (float)m; float t = u2f((int)C[AG_CELL_W(CF_X, i)]) * fm; sx += t; t = u2f((int)C[AG_CELL_W(CF_Y, i)]) * fm; sy += t; tm += m; }
-  const float px = ag_divf(sx, (float)tm), py = ag_divf(sy, (float)tm);   // (a dead agent: 0 / 0 = NaN, as Player::x() gives)
+  // a dead agent (the observation of the terminal step, before any respawn): its record stays all-zero with cell count 0 -- Player::x() would
+  // give 0 / 0 = NaN, every offset of every row would be NaN and the row order meaningless, and the vector goes straight into a learner
+  if (n == 0) return;
+  const float px = ag_divf(sx, (float)tm), py = ag_divf(sy, (float)tm);
   AG_SERIAL { out[0] = px; out[1] = py; out[2] = (float)tm; out[3] = (float)n; }
   AG_GLOBAL float *oc = out + 4, *op = oc + 3 * o.KC, *ov = op + 2 * o.KP, *oo = ov + 3 * o.KV;
   AG_LANES(i, n < o.KC ? n : o.KC) { oc[3 * i] = u2f((int)C[AG_CELL_W(CF_X, i)]) - px; oc[3 * i + 1] = u2f((int)C[AG_CELL_W(CF_Y, i)]) - py; oc[3 * i + 2] = (float)C[AG_CELL_W(CF_M, i)]; }

@@ -1,27 +1,25 @@
-"""gym-style wrapper with the surface of the reference's gym_agario.AgarioEnv
-(/root/reference/gym_agario/AgarioEnv.py:46-404) on top of agarcl_amd.agarcl.
+"""The gym-facing environment class of this repository: `AgarioEnv`, the N = 1 user surface over the batched HIP engine.
 
-Same constructor keywords ("difficulty" presets + overrides, AgarioEnv.py:298-363), same return shapes:
-reset() -> (obs, {}), step(a) -> (obs, reward, done, truncated=False, {'steps', 'untransformed_rewards'}),
-single-agent unwrapping (AgarioEnv.py:114-118), episodic cut-off after `number_steps` (AgarioEnv.py:111-112).
-gymnasium is optional: when it is importable the class derives from gymnasium.Env and exposes real spaces.
-render() and the video recorder (AgarioEnv.py:134-181, 366-404) are provided on top of the engine's rule-based rasteriser: "rgb_array"
-returns the screen observation or a 512 x 512 frame (get_frame), recorded frames are painted as the reference paints them and
-generate_video writes the same Motion-JPEG container (cv2 when importable, else agarcl_amd/video.py).  There is no OpenGL window: render
-mode "human" has nothing to show on a GPU server and returns None.
+It keeps the *interface* a user of the reference's gym wrapper relies on (/root/reference/gym_agario/AgarioEnv.py:46-404 is the
+counterpart): constructor keywords (a "difficulty" preset plus per-option overrides), `reset() -> (obs, {})`,
+`step(a) -> (obs, reward, done, False, {"steps", "untransformed_rewards"})`, single-agent unwrapping, the episodic cut-off after
+`number_steps` steps, `seed`, `render`, the video recorder, `save_env_state` / `load_env_state`, and the three gymnasium ids.
+The implementation is this repository's own: options live in one table, every observation kind is a small builder, actions are
+validated in one vectorised check, and recorded agent-view frames are coloured by a palette look-up on a per-pixel class index.
+
+gymnasium is optional (it is not installed in the build image): when importable the class derives from gymnasium.Env and carries
+real spaces.  There is no OpenGL window on a GPU server: render mode "human" shows nothing and returns None; "rgb_array" returns
+the screen observation, or the engine's 512 x 512 frame for the grid / GoBigger observations.
 """
 import os
 
 import numpy as np
-
-from .agar_utils import Color, get_color_array
 
 
 def _binding():
     """The `agarcl` module this wrapper drives: the compiled pybind11 module over the C ABI (repo root, built by
     agarcl_amd/build.py:build_pybind) when it is importable, else the ctypes mirror agarcl_amd/agarcl.py -- both are the same
     HIP engine; AGARCL_BINDING=ctypes|pybind pins the choice."""
-    import os
     want = os.environ.get("AGARCL_BINDING", "")
     if want != "ctypes":
         try:
@@ -45,6 +43,95 @@ except Exception:  # pragma: no cover - gymnasium is not installed in the build 
     _spaces = None
     _Base = object
 
+OBS_TYPES = ("ram", "screen", "grid", "gobigger")
+
+# ---- options --------------------------------------------------------------------------------------------------------------
+# keyword -> default, per preset.  "normal" is the base row; the other presets only list what differs.  Everything a caller passes
+# overrides the preset (the counterpart's defaults: AgarioEnv.py:313-349).
+_PRESETS = {
+    "normal": dict(ticks_per_step=4, num_frames=1, arena_size=1000, num_pellets=1000, num_viruses=0, num_bots=0, pellet_regen=True,
+                   allow_respawn=True, reward_type=1),
+    "empty": {},
+    "trivial": dict(arena_size=50, num_pellets=200, num_viruses=0, num_bots=0),
+}
+# options that are not part of a preset: keyword -> default
+_PLAIN = dict(grid_size=128, num_agents=1, c_death=0, mode=0, load_env_snapshot=False, agent_view=False, add_noise=True,
+              number_steps=500, env_type=0, multi_agent=False)
+# the engine constructor's positional order (environment/bindings.cpp:102,146; the screen / GoBigger classes append to it)
+_CTOR_ORDER = ("num_agents", "ticks_per_step", "arena_size", "pellet_regen", "num_pellets", "num_viruses", "num_bots", "reward_type",
+               "c_death", "mode", "load_env_snapshot")
+_GRID_KEYS = ("num_frames", "grid_size", "observe_cells", "observe_others", "observe_viruses", "observe_pellets")
+_RAM_KEYS = ("k_cells", "k_pellets", "k_viruses", "k_others")
+
+
+def _resolve_options(kwargs):
+    """preset + overrides -> {option: value}; raises ValueError for an unknown preset or a bad ticks_per_step"""
+    preset = str(kwargs.get("difficulty", "normal")).lower()
+    if preset not in _PRESETS:
+        raise ValueError("unknown difficulty preset %r (choose from %s)" % (preset, ", ".join(sorted(_PRESETS))))
+    opts = dict(_PRESETS["normal"]); opts.update(_PRESETS[preset]); opts.update(_PLAIN)
+    opts.update({k: v for k, v in kwargs.items() if k in opts})
+    opts["multi_agent"] = bool(opts["multi_agent"]) or opts["num_agents"] > 1
+    t = opts["ticks_per_step"]
+    if isinstance(t, bool) or not isinstance(t, int) or t < 1:
+        raise ValueError("ticks_per_step must be an integer >= 1, got %r" % (t,))
+    return opts
+
+
+# ---- one builder per observation kind: (options, raw kwargs) -> (engine object, observation shape) -------------------------------
+def _build_grid(o, kw):
+    # (the counterpart hands an undefined name to the constructor here, AgarioEnv.py:226; the ten engine arguments are what is meant)
+    env = agarcl.GridEnvironment(*[o[k] for k in _CTOR_ORDER[:10]])
+    cfg = dict(num_frames=1, grid_size=128, observe_cells=True, observe_others=True, observe_viruses=True, observe_pellets=True)
+    cfg.update({k: kw[k] for k in _GRID_KEYS + ("literal_frame_index",) if k in kw})
+    env.configure_observation(cfg)
+    c, w, h = env.observation_shape()
+    return env, (w, h, c)          # channel-last, as _observe() hands the frames out
+
+
+def _build_screen(o, kw):
+    if not agarcl.has_screen_env:
+        raise ValueError("this agarcl module was built without a ScreenEnvironment")
+    side = kw.get("screen_len", 84)
+    env = agarcl.ScreenEnvironment(*([o[k] for k in _CTOR_ORDER] + [side, side, o["agent_view"]]))
+    return env, tuple(env.observation_shape())
+
+
+def _build_gobigger(o, kw):
+    head = [kw.get("map_width", 512), kw.get("map_height", 512), kw.get("frame_limit", 1000)]
+    env = agarcl.GoBiggerEnvironment(*(head + [o[k] for k in _CTOR_ORDER] + [o["agent_view"]]))
+    return env, tuple(env.observation_shape())
+
+
+def _build_ram(o, kw):
+    # an extension: the counterpart names "ram" and then refuses to build it (AgarioEnv.py:52,211; BASELINE configs[0]).  Here it is a
+    # flat float32 vector per agent (include/agarcl_batch.h agarcl_ram_obs); always through the ctypes classes -- the compiled module
+    # keeps exactly the reference's class list
+    from . import agarcl as mirror
+    env = mirror.RamEnvironment(*[o[k] for k in _CTOR_ORDER[:10]])
+    env.configure_observation({k: kw[k] for k in _RAM_KEYS if k in kw})
+    return env, tuple(env.observation_shape())
+
+
+_BUILDERS = {"grid": _build_grid, "screen": _build_screen, "gobigger": _build_gobigger, "ram": _build_ram}
+
+# ---- recorded agent-view frames: class index per pixel -> colour ------------------------------------------------------------
+# classes of the 4-channel agent-view frame (channel tests of the counterpart's video painter, AgarioEnv.py:159-181), listed from the
+# one that wins to the one that loses; whatever matches none is background
+_VIDEO_PALETTE = np.array([(255, 0, 0),       # 0 background
+                           (255, 255, 255),   # 1 pellet
+                           (153, 51, 204),    # 2 other player / bot
+                           (0, 255, 0),       # 3 virus
+                           (0, 0, 255),       # 4 the agent itself
+                           (26, 0, 0)],       # 5 grid line
+                          dtype=np.uint8)
+
+
+def _agent_view_classes(frame):
+    """frame: uint8 [W][H][4] (pellets, others, viruses, alpha) -> class index per pixel (see _VIDEO_PALETTE)"""
+    pel, oth, vir, alpha = (frame[..., k] for k in range(4))
+    return np.select([alpha <= 30, alpha <= 230, vir == 255, oth == 255, pel != 255], [5, 4, 3, 2, 1], default=0)
+
 
 class AgarioEnv(_Base):
     metadata = {"render_modes": ["human", "rgb_array"], "render_fps": 60}
@@ -52,193 +139,131 @@ class AgarioEnv(_Base):
     def __init__(self, obs_type="grid", render_mode=None, **kwargs):
         if _gym is not None:
             super().__init__()
-        if obs_type not in ("ram", "screen", "grid", "gobigger"):
-            raise ValueError(obs_type)
-        self._env, self.observation_shape = self._make_environment(obs_type, kwargs)
-        self.steps = None
-        self.obs_type = obs_type
-        self.render_mode = render_mode
-        self.video_recorder = []
-        self.video_recorder_enabled = False
-        self.agent_view = kwargs.get("agent_view", False)
-        self.add_noise = kwargs.get("add_noise", True)
-        self.number_of_steps = kwargs.get("number_steps", 500)
-        self.mode = kwargs.get("mode", 0)
-        self.env_type = kwargs.get("env_type", 0)  # 0 episodic, 1 continuing
+        if obs_type not in OBS_TYPES:
+            raise ValueError("obs_type must be one of %s, got %r" % (OBS_TYPES, obs_type))
+        opts = _resolve_options(kwargs)
+        for name, value in opts.items():      # every option is also an attribute (num_agents, arena_size, mode, agent_view, ...)
+            setattr(self, name, value)
+        self.number_of_steps = opts["number_steps"]
+        self.obs_type, self.render_mode = obs_type, render_mode
+        self._env, self.observation_shape = _BUILDERS[obs_type](opts, kwargs)
+        self.steps = None                     # None until the first reset()
+        self.video_recorder, self.video_recorder_enabled = [], False
         self._seed = None
-        if _spaces is not None:   # AgarioEnv.py:226-268
+        if _spaces is not None:
             self.action_space = _spaces.Tuple((_spaces.Box(low=-1, high=1, shape=(2,)), _spaces.Discrete(3)))
-            if obs_type == "grid":
-                self.observation_space = _spaces.Box(-1, np.iinfo(np.int32).max, self.observation_shape, dtype=np.int32)
-            elif obs_type == "screen":
-                self.observation_space = _spaces.Box(low=0, high=255, shape=self.observation_shape, dtype=np.uint8)
-            elif obs_type == "ram":
-                self.observation_space = _spaces.Box(low=-np.inf, high=np.inf, shape=self.observation_shape, dtype=np.float32)
-            else:
-                self.observation_space = _spaces.Box(low=0, high=255, shape=self.observation_shape, dtype=np.float32)
+            lo, hi, dt = {"grid": (-1, np.iinfo(np.int32).max, np.int32), "screen": (0, 255, np.uint8),
+                          "ram": (-np.inf, np.inf, np.float32), "gobigger": (0, 255, np.float32)}[obs_type]
+            self.observation_space = _spaces.Box(low=lo, high=hi, shape=self.observation_shape, dtype=dt)
 
-    # -- AgarioEnv.py:298-363 -------------------------------------------------------------------------
-    def _get_env_args(self, kwargs):
-        difficulty = kwargs.get("difficulty", "normal").lower()
-        if difficulty not in ["normal", "empty", "trivial"]:
-            raise ValueError("Unrecognized difficulty: %s" % difficulty)
-        d = dict(ticks_per_step=4, num_frames=1, arena_size=1000, num_pellets=1000, num_viruses=0, num_bots=0,
-                 pellet_regen=True, allow_respawn=True, reward_type=1)
-        if difficulty == "trivial":
-            d.update(arena_size=50, num_pellets=200, num_viruses=0, num_bots=0)
-        self.grid_size = kwargs.get("grid_size", 128)
-        self.multi_agent = kwargs.get("multi_agent", False)
-        self.num_agents = kwargs.get("num_agents", 1)
-        for k in ("ticks_per_step", "num_frames", "arena_size", "num_pellets", "num_viruses", "num_bots", "pellet_regen",
-                  "allow_respawn", "reward_type"):
-            setattr(self, k, kwargs.get(k, d[k]))
-        self.c_death = kwargs.get("c_death", 0)
-        self.mode = kwargs.get("mode", 0)
-        self.load_env_snapshot = kwargs.get("load_env_snapshot", False)
-        self.multi_agent = self.multi_agent or self.num_agents > 1
-        if type(self.ticks_per_step) is not int or self.ticks_per_step <= 0:
-            raise ValueError("ticks_per_step must be a positive integer")
-        return (self.num_agents, self.ticks_per_step, self.arena_size, self.pellet_regen, self.num_pellets,
-                self.num_viruses, self.num_bots, self.reward_type, self.c_death, self.mode, self.load_env_snapshot)
-
-    def _make_environment(self, obs_type, kwargs):
-        base_args = self._get_env_args(kwargs)
-        if obs_type == "grid":
-            # (the reference passes an undefined name here, AgarioEnv.py:226; the evident intent is the ten constructor arguments)
-            env = agarcl.GridEnvironment(*base_args[:10])
-            cfg = dict(num_frames=1, grid_size=128, observe_cells=True, observe_others=True, observe_viruses=True, observe_pellets=True)
-            cfg.update({k: kwargs[k] for k in list(cfg) + ["literal_frame_index"] if k in kwargs})
-            env.configure_observation(cfg)
-            channels, width, height = env.observation_shape()
-            return env, (width, height, channels)
-        if obs_type == "screen":             # AgarioEnv.py:235-250
-            if not agarcl.has_screen_env:
-                raise ValueError("agarcl was not compiled to include ScreenEnvironment")
-            screen_len = kwargs.get("screen_len", 84)
-            self.agent_view = kwargs.get("agent_view", False)
-            env = agarcl.ScreenEnvironment(*(base_args + (screen_len, screen_len, self.agent_view)))
-            return env, tuple(env.observation_shape())
-        if obs_type == "gobigger":           # AgarioEnv.py:251-264
-            full_args = (kwargs.get("map_width", 512), kwargs.get("map_height", 512), kwargs.get("frame_limit", 1000)) + base_args + (kwargs.get("agent_view", False),)
-            env = agarcl.GoBiggerEnvironment(*full_args)
-            return env, tuple(env.observation_shape())
-        if obs_type == "ram":
-            # an extension: the reference names "ram" (AgarioEnv.py:52, BASELINE configs[0]) and then raises for it (AgarioEnv.py:211).
-            # Here it is a flat float32 vector per agent (include/agarcl_batch.h agarcl_ram_obs); always through the ctypes classes,
-            # the compiled module keeps exactly the reference's class list
-            from . import agarcl as mirror
-            env = mirror.RamEnvironment(*base_args[:10])
-            env.configure_observation({k: kwargs[k] for k in ("k_cells", "k_pellets", "k_viruses", "k_others") if k in kwargs})
-            return env, tuple(env.observation_shape())
-        raise ValueError(obs_type)
-
-    # -- AgarioEnv.py:270-296 (validation; the reference samples noise and then discards it) --------------
-    def _sanitize_actions(self, actions):
-        if not self.multi_agent and type(actions) is not list:
+    # ---- actions ------------------------------------------------------------------------------------------------------------
+    def _checked_actions(self, actions):
+        """one ((dx, dy), a) pair, or a list of them with several agents -> [(dx, dy, a)] for the engine; ValueError when the count or
+        a value is outside the action space (the sampled noise of the counterpart is never applied: AgarioEnv.py:282-295)"""
+        if not self.multi_agent and not isinstance(actions, list):
             actions = [actions]
-        if type(actions) is not list:
-            raise ValueError("Action list must be a list of two-element tuples")
+        if not isinstance(actions, list):
+            raise ValueError("with several agents the actions come as a list of ((dx, dy), a) pairs")
         if len(actions) != self.num_agents:
-            raise ValueError("Number of actions %d does not match number of agents %d" % (len(actions), self.num_agents))
-        out = []
-        for tgt, a in actions:
-            tx, ty = float(tgt[0]), float(tgt[1])
-            if not (-1.0 <= tx <= 1.0 and -1.0 <= ty <= 1.0 and int(a) in (0, 1, 2)):
-                raise ValueError("action %r not in action space" % ((tgt, a),))
-            out.append((tx, ty, int(a)))
-        return out
+            raise ValueError("%d actions for %d agents" % (len(actions), self.num_agents))
+        try:
+            move = np.array([[a[0][0], a[0][1]] for a in actions], dtype=np.float64).reshape(len(actions), 2)
+            kind = np.array([int(a[1]) for a in actions], dtype=np.int64)
+        except (TypeError, IndexError) as e:
+            raise ValueError("an action is a ((dx, dy), a) pair: %s" % e)
+        if not (np.all(np.abs(move) <= 1.0) and np.all((kind >= 0) & (kind <= 2))):    # (NaN fails the first test)
+            raise ValueError("action outside the action space [-1, 1]^2 x {0, 1, 2}: %r" % (actions,))
+        return [(float(m[0]), float(m[1]), int(k)) for m, k in zip(move, kind)]
 
-    def _make_observations(self):
-        states = self._env.get_state()
-        assert len(states) == self.num_agents
-        if self.obs_type == "grid":
-            return [np.transpose(s, [1, 2, 0]) for s in states]  # NCHW -> NHWC, AgarioEnv.py:192-194
-        return states                                            # screen: the (1, W, H, 3) frame as is, AgarioEnv.py:196-197
+    # ---- observations -------------------------------------------------------------------------------------------------------
+    def _observe(self):
+        per_agent = self._env.get_state()
+        assert len(per_agent) == self.num_agents
+        if self.obs_type == "grid":            # the engine's frames are channel-first; users get (grid, grid, channels)
+            per_agent = [frame.transpose(1, 2, 0) for frame in per_agent]
+        return per_agent
+
+    def _unwrap(self, per_agent):
+        return per_agent if self.multi_agent else per_agent[0]
+
+    # ---- gym surface --------------------------------------------------------------------------------------------------------
+    def reset(self, **kwargs):
+        self._env.reset()
+        self.steps = 0
+        return self._unwrap(self._observe()), {}
 
     def step(self, actions):
-        assert self.steps is not None, "Cannot call step() before calling reset()"
-        self._env.take_actions(self._sanitize_actions(actions))
+        assert self.steps is not None, "reset() must be called before the first step()"
+        self._env.take_actions(self._checked_actions(actions))
         rewards = self._env.step()
         assert len(rewards) == self.num_agents
-        self.observations = self._make_observations()
-        if self.video_recorder_enabled:   # (one agent, as in the reference: AgarioEnv.py:99-101)
-            self.video_recorder.append(self._make_video_observation(self.observations[0]))
-        dones = self._env.dones()
-        truncations = [False] * len(dones)
-        if self.steps >= self.number_of_steps and self.env_type == 0:
-            dones = [True] * len(dones)
-        if not self.multi_agent:
-            self.observations, rewards, dones, truncations = self.observations[0], rewards[0], dones[0], truncations[0]
+        per_agent = self._observe()
+        if self.video_recorder_enabled:       # one agent's view is recorded
+            self.video_recorder.append(self._make_video_observation(per_agent[0]))
+        # an episodic env (env_type 0) ends after number_steps steps whatever the engine says; the comparison is made before this
+        # step is counted, so the first `number_steps` steps of an episode do not end it
+        out_of_time = self.env_type == 0 and self.steps >= self.number_of_steps
+        dones = [True if out_of_time else bool(d) for d in self._env.dones()]
         self.steps += 1
-        return self.observations, rewards, dones, truncations, {"steps": self.steps, "untransformed_rewards": rewards}
-
-    def reset(self, **kwargs):
-        self.steps = 0
-        self._env.reset()
-        obs = self._make_observations()
-        return (obs if self.multi_agent else obs[0]), {}
+        self.observations = self._unwrap(per_agent)
+        reward = self._unwrap(rewards)
+        info = {"steps": self.steps, "untransformed_rewards": reward}
+        return self.observations, reward, self._unwrap(dones), self._unwrap([False] * len(dones)), info
 
     def seed(self, seed=None):
-        if seed is not None:
-            self._seed = seed
-            self._env.seed(seed)
-            return [self._seed]
+        if seed is None:
+            return None
+        self._seed = seed
+        self._env.seed(seed)
+        return [seed]
 
-    def render(self):                       # AgarioEnv.py:134-147
+    def render(self):
         if self.render_mode == "human":
-            self._env.render()              # (no window exists on a GPU server: a no-op, like the reference built without a display)
-        if self.render_mode == "rgb_array":
+            self._env.render()                # nothing to show without a display
+        elif self.render_mode == "rgb_array":
             if self.obs_type == "screen":
                 return getattr(self, "observations", None)
             if self.obs_type in ("grid", "gobigger"):
                 return self._env.get_frame()
         return None
 
-    def _make_video_observation(self, observation):   # AgarioEnv.py:159-181
+    # ---- video recorder -----------------------------------------------------------------------------------------------------
+    def _make_video_observation(self, observation):
+        """the frame one recorded step contributes: the engine's 512 x 512 picture for grid / GoBigger, the screen observation as it is,
+        or -- for the 4-channel agent view -- a colour picture made from the channels"""
         if self.obs_type in ("grid", "gobigger"):
             return self._env.get_frame()[0]
         if not self.agent_view:
             return observation
-        observation = observation[0]
-        rgb = np.zeros_like(observation[..., :3])
-        rgb[..., 0].fill(255)
-        pellets_mask = observation[..., 0] != 255
-        bots_mask = observation[..., 1] == 255
-        virus_mask = observation[..., 2] == 255
-        main_agent_mask = (observation[..., 3] <= 230) & (observation[..., 3] > 30)
-        grid_lines_mask = observation[..., 3] <= 30
-        rgb[pellets_mask] = get_color_array(Color.WHITE)
-        rgb[bots_mask] = get_color_array(Color.PURPLE)
-        rgb[virus_mask] = get_color_array(Color.GREEN)
-        rgb[main_agent_mask] = get_color_array(Color.BLUE)
-        rgb[grid_lines_mask] = [26, 0, 0]
-        return rgb
+        return _VIDEO_PALETTE[_agent_view_classes(observation[0])]
 
-    def enable_video_recorder(self):        # AgarioEnv.py:372-376
+    def enable_video_recorder(self):
         self.video_recorder_enabled = True
 
     def disable_video_recorder(self):
         self.video_recorder_enabled = False
 
-    def generate_video(self, path, video_name):   # AgarioEnv.py:379-404: Motion-JPEG, 60 frames per second
-        if not os.path.exists(path):
-            os.makedirs(path, exist_ok=True)
-        full_path = os.path.join(path, video_name)
+    def generate_video(self, path, video_name):
+        """writes the recorded frames as a Motion-JPEG AVI at 60 frames per second; returns the file's path, or None when there is
+        nothing to write"""
         if not self.video_recorder_enabled:
-            print("Video recorder is not enabled. Please enable it before generating video")
+            print("generate_video: the recorder is off (enable_video_recorder() first)")
             return None
-        if len(self.video_recorder) == 0:
-            print("No frames to generate video")
+        if not self.video_recorder:
+            print("generate_video: no frame has been recorded yet")
             return None
-        from .video import write_mjpeg_avi
         frames = []
-        for frame in self.video_recorder:
+        for k, frame in enumerate(self.video_recorder):
             if not isinstance(frame, np.ndarray):
-                raise TypeError("Error: A frame is not a numpy array.")
-            frames.append(frame[0] if frame.ndim == 4 else frame)   # the plain screen observation is (1, W, H, 3)
-        write_mjpeg_avi(full_path, frames, fps=60.0)
-        return full_path
+                raise TypeError("recorded frame %d is a %s, not a numpy array" % (k, type(frame).__name__))
+            frames.append(frame[0] if frame.ndim == 4 else frame)     # the plain screen observation carries a leading axis of 1
+        os.makedirs(path, exist_ok=True)
+        target = os.path.join(path, video_name)
+        from .video import write_mjpeg_avi
+        write_mjpeg_avi(target, frames, fps=60.0)
+        return target
 
+    # ---- pass-throughs ------------------------------------------------------------------------------------------------------
     def close(self):
         self._env.close()
 
@@ -250,12 +275,11 @@ class AgarioEnv(_Base):
 
 
 def register():
-    """gymnasium ids of the reference (gym_agario/__init__.py:9-23); no-op without gymnasium."""
+    """the three gymnasium ids (gym_agario/__init__.py:9-23 of the counterpart); False without gymnasium"""
     if _gym is None:
         return False
     from gymnasium.envs.registration import register as _reg
-    _reg(id="agario-grid-v0", entry_point="gym_agario.AgarioEnv:AgarioEnv", kwargs={"obs_type": "grid"})
-    if agarcl.has_screen_env:  # only register the screen environment if it is available
-        _reg(id="agario-screen-v0", entry_point="gym_agario.AgarioEnv:AgarioEnv", kwargs={"obs_type": "screen"})
-    _reg(id="agario-gobigger-v0", entry_point="gym_agario.AgarioEnv:AgarioEnv", kwargs={"obs_type": "gobigger"})
+    kinds = ["grid"] + (["screen"] if agarcl.has_screen_env else []) + ["gobigger"]
+    for kind in kinds:
+        _reg(id="agario-%s-v0" % kind, entry_point="gym_agario.AgarioEnv:AgarioEnv", kwargs={"obs_type": kind})
     return True

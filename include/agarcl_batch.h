@@ -175,7 +175,8 @@ int agarcl_screen_obs(agarcl_env *env, int32_t width, int32_t height, int32_t ag
  * D = 4 + 3 k_cells + 2 k_pellets + 3 k_viruses + 3 k_others, returned through *dim (out == NULL only queries D):
  *   px, py, total mass, cell count | k_cells x (dx, dy, mass) own cells in cell order | k_pellets x (dx, dy) nearest pellets, nearest first
  *   (ties: lower index) | k_viruses x (dx, dy, mass) nearest viruses | k_others x (dx, dy, mass) nearest cells of the other players;
- * dx = x - px, dy = y - py; absent rows are zero.  `out` is an HBM pointer if on_device != 0, else a host buffer. */
+ * dx = x - px, dy = y - py; absent rows are zero.  A dead agent (no cells: the terminal step, before any respawn) gets an all-zero record
+ * with cell count 0 -- never NaN.  `out` is an HBM pointer if on_device != 0, else a host buffer. */
 int agarcl_ram_obs(agarcl_env *env, int32_t k_cells, int32_t k_pellets, int32_t k_viruses, int32_t k_others, float *out, int32_t on_device, int32_t *dim);
 
 /* replaces: GoBiggerEnvironment::get_state() (bindings.cpp:28-47,353) -> GoBiggerObservation::add_frame

@@ -38,6 +38,8 @@ def ram_obs(state_blob, agent_slot_pids, k_cells=16, k_pellets=16, k_viruses=8, 
         with np.errstate(invalid="ignore", divide="ignore"):
             px = F(sx) / F(tm); py = F(sy) / F(tm)
         row = out[a]
+        if tm == 0:      # a dead agent: the record stays all-zero with cell count 0 (include/agarcl_batch.h)
+            continue
         row[0], row[1], row[2], row[3] = px, py, F(tm), F(len(pl["cell_mass"]))
         o = 4
         with np.errstate(invalid="ignore"):

@@ -70,6 +70,21 @@ def test_emulated_quiet_path_long_rollout(emu_lib, oracle_lib, cfg):
     assert msg > 0    # somebody ate
 
 
+def test_emulated_quiet_run_with_lazily_loaded_pellets(emu_lib, oracle_lib, monkeypatch):
+    """AGARCL_NO_FRONT=1: every arena-step goes through the general engine's own quiet run, whose launch has NOT read the pellets when the
+    tracked pellet is eaten without a pass -- RegPel::swap_pop must fetch them first (ADVICE r3: without it the swap wrote unloaded
+    registers back and a later load undid it: 'step 99 arena 2: pellet_x[520] 274.2 vs 0.0')."""
+    from agarcl_amd import _capi
+    monkeypatch.setenv("AGARCL_NO_FRONT", "1")
+    cfg = dict(arena_size=1000, num_pellets=1000, num_viruses=0, mode=0)
+    A = 8
+    eng = _capi.BatchedEngine(A, lib=emu_lib, **cfg)
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    ok, msg = run_quiet_rollout(eng, oras, 400, 31000 + np.arange(A), rng_seed=17)
+    assert ok, msg
+    assert msg > 0    # somebody ate
+
+
 def test_emulated_engine_level_60hz(emu_lib, oracle_lib):
     """BASELINE configs[0] as bench/main.cpp drives it: Engine::tick at dt = 1/60 s (600-tick recombine deadlines), agent +
     the four bot kinds on the default 250x250 arena, through agarcl_set_targets / agarcl_tick on the kernel source."""

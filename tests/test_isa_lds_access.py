@@ -22,22 +22,30 @@ def flat_counts(tmp_path_factory):
     if not os.path.exists(SO) or not shutil.which("objcopy"):
         pytest.skip("library not built")
     d = str(tmp_path_factory.mktemp("isa"))
-    fat, co = os.path.join(d, "fatbin"), os.path.join(d, "dev.co")
+    fat = os.path.join(d, "fatbin")
     subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", SO, fat])
-    subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--type=o", "--unbundle", "--input=" + fat,
-                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
-    counts, fn = {}, None   # function -> [flat loads, flat stores + atomics]
-    p = subprocess.Popen([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], stdout=subprocess.PIPE, text=True)
+    # the library is linked from several translation units (agarcl_amd/build.py): the section holds one offload bundle per unit
+    blob, magic = open(fat, "rb").read(), b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    assert starts, "no offload bundle in the library"
+    counts = {}   # function -> [flat loads, flat stores + atomics]
     head = re.compile(r"^[0-9a-f]+ <(.*)>:$")
-    for line in p.stdout:
-        m = head.match(line)
-        if m:
-            fn = m.group(1); counts.setdefault(fn, [0, 0])
-        elif fn and "flat_load" in line:
-            counts[fn][0] += 1
-        elif fn and ("flat_store" in line or "flat_atomic" in line):
-            counts[fn][1] += 1
-    assert p.wait() == 0
+    for k, (b0, b1) in enumerate(zip(starts, starts[1:] + [len(blob)])):
+        one, co = os.path.join(d, "bundle%d" % k), os.path.join(d, "dev%d.co" % k)
+        open(one, "wb").write(blob[b0:b1])
+        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--type=o", "--unbundle", "--input=" + one,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        fn = None
+        p = subprocess.Popen([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], stdout=subprocess.PIPE, text=True)
+        for line in p.stdout:
+            m = head.match(line)
+            if m:
+                fn = m.group(1); counts.setdefault(fn, [0, 0])
+            elif fn and "flat_load" in line:
+                counts[fn][0] += 1
+            elif fn and ("flat_store" in line or "flat_atomic" in line):
+                counts[fn][1] += 1
+        assert p.wait() == 0
     return counts
 
 
