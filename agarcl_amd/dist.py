@@ -42,6 +42,7 @@ class ResultGatherer:
                          for _ in range(depth)]
         self.work = [None] * depth
         self.n_local = n_local
+        self.reset_stats()
         # dist.gather needs equally sized contributions: shard_bounds() gives unequal blocks when total % world != 0,
         # so such a job must pad its shards to the largest one (or pick a divisible arena count).  Fail at construction.
         sizes = [None] * self.world
@@ -49,15 +50,27 @@ class ResultGatherer:
         if any(s != sizes[0] for s in sizes):
             raise ValueError("ResultGatherer: every rank must contribute the same number of rows, got %s" % (sizes,))
 
+    def reset_stats(self):
+        """diagnostics: host seconds spent waiting for collectives, collectives started, payload bytes this rank sent"""
+        self.wait_s, self.calls, self.bytes_sent = 0.0, 0, 0
+
+    def _wait(self, s):
+        import time
+        t = time.perf_counter()
+        self.work[s].wait()
+        self.wait_s += time.perf_counter() - t
+        self.work[s] = None
+
     def pack(self, k, rewards, dones):
         s = k % self.depth
         if self.work[s] is not None:
-            self.work[s].wait()
+            self._wait(s)
         buf = self.send[s]
         buf[:, 0].copy_(rewards.reshape(-1))
         buf[:, 1].copy_(dones.reshape(-1))
         self.work[s] = self.dist.gather(buf, self.recv[s] if self.rank == 0 else None, dst=0, group=self.group,
                                         async_op=True)
+        self.calls += 1; self.bytes_sent += buf.numel() * buf.element_size()
         return s
 
     def gather_packed(self, slot, packed):
@@ -67,17 +80,16 @@ class ResultGatherer:
         self.wait_slot(slot)
         self.work[slot] = self.dist.gather(packed, self.recv[slot] if self.rank == 0 else None, dst=0, group=self.group,
                                            async_op=True)
+        self.calls += 1; self.bytes_sent += packed.numel() * packed.element_size()
 
     def wait_slot(self, slot):
         if self.work[slot] is not None:
-            self.work[slot].wait()
-            self.work[slot] = None
+            self._wait(slot)
 
     def wait_all(self):
         for i, w in enumerate(self.work):
             if w is not None:
-                w.wait()
-                self.work[i] = None
+                self._wait(i)
 
     def gathered(self, slot):
         """rank 0: float32 [world * n_local, 2] of the given slot (after its work completed)."""
@@ -98,14 +110,22 @@ class TensorGatherer:
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.recv = [torch.empty(tuple(shape), dtype=dtype, device=device) for _ in range(self.world)] if self.rank == 0 else None
         self.work = None
+        self.reset_stats()
+
+    def reset_stats(self):
+        self.wait_s, self.calls, self.bytes_sent = 0.0, 0, 0
 
     def gather(self, tensor):
         self.wait()
         self.work = self.dist.gather(tensor, self.recv, dst=0, group=self.group, async_op=True)
+        self.calls += 1; self.bytes_sent += tensor.numel() * tensor.element_size()
 
     def wait(self):
         if self.work is not None:
+            import time
+            t = time.perf_counter()
             self.work.wait()
+            self.wait_s += time.perf_counter() - t
             self.work = None
 
     def gathered(self):

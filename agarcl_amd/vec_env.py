@@ -102,13 +102,66 @@ class VecEnvironment:
 
     def ram_obs(self, out=None, k_cells=16, k_pellets=16, k_viruses=8, k_others=16):
         """float32 CUDA tensor [A, n_agents, D] of the "ram" observation (include/agarcl_batch.h agarcl_ram_obs), written by one launch on
-        the env's stream; pass the previous tensor as `out` to reuse it."""
+        the env's stream into the env's own tensor of this configuration (or into `out`)."""
         torch = self.torch
         D = 4 + 3 * k_cells + 2 * k_pellets + 3 * k_viruses + 3 * k_others
         if out is None:
-            out = torch.empty((self.num_arenas, self.num_agents, D), dtype=torch.float32, device=self.device)
+            out = self._obs_tensor(("ram", k_cells, k_pellets, k_viruses, k_others), (self.num_arenas, self.num_agents, D), torch.float32)
         self.engine.ram_obs(k_cells, k_pellets, k_viruses, k_others, out_ptr=out.data_ptr())
         return out
+
+    # ---- observations as persistent CUDA tensors: one tensor per (kind, configuration), created on first use and rewritten in place by
+    # every later call on the env's stream -- no allocation, no host copy, no synchronisation inside a rollout loop --------------------------
+    def _obs_tensor(self, key, shape, dtype):
+        cache = self.__dict__.setdefault("_obs_cache", {})
+        t = cache.get(key)
+        if t is None:
+            t = cache[key] = self.torch.zeros(shape, dtype=dtype, device=self.device)
+        return t
+
+    def grid_obs(self, grid_size=128, cells=True, others=True, viruses=True, pellets=True, out=None):
+        """int32 CUDA tensor [A, n_agents, C, G, G], C = 1 + cells + 2 others + 2 viruses + 2 pellets (GridEnvironment.hpp:188-196), of the
+        state after the last step.  Without `out` the env's own tensor of this configuration is rewritten through the incremental path
+        (agarcl_grid_obs on_device = 2: only the words the previous call scattered are cleared); it belongs to the env -- read it, copy it,
+        do not write into it.  With `out` (a contiguous CUDA int32 tensor of that shape) the stateless full-clear path is used."""
+        torch = self.torch
+        C = 1 + int(bool(cells)) + 2 * (int(bool(others)) + int(bool(viruses)) + int(bool(pellets)))
+        shape = (self.num_arenas, self.num_agents, C, int(grid_size), int(grid_size))
+        if out is None:
+            t = self._obs_tensor(("grid", int(grid_size), bool(cells), bool(others), bool(viruses), bool(pellets)), shape, torch.int32)
+            self.engine.grid_obs(grid_size, cells, others, viruses, pellets, out_ptr=t.data_ptr(), persistent=True)
+            return t
+        if out.dtype != torch.int32 or tuple(out.shape) != shape or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("out must be a contiguous int32 tensor of shape %s on %s" % (shape, self.device))
+        self.engine.grid_obs(grid_size, cells, others, viruses, pellets, out_ptr=out.data_ptr(), persistent=False)
+        return out
+
+    def screen_obs(self, width=84, height=84, agent_view=False, out=None):
+        """uint8 CUDA tensor [A, n_agents, height, width, 3] (4 channels with agent_view), rows bottom-up like glReadPixels
+        (include/agarcl_batch.h agarcl_screen_obs); the env's own tensor of this configuration unless `out` is given."""
+        torch = self.torch
+        shape = (self.num_arenas, self.num_agents, int(height), int(width), 4 if agent_view else 3)
+        if out is None:
+            out = self._obs_tensor(("screen", int(width), int(height), bool(agent_view)), shape, torch.uint8)
+        elif out.dtype != torch.uint8 or tuple(out.shape) != shape or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("out must be a contiguous uint8 tensor of shape %s on %s" % (shape, self.device))
+        self.engine.screen_obs(width, height, out_ptr=out.data_ptr(), agent_view=agent_view)
+        return out
+
+    def gobigger_obs(self, grid_size=128, cap_food=256, cap_virus=64, cap_spore=64, cap_clone=32):
+        """the GoBigger observation as padded CUDA tensors (include/agarcl_batch.h agarcl_gobigger_obs): {"hdr": i32 [A, P, 8],
+        "food" / "virus" / "spore": f32 [A, P, cap, 4], "clone": f32 [A, P, cap_clone, 7]}, P = players per arena; the env's own tensors."""
+        torch = self.torch
+        A, P = self.num_arenas, self.engine.players
+        key = ("gobigger", int(grid_size), int(cap_food), int(cap_virus), int(cap_spore), int(cap_clone))
+        t = {"hdr": self._obs_tensor(key + ("hdr",), (A, P, 8), torch.int32),
+             "food": self._obs_tensor(key + ("food",), (A, P, cap_food, 4), torch.float32),
+             "virus": self._obs_tensor(key + ("virus",), (A, P, cap_virus, 4), torch.float32),
+             "spore": self._obs_tensor(key + ("spore",), (A, P, cap_spore, 4), torch.float32),
+             "clone": self._obs_tensor(key + ("clone",), (A, P, cap_clone, 7), torch.float32)}
+        self.engine.gobigger_obs(grid_size, cap_food, cap_virus, cap_spore, cap_clone,
+                                 out_ptrs=[t[k].data_ptr() for k in ("hdr", "food", "virus", "spore", "clone")])
+        return t
 
     def dones(self):
         return self.dones_u8.bool()

@@ -281,6 +281,9 @@ def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, 
         one_step(k)
     flush(); drain()
     eng.work(reset=True)                        # (synchronising) the kernels' work counters restart with the timed region
+    for g_ in (gather, obs_gather):
+        if g_ is not None:
+            g_.reset_stats()
     # HIP events on the launch stream (the engine's own pair: created once, recorded without the system-scope fence of an ordinary
     # event record); marking them once here creates them outside the timed region
     eng.timer_mark(0); eng.timer_mark(1)
@@ -296,20 +299,48 @@ def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, 
     eng.timer_mark(1)
     drain()
     torch.cuda.synchronize()
+    elapsed_own = time.perf_counter() - t0     # this rank's own time, before it waits for the others
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms = eng.timer_elapsed_ms() / K    # HIP events on the launch stream (the engine adopts torch's current stream): avg per step
+    # per-rank record (so that a poor scaling curve can be read off the line): this rank's own wall time and step time by HIP events,
+    # the host time it spent waiting for collectives, the payload bytes it contributed
+    rank_info = {"rank": rank, "ms_per_step": elapsed_own / K * 1e3, "kernel_ms_per_step": kernel_ms,
+                 "gather_wait_ms_total": (gather.wait_s if gather is not None else 0.0) * 1e3 + (obs_gather.wait_s if obs_gather is not None else 0.0) * 1e3,
+                 "result_collectives": gather.calls if gather is not None else 0, "result_bytes_sent": gather.bytes_sent if gather is not None else 0,
+                 "obs_collectives": obs_gather.calls if obs_gather is not None else 0, "obs_bytes_sent": obs_gather.bytes_sent if obs_gather is not None else 0}
+    ranks = [rank_info]
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    res = dict(elapsed=elapsed, kernel_ms=kernel_ms, work=eng.work(), flags=eng.flags(),
+        ranks = [None] * world
+        dist.all_gather_object(ranks, rank_info)
+    res = dict(elapsed=elapsed, kernel_ms=kernel_ms, ranks=ranks, work=eng.work(), flags=eng.flags(),
                counts=eng.counts().astype(np.float64).mean(axis=0), players=eng.players, fused=int(eng.L.agarcl_debug_fused(eng.h)),
                pellet_cap=(cfg["num_pellets"] + 63) // 64 * 64)
     env.close()
     return res
+
+
+def obs_bytes(res, A, cfg, with_obs, with_screen, with_ram):
+    """(requested, streaming-model) observation bytes per step.  Streaming model: the whole tensor is written once per step.
+    Requested by this implementation: the grid tensor is persistent (agarcl_grid_obs on_device = 2), so a step rewrites the dense
+    out-of-bounds channel and, per word scattered, clears the old one and writes the new one plus their undo-list entries (16 B; the view
+    covers at most (300 / arena)^2 of the arena's pellets and viruses)"""
+    model_extra = (A * 8 * 128 * 128 * 4 if with_obs else 0) + (A * 84 * 84 * 3 if with_screen else 0) + (A * cfg["num_agents"] * 152 * 4 if with_ram else 0)
+    extra = model_extra
+    if with_obs:
+        n_pel, n_vir, n_food, n_cells = res["counts"]
+        vis = min(1.0, (300.0 / cfg["arena_size"]) ** 2)
+        extra = A * (128 * 128 * 4 + 16.0 * (vis * 2 * (n_pel + n_vir) + 3 * n_cells))
+    kernel = None
+    if with_obs: kernel = "k_step + k_grid_obs (persistent tensor: incremental clear)"
+    if with_screen: kernel = "k_step + k_screen_obs"
+    if with_ram: kernel = "k_step + k_ram_obs"
+    return float(extra), float(model_extra), kernel
 
 
 def roofline_block(res, A, K, ticks, cfg, workload, extra_bytes=0.0, kernel=None, model_extra=None):
@@ -330,7 +361,17 @@ def roofline_block(res, A, K, ticks, cfg, workload, extra_bytes=0.0, kernel=None
     except Exception:
         pass
     moved = traffic if traffic else req
-    out = {"bound": "hbm", "achieved": moved / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved / t / 1e9 / HBM_PEAK_GBS,
+    frac = moved / t / 1e9 / HBM_PEAK_GBS
+    out = {"bound": "hbm", "achieved": moved / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
+           # the two fractions, named for what they are:
+           #   frac_hbm_traffic     = bytes that really left / entered HBM (PMC) / time / peak -- what the hardware did; == frac when PMC data
+           #                          of this kernel source is committed, else None (frac then rests on the requested bytes)
+           #   frac_streaming_model = SURVEY 8(d)'s B_tick model (every live entity once per tick) / time / peak -- NOT a bound for this
+           #                          engine: it exceeds 1 where the engine does not move the model's bytes
+           "frac_hbm_traffic": (traffic / t / 1e9 / HBM_PEAK_GBS) if traffic else None,
+           "frac_streaming_model": model / t / 1e9 / HBM_PEAK_GBS,
+           "regime": ("bandwidth: the step's time is its bytes" if frac >= 0.30 else
+                      "latency: launch floor, dependent instruction chains and serial pellet passes set the step's time, not its bytes"),
            "traffic": traffic, "traffic_source": tag, "requested_bytes_per_step": req, "algorithmic_bytes_per_step": req,
            # how much of what leaves HBM the kernels asked for (1 = no wasted re-reads / partial lines / spills); None without PMC data
            "frac_of_requested": (req / traffic) if traffic else None, "kernel_ms": res["kernel_ms"],
@@ -376,6 +417,10 @@ def main():
     # one process per GPU.  (AGAR_BENCH_BACKEND=gloo + fewer GPUs than ranks is only for exercising the
     # multi-rank code path on a single-GPU box; the driver's runs use nccl == RCCL over xGMI.)
     backend = os.environ.get("AGAR_BENCH_BACKEND", "nccl")
+    if world > 1 and backend == "nccl" and world > torch.cuda.device_count():
+        # (device_count() does not initialise the GPU.)  RCCL refuses two ranks on one device deep inside init ("duplicate GPU"); say it here
+        raise SystemExit("--gpus %d over nccl (RCCL) needs %d GPUs on this node, torch sees %d: one process per GPU "
+                         "(AGAR_BENCH_BACKEND=gloo exercises the multi-rank path on fewer GPUs)" % (world, world, torch.cuda.device_count()))
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -405,27 +450,15 @@ def main():
         devs = ["%s:%d" % (os.uname().nodename, dev_index)]
     value = world * A * ticks * K / res["elapsed"]
     if rank == 0:
-        # observation bytes.  Streaming model: the whole tensor is written once per step.  Requested by this
-        # implementation: the grid tensor is persistent (agarcl_grid_obs on_device = 2), so a step rewrites the dense out-of-bounds
-        # channel and, per word scattered, clears the old one and writes the new one plus their undo-list entries (16 B; the
-        # view covers at most (300 / arena)^2 of the arena's pellets and viruses)
-        model_extra = (A * 8 * 128 * 128 * 4 if with_obs else 0) + (A * 84 * 84 * 3 if with_screen else 0) + (A * cfg["num_agents"] * 152 * 4 if with_ram else 0)
-        extra = model_extra
-        if with_obs:
-            n_pel, n_vir, n_food, n_cells = res["counts"]
-            vis = min(1.0, (300.0 / cfg["arena_size"]) ** 2)
-            extra = A * (128 * 128 * 4 + 16.0 * (vis * 2 * (n_pel + n_vir) + 3 * n_cells))
-        kernel = None
-        if with_obs: kernel = "k_step + k_grid_obs (persistent tensor: incremental clear)"
-        if with_screen: kernel = "k_step + k_screen_obs"
-        if with_ram: kernel = "k_step + k_ram_obs"
+        extra, model_extra, kernel = obs_bytes(res, A, cfg, with_obs, with_screen, with_ram)
         roof = roofline_block(res, A, K, ticks, cfg, args.workload, float(extra), kernel, float(model_extra))
         roof["note"] = ("achieved = HBM bytes one env step moves (PMC FETCH_SIZE x2 + WRITE_SIZE of the same kernel source when profiles/ "
                         "holds them -> `traffic`; otherwise the bytes the kernels request, counted by the kernels themselves) / the step's "
                         "HIP-event time; frac <= 1 by construction.  model_speedup = SURVEY 8(d)'s streaming-model bytes over the same time: "
                         "it exceeds 1 because the engine does not stream (state stays in registers across the ticks of a step, pellets are "
-                        "read only when a cell leaves its pellet-free disc).  At 4096 arenas the step is launch/latency bound, see "
-                        "roofline_large for the bandwidth-bound regime")
+                        "read only when a cell leaves its pellet-free disc): it is reported as frac_streaming_model and is not a bound.  "
+                        "frac == frac_hbm_traffic when PMC data of this kernel source is committed.  `regime` says which side of the "
+                        "latency / bandwidth turn this size is on; see roofline_large / roofline_xlarge for the bandwidth regime")
         if world > 1:
             par = "arena-sharded x%d; every step's (reward, done) gathered to rank 0 %s%s" % (
                 world, "in asynchronous blocks of %d steps" % args.gather_block if args.gather == "block" else "by one collective per step",
@@ -439,6 +472,8 @@ def main():
             "config": {"workload": desc % A, "arenas_total": world * A, "ticks_per_step": ticks, "parallelism": par},
             "gym_steps_per_s": value / ticks,
             "world_size": world, "backend": (backend if world > 1 else None), "rank_devices": devs,
+            # one entry per rank: its own wall / HIP-event step time, host time spent waiting for collectives, collectives and bytes it sent
+            "ranks": res["ranks"], "result_gather": (args.gather if world > 1 else None), "obs_gather_ran": bool(world > 1 and args.gather_obs != "none"),
             "roofline": roof,
             "capacity_flags_raised": int((res["flags"] != 0).sum()),
         }
@@ -473,13 +508,17 @@ def main():
             out["roofline_sweep"] = sweep
         if world == 1 and not args.no_full and args.workload == "C2":
             # the other two regimes in the same run: the full rule set at mass 1000 (BASELINE configs[2]) and a learning agent's mid-game
+            # ... and BASELINE configs[0] (the bench/main.cpp population, batched) and configs[4] (grid / screen observation on top of the
+            # full rule set): every BASELINE config has a figure on the driver's clock
             full = {}
-            for name, fk, fw in (("C3m6", 100, 20), ("mid", 150, 400)):
+            for name, fk, fw in (("C3m6", 100, 20), ("mid", 150, 400), ("C1", 100, 20), ("C5", 60, 20), ("C5s", 60, 20)):
                 try:
                     w2 = dict(WORKLOADS[name]); w2.pop("desc"); ra = w2.pop("rand_act", False); sm = w2.pop("start_mass", 0)
+                    wo, ws, wr = w2.pop("grid_obs", False), w2.pop("screen_obs", False), w2.pop("ram_obs", False)
                     c2 = dict(CFG); c2.update(w2)
-                    r2 = run_workload(torch, np, VecEnvironment, agdist, dev, dev_index, 0, 1, A, fk, fw, c2, ra, False, False, "block", "none", 32, sm)
-                    rf = roofline_block(r2, A, fk, ticks, c2, name)
+                    r2 = run_workload(torch, np, VecEnvironment, agdist, dev, dev_index, 0, 1, A, fk, fw, c2, ra, wo, ws, "block", "none", 32, sm, wr)
+                    ex, mex, kern = obs_bytes(r2, A, c2, wo, ws, wr)
+                    rf = roofline_block(r2, A, fk, ticks, c2, name, ex, kern, mex)
                     rf["value_env_steps_per_s"] = A * ticks * fk / r2["elapsed"]; rf["ms_per_step"] = r2["elapsed"] / fk * 1e3
                     rf["mean_counts_pellets_viruses_foods_cells"] = [float(x) for x in r2["counts"]]
                     rf["workload"] = WORKLOADS[name]["desc"] % A
@@ -509,6 +548,9 @@ def main():
                 pass
         if world == 1 and not args.no_cpu_baseline and args.workload == "C2":
             out["cpu_baseline"] = cpu_baseline()
+            c1 = out.get("roofline_full", {}).get("C1@%d" % A)
+            if c1 and "error" not in c1:   # the reference engine on the same population (bench/main.cpp:14-38), one host core
+                c1["cpu_reference_ticks_per_s_1core"] = out["cpu_baseline"]["c1_ticks_per_s_1core"]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

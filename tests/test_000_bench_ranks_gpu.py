@@ -30,6 +30,16 @@ def test_bench_two_ranks_end_to_end_gpu(extra):
     assert b["config"]["arenas_total"] == 2 * arenas
     assert abs(b["value"] - 2 * arenas * 4 * 40 / (b["ms_per_step"] * 1e-3 * 40)) / b["value"] < 1e-6   # whole-job aggregate
     assert ("screen frames" in b["config"]["parallelism"]) == ("--gather-obs" in extra)
+    # what a poor scaling curve would be read from: one record per rank, and whether the observation gather ran
+    assert b["obs_gather_ran"] == ("--gather-obs" in extra) and b["result_gather"] == ("step" if "--gather" in extra else "block")
+    assert [r["rank"] for r in b["ranks"]] == [0, 1]
+    for r in b["ranks"]:
+        assert r["ms_per_step"] > 0 and r["kernel_ms_per_step"] > 0 and r["gather_wait_ms_total"] >= 0
+        if "--gather" in extra:   # one collective per step, 8 bytes per arena
+            assert r["result_collectives"] == 40 and r["result_bytes_sent"] == 40 * arenas * 8
+        else:                     # whole 32-step blocks of the result ring: steps 10 .. 49 complete block 0 and leave block 1 partial (flushed as a block)
+            assert r["result_collectives"] == 2 and r["result_bytes_sent"] == 2 * 32 * arenas * 8
+        assert r["obs_collectives"] == (40 if "--gather-obs" in extra else 0) and r["obs_bytes_sent"] == (40 * arenas * 84 * 84 * 3 if "--gather-obs" in extra else 0)
 
 
 @pytest.mark.gpu
@@ -70,8 +80,19 @@ def test_bench_line_as_the_driver_runs_it_gpu():
     assert b["roofline_large"]["arenas"] == 65536 and b["roofline_xlarge"]["arenas"] == 262144
     assert [e["arenas"] for e in b["roofline_sweep"]] == [16384, 131072] and all("error" not in e and e["ms_per_step"] > 0 and 0 < e["frac"] <= 1 for e in b["roofline_sweep"])
     full = b["roofline_full"]
-    assert set(full) == {"C3m6@4096", "mid@4096"}
+    assert set(full) == {"C3m6@4096", "mid@4096", "C1@4096", "C5@4096", "C5s@4096"}     # every BASELINE config on the driver's clock
     for v in full.values():
         assert "error" not in v and v["kernel_ms"] > 0 and v["work_per_step"]["general_engine_arena_steps"] > 4000
+    assert full["C1@4096"]["cpu_reference_ticks_per_s_1core"] > 0                        # bench/main.cpp's population on the reference engine
+    assert full["C5@4096"]["streaming_model_bytes_per_step"] > 4096 * 8 * 128 * 128 * 4 and "k_grid_obs" in full["C5@4096"]["kernel"]
+    assert "k_screen_obs" in full["C5s@4096"]["kernel"]
+    # both fractions under unambiguous names in every block, and the regime the size is in
+    blocks = [r, b["roofline_large"], b["roofline_xlarge"]] + list(full.values())
+    for v in blocks:
+        assert v["frac_streaming_model"] > 0 and v["regime"].split(":")[0] in ("latency", "bandwidth")
+        assert (v["frac_hbm_traffic"] is None) == (v["traffic"] is None)
+        if v["traffic"] is not None:
+            assert abs(v["frac_hbm_traffic"] - v["frac"]) < 1e-12
+    assert b["ranks"][0]["rank"] == 0 and b["obs_gather_ran"] is False
     assert full["mid@4096"]["mean_counts_pellets_viruses_foods_cells"][3] > 1.5      # the agents have grown and split
     assert b["capacity_flags_raised"] == 0
