@@ -32,7 +32,14 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-PARTS = [(ns, av) for ns in (4, 8, 16, 32) for av in (1, 0)]   # (pellet slots per lane, all buckets visible): one translation unit each
+# (pellet slots per lane, all buckets visible, kind): one translation unit each; kind 0 = k_step / k_reset / k_respawn, 1 = k_quiet / k_fused
+PARTS = [(ns, av, kind) for ns in (16, 32, 8, 4) for av in (1, 0) for kind in (0, 1)]
+# the step units only: without machine-level loop-invariant code motion.  What it hoists in front of k_step's loops (lane masks, table
+# constants, per-lane offsets: ~45 registers' worth) does not fit the 128-register budget and is spilled right there -- 11.5 KB of scratch
+# written per arena-step.  Measured on MI355X (product flags / this, us per step): mode 6 at 4096 arenas 420.9 / 424.4, mid-game 78.1 / 76.6,
+# C1 208.6 / 207.3; k_step's WRITE_SIZE per 4096-arena launch 57.1 -> 28.8 MB, scratch 460 -> 276 bytes per lane.  (The front kernels keep
+# it: C2 at 4096 arenas 8.94 / 9.05.)
+STEP_FLAGS = ["-mllvm", "-disable-machine-licm"]
 
 
 def _compile(args):
@@ -41,9 +48,9 @@ def _compile(args):
 
 
 def build(force=False, verbose=False, extra=(), out=OUT, single=False, jobs=None):
-    """Nine translation units compiled in parallel -- the main unit (-DAG_SPLIT_BUILD: host code, C ABI, observation kernels) and one
-    part unit per (NS, AV) pair (-DAG_PART_NS / -DAG_PART_AV: the step / reset kernels of that pair, agar_engine.hip "split build") --
-    linked into one shared library.  single=True compiles the same source as one unit (3-4 minutes instead of < 1).
+    """Seventeen translation units compiled in parallel -- the main unit (-DAG_SPLIT_BUILD: host code, C ABI, observation kernels) and two
+    part units per (NS, AV) pair (-DAG_PART_NS / -DAG_PART_AV / -DAG_PART_KIND: the step or the front kernels of that pair, agar_engine.hip
+    "split build") -- linked into one shared library.  single=True compiles the same source as one unit (3-4 minutes instead of < 1).
     extra/out: diagnostic variants only (e.g. -DAGAR_PROFILE -> build_variants/lib_PROF.so, used by scripts/; build_variants/ is
     git-ignored and travels to the GPU box only while it exists -- delete it when the measurements are done)."""
     if not force and not needs_build() and out == OUT:
@@ -51,7 +58,7 @@ def build(force=False, verbose=False, extra=(), out=OUT, single=False, jobs=None
     base = [hipcc()] + FLAGS + list(extra)
     if verbose:
         base.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    if single or os.environ.get("AGARCL_BUILD_SINGLE") == "1":
+    if single or os.environ.get("AGARCL_BUILD_SINGLE") == "1":   # (one unit: STEP_FLAGS would then reach the front kernels too, so they are left out)
         subprocess.check_call(base + ["-o", out, SRC])
         return out
     import tempfile
@@ -59,8 +66,9 @@ def build(force=False, verbose=False, extra=(), out=OUT, single=False, jobs=None
     comp = [f for f in base if f != "-shared"]
     with tempfile.TemporaryDirectory(prefix="agarcl_build_") as tmp:
         units = [comp + ["-DAG_SPLIT_BUILD", "-c", SRC, "-o", os.path.join(tmp, "main.o")]]
-        for ns, av in PARTS:
-            units.append(comp + ["-DAG_PART_NS=%d" % ns, "-DAG_PART_AV=%d" % av, "-c", SRC, "-o", os.path.join(tmp, "part_%d_%d.o" % (ns, av))])
+        for ns, av, kind in PARTS:
+            units.append(comp + (STEP_FLAGS if kind == 0 else []) + ["-DAG_PART_NS=%d" % ns, "-DAG_PART_AV=%d" % av, "-DAG_PART_KIND=%d" % kind, "-c", SRC,
+                                 "-o", os.path.join(tmp, "part_%d_%d_%d.o" % (ns, av, kind))])
         with ThreadPoolExecutor(max_workers=jobs or min(len(units), os.cpu_count() or 1)) as pool:
             objs = list(pool.map(_compile, units))
         subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)

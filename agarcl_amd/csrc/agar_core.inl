@@ -27,6 +27,8 @@
 #define AG_DEV static inline
 #define AG_MEM inline
 #define AG_LANES(i, n) for (int i = 0; i < (n); ++i)
+#define AG_LANE_OR_0 0
+#define AG_LANE_STEP 1
 #define AG_SERIAL if (true)
 AG_DEV int ag_uni(int v) { return v; }
 AG_DEV unsigned ag_uniu(unsigned v) { return v; }
@@ -44,6 +46,8 @@ AG_DEV bool ag_any(bool p) { return p; }
 #define AG_MEM __device__ __forceinline__
 #define AG_MEM_NOINLINE __device__   // (with __attribute__((noinline)): a real call, for rare code whose registers must stay out of a hot loop's budget)
 #define AG_LANES(i, n) for (int i = AG_LANE; i < (n); i += 64)
+#define AG_LANE_OR_0 AG_LANE   // (lane-strided loops with another start: for (i = start + AG_LANE_OR_0; i < n; i += AG_LANE_STEP))
+#define AG_LANE_STEP 64
 #define AG_SERIAL if (AG_LANE == 0)
 AG_DEV int ag_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 AG_DEV unsigned ag_uniu(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
@@ -174,10 +178,15 @@ static inline
 #else
 __host__ __device__ inline
 #endif
-size_t ag_lds_layout(int P, int *cells_off) {
+// behind the cells: the arena's viruses (x, y, radius, mass: a read cache, see stage_viruses) and ejected foods (x, y, vx, vy: the working
+// copy of a launch, see Foods) -- VC and FC entries each (AgDims)
+size_t ag_lds_layout(int P, int VC, int FC, int *cells_off, int *vir_off = nullptr, int *food_off = nullptr) {
   int co = L_PLS + 4 * P * PL_WORDS;
   if (cells_off) *cells_off = co;
-  return (size_t)co + (size_t)P * CELL_STRIDE;
+  int vo = co + P * CELL_STRIDE, fo = vo + 16 * VC;
+  if (vir_off) *vir_off = vo;
+  if (food_off) *food_off = fo;
+  return (size_t)fo + (size_t)16 * (size_t)FC;
 }
 
 struct Cells {  // LDS arrays of one player
@@ -231,6 +240,8 @@ template <int NS, bool AV> struct AgCtx {
   const AgState *gs;
   const AG_GLOBAL float *act_dxdy; const AG_GLOBAL int32_t *act;
   int arena, P, PC, cells_off, slot, ts_lg;
+  int vir_off, food_off, VC, FC;   // LDS blocks of the virus cache and the food working copy, their capacities (AgDims::VC / FC)
+  bool food_dirty;                 // the LDS foods differ from HBM (arena_store writes them back)
   unsigned char *lds;
   UBlock S;    // arena words (AR_*): register-resident for the whole launch
   UBlock PB;   // current player's words (PL_*): valid inside tick_player only; LDS PLS is its home
@@ -257,13 +268,25 @@ template <int NS, bool AV> AG_DEV Cells created_of(const AgCtx<NS, AV> &c) {
   k.cmc = nullptr; k.crad = nullptr; k.cms = nullptr;
   return k;
 }
+// LDS-staged entities (north star: "LDS-staged ... per arena tile").  A mid-game tick used to make three dependent round trips to L2 / HBM
+// for them -- the viruses and their radii in the virus test, the foods in the food test, foods and viruses again in the food move -- and 48 %
+// of a mid-game wavefront's cycles were waits.  Now:
+//   Foods  x, y, vx, vy of every ejected food: THE working copy for the whole launch (loaded once by arena_load, every rule reads and writes
+//          LDS, arena_store writes back what is live when anything changed).  Ids stay in HBM: only appends, erases and swaps touch them.
+//   Virs   x, y, radius (the mass table's entry: Engine.hpp:1223-1252 needs it per test), mass of every virus: a READ cache.  Viruses change
+//          only on events (eaten, fed, regenerated); those paths keep working on HBM -- which also holds velocity, hits and id -- and call
+//          stage_viruses() afterwards.
+struct Foods { float *x, *y, *vx, *vy; };
+struct Virs { float *x, *y, *r; unsigned *m; };
+template <int NS, bool AV> AG_DEV Foods foods_of(const AgCtx<NS, AV> &c) { float *b = (float *)(c.lds + c.food_off); Foods f; f.x = b; f.y = b + c.FC; f.vx = b + 2 * c.FC; f.vy = b + 3 * c.FC; return f; }
+template <int NS, bool AV> AG_DEV Virs virs_of(const AgCtx<NS, AV> &c) { float *b = (float *)(c.lds + c.vir_off); Virs v; v.x = b; v.y = b + c.VC; v.r = b + 2 * c.VC; v.m = (unsigned *)(b + 3 * c.VC); return v; }
 // HBM slices of this arena (pointer + capacity fetched with scalar loads when a rare path needs them)
 #define G_SLICE(name, type, field, cap) template <int NS, bool AV> AG_DEV AG_GLOBAL type *name(const AgCtx<NS, AV> &c) { return (AG_GLOBAL type *)(c.gs->field + (size_t)c.arena * (size_t)(cap)); }
 G_SLICE(g_pxy, float, pel_xy, 2 * c.PC) G_SLICE(g_pid, int32_t, pel_id, c.PC)
-G_SLICE(g_vx, float, vir_x, c.gs->d.VC) G_SLICE(g_vy, float, vir_y, c.gs->d.VC) G_SLICE(g_vvx, float, vir_vx, c.gs->d.VC) G_SLICE(g_vvy, float, vir_vy, c.gs->d.VC)
-G_SLICE(g_vm, int32_t, vir_mass, c.gs->d.VC) G_SLICE(g_vh, int32_t, vir_hits, c.gs->d.VC) G_SLICE(g_vid, int32_t, vir_id, c.gs->d.VC)
-G_SLICE(g_fx, float, food_x, c.gs->d.FC) G_SLICE(g_fy, float, food_y, c.gs->d.FC) G_SLICE(g_fvx, float, food_vx, c.gs->d.FC) G_SLICE(g_fvy, float, food_vy, c.gs->d.FC)
-G_SLICE(g_fid, int32_t, food_id, c.gs->d.FC)
+G_SLICE(g_vx, float, vir_x, c.VC) G_SLICE(g_vy, float, vir_y, c.VC) G_SLICE(g_vvx, float, vir_vx, c.VC) G_SLICE(g_vvy, float, vir_vy, c.VC)
+G_SLICE(g_vm, int32_t, vir_mass, c.VC) G_SLICE(g_vh, int32_t, vir_hits, c.VC) G_SLICE(g_vid, int32_t, vir_id, c.VC)
+G_SLICE(g_fx, float, food_x, c.FC) G_SLICE(g_fy, float, food_y, c.FC) G_SLICE(g_fvx, float, food_vx, c.FC) G_SLICE(g_fvy, float, food_vy, c.FC)
+G_SLICE(g_fid, int32_t, food_id, c.FC)
 G_SLICE(g_mt, uint64_t, mt, 312)
 // tile-transposed arrays (agar_types.h): word w of the returned block is [AG_TW(w)]
 template <int NS, bool AV> AG_DEV AG_GLOBAL int32_t *g_ar(const AgCtx<NS, AV> &c) { const int ag_ts_lg = c.ts_lg; return (AG_GLOBAL int32_t *)(c.gs->ar + AG_TILE_BASE(c.arena, AR_WORDS)); }
@@ -350,6 +373,12 @@ template <int NS, bool AV> AG_DEV void pel_get(const AgCtx<NS, AV> &c, int i, fl
 #endif
 }
 
+#ifndef AGAR_CPU_EMU
+// one 4-byte word per active lane from its own global address into LDS at (wave-uniform base) + lane * 4, without a destination register
+template <class GT, class LT> AG_DEV void ag_glds4(GT *g, LT *lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)lds_base, 4, 0, 0);
+}
+#endif
 // ---- load / store arena state between HBM and LDS / registers -------------------------------------
 template <int NS, bool AV> AG_DEV void arena_load(AgCtx<NS, AV> &c, bool want_pellets = false) {
   // Every load below is independent of every other (no count is needed to form an address), so the arena arrives in
@@ -374,7 +403,41 @@ template <int NS, bool AV> AG_DEV void arena_load(AgCtx<NS, AV> &c, bool want_pe
       for (int f = 0; f < CF_ALL; f++) l[f * AG_CC + i] = g[AG_CELL_W(f, i)];
     }
   }
+  // viruses (x, y, mass -> radius) and the first 64 foods: their addresses need no count either, and on the device the words go STRAIGHT
+  // into LDS (global_load_lds: wave-uniform LDS base + lane * 4, per-lane source address) -- no destination registers, so the arena's
+  // other loads (46 registers in flight with 1000 pellets) keep theirs.  An unfed virus weighs 100, so its radius is the one table entry
+  // requested here; only fed viruses (rare) look theirs up after the masses have arrived.
+  {
+    Virs V = virs_of(c); auto gx = g_vx(c); auto gy = g_vy(c); auto gm = g_vm(c);
+    Foods F = foods_of(c); auto fx = g_fx(c); auto fy = g_fy(c); auto fvx = g_fvx(c); auto fvy = g_fvy(c);
+    const float r100 = g_lut_r(c)[AG_VIRUS_MASS];
+    const int first = c.FC < 64 ? c.FC : 64;
+#if defined(AGAR_CPU_EMU) || defined(AG_NO_GLDS)   // (AG_NO_GLDS: measurement builds only -- through registers)
+    AG_LANES(i, c.VC) { V.x[i] = gx[i]; V.y[i] = gy[i]; V.m[i] = (unsigned)gm[i]; }
+    AG_LANES(i, first) { F.x[i] = fx[i]; F.y[i] = fy[i]; F.vx[i] = fvx[i]; F.vy[i] = fvy[i]; }
+#else
+    for (int base = 0; base < c.VC; base += 64) {
+      const int i = base + AG_LANE;
+      if (i < c.VC) { ag_glds4(gx + i, V.x + base); ag_glds4(gy + i, V.y + base); ag_glds4(gm + i, V.m + base); }
+    }
+    { const int i = AG_LANE; if (i < first) { ag_glds4(fx + i, F.x); ag_glds4(fy + i, F.y); ag_glds4(fvx + i, F.vx); ag_glds4(fvy + i, F.vy); } }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (an LDS-DMA is a pending LDS write on the VM counter)
+#endif
+    ag_lds_order();
+    AG_LANES(i, c.VC) { const unsigned m = V.m[i]; V.r[i] = m == AG_VIRUS_MASS ? r100 : lut(g_lut_r(c), m); }
+    const int nf = SR(c, AR_NFOOD);
+    if (AG_RARE(nf > 64)) { for (int i = 64 + AG_LANE_OR_0; i < nf; i += AG_LANE_STEP) { F.x[i] = fx[i]; F.y[i] = fy[i]; F.vx[i] = fvx[i]; F.vy[i] = fvy[i]; } }
+    c.food_dirty = false;
+  }
   c.pel_dirty = false; c.pel_all = false; PEL_CLEAN(c); c.ncreated = 0;
+  ag_lds_order();
+}
+// Viruses changed in HBM (eaten, fed, regenerated, reset): the LDS cache is read again.  Lane-level stores to HBM made by this wave come first.
+template <int NS, bool AV> AG_DEV void stage_viruses(AgCtx<NS, AV> &c) {
+  ag_mem_fence();
+  Virs V = virs_of(c); auto gx = g_vx(c); auto gy = g_vy(c); auto gm = g_vm(c);
+  const int nv = SR(c, AR_NVIR);
+  AG_LANES(i, nv) { const unsigned m = (unsigned)gm[i]; V.x[i] = gx[i]; V.y[i] = gy[i]; V.m[i] = m; V.r[i] = lut(g_lut_r(c), m); }
   ag_lds_order();
 }
 // Pellet capacity is exactly NS*64 and HBM keeps the sentinel at every index >= n_pellets, so the load is NS
@@ -385,15 +448,18 @@ template <int NS, bool AV> AG_DEV void ensure_pellets(AgCtx<NS, AV> &c) {
   AG_PEL_FOR(s, lane, i) { PELX(c, s, lane) = gxy[2 * i]; PELY(c, s, lane) = gxy[2 * i + 1]; }
   c.pel_loaded = true;
 }
+// the pellet registers that differ from HBM go back (after a reset: the whole register file incl. sentinels)
+template <int NS, bool AV> AG_DEV void pellets_store(AgCtx<NS, AV> &c) {
+  if (!c.pel_dirty) return;
+  auto gxy = g_pxy(c);
+  if (c.pel_all) { AG_PEL_FOR(s, lane, i) { gxy[2 * i] = PELX(c, s, lane); gxy[2 * i + 1] = PELY(c, s, lane); } }
+  else { AG_PEL_FOR(s, lane, i) { if (PEL_DIRTY(c, s, lane)) { gxy[2 * i] = PELX(c, s, lane); gxy[2 * i + 1] = PELY(c, s, lane); } } }
+}
 template <int NS, bool AV> AG_DEV void arena_store(AgCtx<NS, AV> &c) {
   ag_lds_order();
   const int ag_ts_lg = c.ts_lg;
   int np = SR(c, AR_NPEL);
-  if (c.pel_dirty) {  // the slots that changed (after a reset: the whole register file incl. sentinels)
-    auto gxy = g_pxy(c);
-    if (c.pel_all) { AG_PEL_FOR(s, lane, i) { gxy[2 * i] = PELX(c, s, lane); gxy[2 * i + 1] = PELY(c, s, lane); } }
-    else { AG_PEL_FOR(s, lane, i) { if (PEL_DIRTY(c, s, lane)) { gxy[2 * i] = PELX(c, s, lane); gxy[2 * i + 1] = PELY(c, s, lane); } } }
-  }
+  pellets_store(c);
   int total_cells = 0;
   for (int p = 0; p < c.P; p++) {
     int n = ag_uni(PLS(c, p)[PL_NCELLS]);
@@ -405,6 +471,10 @@ template <int NS, bool AV> AG_DEV void arena_store(AgCtx<NS, AV> &c) {
 #endif
       for (int f = 0; f < CF_ALL; f++) g[AG_CELL_W(f, i)] = l[f * AG_CC + i];
     }
+  }
+  if (c.food_dirty) {  // the live foods (ids are kept current in HBM by the rules themselves)
+    Foods F = foods_of(c); auto fx = g_fx(c); auto fy = g_fy(c); auto fvx = g_fvx(c); auto fvy = g_fvy(c);
+    AG_LANES(i, SR(c, AR_NFOOD)) { fx[i] = F.x[i]; fy[i] = F.y[i]; fvx[i] = F.vx[i]; fvy[i] = F.vy[i]; }
   }
   ub_store_t(c.S, g_ar(c), AR_WORDS, ag_ts_lg);
   {  // diagnostics (agarcl_debug_work): pellet-array transfers of this launch; flag watch word (agarcl_poll_flags)
@@ -535,7 +605,7 @@ template <int NS, bool AV> AG_DEV void add_viruses(AgCtx<NS, AV> &c, int n) {
   draw_locations(c, n, r, [&](int j, float x, float y) {
     int k = nv + j; vx[k] = x; vy[k] = y; vvx[k] = 0.0f; vvy[k] = 0.0f; vm[k] = (int)AG_VIRUS_MASS; vh[k] = 0; vid[k] = idc + 1 + j; });
   SW(c, AR_NVIR, nv + n); SW(c, AR_IDC, idc + n);
-  ag_mem_fence();
+  stage_viruses(c);
 }
 template <int NS, bool AV> AG_DEV void create_squared_pellets(AgCtx<NS, AV> &c) {
   float W = c.gs->g.W;
@@ -842,6 +912,13 @@ AG_DEV void ag_set_priority(int load) {
 // a handful of taken branches between small blocks of a 150 KB kernel, each an instruction-fetch stall; the walk below has none.)
 // Phases: sweep sN starts when sweep sN - 1 reaches its local level D + 1, so phase sN holds the levels LN = 1 .. D of sweep sN together
 // with LO = LN + D of sweep sN - 1 (phase 5, the static sweep, runs on to LN = LL).
+#if defined(AGAR_CPU_EMU) && defined(AGAR_STATS_LEVELS)
+// measurement only (tests/emu, -DAGAR_STATS_LEVELS): how many visited levels could be taken two at a time
+struct AgLevelStats { long calls, visited, merged_away, misspec, calls_dense, visited_dense, merged_dense, misspec_dense, by_n[33][3]; };
+static AgLevelStats ag_level_stats;
+extern "C" void agarcl_emu_level_stats(long *out) { memcpy(out, &ag_level_stats, sizeof(ag_level_stats)); }
+extern "C" void agarcl_emu_level_stats_reset() { memset(&ag_level_stats, 0, sizeof(ag_level_stats)); }
+#endif
 template <int NS, bool AV> AG_DEV void self_collisions(AgCtx<NS, AV> &c, const Cells &s, int n, float tx, float ty) {
   // (move_player has just refreshed every cell's radius cache, so s.crad[] is valid for all n cells)
   const int NP = n * (n - 1) / 2;   // pairs (a, b), a < b, numbered row-major: k = a n - a (a + 1) / 2 + b - a - 1
@@ -893,6 +970,31 @@ template <int NS, bool AV> AG_DEV void self_collisions(AgCtx<NS, AV> &c, const C
       const int a0O = LO - (n - 1) > 0 ? LO - (n - 1) : 0, wO = validO ? (LO - 1) / 2 - a0O + 1 : 0;
       const int a0N = LN - (n - 1) > 0 ? LN - (n - 1) : 0, wN = (LN - 1) / 2 - a0N + 1;
       bool he = false, ho = false;
+#if defined(AGAR_CPU_EMU) && defined(AGAR_STATS_LEVELS)
+      // could this level-time and the next one (LN + 1 / LO + 1) have been visited together?  Yes iff the pairs of both that touch at the
+      // positions BEFORE this visit share no cell; a misspeculation is a pair of the next level-time that touches only after this one moved
+      bool st_mergeable = false; unsigned long long st_batch_next = 0ull;   // (bit k: pair k of the next level-time touched before)
+      auto st_pairs = [&](int LNx, int *pa, int *pb) -> int {   // pairs of level-time LNx of this phase: older sweep first
+        int cnt = 0; const int LOx = LNx + D; const bool vO = sN >= 1 && LOx <= LL && LNx <= eo;
+        if (vO) { const int a0 = LOx - (n - 1) > 0 ? LOx - (n - 1) : 0; for (int a = a0; a <= (LOx - 1) / 2; a++) { pa[cnt] = a; pb[cnt] = LOx - a; cnt++; } }
+        if (LNx <= plen) { const int a0 = LNx - (n - 1) > 0 ? LNx - (n - 1) : 0; for (int a = a0; a <= (LNx - 1) / 2; a++) { pa[cnt] = a; pb[cnt] = LNx - a; cnt++; } }
+        return cnt;
+      };
+      int st_na[64], st_nb[64], st_nn = 0;
+      static thread_local bool st_skip = false; static thread_local int st_skip_LN = -1, st_skip_sN = -1;
+      const bool st_was_merged = st_skip && st_skip_LN == LN && st_skip_sN == sN; st_skip = false;
+      {
+        int ca[64], cb[64]; const int cn = st_pairs(LN, ca, cb);
+        unsigned used = 0u; bool ok = true;
+        for (int k = 0; k < cn; k++) if (touches(s.x[ca[k]], s.y[ca[k]], s.crad[ca[k]], s.x[cb[k]], s.y[cb[k]], s.crad[cb[k]])) { const unsigned m = (1u << ca[k]) | (1u << cb[k]); if (used & m) ok = false; used |= m; }
+        const bool next_in_phase = (LN + 1 <= plen) || (sN >= 1 && LN + 1 <= eo);
+        if (next_in_phase && LN != eo) {   // (a sweep-end check sits between the two: not merged)
+          st_nn = st_pairs(LN + 1, st_na, st_nb); bool any_next = false;
+          for (int k = 0; k < st_nn; k++) if (touches(s.x[st_na[k]], s.y[st_na[k]], s.crad[st_na[k]], s.x[st_nb[k]], s.y[st_nb[k]], s.crad[st_nb[k]])) { const unsigned m = (1u << st_na[k]) | (1u << st_nb[k]); if (used & m) ok = false; used |= m; st_batch_next |= 1ull << k; any_next = true; }
+          st_mergeable = ok && any_next && !st_was_merged;
+        }
+      }
+#endif
 #ifdef AGAR_CPU_EMU
       // lane j: a pair of the older sweep first, then of the newer one; only x, y, r are read before the pair is known to touch
       auto visit = [&](int j, int &sw) -> bool {
@@ -929,6 +1031,20 @@ template <int NS, bool AV> AG_DEV void self_collisions(AgCtx<NS, AV> &c, const C
       }
 #endif
       ag_lds_order();
+#if defined(AGAR_CPU_EMU) && defined(AGAR_STATS_LEVELS)
+      {
+        const bool dense = __builtin_popcountll(H) >= 14;
+        ag_level_stats.visited++; if (dense) ag_level_stats.visited_dense++;
+        if (n <= 32) ag_level_stats.by_n[n][0]++;
+        if (st_was_merged) { ag_level_stats.merged_away++; if (dense) ag_level_stats.merged_dense++; if (n <= 32) ag_level_stats.by_n[n][1]++; }
+        if (st_mergeable) {
+          bool bad = false;
+          for (int k = 0; k < st_nn; k++) if (!((st_batch_next >> k) & 1ull) && touches(s.x[st_na[k]], s.y[st_na[k]], s.crad[st_na[k]], s.x[st_nb[k]], s.y[st_nb[k]], s.crad[st_nb[k]])) bad = true;
+          if (bad) { ag_level_stats.misspec++; if (dense) ag_level_stats.misspec_dense++; if (n <= 32) ag_level_stats.by_n[n][2]++; }
+          else { st_skip = true; st_skip_LN = LN + 1; st_skip_sN = sN; }
+        }
+      }
+#endif
 #if defined(AGAR_PROFILE_LEVELS) && !defined(AGAR_CPU_EMU)
       AG_SERIAL { atomicAdd(c.gs->qstat + 2, 1); if (he || ho) atomicAdd(c.gs->qstat + 3, 1); }   // diagnostic build: levels visited / with a touching pair
 #endif
@@ -1009,13 +1125,12 @@ template <int NS, bool AV> AG_DEV bool virus_collisions(AgCtx<NS, AV> &c, const 
   if (nv == 0) return false;
   unsigned maxm = n == 1 ? ag_uniu(s.m[0]) : wave_max(n, [&](int i) { return s.m[i]; });
   if (maxm < 111u) return false;  // virus mass >= 100 and can_eat needs mass > 1.1 * virus mass
-  auto vx_ = g_vx(c); auto vy_ = g_vy(c); auto vm_ = g_vm(c);
-  int vgw = c.gs->g.vgw, vgh = c.gs->g.vgh; unsigned VC = (unsigned)c.gs->d.VC;
-  // One pass, a lane per virus against all cells, proves the common case -- no cell reaches a virus it can eat -- in two round trips to
-  // HBM (the viruses, then their radii) instead of two per cell: with 14 cells of 111+ mass the per-cell scans below were 28 dependent
-  // round trips a tick.  Same predicate as the scan, so a miss here is a miss there; nothing has changed in between.
+  const Virs V = virs_of(c);   // x, y, radius, mass in LDS (stage_viruses)
+  int vgw = c.gs->g.vgw, vgh = c.gs->g.vgh; unsigned VC = (unsigned)c.VC;
+  // One pass, a lane per virus against all cells, proves the common case -- no cell reaches a virus it can eat.  Same predicate as the scan
+  // below, so a miss here is a miss there; nothing has changed in between.
   if (!wave_any(nv, [&](int vi) {
-        float vx = vx_[vi], vy = vy_[vi]; unsigned vmass = (unsigned)vm_[vi]; float vr = radius_of(c, vmass);
+        float vx = V.x[vi], vy = V.y[vi]; unsigned vmass = V.m[vi]; float vr = V.r[vi];
         int bx = f2i(vx) / AG_VIRUS_GRID, by = f2i(vy) / AG_VIRUS_GRID; bool h = bx >= 0 && bx < vgw && by >= 0 && by < vgh, any = false;
         for (int k = 0; k < n; k++) {
           unsigned m = s.m[k]; float x = s.x[k], y = s.y[k];
@@ -1031,17 +1146,17 @@ template <int NS, bool AV> AG_DEV bool virus_collisions(AgCtx<NS, AV> &c, const 
     float r = radius_of(c, m);
     int gx = f2i(x) / AG_VIRUS_GRID, gy = f2i(y) / AG_VIRUS_GRID;
     unsigned key = wave_min(nv, [&](int vi) -> unsigned {
-      float vx = vx_[vi], vy = vy_[vi]; unsigned vmass = (unsigned)vm_[vi];
+      float vx = V.x[vi], vy = V.y[vi]; unsigned vmass = V.m[vi];
       int bx = f2i(vx) / AG_VIRUS_GRID, by = f2i(vy) / AG_VIRUS_GRID;
       int ddx = bx - gx, ddy = by - gy;
       bool ok = ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1 && bx >= 0 && bx < vgw && by >= 0 && by < vgh;
-      ok = ok && can_eat_mass(m, vmass) && collides(x, y, r, vx, vy, radius_of(c, vmass));
+      ok = ok && can_eat_mass(m, vmass) && collides(x, y, r, vx, vy, V.r[vi]);
       return ok ? (unsigned)((ddx + 1) * 3 + (ddy + 1)) * VC + (unsigned)vi : UINT_MAX;
     });
     if (key == UINT_MAX) continue;
     int vi = (int)(key % VC);
     if (can_eat_virus) {
-      unsigned vmass = ag_uniu((unsigned)vm_[vi]);
+      unsigned vmass = ag_uniu(V.m[vi]);
       AG_SERIAL { s.m[k] = clamp_mass(m + vmass); }
     } else {
       // disrupt
@@ -1054,7 +1169,7 @@ template <int NS, bool AV> AG_DEV bool virus_collisions(AgCtx<NS, AV> &c, const 
       float cvx = ag_unif(s.vx[k]), cvy = ag_unif(s.vy[k]);
       float theta = v_direction(cvx, cvy);
       float sp = lut(g_lut_ms(c), AG_CELL_POP_SIZE);
-      float virx = ag_unif(vx_[vi]), viry = ag_unif(vy_[vi]);
+      float virx = ag_unif(V.x[vi]), viry = ag_unif(V.y[vi]);
       int idc = SR(c, AR_IDC), nc0 = c.ncreated;
       unsigned dl = (unsigned)SR(c, AR_CLOCK) + (unsigned)c.gs->g.recomb_ticks;
       if (nc0 + num_new > AG_CC) flag(c, 1u);
@@ -1117,34 +1232,36 @@ template <int NS, bool AV> AG_DEV int pellets_eat(AgCtx<NS, AV> &c, const Cells 
       if (cK <= K) break;
       K = cK;
     }
-    if (K > AG_CAND_CAP / 4) { flag(c, 8u); }
-    // candidate records (key, index, x, y) in LDS, ascending index; key = (bucket visit rank, index)
-    unsigned PC = (unsigned)c.PC;
+    if (K > AG_CAND_CAP / 2) { flag(c, 8u); }
+    // candidate records (key, squared distance to the cell) in LDS, ascending index; key = (bucket visit rank) * capacity + index.  The cell
+    // does not move while it eats -- only its radius grows -- so the distance the replay compares is the one computed here (the same fp32
+    // operations on the same operands as sqr_dist in the replay would be), and the index is the key's low bits: 8 bytes per candidate
+    const unsigned PC = (unsigned)c.PC;   // NS * 64: a power of two
     unsigned *cand = (unsigned *)L_I(c, L_CAND);
     pel_launder(c);
     int ncand = pel_compact(c, [&](float qx, float qy, int) { return hit(qx, qy, rrK); }, [&](float qx, float qy, int i, int rank) {
-      if (rank < AG_CAND_CAP / 4) {
+      if (rank < AG_CAND_CAP / 2) {
         int ddx = f2i(qx) / AG_PELLET_GRID - gx, ddy = f2i(qy) / AG_PELLET_GRID - gy;
-        cand[4 * rank] = (unsigned)((ddx + 1) * 3 + (ddy + 1)) * PC + (unsigned)i;
-        cand[4 * rank + 1] = (unsigned)i; cand[4 * rank + 2] = (unsigned)f2u(qx); cand[4 * rank + 3] = (unsigned)f2u(qy);
+        cand[2 * rank] = (unsigned)((ddx + 1) * 3 + (ddy + 1)) * PC + (unsigned)i;
+        cand[2 * rank + 1] = (unsigned)f2u(sqr_dist(x, y, qx, qy));
       }
     });
-    if (ncand > AG_CAND_CAP / 4) ncand = AG_CAND_CAP / 4;
+    if (ncand > AG_CAND_CAP / 2) ncand = AG_CAND_CAP / 2;
     ag_lds_order();
     int ne0 = SR(c, AR_NEVP);
     int *T = L_I(c, L_TMP); int *evp = L_I(c, L_EVP);
     auto lut_r = g_lut_r(c);
     AG_SERIAL {
-      for (int a = 1; a < ncand; a++) {  // insertion sort of the 4-word records by key
-        unsigned k0 = cand[4 * a], k1 = cand[4 * a + 1], k2 = cand[4 * a + 2], k3 = cand[4 * a + 3]; int b = a - 1;
-        while (b >= 0 && cand[4 * b] > k0) { cand[4 * b + 4] = cand[4 * b]; cand[4 * b + 5] = cand[4 * b + 1]; cand[4 * b + 6] = cand[4 * b + 2]; cand[4 * b + 7] = cand[4 * b + 3]; b--; }
-        cand[4 * b + 4] = k0; cand[4 * b + 5] = k1; cand[4 * b + 6] = k2; cand[4 * b + 7] = k3;
+      for (int a = 1; a < ncand; a++) {  // insertion sort of the 2-word records by key
+        unsigned k0 = cand[2 * a], k1 = cand[2 * a + 1]; int b = a - 1;
+        while (b >= 0 && cand[2 * b] > k0) { cand[2 * b + 2] = cand[2 * b]; cand[2 * b + 3] = cand[2 * b + 1]; b--; }
+        cand[2 * b + 2] = k0; cand[2 * b + 3] = k1;
       }
       unsigned mc = m; int ne = ne0;
       for (int a = 0; a < ncand; a++) {
         float rc = lut(lut_r, mc); float rrc = rc * rc;
-        if (rrc >= sqr_dist(x, y, u2f((int)cand[4 * a + 2]), u2f((int)cand[4 * a + 3]))) {
-          if (ne < AG_EV_CAP) evp[ne] = (int)cand[4 * a + 1];
+        if (rrc >= u2f((int)cand[2 * a + 1])) {
+          if (ne < AG_EV_CAP) evp[ne] = (int)(cand[2 * a] & (PC - 1u));
           ne++; mc = clamp_mass(mc + AG_PELLET_MASS);
         }
       }
@@ -1167,19 +1284,19 @@ template <int NS, bool AV> AG_DEV int eat_food(AgCtx<NS, AV> &c, const Cells &s,
   if (m < AG_FOOD_MASS) return 0;
   float x = ag_unif(s.x[k]), y = ag_unif(s.y[k]);
   float r = radius_of(c, m), fr = radius_of(c, AG_FOOD_MASS);
-  auto fx = g_fx(c); auto fy = g_fy(c); auto fvx = g_fvx(c); auto fvy = g_fvy(c); auto fid = g_fid(c);
-  auto eaten = [&](int i) -> bool { return can_eat_mass(m, AG_FOOD_MASS) && collides(x, y, r, fx[i], fy[i], fr); };
+  const Foods F = foods_of(c); auto fid = g_fid(c);
+  auto eaten = [&](int i) -> bool { return can_eat_mass(m, AG_FOOD_MASS) && collides(x, y, r, F.x[i], F.y[i], fr); };
   int cnt = wave_count(nf, [&](int i) { return eaten(i); });
   if (cnt == 0) return 0;
   // order-preserving erase(remove_if(...)) in place: rank <= i, chunks ascending, and within a 64-chunk
   // all lanes load before any lane stores
   int kept = wave_compact(nf, [&](int i) { return !eaten(i); }, [&](int i, int rank) {
-    float a = fx[i], b = fy[i], e = fvx[i], f = fvy[i]; int id = fid[i];
-    fx[rank] = a; fy[rank] = b; fvx[rank] = e; fvy[rank] = f; fid[rank] = id;
+    float a = F.x[i], b = F.y[i], e = F.vx[i], f = F.vy[i]; int id = fid[i];
+    F.x[rank] = a; F.y[rank] = b; F.vx[rank] = e; F.vy[rank] = f; fid[rank] = id;
   });
-  SW(c, AR_NFOOD, kept);
+  SW(c, AR_NFOOD, kept); c.food_dirty = true;
   AG_SERIAL { s.m[k] = clamp_mass(m + (unsigned)(nf - kept) * AG_FOOD_MASS); }
-  ag_mem_fence();
+  ag_mem_fence();   // (the ids moved in HBM; the next cell's erase reads them through other lanes)
   return nf - kept;
 }
 template <int NS, bool AV> AG_DEV void maybe_emit_food(AgCtx<NS, AV> &c, const Cells &s, int n) {
@@ -1188,8 +1305,8 @@ template <int NS, bool AV> AG_DEV void maybe_emit_food(AgCtx<NS, AV> &c, const C
   if (PR(c, PL_ACTION) == 1 && cd == 0) {
     int nf = SR(c, AR_NFOOD), idc = SR(c, AR_IDC);
     float tx = PRF(c, PL_TX), ty = PRF(c, PL_TY);
-    int FC = c.gs->d.FC;
-    auto fx = g_fx(c); auto fy = g_fy(c); auto fvx = g_fvx(c); auto fvy = g_fvy(c); auto fid = g_fid(c);
+    int FC = c.FC;
+    const Foods F = foods_of(c); auto fid = g_fid(c);
     int made = wave_compact(n, [&](int i) { return s.m[i] >= AG_CELL_MIN_SIZE + AG_FOOD_MASS; }, [&](int i, int rank) {
       float x = s.x[i], y = s.y[i];
       float ddx = tx - x, ddy = ty - y;
@@ -1198,12 +1315,13 @@ template <int NS, bool AV> AG_DEV void maybe_emit_food(AgCtx<NS, AV> &c, const C
       float r = radius_of(c, s.m[i]);
       float ox = dirx * r, oy = diry * r;
       int f = nf + rank;
-      if (f < FC) { fx[f] = x + ox; fy[f] = y + oy; fvx[f] = dirx * AG_FOOD_SPEED; fvy[f] = diry * AG_FOOD_SPEED; fid[f] = idc + 1 + rank; }
+      if (f < FC) { F.x[f] = x + ox; F.y[f] = y + oy; F.vx[f] = dirx * AG_FOOD_SPEED; F.vy[f] = diry * AG_FOOD_SPEED; fid[f] = idc + 1 + rank; }
       s.m[i] = clamp_mass(s.m[i] - AG_FOOD_MASS);
     });
     int nf2 = nf + made;
     if (nf2 > FC) { flag(c, 2u); nf2 = FC; }
     SW(c, AR_NFOOD, nf2); SW(c, AR_IDC, idc + made);
+    if (made) c.food_dirty = true;
     cd = 10;
     ag_mem_fence();
   }
@@ -1233,40 +1351,45 @@ template <int NS, bool AV> AG_DEV void move_foods(AgCtx<NS, AV> &c) {
   int nf = SR(c, AR_NFOOD);
   if (nf == 0) return;
   float dt = c.gs->g.dt, W = c.gs->g.W; float fr = radius_of(c, AG_FOOD_MASS);
-  auto fx = g_fx(c); auto fy = g_fy(c); auto fvx = g_fvx(c); auto fvy = g_fvy(c); auto fid = g_fid(c);
-  bool moving = wave_any(nf, [&](int i) { return !(vmag(fvx[i], fvy[i]) == 0); });
+  const Foods F = foods_of(c);   // the launch's working copy (LDS)
+  bool moving = wave_any(nf, [&](int i) { return !(vmag(F.vx[i], F.vy[i]) == 0); });
   if (!moving) return;
   int nv = SR(c, AR_NVIR);
-  auto vx = g_vx(c); auto vy = g_vy(c); auto vvx = g_vvx(c); auto vvy = g_vvy(c); auto vm = g_vm(c); auto vh = g_vh(c); auto vid = g_vid(c);
+  const Virs V = virs_of(c);
   auto advance = [&](float &x, float &y, float &ux, float &uy) { v_decelerate(ux, uy, AG_FOOD_DECEL, dt); float t = ux * dt; x += t; t = uy * dt; y += t; boundary(W, x, y, fr); };
   // does any moving food reach a virus after its move?  (virus radii only grow by being fed)
-  // (a lane per (food, virus) pair: all loads of a pass are in flight together -- a loop over the viruses inside a lane was two dependent
-  // round trips to HBM per virus, 50 a tick in every arena with a moving food)
+  // (a lane per (food, virus) pair, everything out of LDS)
   bool hits = nv > 0 && wave_any(nf * nv, [&](int k) {
     int i = k / nv, v = k - i * nv;
-    float x = fx[i], y = fy[i], ux = fvx[i], uy = fvy[i], wx = vx[v], wy = vy[v], wr = radius_of(c, (unsigned)vm[v]);
+    float x = F.x[i], y = F.y[i], ux = F.vx[i], uy = F.vy[i], wx = V.x[v], wy = V.y[v], wr = V.r[v];
     if (vmag(ux, uy) == 0) return false;
     advance(x, y, ux, uy);
     return collides(x, y, fr, wx, wy, wr);
   });
+  c.food_dirty = true;
   if (!hits) {
     AG_LANES(i, nf) {
-      float x = fx[i], y = fy[i], ux = fvx[i], uy = fvy[i];
-      if (!(vmag(ux, uy) == 0)) { advance(x, y, ux, uy); fx[i] = x; fy[i] = y; fvx[i] = ux; fvy[i] = uy; }
+      float x = F.x[i], y = F.y[i], ux = F.vx[i], uy = F.vy[i];
+      if (!(vmag(ux, uy) == 0)) { advance(x, y, ux, uy); F.x[i] = x; F.y[i] = y; F.vx[i] = ux; F.vy[i] = uy; }
     }
-    ag_mem_fence();
+    ag_lds_order();
     return;
   }
-  int idc0 = SR(c, AR_IDC), VC = c.gs->d.VC; float dt10 = c.gs->g.dt10;
+  // a food reaches a virus (rare): the viruses are fed, grown and spawned in HBM -- which also holds their velocity, hit count and id --
+  // and the LDS cache is read again afterwards; the foods stay in LDS, their ids in HBM
+  auto vx = g_vx(c); auto vy = g_vy(c); auto vvx = g_vvx(c); auto vvy = g_vvy(c); auto vm = g_vm(c); auto vh = g_vh(c); auto vid = g_vid(c);
+  auto fid = g_fid(c);
+  int idc0 = SR(c, AR_IDC), VC = c.VC; float dt10 = c.gs->g.dt10;
   int *T = L_I(c, L_TMP);
+  ag_mem_fence();
   AG_SERIAL {  // exact sequential replay incl. swap-pop and virus feeding.  R: Engine.hpp:632-687
     int n = nf, nvir = nv, idc = idc0, fl = 0;
     for (int i = 0; i < n;) {
-      float x = fx[i], y = fy[i], ux = fvx[i], uy = fvy[i];
+      float x = F.x[i], y = F.y[i], ux = F.vx[i], uy = F.vy[i];
       if (vmag(ux, uy) == 0) { i++; continue; }
       float pvx = ux, pvy = uy;
       advance(x, y, ux, uy);
-      fx[i] = x; fy[i] = y; fvx[i] = ux; fvy[i] = uy;
+      F.x[i] = x; F.y[i] = y; F.vx[i] = ux; F.vy[i] = uy;
       bool hit = false;
       int nscan = nvir;
       for (int v = 0; v < nscan; v++) {
@@ -1286,18 +1409,19 @@ template <int NS, bool AV> AG_DEV void move_foods(AgCtx<NS, AV> &c) {
       if (hit) {
         if (n > 1) {
           int j = n - 1;
-          float a = fx[j], b = fy[j], e = fvx[j], f = fvy[j]; int id = fid[j];
-          fx[j] = fx[i]; fy[j] = fy[i]; fvx[j] = fvx[i]; fvy[j] = fvy[i]; fid[j] = fid[i];
-          fx[i] = a; fy[i] = b; fvx[i] = e; fvy[i] = f; fid[i] = id;
+          float a = F.x[j], b = F.y[j], e = F.vx[j], f = F.vy[j]; int id = fid[j];
+          F.x[j] = F.x[i]; F.y[j] = F.y[i]; F.vx[j] = F.vx[i]; F.vy[j] = F.vy[i]; fid[j] = fid[i];
+          F.x[i] = a; F.y[i] = b; F.vx[i] = e; F.vy[i] = f; fid[i] = id;
         }
         n--;
       } else i++;
     }
     T[0] = n; T[1] = nvir; T[2] = idc; T[3] = fl;
   }
-  ag_mem_fence();
+  ag_lds_order();
   SW(c, AR_NFOOD, ag_uni(T[0])); SW(c, AR_NVIR, ag_uni(T[1])); SW(c, AR_IDC, ag_uni(T[2]));
   int fl = ag_uni(T[3]); if (fl) flag(c, (unsigned)fl);
+  stage_viruses(c);   // (fences first)
 }
 
 // ---- recombine / decay.  R: Engine.hpp:1160-1179, 550-584; Entities.hpp:183-203 -------------------------
@@ -1398,11 +1522,11 @@ template <int NS, bool AV> AG_DEV void tick_player(AgCtx<NS, AV> &c, int p) {
   bool food_work = big;
 #ifndef AG_ABL_FOODTEST
   if (!big && SR(c, AR_NFOOD) > 0) {
-    // one pass over the foods (a lane each) against all cells proves the common case -- nobody touches any food --
-    // instead of one HBM round trip per cell; without an auto-split no mass changes between here and a cell's own turn
-    auto fx = g_fx(c); auto fy = g_fy(c); const float fr = radius_of(c, AG_FOOD_MASS);
+    // one pass over the foods (a lane each, out of LDS) against all cells proves the common case -- nobody touches any food;
+    // without an auto-split no mass changes between here and a cell's own turn
+    const Foods F = foods_of(c); const float fr = radius_of(c, AG_FOOD_MASS);
     food_work = wave_any(SR(c, AR_NFOOD), [&](int j) {
-      float x = fx[j], y = fy[j]; bool h = false;
+      float x = F.x[j], y = F.y[j]; bool h = false;
       for (int i = 0; i < n; i++) { unsigned m = s.m[i]; h = h | (m >= AG_FOOD_MASS && can_eat_mass(m, AG_FOOD_MASS) && collides(s.x[i], s.y[i], cell_rad(c, s, i), x, y, fr)); }
       return h;
     });
@@ -1502,8 +1626,9 @@ template <int NS, bool AV> AG_DEV void remove_viruses(AgCtx<NS, AV> &c) {
     }
     T[0] = n;
   }
-  ag_mem_fence();
+  ag_lds_order();
   SW(c, AR_NVIR, ag_uni(T[0]));
+  stage_viruses(c);   // (fences first)
 }
 // sort(player.cells) by id (Engine.hpp:157); ids are unique so the result is the sorted order.
 template <int NS, bool AV> AG_DEV void sort_cells_by_id(AgCtx<NS, AV> &c, int p) {
@@ -1951,7 +2076,14 @@ AG_DEV void emit_agent_result(const AgState *gs, int slot, int arena, int na, in
 
 // q_done >= 0: the lean kernel (agar_quiet.inl) already did the prologue and the first q_done ticks of this step
 // (single player; q_before = the agent's mass before the step).
-template <int NS, bool AV> AG_DEV void env_step(AgCtx<NS, AV> &c, int ticks, bool with_env, int q_done = -1, int q_before = 0) {
+// QUIET: try a quiet run in front of every general tick (quiet_run).  The host emulation and the general engine behind k_fused (256 registers)
+// do; k_step does NOT: inlined there, the quiet path's ~45 live scalars and its pass sat on top of the general engine's working set in a
+// 128-register budget -- 460 bytes of scratch per lane, 213 spilled registers, 20-29 of them saved in front of every tick whether or not a
+// quiet run followed (12-20 KB of scratch written per arena-step).  Without it k_step needs 28 bytes.  Results are the same either way (a
+// quiet tick is the general tick of a one-cell, food-free arena); an arena that turns quiet in the middle of a k_step step simply finishes
+// that step on general ticks -- the front kernel takes its next one.  (As a real call the quiet run cost more than it saved: the callee
+// saves 53 registers per call, and builds of it were not bit-stable across loop forms -- see DESIGN.md "tried and dropped".)
+template <int NS, bool AV, bool QUIET = true> AG_DEV void env_step(AgCtx<NS, AV> &c, int ticks, bool with_env, int q_done = -1, int q_before = 0) {
   int na = c.gs->d.n_agents, mode = c.gs->g.mode;
   int *before = L_I(c, L_TMP) + 20;  // [n_agents] masses before the ticks, in rewards order (LDS, not private memory)
   if (with_env && q_done >= 0) { AG_SERIAL { before[0] = q_before; } ag_lds_order(); }
@@ -1970,8 +2102,12 @@ template <int NS, bool AV> AG_DEV void env_step(AgCtx<NS, AV> &c, int ticks, boo
   }
   for (int t = q_done > 0 ? q_done : 0; t < ticks;) {
 #ifndef AG_NO_QUIET
-    t += quiet_run(c, ticks - t);
-    if (t >= ticks) break;
+    if constexpr (QUIET) {
+      if (c.P == 1 && SR(c, AR_NFOOD) == 0 && ag_uni(PLS(c, 0)[PL_NCELLS]) == 1) {
+        t += quiet_run(c, ticks - t);
+        if (t >= ticks) break;
+      }
+    }
 #endif
     arena_tick(c); t++;
   }

@@ -82,6 +82,7 @@ struct agarcl_env {
   void *timer_ev[2];               // agarcl_timer_mark / agarcl_timer_elapsed_ms
   int32_t *obs_buf; size_t obs_cap;  // staging for host-side grid observations
   int32_t *undo_list, *undo_count; const int32_t *undo_out; int undo_key;  // incremental clearing of the grid observation (AgObsUndo)
+  uint8_t *undo_sig; int undo_sig_g;   // ... and the out-of-bounds channel's row / column signature of the previous call ([frames][2 G] bytes)
   std::vector<uint32_t> seeds;  // last seed of every arena (BaseEnvironment::seed_, written into JSON snapshots)
   bool fused;     // single-launch step (k_fused) instead of k_quiet + k_step: see k_fused
   bool fused_fixed;                // AGARCL_FUSED=0/1 pins the choice
@@ -97,6 +98,7 @@ struct agarcl_env {
   bool stat_pending, stat_stale_flags;   // a sample is in flight / it was requested before the last reset: its flag word is void
   long step_no, front_runs, stat_req_front, stat_last_front; int32_t stat_last_total;
   int parity;     // launch parity of the k_quiet / k_step pair (selects the unfinished-arena counter)
+  int sched_parity; // launch parity of k_step (selects its work counter: see k_step)
   bool no_front;  // AGARCL_NO_FRONT=1 in the environment: skip k_quiet (diagnostics / A-B timing only)
   bool few_unfinished; // adaptive: the front part leaves < 64 arenas per step to k_step (see launch_step)
   bool front_off; // adaptive: the front part finishes (almost) no arena-step, so the two-kernel step runs k_step alone
@@ -108,7 +110,9 @@ template <int NS, bool AV> AG_DEV void ag_ctx_init(AgCtx<NS, AV> &c, const AgSta
   c.slot = slot;
   c.gs = gs; c.arena = arena; c.lds = lds; c.act_dxdy = (const AG_GLOBAL float *)act_dxdy; c.act = (const AG_GLOBAL int32_t *)act;
   c.P = gs->d.P; c.PC = gs->d.PC; c.ts_lg = gs->d.ts_lg;
-  ag_lds_layout(c.P, &c.cells_off);
+  c.VC = gs->d.VC; c.FC = gs->d.FC;
+  ag_lds_layout(c.P, c.VC, c.FC, &c.cells_off, &c.vir_off, &c.food_off);
+  c.food_dirty = false;
   c.ncreated = 0; c.pel_dirty = false; c.pel_loaded = false; c.pel_all = false; PEL_CLEAN(c);
 }
 #define AG_DISPATCH_NS(ns, CALL) do { if (e->all_vis) { switch (ns) { case 4: CALL(4, true); break; case 8: CALL(8, true); break; case 16: CALL(16, true); break; default: CALL(32, true); break; } } \
@@ -146,7 +150,7 @@ __device__ __forceinline__ int ag_xcd_swizzle(int bid, int nwg) {
 // use_q: k_quiet ran in front of this launch and left a work list (qlist / qcount) of the arenas it did not finish; only
 // those are visited, resuming where the front part stopped.  A quiet-dominated step therefore costs this launch one
 // scalar load per workgroup whatever the arena count.
-template <int NS, bool AV, int TSLG> __global__ void __launch_bounds__(64) AG_KSTEP_ATTR k_step(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int use_q, int parity) {
+template <int NS, bool AV, int TSLG> __global__ void __launch_bounds__(64) AG_KSTEP_ATTR k_step(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int use_q, int parity, int sp) {
   const int A = gs->d.A;
   int total = A;
   if (use_q) {
@@ -154,7 +158,18 @@ template <int NS, bool AV, int TSLG> __global__ void __launch_bounds__(64) AG_KS
     total = qc[parity];
     if (blockIdx.x == 0 && threadIdx.x == 0) qc[parity ^ 1] = 0;   // re-arm the other parity's counter for the next step's k_quiet
   }
-  for (int it = TSLG ? ag_xcd_swizzle((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x; it < total; it += (int)gridDim.x) {
+  // Work beyond the grid is handed out dynamically: a workgroup that has finished its arena draws the next item from a counter (sched[sp];
+  // this launch re-arms sched[sp ^ 1], which the previous launch used and the next one will).  With a fixed stride every wavefront slot owned
+  // arenas it, it + 4096, ... whatever they cost, and an arena-step of the full rule set costs anything between 0.4 and 2.4 times the mean
+  // (DESIGN.md section 4.4): at 32768 arenas the launch waited for the slot whose eight arenas happened to be dense clumps.
+  auto sched = (AG_GLOBAL int32_t *)gs->sched;
+  if (blockIdx.x == 0 && threadIdx.x == 0) sched[sp ^ 1] = 0;
+  for (int it = TSLG ? ag_xcd_swizzle((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x; it < total;
+#ifdef AG_KSTEP_STATIC   // (measurement builds only: the fixed stride)
+       it += (int)gridDim.x) {
+#else
+       it = (int)gridDim.x + (total > (int)gridDim.x ? ag_uni(threadIdx.x == 0 ? __hip_atomic_fetch_add(sched + sp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0) : total)) {
+#endif
     int arena = it, q_done = -1, q_before = 0;
     if (use_q) {
       arena = ((const AG_GLOBAL int32_t *)gs->qlist)[(size_t)parity * A + it];
@@ -169,7 +184,7 @@ template <int NS, bool AV, int TSLG> __global__ void __launch_bounds__(64) AG_KS
 #endif
     arena_load(c, true);   // a general tick is (almost) certain: the pellets join the first round trip
     AG_T(c, 0);
-    env_step(c, ticks, with_env != 0, q_done, q_before);
+    env_step<NS, AV, false>(c, ticks, with_env != 0, q_done, q_before);   // (general ticks only: see env_step)
     AG_T(c, 10);
     arena_store(c);
     AG_T(c, 11);
@@ -271,23 +286,31 @@ __global__ void k_tile_scatter(uint32_t *dst, const uint32_t *src, int R, int ag
 
 // ---- split build (build.py): the step / reset kernels of ONE (NS, AV) pair per translation unit -----------------------------------------
 // The 8 (pellet slots, all-visible) pairs x (2 layouts x 5 lane-group sizes) instantiations of the step kernels are what makes this file
-// slow to compile (3 m 47 s in one piece).  build.py therefore compiles it nine times in parallel: eight "part" units (-DAG_PART_NS=<4|8|16|32>
-// -DAG_PART_AV=<0|1>: only the kernel templates above and their explicit instantiations for that pair; the rest of the file is skipped) and the
-// main unit (-DAG_SPLIT_BUILD: everything else, with the step kernels declared `extern template`), linked into one libagarcl_hip.so.  The
-// same source without either macro still builds as a single unit.
+// slow to compile (3 m 47 s in one piece).  build.py therefore compiles it seventeen times in parallel: per pair a "step" unit
+// (-DAG_PART_NS=<4|8|16|32> -DAG_PART_AV=<0|1> -DAG_PART_KIND=0: k_step, k_reset, k_respawn) and a "front" unit (-DAG_PART_KIND=1: k_quiet and
+// k_fused with the general engine behind it) -- only the kernel templates above and their explicit instantiations, the rest of the file is
+// skipped -- and the main unit (-DAG_SPLIT_BUILD: everything else, with the step kernels declared `extern template`), linked into one
+// libagarcl_hip.so.  The step units are compiled with machine-level loop-invariant code motion off (build.py STEP_FLAGS: what it hoists in
+// front of k_step's loops does not fit 128 registers and is spilled on the spot).  The same source without these macros still builds as a
+// single unit.
 #if !defined(AGAR_CPU_EMU) && (defined(AG_PART_NS) || defined(AG_SPLIT_BUILD))
-#define AG_INST_STEP(X, N, V, T) X template __global__ void k_step<N, V, T>(const AgState *__restrict__, const float *, const int32_t *, int, int, int, int, int);
+#define AG_INST_STEP(X, N, V, T) X template __global__ void k_step<N, V, T>(const AgState *__restrict__, const float *, const int32_t *, int, int, int, int, int, int);
 #define AG_INST_FRONT(X, N, V, Q, T) \
   X template __global__ void k_quiet<N, V, Q, T>(const AgHot, const AgState *__restrict__, const float *, const int32_t *, int, int, int, int); \
   X template __global__ void k_fused<N, V, Q, T>(const AgHot, const AgState *__restrict__, const float *, const int32_t *, int, int, int, int);
-#define AG_INST_LAYOUT(X, N, V, T) AG_INST_STEP(X, N, V, T) AG_INST_FRONT(X, N, V, 1, T) AG_INST_FRONT(X, N, V, 2, T) AG_INST_FRONT(X, N, V, 4, T) AG_INST_FRONT(X, N, V, 8, T) AG_INST_FRONT(X, N, V, 16, T)
-#define AG_INST_PAIR(X, N, V) AG_INST_LAYOUT(X, N, V, 0) AG_INST_LAYOUT(X, N, V, 6) \
+#define AG_INST_FRONTS(X, N, V, T) AG_INST_FRONT(X, N, V, 1, T) AG_INST_FRONT(X, N, V, 2, T) AG_INST_FRONT(X, N, V, 4, T) AG_INST_FRONT(X, N, V, 8, T) AG_INST_FRONT(X, N, V, 16, T)
+#define AG_INST_KIND0(X, N, V) AG_INST_STEP(X, N, V, 0) AG_INST_STEP(X, N, V, 6) \
   X template __global__ void k_reset<N, V>(const AgState *__restrict__, const uint8_t *, int); \
   X template __global__ void k_respawn<N, V>(const AgState *__restrict__);
+#define AG_INST_KIND1(X, N, V) AG_INST_FRONTS(X, N, V, 0) AG_INST_FRONTS(X, N, V, 6)
 #ifdef AG_PART_NS
-AG_INST_PAIR(, AG_PART_NS, (AG_PART_AV != 0))
+#if AG_PART_KIND == 0
+AG_INST_KIND0(, AG_PART_NS, (AG_PART_AV != 0))
 #else
-#define AG_INST_ALL(N) AG_INST_PAIR(extern, N, true) AG_INST_PAIR(extern, N, false)
+AG_INST_KIND1(, AG_PART_NS, (AG_PART_AV != 0))
+#endif
+#else
+#define AG_INST_ALL(N) AG_INST_KIND0(extern, N, true) AG_INST_KIND0(extern, N, false) AG_INST_KIND1(extern, N, true) AG_INST_KIND1(extern, N, false)
 AG_INST_ALL(4) AG_INST_ALL(8) AG_INST_ALL(16) AG_INST_ALL(32)
 #endif
 #endif
@@ -404,7 +427,7 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
 #undef CALL
 #undef CALLQ
   }
-#define CALL(N, V) hipLaunchKernelGGL((k_step<N, V, T>), dim3(kgrid), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, use_q, e->parity)
+#define CALL(N, V) hipLaunchKernelGGL((k_step<N, V, T>), dim3(kgrid), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, use_q, e->parity, e->sched_parity)
   // grid of k_step: every arena (grid-stride from 4096 workgroups on), or -- working off a list the statistics say is short --
   // 256 workgroups, which dispatch faster (the loop still visits every listed arena if the list is long after all)
   const int kfull = e->d.A < 4096 ? e->d.A : 4096, kgrid = use_q && e->few_unfinished && kfull > AG_KSTEP_SMALL_GRID ? AG_KSTEP_SMALL_GRID : kfull;
@@ -416,6 +439,7 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
 #undef T
 #undef CALL
   if (use_q) e->parity ^= 1;
+  e->sched_parity ^= 1;
   HIPCHK(hipGetLastError());
 #endif
   return 0;
@@ -523,7 +547,7 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
 #endif
   agarcl_env *e = new agarcl_env();
   e->cfg = *cfg; e->device = device; e->own_stream = true; e->d_act_dxdy = nullptr; e->d_act = nullptr;
-  e->slot = 0; e->d_state = nullptr; e->act_dxdy = nullptr; e->act = nullptr; e->timer_ev[0] = e->timer_ev[1] = nullptr; e->obs_buf = nullptr; e->obs_cap = 0; e->undo_list = e->undo_count = nullptr; e->undo_out = nullptr; e->undo_key = -1;
+  e->slot = 0; e->d_state = nullptr; e->act_dxdy = nullptr; e->act = nullptr; e->timer_ev[0] = e->timer_ev[1] = nullptr; e->obs_buf = nullptr; e->obs_cap = 0; e->undo_sig = nullptr; e->undo_sig_g = 0; e->undo_list = e->undo_count = nullptr; e->undo_out = nullptr; e->undo_key = -1;
 #ifdef AGAR_CPU_EMU
   e->stream = nullptr;
 #else
@@ -547,7 +571,9 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   if (g.squared) { int pps = (int)(g.W / 2.0f); npel = 4 * pps; }
   d.PC = ((npel > 0 ? npel : 1) + 63) / 64 * 64;
   d.VC = cfg->cap_viruses > 0 ? cfg->cap_viruses : cfg->num_viruses + 64;
-  d.FC = cfg->cap_foods > 0 ? cfg->cap_foods : 256;
+  // (foods live in LDS during a launch, 16 bytes each: 128 keep the single-player layout within the 10 KB per wavefront that 16 resident
+  // wavefronts per CU leave; nominal play stays far below -- <= ~60 ejected foods in 20k-tick mode-6 roll-outs)
+  d.FC = cfg->cap_foods > 0 ? cfg->cap_foods : 128;
   // layout of the per-arena word arrays (agar_types.h): tiles of 64 arenas where the lean front kernel runs with one to four
   // lanes per arena (single-player batches from 32768 arenas on), arena-major otherwise.  AGARCL_TILE_LG=0/6 pins it.
   d.ts_lg = (d.P == 1 && d.A >= 32768) ? 6 : 0;
@@ -555,13 +581,13 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   if (d.P > AG_MAX_PLAYERS) { agarcl_destroy(e); return fail(AGARCL_E_UNSUPPORTED, "too many players per arena"); }
   if (cfg->cap_cells != 0 && cfg->cap_cells != AG_CC) { agarcl_destroy(e); return fail(AGARCL_E_INVALID, "cap_cells is fixed at 32 in this build"); }
   e->d = d; e->g = g;
-  e->lds_bytes = ag_lds_layout(d.P, nullptr);
+  e->lds_bytes = ag_lds_layout(d.P, d.VC, d.FC, nullptr);
   e->all_vis = g.pgw <= 2 && g.pgh <= 2;
   e->ns = d.PC <= 256 ? 4 : d.PC <= 512 ? 8 : d.PC <= 1024 ? 16 : 32;
   int pc_needed = d.PC;
   d.PC = e->ns * 64; e->d = d;  // pellet capacity == register file size: loads / stores need no bounds test
   if (pc_needed > 2048) { agarcl_destroy(e); return fail(AGARCL_E_UNSUPPORTED, "more than 2048 pellets per arena do not fit the pellet register file layout"); }
-  if (e->lds_bytes > 160 * 1024) { agarcl_destroy(e); return fail(AGARCL_E_UNSUPPORTED, "arena does not fit the 160 KiB LDS of a CU (too many pellets)"); }
+  if (e->lds_bytes > 160 * 1024) { agarcl_destroy(e); return fail(AGARCL_E_UNSUPPORTED, "arena does not fit the 160 KiB LDS of a CU (too many players, or virus / food capacities too large)"); }
   AgState &s = e->s; memset(&s, 0, sizeof(s));
   s.d = d; s.g = g;
   size_t A = (size_t)d.A;
@@ -588,6 +614,7 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   s.prof = alloc<unsigned long long>(e, (size_t)d.A * 16);
   s.qinfo = alloc<int32_t>(e, (size_t)d.A * 2);
   s.qcount = alloc<int32_t>(e, 2); e->parity = 0;
+  s.sched = alloc<int32_t>(e, 2); e->sched_parity = 0;
   s.qlist = alloc<int32_t>(e, 2 * (size_t)d.A);
   { const char *nf = getenv("AGARCL_NO_FRONT"); e->no_front = nf && nf[0] == '1'; }
   // modes 0-4 start agents at mass 25 (quiet-dominated); 5 and 6 start at mass 1000 (general path every step)
@@ -1232,7 +1259,7 @@ extern "C" int agarcl_grid_obs(agarcl_env *e, int32_t G, int32_t cells, int32_t 
   const size_t GG = (size_t)G * G;
   // on_device == 2: the caller's buffer still holds this env's previous observation (same grid, same channels): clear only
   // what was written then.  The first such call (or a different buffer / configuration) clears everything and starts the list.
-  AgObsUndo un{nullptr, nullptr, 0, 0};
+  AgObsUndo un{nullptr, nullptr, 0, 0, nullptr};
   if ((on_device == 2 || !on_device) && C > 1) {   // (host copies go through the engine's own staging buffer: persistent by construction)
     const int ucap = OBS_UNDO_CAP(e->d.PC), key = G * 16 + o.cells + 2 * o.others + 4 * o.viruses + 8 * o.pellets;
     if (!e->undo_list) { e->undo_list = alloc<int32_t>(e, n * (size_t)ucap); e->undo_count = alloc<int32_t>(e, n); }
@@ -1240,6 +1267,10 @@ extern "C" int agarcl_grid_obs(agarcl_env *e, int32_t G, int32_t cells, int32_t 
       un.list = e->undo_list; un.count = e->undo_count; un.cap = ucap;
       un.clear = e->undo_out == dst && e->undo_key == key;
       e->undo_out = dst; e->undo_key = key;
+      if (e->undo_sig_g < G) {   // (a larger grid than any before: the signature array grows; the old one stays allocated until the env goes)
+        e->undo_sig = alloc<uint8_t>(e, n * 2 * (size_t)G); e->undo_sig_g = e->undo_sig ? G : 0; un.clear = 0;
+      }
+      un.sig = e->undo_sig;   // (null: every call stores the whole channel, as before)
     }
   }
   const bool split = !un.clear && (GG & 3) == 0 && C > 1 && (((size_t)dst) & 15) == 0;

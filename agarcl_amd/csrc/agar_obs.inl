@@ -35,7 +35,10 @@ struct AgObsCfg { int G, cells, others, viruses, pellets; };
 // instead of streaming zeros over channels 1.. (512 KB per 128 x 128 frame, three quarters of the observation's time) the
 // kernel zeroes exactly the words it wrote last time -- it keeps their offsets in a per-frame undo list -- and records the
 // new ones.  undo == nullptr: off.  clear: the list of the previous call is valid for this buffer.
-struct AgObsUndo { int32_t *list; int32_t *count; int cap; int clear; };
+// sig: with the list, the out-of-bounds channel's signature of the previous call -- per frame G bytes "grid row i is inside the arena in x"
+// followed by G bytes "column j is inside in y" (the mask is their outer product): channel 0 is 64 KB of the 128 x 128 frame and changes
+// only when the view window moves across an arena wall, so a persistent tensor gets only the rows / columns whose byte changed.
+struct AgObsUndo { int32_t *list; int32_t *count; int cap; int clear; uint8_t *sig; };
 #define OBS_ECAP 1024  // viruses + cells of all players staged per frame (16 players x 32 cell slots = 512 cells at most; entities
                        // beyond the cap -- more than ~500 viruses -- are not drawn)
 #define OBS_PELLET_WORDS 2   // words a pellet writes (channels "at least one" and "count")
@@ -69,7 +72,7 @@ OBS_DEV void obs_player(const AgState *gs, int arena, int p, float &px, float &p
 // zero_fill: also write the zeros of channels 1.. (the host emulation and odd grid sizes); on the GPU the bulk zero fill
 // is a separate streaming kernel (k_grid_zero: plain 16-byte stores at the rate of a memset, 6.8 TB/s measured) and
 // this function only writes channel 0 and scatters the entities.
-OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o, int32_t *out, bool zero_fill = true, AgObsUndo un = AgObsUndo{nullptr, nullptr, 0, 0}, int frame = 0) {
+OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o, int32_t *out, bool zero_fill = true, AgObsUndo un = AgObsUndo{nullptr, nullptr, 0, 0, nullptr}, int frame = 0) {
   const int G = o.G, GG = G * G, C = obs_channels(o);
 #ifndef AGAR_CPU_EMU
   __shared__ int un_cnt;
@@ -107,7 +110,30 @@ OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o,
   OBS_BARRIER();
   auto oob = [&](int k) -> int32_t { int i = k / G, j = k - i * G; return (inx[i] & iny[j]) ? 0 : -1; };
 #ifndef AGAR_CPU_EMU
-  if ((GG & 3) == 0 && (((size_t)out) & 15) == 0) {
+  // persistent tensor (the undo list of the previous call is valid): channel 0 still holds the previous mask.  Only the rows whose x byte and
+  // the columns whose y byte changed are stored again -- none at all while the window stays clear of the walls or does not move
+  bool mask_done = false;
+  if (ul && un.sig) {
+    __shared__ int n_rows, n_cols; __shared__ uint16_t ch_rows[1024], ch_cols[1024];
+    uint8_t *sg = un.sig + (size_t)frame * 2 * G;
+    const bool incremental = un.clear && !zero_fill;   // (block-uniform; zero_fill here means "the list overflowed": everything is rewritten)
+    if (incremental) {
+      if (threadIdx.x == 0) { n_rows = 0; n_cols = 0; }
+      __syncthreads();
+      OBS_FOR(i, G) {
+        if (sg[i] != inx[i]) ch_rows[atomicAdd(&n_rows, 1)] = (uint16_t)i;
+        if (sg[G + i] != iny[i]) ch_cols[atomicAdd(&n_cols, 1)] = (uint16_t)i;
+      }
+      __syncthreads();
+      const int nr = n_rows, nc = n_cols;
+      OBS_FOR(k, nr * G) { const int i = ch_rows[k / G], j = k % G; out[i * G + j] = (inx[i] & iny[j]) ? 0 : -1; }
+      OBS_FOR(k, nc * G) { const int j = ch_cols[k / G], i = k % G; out[i * G + j] = (inx[i] & iny[j]) ? 0 : -1; }
+      mask_done = true;
+    }
+    OBS_FOR(i, G) { sg[i] = inx[i]; sg[G + i] = iny[i]; }
+  }
+  if (mask_done) { }
+  else if ((GG & 3) == 0 && (((size_t)out) & 15) == 0) {
     // 16 bytes per lane per store (1 KiB per wave-instruction), streaming (non-temporal): the tensor is written once
     // and read by somebody else
     typedef int32_t v4 __attribute__((ext_vector_type(4)));

@@ -45,7 +45,7 @@ enum {
 #define AG_CC 32        // cell capacity per player (reference: unbounded vector, nominal limit 14)
 #define AG_EV_CAP 256   // pellet eat events per arena-tick
 #define AG_EVV_CAP 16   // virus eat events per arena-tick (<= players)
-#define AG_CAND_CAP 1024 // words of the ordered-replay candidate list: 256 records of (key, index, x, y)
+#define AG_CAND_CAP 512  // words of the ordered-replay candidate list: 256 records of (key, squared distance); also the 64 (x, y) pairs staged by add_pellets
 #define AG_VT_CAP 256   // virus_eaten_ticks kept per player (the reference vector is unbounded; > 256 virus meals inside 3600 ticks raises a flag)
 #define AG_LUT_SIZE (1 << 19)
 #define AG_ANTI_LUT 256
@@ -137,6 +137,7 @@ struct AgState {
                           //     [1] OR of every capacity flag raised (the flag watch of agarcl_poll_flags)
   int32_t *qcount;        // [2] number of arenas k_quiet left unfinished, ping-pong by launch parity (k_step exits at once on 0)
   int32_t *qlist;         // [2][A] the arenas k_quiet left unfinished (same parity), in arrival order: k_step's work list
+  int32_t *sched;         // [2] k_step's work counter (items beyond the grid are drawn from it), ping-pong by launch parity
   unsigned long long *prof;  // [16] phase cycle sums (diagnostic builds only; may be null)
 };
 // The three pointers the lean front part needs before it can request an arena's state.  They travel as kernel arguments

@@ -54,7 +54,7 @@ typedef struct agarcl_config {
   double dt;              /* seconds per tick; 0 -> DEFAULT_DT = 1/30 (BaseEnvironment.hpp:14) */
   int32_t cap_cells;      /* cells per player, 0 -> 32 (reference: unbounded vector, nominal limit 14) */
   int32_t cap_viruses;    /* 0 -> num_viruses + 64 */
-  int32_t cap_foods;      /* 0 -> 256 */
+  int32_t cap_foods;      /* 0 -> 128 (ejected foods live in LDS during a launch: 16 bytes each) */
   /* ScreenEnvironment semantics (environment/envs/ScreenEnvironment.hpp:233-243): a dead agent is respawned right
    * after the ticks of a step in EVERY mode, and that step's rewards get + c_death (BaseEnvironment.hpp:116-120) */
   int32_t screen_respawn;

@@ -104,6 +104,44 @@ def test_grid_obs_persistent_buffer(hip_engine_cls, cfg):
 
 
 @pytest.mark.gpu
+def test_grid_obs_persistent_buffer_walls(hip_engine_cls):
+    """The out-of-bounds channel of a persistent tensor is updated row- and column-wise from the previous call's signature:
+    a 150 x 150 arena, where every view window (100 .. 300 wide) reaches over the walls and the mask moves with the agent every step;
+    agents driven into corners and along walls, a masked reset that teleports some of them, and a stretch without any movement (no row or
+    column changes: channel 0 is not touched).  Equal to the full-clear path after every step."""
+    import torch
+    A = 64
+    eng = hip_engine_cls(A, arena_size=150, num_pellets=150, num_viruses=2, mode=0)
+    eng.seed(None, 99); eng.reset(reset_ids=True)
+    rng = np.random.RandomState(5)
+    keep = torch.full((A, 1, 8, 128, 128), 7, dtype=torch.int32, device="cuda")
+    fresh = torch.empty_like(keep)
+    torch.cuda.synchronize()
+    drive = np.zeros((A, 1, 2), np.float32)
+    changed_steps = 0
+    prev0 = None
+    for t in range(90):
+        if t % 15 == 0:      # a new heading per arena: corners, walls, diagonals
+            drive = rng.choice([-1.0, 0.0, 1.0], size=(A, 1, 2)).astype(np.float32)
+        if 45 <= t < 55:
+            drive = np.zeros((A, 1, 2), np.float32)       # nobody moves: the mask stands
+        eng.set_actions(drive, np.zeros((A, 1), np.int32)); eng.step()
+        if t == 30:
+            mask = (np.arange(A) % 3 == 0).astype(np.uint8); eng.reset(mask)      # some agents jump elsewhere
+        eng.grid_obs(128, out_ptr=keep.data_ptr(), persistent=True)
+        eng.grid_obs(128, out_ptr=fresh.data_ptr())
+        eng.sync()
+        assert torch.equal(keep, fresh), t
+        ch0 = keep[:, 0, 0].clone()
+        assert (ch0 == -1).any().item() and (ch0 == 0).any().item()               # the window really crosses the walls
+        if prev0 is not None and not torch.equal(ch0, prev0):
+            changed_steps += 1
+        prev0 = ch0
+    assert changed_steps > 40          # the incremental path had rows / columns to move in most steps
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_grid_obs_host_path_repeated(hip_engine_cls, oracle_lib):
     """The host-copy path goes through the engine's staging buffer, which it treats as persistent (incremental clear) -- unless
     something else used the buffer in between (screen / GoBigger host copies share it): same config every step, against the oracle."""
