@@ -99,6 +99,7 @@ struct agarcl_env {
   long step_no, front_runs, stat_req_front, stat_last_front; int32_t stat_last_total;
   int parity;     // launch parity of the k_quiet / k_step pair (selects the unfinished-arena counter)
   int sched_parity; // launch parity of k_step (selects its work counter: see k_step)
+  long order_age; bool order_ready, no_order;   // k_order: k_step launches over the whole batch so far / order[] holds a permutation / AGARCL_NO_ORDER=1 (A/B timing)
   bool no_front;  // AGARCL_NO_FRONT=1 in the environment: skip k_quiet (diagnostics / A-B timing only)
   bool few_unfinished; // adaptive: the front part leaves < 64 arenas per step to k_step (see launch_step)
   bool front_off; // adaptive: the front part finishes (almost) no arena-step, so the two-kernel step runs k_step alone
@@ -150,7 +151,7 @@ __device__ __forceinline__ int ag_xcd_swizzle(int bid, int nwg) {
 // use_q: k_quiet ran in front of this launch and left a work list (qlist / qcount) of the arenas it did not finish; only
 // those are visited, resuming where the front part stopped.  A quiet-dominated step therefore costs this launch one
 // scalar load per workgroup whatever the arena count.
-template <int NS, bool AV, int TSLG> __global__ void __launch_bounds__(64) AG_KSTEP_ATTR k_step(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int use_q, int parity, int sp) {
+template <int NS, bool AV, int TSLG> __global__ void __launch_bounds__(64) AG_KSTEP_ATTR k_step(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int use_q, int parity, int sp, const int32_t *order) {
   const int A = gs->d.A;
   int total = A;
   if (use_q) {
@@ -164,13 +165,16 @@ template <int NS, bool AV, int TSLG> __global__ void __launch_bounds__(64) AG_KS
   // (DESIGN.md section 4.4): at 32768 arenas the launch waited for the slot whose eight arenas happened to be dense clumps.
   auto sched = (AG_GLOBAL int32_t *)gs->sched;
   if (blockIdx.x == 0 && threadIdx.x == 0) sched[sp ^ 1] = 0;
-  for (int it = TSLG ? ag_xcd_swizzle((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x; it < total;
+  for (int it = (TSLG && !order) ? ag_xcd_swizzle((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x; it < total;
 #ifdef AG_KSTEP_STATIC   // (measurement builds only: the fixed stride)
        it += (int)gridDim.x) {
 #else
        it = (int)gridDim.x + (total > (int)gridDim.x ? ag_uni(threadIdx.x == 0 ? __hip_atomic_fetch_add(sched + sp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0) : total)) {
 #endif
-    int arena = it, q_done = -1, q_before = 0;
+    // order: the arenas by descending cost of their last visit (k_order).  The expensive ones go first, so that the launch does not end with
+    // a dense clump that was started last (longest-processing-time-first list scheduling)
+    int arena = order ? ((const AG_GLOBAL int32_t *)order)[it] : it, q_done = -1, q_before = 0;
+    const unsigned long long t_begin = __builtin_readcyclecounter();
     if (use_q) {
       arena = ((const AG_GLOBAL int32_t *)gs->qlist)[(size_t)parity * A + it];
       auto qi = (const AG_GLOBAL int32_t *)(gs->qinfo + (size_t)arena * 2);
@@ -191,6 +195,7 @@ template <int NS, bool AV, int TSLG> __global__ void __launch_bounds__(64) AG_KS
 #ifdef AGAR_PROFILE
     if (threadIdx.x == 0 && gs->prof) for (int i = 0; i < AG_NPROF; i++) gs->prof[(size_t)arena * AG_NPROF + i] += c.tacc[i];
 #endif
+    if (threadIdx.x == 0) ((AG_GLOBAL uint32_t *)gs->cost)[arena] = (uint32_t)(__builtin_readcyclecounter() - t_begin);
     ag_lds_order();
   }
 }
@@ -274,6 +279,24 @@ template <int NS, bool AV> __global__ void __launch_bounds__(64) k_respawn(const
   arena_store(c);
 }
 #ifndef AG_PART_NS   // (split build: plain kernels live in the main unit only)
+// order[] = the arenas by descending cost (one 1024-thread workgroup; a counting sort over 1024 cost classes scaled to the largest cost --
+// within a class the order is whatever the atomics give: it only steers scheduling, never results)
+__global__ void __launch_bounds__(1024) k_order(const uint32_t *__restrict__ cost, int32_t *__restrict__ order, int A) {
+  __shared__ unsigned hist[1024]; __shared__ unsigned mx;
+  const int t = (int)threadIdx.x;
+  hist[t] = 0u; if (t == 0) mx = 1u;
+  __syncthreads();
+  unsigned m = 0u; for (int a = t; a < A; a += 1024) { const unsigned c = cost[a]; m = c > m ? c : m; }
+  atomicMax(&mx, m);
+  __syncthreads();
+  const unsigned long long top = mx;
+  auto cls = [&](unsigned c) -> int { return 1023 - (int)(((unsigned long long)c * 1023ull) / top); };   // class 0 = the most expensive
+  for (int a = t; a < A; a += 1024) atomicAdd(&hist[cls(cost[a])], 1u);
+  __syncthreads();
+  if (t == 0) { unsigned run = 0u; for (int k = 0; k < 1024; k++) { const unsigned n = hist[k]; hist[k] = run; run += n; } }   // (1024 serial adds: ~2 us, every 8th step)
+  __syncthreads();
+  for (int a = t; a < A; a += 1024) order[atomicAdd(&hist[cls(cost[a])], 1u)] = a;
+}
 __global__ void k_set_ar_word(int32_t *ar, int ag_ts_lg, int word, int n, int value) {  // one arena word of every arena
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) ar[AG_TILE_BASE(i, AR_WORDS) + AG_TW(word)] = value;
@@ -294,7 +317,7 @@ __global__ void k_tile_scatter(uint32_t *dst, const uint32_t *src, int R, int ag
 // front of k_step's loops does not fit 128 registers and is spilled on the spot).  The same source without these macros still builds as a
 // single unit.
 #if !defined(AGAR_CPU_EMU) && (defined(AG_PART_NS) || defined(AG_SPLIT_BUILD))
-#define AG_INST_STEP(X, N, V, T) X template __global__ void k_step<N, V, T>(const AgState *__restrict__, const float *, const int32_t *, int, int, int, int, int, int);
+#define AG_INST_STEP(X, N, V, T) X template __global__ void k_step<N, V, T>(const AgState *__restrict__, const float *, const int32_t *, int, int, int, int, int, int, const int32_t *);
 #define AG_INST_FRONT(X, N, V, Q, T) \
   X template __global__ void k_quiet<N, V, Q, T>(const AgHot, const AgState *__restrict__, const float *, const int32_t *, int, int, int, int); \
   X template __global__ void k_fused<N, V, Q, T>(const AgHot, const AgState *__restrict__, const float *, const int32_t *, int, int, int, int);
@@ -427,10 +450,18 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
 #undef CALL
 #undef CALLQ
   }
-#define CALL(N, V) hipLaunchKernelGGL((k_step<N, V, T>), dim3(kgrid), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, use_q, e->parity, e->sched_parity)
+#define CALL(N, V) hipLaunchKernelGGL((k_step<N, V, T>), dim3(kgrid), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, use_q, e->parity, e->sched_parity, order)
   // grid of k_step: every arena (grid-stride from 4096 workgroups on), or -- working off a list the statistics say is short --
   // 256 workgroups, which dispatch faster (the loop still visits every listed arena if the list is long after all)
   const int kfull = e->d.A < 4096 ? e->d.A : 4096, kgrid = use_q && e->few_unfinished && kfull > AG_KSTEP_SMALL_GRID ? AG_KSTEP_SMALL_GRID : kfull;
+  // a batch beyond the grid visiting every arena: expensive arenas first (k_order over the cycle counts of their last visits, refreshed
+  // every 8th step -- the same arenas are expensive step after step)
+  const int32_t *order = nullptr;
+  if (!use_q && e->d.A > kfull && !e->no_order) {
+    if (e->order_age >= 1 && (e->order_age & 7) == 1) { hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, e->stream, (const uint32_t *)e->s.cost, e->s.order, e->d.A); e->order_ready = true; }
+    e->order_age++;
+    if (e->order_ready) order = e->s.order;
+  }
 #define T 6
   if (tiled) AG_DISPATCH_NS(e->ns, CALL);
 #undef T
@@ -576,7 +607,8 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   d.FC = cfg->cap_foods > 0 ? cfg->cap_foods : 128;
   // layout of the per-arena word arrays (agar_types.h): tiles of 64 arenas where the lean front kernel runs with one to four
   // lanes per arena (single-player batches from 32768 arenas on), arena-major otherwise.  AGARCL_TILE_LG=0/6 pins it.
-  d.ts_lg = (d.P == 1 && d.A >= 32768) ? 6 : 0;
+  // (modes 5 and 6 start every agent at mass 1000: the front kernel never runs, and the general engine alone is 2-10 % faster arena-major)
+  d.ts_lg = (d.P == 1 && d.A >= 32768 && cfg->mode_number <= 4) ? 6 : 0;
   { const char *t = getenv("AGARCL_TILE_LG"); if (t && (t[0] == '0' || t[0] == '6') && !t[1]) d.ts_lg = t[0] - '0'; }
   if (d.P > AG_MAX_PLAYERS) { agarcl_destroy(e); return fail(AGARCL_E_UNSUPPORTED, "too many players per arena"); }
   if (cfg->cap_cells != 0 && cfg->cap_cells != AG_CC) { agarcl_destroy(e); return fail(AGARCL_E_INVALID, "cap_cells is fixed at 32 in this build"); }
@@ -615,6 +647,8 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   s.qinfo = alloc<int32_t>(e, (size_t)d.A * 2);
   s.qcount = alloc<int32_t>(e, 2); e->parity = 0;
   s.sched = alloc<int32_t>(e, 2); e->sched_parity = 0;
+  s.cost = alloc<uint32_t>(e, (size_t)d.A); s.order = alloc<int32_t>(e, (size_t)d.A); e->order_age = 0; e->order_ready = false;
+  { const char *no = getenv("AGARCL_NO_ORDER"); e->no_order = no && no[0] == '1'; }
   s.qlist = alloc<int32_t>(e, 2 * (size_t)d.A);
   { const char *nf = getenv("AGARCL_NO_FRONT"); e->no_front = nf && nf[0] == '1'; }
   // modes 0-4 start agents at mass 25 (quiet-dominated); 5 and 6 start at mass 1000 (general path every step)

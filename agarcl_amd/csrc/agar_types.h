@@ -138,6 +138,8 @@ struct AgState {
   int32_t *qcount;        // [2] number of arenas k_quiet left unfinished, ping-pong by launch parity (k_step exits at once on 0)
   int32_t *qlist;         // [2][A] the arenas k_quiet left unfinished (same parity), in arrival order: k_step's work list
   int32_t *sched;         // [2] k_step's work counter (items beyond the grid are drawn from it), ping-pong by launch parity
+  uint32_t *cost;         // [A] shader-clock cycles the last k_step visit of every arena took (what k_order sorts by)
+  int32_t *order;         // [A] arenas by descending cost (k_order): the order in which k_step hands them out when the batch exceeds its grid
   unsigned long long *prof;  // [16] phase cycle sums (diagnostic builds only; may be null)
 };
 // The three pointers the lean front part needs before it can request an arena's state.  They travel as kernel arguments
