@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_SO = os.environ.get("AGARCL_HIP_SO") or os.path.join(_HERE, "libagarcl_hip.so")
 
 E_UNSUPPORTED = -3
+ARENA_WORDS = 48     # include/agarcl_batch.h AGARCL_ARENA_WORDS
 PACKED_SLOTS = 64   # include/agarcl_batch.h AGARCL_PACKED_SLOTS
 
 
@@ -31,7 +32,7 @@ class Config(C.Structure):
         ("pellet_regen", C.c_int32), ("num_pellets", C.c_int32), ("num_viruses", C.c_int32),
         ("num_bots", C.c_int32), ("reward_type", C.c_int32), ("c_death", C.c_int32),
         ("mode_number", C.c_int32), ("dt", C.c_double), ("cap_cells", C.c_int32),
-        ("cap_viruses", C.c_int32), ("cap_foods", C.c_int32), ("screen_respawn", C.c_int32), ("reserved", C.c_int32 * 4),
+        ("cap_viruses", C.c_int32), ("cap_foods", C.c_int32), ("screen_respawn", C.c_int32), ("example_bots", C.c_int32), ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -131,10 +132,10 @@ class BatchedEngine:
 
     def __init__(self, num_arenas, num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True,
                  num_pellets=1000, num_viruses=0, num_bots=0, reward_type=1, c_death=0, mode=0, dt=1.0 / 30,
-                 device=0, cap_cells=0, cap_viruses=0, cap_foods=0, screen_respawn=False, lib=None):
+                 device=0, cap_cells=0, cap_viruses=0, cap_foods=0, screen_respawn=False, example_bots=0, lib=None):
         self.L = lib if lib is not None else hip_lib()
         self.cfg = Config(num_agents, ticks_per_step, arena_size, int(bool(pellet_regen)), num_pellets, num_viruses,
-                          num_bots, int(reward_type), c_death, mode, dt, cap_cells, cap_viruses, cap_foods, int(bool(screen_respawn)))
+                          num_bots, int(reward_type), c_death, mode, dt, cap_cells, cap_viruses, cap_foods, int(bool(screen_respawn)), int(example_bots))
         self.h = C.c_void_p()
         self.num_arenas = num_arenas
         self.num_agents = num_agents
@@ -334,9 +335,9 @@ class BatchedEngine:
         return out
 
     def arena_words(self, arena):
-        """(ar i32[32], pl i32[players][agarcl_player_words()]) raw words of one arena (agar_types.h AR_* / PL_*)."""
+        """(ar i32[ARENA_WORDS], pl i32[players][agarcl_player_words()]) raw words of one arena (agar_types.h AR_* / PL_*)."""
         P = int(self.L.agarcl_players_per_arena(self.h))
-        ar = np.zeros(32, dtype=np.int32); pl = np.zeros((P, int(self.L.agarcl_player_words())), dtype=np.int32)
+        ar = np.zeros(ARENA_WORDS, dtype=np.int32); pl = np.zeros((max(P, 1), int(self.L.agarcl_player_words())), dtype=np.int32)[:P]
         self._chk(self.L.agarcl_get_arena_words(self.h, arena, _ptr(ar), _ptr(pl)))
         return ar, pl
 

@@ -126,14 +126,14 @@ template <class P, class S> AG_DEV int wave_compact(int n, P pred, S sink) {
 }
 #endif
 
-// ---- uniform block: up to 32 wave-uniform 32-bit words kept in ONE VGPR (lane k = word k) ----------
+// ---- uniform block: up to 64 wave-uniform 32-bit words kept in ONE VGPR (lane k = word k) ----------
 #ifdef AGAR_CPU_EMU
-struct UBlock { int w[32]; };
+struct UBlock { int w[64]; };
 AG_DEV int ub_get(const UBlock &b, int k) { return b.w[k]; }
 AG_DEV void ub_set(UBlock &b, int k, int v) { b.w[k] = v; }
-template <class PT> AG_DEV void ub_load(UBlock &b, PT src, int n) { for (int i = 0; i < 32; i++) b.w[i] = i < n ? src[i] : 0; }
+template <class PT> AG_DEV void ub_load(UBlock &b, PT src, int n) { for (int i = 0; i < 64; i++) b.w[i] = i < n ? src[i] : 0; }
 template <class PT> AG_DEV void ub_store(const UBlock &b, PT dst, int n) { for (int i = 0; i < n; i++) dst[i] = b.w[i]; }
-template <class PT> AG_DEV void ub_load_t(UBlock &b, PT src, int n, int ag_ts_lg) { for (int i = 0; i < 32; i++) b.w[i] = i < n ? src[AG_TW(i)] : 0; }   // tile-transposed source
+template <class PT> AG_DEV void ub_load_t(UBlock &b, PT src, int n, int ag_ts_lg) { for (int i = 0; i < 64; i++) b.w[i] = i < n ? src[AG_TW(i)] : 0; }   // tile-transposed source
 template <class PT> AG_DEV void ub_store_t(const UBlock &b, PT dst, int n, int ag_ts_lg) { for (int i = 0; i < n; i++) dst[AG_TW(i)] = b.w[i]; }
 #else
 struct UBlock { int v; };
@@ -2085,7 +2085,8 @@ AG_DEV void emit_agent_result(const AgState *gs, int slot, int arena, int na, in
 // saves 53 registers per call, and builds of it were not bit-stable across loop forms -- see DESIGN.md "tried and dropped".)
 template <int NS, bool AV, bool QUIET = true> AG_DEV void env_step(AgCtx<NS, AV> &c, int ticks, bool with_env, int q_done = -1, int q_before = 0) {
   int na = c.gs->d.n_agents, mode = c.gs->g.mode;
-  int *before = L_I(c, L_TMP) + 20;  // [n_agents] masses before the ticks, in rewards order (LDS, not private memory)
+  int *before = L_I(c, L_TMP) + 20;  // [n_agents <= 32] masses before the ticks, in rewards order (LDS, not private memory; words 20 .. 51 of the mailbox:
+                                     // players_collision keeps its own tables at 52 .. 116, the scalar mailbox is words 0 .. 19)
   if (with_env && q_done >= 0) { AG_SERIAL { before[0] = q_before; } ag_lds_order(); }
   else if (with_env) {
     for (int i = 0; i < na; i++) {  // take_actions: agent i == player slot i (pids_[i]), BaseEnvironment.hpp:141-176
@@ -2142,14 +2143,15 @@ template <int NS, bool AV> AG_DEV void env_reset(AgCtx<NS, AV> &c, int reset_ids
   c.pel_loaded = true; c.pel_dirty = true; c.pel_all = true; SW(c, AR_SAFE, 0);
   if (c.gs->g.squared) create_squared_pellets(c); else add_pellets(c, c.gs->g.target_pellets);
   add_viruses(c, c.gs->g.target_viruses);
-  int na = c.gs->d.n_agents, mode = c.gs->g.mode, nb = c.P - na;
+  int na = c.gs->d.n_agents, mode = c.gs->g.mode, nb = c.P - na - c.gs->g.example_bots;
   auto rnd = g_rnd(c);
   for (int i = 0; i < c.P; i++) {  // add_player (Engine.hpp:70-83): slot i gets pid next_pid++; agents first, then bots
     int pid = SR(c, AR_NEXT_PID); SW(c, AR_NEXT_PID, (pid + 1) & 0xFFFF);
     // BaseEnvironment::add_bots (mode 0, :374-399): Hungry, HungryShy, Aggressive, AggressiveShy by i % num_bots;
     // custom_add_bot (mode > 6, :401-425): one bot of type mode - 7
     int kind = 0;
-    if (i >= na) { int b = mode > 6 ? mode - 7 : (i - na) % nb; kind = b == 0 ? AG_KIND_HUNGRY : b == 1 ? AG_KIND_HUNGRY_SHY : b == 2 ? AG_KIND_AGGRESSIVE : b == 3 ? AG_KIND_AGGRESSIVE_SHY : AG_KIND_HUNGRY; }
+    if (i >= na + nb) kind = AG_KIND_EXAMPLE;   // bench/main.cpp:21-24: ExampleBots added to the freshly reset engine
+    else if (i >= na) { int b = mode > 6 ? mode - 7 : (i - na) % nb; kind = b == 0 ? AG_KIND_HUNGRY : b == 1 ? AG_KIND_HUNGRY_SHY : b == 2 ? AG_KIND_AGGRESSIVE : b == 3 ? AG_KIND_AGGRESSIVE_SHY : AG_KIND_HUNGRY; }
     int *P = PLS(c, i);
     AG_SERIAL {
       P[PL_PID] = pid; P[PL_KIND] = kind; P[PL_ACTION] = 0; P[PL_TX] = 0; P[PL_TY] = 0; P[PL_CAND_IDX] = -1;   // (AR_SAFE is zeroed above: no tracked pellet either)

@@ -566,7 +566,7 @@ extern "C" int agarcl_destroy(agarcl_env *e) {
 
 extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32_t device, agarcl_env **out) {
   if (!cfg || !out || num_arenas <= 0) return fail(AGARCL_E_INVALID, "agarcl_create: bad arguments");
-  if (cfg->num_agents < 1 || cfg->ticks_per_step < 1 || cfg->arena_size < 8 || cfg->num_pellets < 0 || cfg->num_viruses < 0 || cfg->num_bots < 0)
+  if (cfg->num_agents < 0 || cfg->example_bots < 0 || cfg->ticks_per_step < 1 || cfg->arena_size < 8 || cfg->num_pellets < 0 || cfg->num_viruses < 0 || cfg->num_bots < 0)
     return fail(AGARCL_E_INVALID, "agarcl_create: invalid environment arguments");
   AgParams g; memset(&g, 0, sizeof(g));
   if (set_mode(g, cfg->mode_number) != 0) return fail(AGARCL_E_MODE, "Invalid mode number");
@@ -597,7 +597,8 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   AgDims d;
   // bots exist only in mode 0 (num_bots of them, BaseEnvironment.hpp:374-399) and modes 7-10 (exactly one, :401-425)
   int nbots = cfg->mode_number == 0 ? cfg->num_bots : (cfg->mode_number > 6 ? 1 : 0);
-  d.A = num_arenas; d.n_agents = cfg->num_agents; d.P = cfg->num_agents + nbots;
+  d.A = num_arenas; d.n_agents = cfg->num_agents; d.P = cfg->num_agents + nbots + cfg->example_bots;
+  g.example_bots = cfg->example_bots;
   int npel = cfg->num_pellets;
   if (g.squared) { int pps = (int)(g.W / 2.0f); npel = 4 * pps; }
   d.PC = ((npel > 0 ? npel : 1) + 63) / 64 * 64;

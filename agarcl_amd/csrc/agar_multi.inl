@@ -181,7 +181,7 @@ template <int NS, bool AV> AG_DEV void players_collision(AgCtx<NS, AV> &c) {
   // flat cell list in player order (cells already id-sorted): offsets per order position
   // [P+1] prefix of cell counts and the slot of each order position, in LDS: lanes index them with lane-varying
   // subscripts (the register-resident uniform block can only be read with a wave-uniform index)
-  int *off = L_I(c, L_TMP) + 40, *ordl = L_I(c, L_TMP) + 64;
+  int *off = L_I(c, L_TMP) + 52, *ordl = L_I(c, L_TMP) + 85;   // (33 and 32 words: up to AG_MAX_PLAYERS = 32 players; words 20 .. 51 belong to env_step)
   { int acc = 0; for (int k = 0; k < P; k++) { int slot = SR(c, AR_ORDER0 + k); AG_SERIAL { off[k] = acc; ordl[k] = slot; } acc += ag_uni(PLS(c, slot)[PL_NCELLS]); } AG_SERIAL { off[P] = acc; } }
   ag_lds_order();
   int T = ag_uni(off[P]);
@@ -266,7 +266,8 @@ template <int NS, bool AV> AG_DEV void players_collision(AgCtx<NS, AV> &c) {
 }
 
 // ---- bots.  R: agario/bots/Bot.hpp, HungryBot.hpp, HungryShyBot.hpp, AggressiveBot.hpp, AggressiveShyBot.hpp -------------------
-enum { AG_KIND_AGENT = 0, AG_KIND_HUNGRY = 1, AG_KIND_HUNGRY_SHY = 2, AG_KIND_AGGRESSIVE = 3, AG_KIND_AGGRESSIVE_SHY = 4 };
+enum { AG_KIND_AGENT = 0, AG_KIND_HUNGRY = 1, AG_KIND_HUNGRY_SHY = 2, AG_KIND_AGGRESSIVE = 3, AG_KIND_AGGRESSIVE_SHY = 4,
+       AG_KIND_EXAMPLE = 5 };   // agario/bots/ExampleBot.hpp:45-51: action none, target = its own location
 
 // uniform centroid / mass of player slot p (Player::x/y/mass, core/Player.hpp:102-126)
 template <int NS, bool AV> AG_DEV void player_centroid(const AgCtx<NS, AV> &c, int p, float &px, float &py, unsigned &mass) {
@@ -353,6 +354,7 @@ template <int NS, bool AV> AG_DEV void bot_take_action(AgCtx<NS, AV> &c, int p) 
   float sx, sy; unsigned sm; player_centroid(c, p, sx, sy, sm);
   float tx = PRF(c, PL_TX), ty = PRF(c, PL_TY); int action = PR(c, PL_ACTION);
   bool done = false;
+  if (kind == AG_KIND_EXAMPLE) { PW(c, PL_ACTION, 0); PW(c, PL_TX, f2u(sx)); PW(c, PL_TY, f2u(sy)); return; }   // R: ExampleBot.hpp:45-51
   if (kind == AG_KIND_HUNGRY_SHY) { action = 0; done = bot_shy_check(c, p, sx, sy, tx, ty); }
   else if (kind == AG_KIND_AGGRESSIVE) done = bot_aggressive_check(c, p, sx, sy, tx, ty);
   else if (kind == AG_KIND_AGGRESSIVE_SHY) { done = bot_shy_check(c, p, sx, sy, tx, ty); if (!done) done = bot_aggressive_check(c, p, sx, sy, tx, ty); }

@@ -36,11 +36,11 @@ enum {
 enum {
   AR_TICKS = 0, AR_CLOCK, AR_IDC, AR_NEXT_PID, AR_NPEL, AR_NVIR, AR_NFOOD, AR_FLAGS, AR_MTIDX,
   AR_NEVP, AR_NEVV, AR_DONE, AR_RESPAWNED, AR_ORDER0 /* AG_MAX_PLAYERS slots: player slots in the engine's iteration order */,
-  AR_HM_BUCKETS = AR_ORDER0 + 16, AR_HM_RESIZE,  // rehash-policy state of the players map (survives reset, GameState.hpp:61-67)
+  AR_HM_BUCKETS = AR_ORDER0 + 32, AR_HM_RESIZE,  // rehash-policy state of the players map (survives reset, GameState.hpp:61-67)
   AR_SAFE,  // f32 bits S: no pellet within S + radius of (PL_SAFE_X, PL_SAFE_Y) of player 0; 0 = unknown
-  AR_WORDS = 32
+  AR_WORDS = 48
 };
-#define AG_MAX_PLAYERS 16
+#define AG_MAX_PLAYERS 32   // (bench/main.cpp's Tick/30: 30 ExampleBots in one arena)
 #define AG_PACKED_SLOTS 64  // ring of packed (reward, done) result buffers: step k of an env writes slot k % 64
 #define AG_CC 32        // cell capacity per player (reference: unbounded vector, nominal limit 14)
 #define AG_EV_CAP 256   // pellet eat events per arena-tick
@@ -98,6 +98,7 @@ struct AgParams {
   int reward_type, c_death;
   float pel_r;             // radius of a pellet (lut_r[1]): random_location's margin when pellets regenerate
   int screen_respawn;      // ScreenEnvironment's hook: respawn dead agents right after the ticks, in every mode (ScreenEnvironment.hpp:233-243)
+  int example_bots;        // ExampleBots added after the agents and the mode's bots at every reset (bench/main.cpp:21-24: engine.add_player<ExampleBot>())
   int pgw, pgh, vgw, vgh;  // pellet / virus grid dims (Engine.hpp:964-965,1210-1211)
 };
 

@@ -198,7 +198,7 @@ def json_to_adopt(snapshot, num_players, hm_buckets, hm_next_resize, id_counter=
 
 
 # ---- engine-level helpers ----------------------------------------------------------------------------------------
-AR_IDC, AR_ORDER0, AR_HM_BUCKETS, AR_HM_RESIZE = 2, 13, 29, 30   # agarcl_amd/csrc/agar_types.h
+AR_IDC, AR_ORDER0, AR_HM_BUCKETS, AR_HM_RESIZE = 2, 13, 45, 46   # agarcl_amd/csrc/agar_types.h (32 order slots)
 PL_KIND = 16
 
 

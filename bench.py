@@ -51,7 +51,7 @@ WORKLOADS = {
     "C1r": dict(arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, dt=1.0 / 60, rand_act=True, ram_obs=True,
                 desc="C1 batched + ram observation: %d arenas/GPU x (1 agent + 4 bots), 250x250, 500 pellets, 10 viruses, mode 0, dt 1/60 s, 4 ticks/step, f32 [A][1][152] written once per step"),
 }
-TRAFFIC_FILE = "r03_pmc_traffic.json"   # PMC FETCH_SIZE / WRITE_SIZE per step of the bench workloads, recorded by scripts/profile_round.sh
+TRAFFIC_FILE = "r04_pmc_traffic.json"   # PMC FETCH_SIZE / WRITE_SIZE per step of the bench workloads, recorded by scripts/profile_round.sh
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
 
 
@@ -76,8 +76,10 @@ def requested_bytes(work, counts, P, n_agents, ticks, pellet_cap):
     # stores cell (40) + player (64) + arena (40) + counts (16) + results f64/i32/u8/packed (21) + hand-over (8)
     front = 168.0 + 189.0
     # general engine, per arena-step: arena words r+w (256), player words r+w (192 P), all 32 cell slots read (1536 P) +
-    # live cells written (48 N_c), results (29 A) + counts (16); per tick: viruses x/y/mass (12 N_v) and foods (20 N_f) read
-    general = 256.0 + 192.0 * P + 1536.0 * P + 48.0 * n_cells + 29.0 * n_agents + 16.0 + ticks * (12.0 * n_vir + 20.0 * n_food)
+    # live cells written (48 N_c), results (29 A) + counts (16) + its cycle count (4); viruses and foods are staged in LDS ONCE per launch
+    # (round 4): x / y / mass of the whole virus table (12 (N_v + 64): the capacity, no count is known when the loads are issued), the first
+    # 64 foods (x, y, vx, vy: 1024) read, the live foods written back (16 N_f)
+    general = 256.0 + 192.0 * P + 1536.0 * P + 48.0 * n_cells + 29.0 * n_agents + 20.0 + 12.0 * (round(n_vir) + 64.0) + 1024.0 + 16.0 * n_food
     return front * front_steps + general * general_steps + pellet_moves * pellet_cap * 8.0
 
 
@@ -176,6 +178,62 @@ def cpu_baseline(seconds_budget=12.0, c3_budget=6.0):
             "c1_ticks_per_s_1core": c1_rate,
             "c1_sample": "BASELINE configs[0] as bench/main.cpp runs it: 250x250, 500 pellets, 10 viruses, agent + 4 bot kinds, "
                          "dt 1/60 s, random policy, 10000 ticks on one core"}
+
+
+TICK_BOTS = (0, 5, 10, 20, 30)   # bench/main.cpp:38  BENCHMARK(Tick)->Arg(0)->Arg(5)->Arg(10)->Arg(20)->Arg(30)
+
+
+def tick_population(n_bots, dt=1.0 / 60):
+    """bench/main.cpp:14-24: a default engine (250 x 250, 500 pellets, 10 viruses) with N ExampleBots and no Player, ticked at dt = 1/60 s"""
+    return dict(num_agents=0, ticks_per_step=4, arena_size=250, pellet_regen=True, num_pellets=500, num_viruses=10, num_bots=0, reward_type=1,
+                c_death=0, mode=0, dt=dt, example_bots=n_bots)
+
+
+def run_tick_workload(n_bots, A, K, Wm, device=0):
+    """The literal bench/main.cpp Tick/N population batched: A arenas, K timed launches of 4 engine ticks each (agarcl_tick: no env around it)."""
+    import numpy as np
+    from agarcl_amd import _capi
+    cfg = tick_population(n_bots)
+    eng = _capi.BatchedEngine(A, device=device, **cfg)
+    eng.seed(None, 10000); eng.reset(reset_ids=True)
+    for _ in range(Wm):
+        eng.tick(4)
+    eng.work(reset=True)
+    eng.timer_mark(0); eng.timer_mark(1); eng.sync()
+    t0 = time.perf_counter()
+    eng.timer_mark(0)
+    for _ in range(K):
+        eng.tick(4)
+    eng.timer_mark(1)
+    eng.sync()
+    elapsed = time.perf_counter() - t0
+    res = dict(elapsed=elapsed, kernel_ms=eng.timer_elapsed_ms() / K, work=eng.work(), flags=eng.flags(), counts=eng.counts().astype(np.float64).mean(axis=0),
+               players=eng.players, fused=0, pellet_cap=(cfg["num_pellets"] + 63) // 64 * 64, ranks=[])
+    eng.close()
+    return res, cfg
+
+
+def tick_reference_rate(n_bots, seconds=0.6):
+    """the same population on the reference engine, one host core: engine ticks per second (oracle/_ref, kind "reference"; else the C port)"""
+    try:
+        from oracle import refbind as B
+        if not B.available():
+            raise ImportError
+        env, kind = B.RefEnv(**tick_population(n_bots)), "reference"
+    except Exception:
+        from oracle import orabind as B
+        if not B.available():
+            B.build()
+        env, kind = B.OraEnv(**tick_population(n_bots)), "port"
+    env.seed(42); env.reset(True)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(200):
+            env.tick()
+        n += 200
+    rate = n / (time.perf_counter() - t0)
+    env.close()
+    return rate, kind
 
 
 def spawn_ranks(n):
@@ -392,7 +450,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large", action="store_true", help="skip the %d-arena roofline_large run" % LARGE_ARENAS)
     ap.add_argument("--no-full", action="store_true", help="skip the roofline_full runs (C3 / mode 6 and the mid-game workload)")
-    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS), help="C2 = the headline metric's configuration")
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS) + ["tick%d" % n for n in TICK_BOTS],
+                    help="C2 = the headline metric's configuration; tickN = bench/main.cpp's Tick/N population (N ExampleBots, no Player), batched")
     ap.add_argument("--gather", default="block", choices=["block", "step"], help="multi-GPU: how (reward, done) reaches rank 0")
     ap.add_argument("--gather-block", type=int, default=32, choices=[8, 16, 32], help="multi-GPU, --gather block: steps per collective")
     ap.add_argument("--gather-obs", default="none", choices=["none", "screen"], help="multi-GPU: also gather every step's uint8 frames")
@@ -402,6 +461,23 @@ def main():
         raise SystemExit(spawn_ranks(args.gpus))            # children first: no GPU call has been made in this process
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: the number of rank processes must equal --gpus" % (args.gpus, world))
+    if args.workload.startswith("tick"):      # the literal bench/main.cpp population: engine-level ticks, single GPU
+        if world != 1:
+            raise SystemExit("--workload tickN is a single-GPU measurement")
+        nb = int(args.workload[4:])
+        res, cfg = run_tick_workload(nb, args.arenas, args.steps, args.warmup)
+        roof = roofline_block(res, args.arenas, args.steps, 4, cfg, args.workload, kernel="k_step (agarcl_tick: 4 engine ticks per launch)")
+        out = {"metric": "env-steps/sec (arenas x ticks/s)", "value": args.arenas * 4 * args.steps / res["elapsed"], "unit": "env-steps/s", "n_gpus": 1,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "bench/main.cpp Tick/%d batched: %d arenas x %d ExampleBots (no Player), default engine 250x250 / 500 pellets / 10 viruses, dt 1/60 s, "
+                                      "4 ticks per launch" % (nb, args.arenas, nb), "arenas_total": args.arenas, "ticks_per_step": 4, "parallelism": "single GPU"},
+               "roofline": roof, "capacity_flags_raised": int((res["flags"] != 0).sum())}
+        if not args.no_cpu_baseline:
+            rate, kind = tick_reference_rate(nb, 2.0)
+            out["cpu_baseline"] = {"value": rate, "unit": "env-steps/s", "cores": 1, "kind": kind, "sample": "2 s of Engine::tick at dt 1/60 s on the same population, one core"}
+        print(json.dumps(out))
+        return
     wl = dict(WORKLOADS[args.workload])
     desc, rand_act, with_obs, with_screen = wl.pop("desc"), wl.pop("rand_act", False), wl.pop("grid_obs", False), wl.pop("screen_obs", False)
     start_mass = wl.pop("start_mass", 0)
@@ -546,6 +622,20 @@ def main():
                         r["frac_of_measured_copy"] = r["achieved"] / copy_gbs
             except Exception:
                 pass
+        if world == 1 and not args.no_full and args.workload == "C2":
+            # bench/main.cpp:14-38 literally: Tick/{0,5,10,20,30} -- N ExampleBots and no Player on the default engine -- batched at this arena
+            # count, with the reference engine's own rate on one host core beside each
+            table = {}
+            for nb in TICK_BOTS:
+                try:
+                    r3, _ = run_tick_workload(nb, A, 50, 10, dev_index)
+                    ent = {"gpu_env_steps_per_s": A * 4 * 50 / r3["elapsed"], "gpu_us_per_4_ticks": r3["kernel_ms"] * 1e3}
+                    if not args.no_cpu_baseline:
+                        ent["cpu_ticks_per_s_1core"], ent["cpu_kind"] = tick_reference_rate(nb)
+                    table["Tick/%d@%d" % (nb, A)] = ent
+                except Exception as ex:
+                    table["Tick/%d@%d" % (nb, A)] = {"error": str(ex)}
+            out["bench_main_cpp_tick"] = table
         if world == 1 and not args.no_cpu_baseline and args.workload == "C2":
             out["cpu_baseline"] = cpu_baseline()
             c1 = out.get("roofline_full", {}).get("C1@%d" % A)

@@ -58,7 +58,11 @@ typedef struct agarcl_config {
   /* ScreenEnvironment semantics (environment/envs/ScreenEnvironment.hpp:233-243): a dead agent is respawned right
    * after the ticks of a step in EVERY mode, and that step's rewards get + c_death (BaseEnvironment.hpp:116-120) */
   int32_t screen_respawn;
-  int32_t reserved[4];
+  /* replaces: bench/main.cpp:15-24 `engine.add_player<ExampleBot>()` x N (agario/bots/ExampleBot.hpp:45-51: action none, target = own
+   * location): N ExampleBots join every arena after the agents and the mode's bots at every reset.  With them num_agents may be 0 (an
+   * engine without a Player, as the reference's Tick benchmark builds it; drive it with agarcl_tick).  Players per arena <= 32. */
+  int32_t example_bots;
+  int32_t reserved[3];
 } agarcl_config;
 
 typedef struct agarcl_env agarcl_env;
@@ -216,7 +220,7 @@ int agarcl_get_seeds(agarcl_env *env, uint32_t *out_host);
 /* raw words of one arena: ar_out i32[AGARCL_ARENA_WORDS] (agar_types.h AR_*), pl_out i32[players][AGARCL_PLAYER_WORDS] (PL_*, slot-major);
  * either may be NULL.  agarcl_player_words() returns AGARCL_PLAYER_WORDS of the library that is loaded (callers without the header size
  * their buffer by it). */
-#define AGARCL_ARENA_WORDS 32
+#define AGARCL_ARENA_WORDS 48
 #define AGARCL_PLAYER_WORDS 24
 int agarcl_get_arena_words(agarcl_env *env, int32_t arena, int32_t *ar_out, int32_t *pl_out);
 int agarcl_player_words(void);

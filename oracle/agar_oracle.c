@@ -47,7 +47,8 @@
 #define SHY_RADIUS 25.0f
 #define AGGRESSIVE_RADIUS 20.0f
 
-enum { KIND_AGENT = 0, KIND_HUNGRY = 1, KIND_HUNGRY_SHY = 2, KIND_AGGRESSIVE = 3, KIND_AGGRESSIVE_SHY = 4 };
+enum { KIND_AGENT = 0, KIND_HUNGRY = 1, KIND_HUNGRY_SHY = 2, KIND_AGGRESSIVE = 3, KIND_AGGRESSIVE_SHY = 4,
+       KIND_EXAMPLE = 5 }; /* R: agario/bots/ExampleBot.hpp:45-51 */
 
 typedef struct { float x, y; int id; } OPellet;
 typedef struct { float x, y, vx, vy; unsigned mass; int hits; int id; } OVirus;
@@ -74,6 +75,7 @@ typedef struct {
 struct OArena {
   /* config (R: GameState.hpp:15-39, BaseEnvironment.hpp:36-67) */
   int num_agents, ticks_per_step, num_bots, reward_type, c_death, mode;
+  int example_bots; /* R: bench/main.cpp:21-24 -- ExampleBots added to the freshly reset engine */
   float W, H; size_t target_pellets, target_viruses; int pellet_regen;
   int mass_decay, squared, agent_mass, regen; /* R: Engine.hpp:362-416 */
   long long recomb_ticks, clock; /* virtual steady clock in ticks */
@@ -883,6 +885,7 @@ static void bot_take_action(OArena *a, OPlayer *p) {
     case KIND_HUNGRY_SHY: p->action = 0; if (!shy_check(a, p)) nearest_pellet(a, p, &p->tx, &p->ty); break;
     case KIND_AGGRESSIVE: if (!aggressive_check(a, p)) { p->action = 0; nearest_pellet(a, p, &p->tx, &p->ty); } break;
     case KIND_AGGRESSIVE_SHY: if (!shy_check(a, p) && !aggressive_check(a, p)) { p->action = 0; nearest_pellet(a, p, &p->tx, &p->ty); } break;
+    case KIND_EXAMPLE: p->action = 0; p->tx = player_x(p); p->ty = player_y(p); break; /* R: ExampleBot.hpp:45-51: none, target = location() */
     default: break;
   }
 }
@@ -1086,12 +1089,19 @@ static void env_reset(OArena *a) { /* R: BaseEnvironment.hpp:179-204, 374-425 */
     int k = a->mode - 7;
     add_player(a, k == 0 ? KIND_HUNGRY : k == 1 ? KIND_HUNGRY_SHY : k == 2 ? KIND_AGGRESSIVE : k == 3 ? KIND_AGGRESSIVE_SHY : KIND_HUNGRY);
   }
+  for (int i = 0; i < a->example_bots; i++) add_player(a, KIND_EXAMPLE); /* R: bench/main.cpp:21-24,31-35 */
 }
 
+OArena *ora_create_ex(int num_agents, int ticks_per_step, int arena_size, int pellet_regen, int num_pellets,
+                      int num_viruses, int num_bots, int reward_type, int c_death, int mode, int recomb_ticks, int example_bots);
 OArena *ora_create(int num_agents, int ticks_per_step, int arena_size, int pellet_regen, int num_pellets,
                    int num_viruses, int num_bots, int reward_type, int c_death, int mode, int recomb_ticks) {
+  return ora_create_ex(num_agents, ticks_per_step, arena_size, pellet_regen, num_pellets, num_viruses, num_bots, reward_type, c_death, mode, recomb_ticks, 0);
+}
+OArena *ora_create_ex(int num_agents, int ticks_per_step, int arena_size, int pellet_regen, int num_pellets,
+                   int num_viruses, int num_bots, int reward_type, int c_death, int mode, int recomb_ticks, int example_bots) {
   OArena *a = (OArena *)calloc(1, sizeof(OArena));
-  a->num_agents = num_agents; a->ticks_per_step = ticks_per_step; a->num_bots = num_bots;
+  a->num_agents = num_agents; a->ticks_per_step = ticks_per_step; a->num_bots = num_bots; a->example_bots = example_bots;
   a->reward_type = reward_type != 0; a->c_death = c_death; a->mode = mode;
   a->W = (float)arena_size; a->H = (float)arena_size;
   a->target_pellets = (size_t)num_pellets; a->target_viruses = (size_t)num_viruses; a->pellet_regen = pellet_regen;

@@ -26,6 +26,10 @@ typedef struct OArena OArena;
  * (which consumes pids 0..num_agents+num_bots-1 exactly like the reference ctor does). */
 OArena *ora_create(int num_agents, int ticks_per_step, int arena_size, int pellet_regen, int num_pellets,
                    int num_viruses, int num_bots, int reward_type, int c_death, int mode, int recomb_ticks);
+/* ... plus `example_bots` ExampleBots (agario/bots/ExampleBot.hpp:45-51) added after the agents and the mode's bots at every reset, as
+ * bench/main.cpp:21-24,31-35 adds them to a freshly reset engine; num_agents may then be 0 */
+OArena *ora_create_ex(int num_agents, int ticks_per_step, int arena_size, int pellet_regen, int num_pellets,
+                      int num_viruses, int num_bots, int reward_type, int c_death, int mode, int recomb_ticks, int example_bots);
 void ora_destroy(OArena *a);
 void ora_seed(OArena *a, unsigned s);                 /* BaseEnvironment.hpp:211, Engine.hpp:242-245 */
 void ora_reset(OArena *a, int reset_ids);             /* BaseEnvironment.hpp:179-204 */

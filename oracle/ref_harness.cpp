@@ -49,6 +49,7 @@ steady_clock::time_point steady_clock::now() noexcept {
 }}}
 
 #include <agario/engine/Engine.hpp>
+#include <agario/bots/ExampleBot.hpp>
 #include <environment/envs/BaseEnvironment.hpp>
 
 using Engine = agario::Engine<false>;
@@ -79,6 +80,9 @@ struct RefEnv : public Base {
     auto &player = this->engine_.player(this->pids_[agent_index]);
     if (player.dead()) { this->engine_.respawn(player); this->is_main_player_respawned = true; }
   }
+  // bench/main.cpp:21-24,31-35: `example_bots` ExampleBots (the reference's own class, agario/bots/ExampleBot.hpp) join the freshly reset engine
+  int example_bots = 0;
+  void add_example_bots() { for (int i = 0; i < example_bots; i++) this->engine_.template add_player<agario::bot::ExampleBot<false>>(); }
   Engine &eng() { return this->engine_; }
   std::vector<agario::pid> &pids() { return this->pids_; }
   void set_done(int i, bool v) { this->dones_[i] = v; }
@@ -110,9 +114,15 @@ int remaining_ticks(const VClock &c, Cell &cell) {
 
 extern "C" {
 
+void *ref_env_create_ex(int num_agents, int ticks_per_step, int arena_size, int pellet_regen, int num_pellets, int num_viruses, int num_bots,
+                        int reward_type, int c_death, int mode, int recomb_ticks, int example_bots);
 void *ref_env_create(int num_agents, int ticks_per_step, int arena_size, int pellet_regen,
                      int num_pellets, int num_viruses, int num_bots, int reward_type, int c_death,
                      int mode, int recomb_ticks) {
+  return ref_env_create_ex(num_agents, ticks_per_step, arena_size, pellet_regen, num_pellets, num_viruses, num_bots, reward_type, c_death, mode, recomb_ticks, 0);
+}
+void *ref_env_create_ex(int num_agents, int ticks_per_step, int arena_size, int pellet_regen, int num_pellets, int num_viruses, int num_bots,
+                        int reward_type, int c_death, int mode, int recomb_ticks, int example_bots) {
   static std::mutex ctor_mutex;  // the std::cout redirection below is process-global
   std::lock_guard<std::mutex> lock(ctor_mutex);
   Silence s;
@@ -122,6 +132,8 @@ void *ref_env_create(int num_agents, int ticks_per_step, int arena_size, int pel
                          num_viruses, num_bots, reward_type != 0, c_death, mode, false);
     e->clock.recomb = recomb_ticks;
     e->clock.engine_ticks = &e->eng().state.ticks;
+    e->example_bots = example_bots;
+    e->add_example_bots();   // (the constructor has reset once: BaseEnvironment.hpp:66)
     g_clock = prev;
     return e;
   } catch (const std::exception &ex) {
@@ -142,6 +154,7 @@ void ref_env_reset(void *h, int reset_ids) {
   if (reset_ids) agario::Ball::global_id = 1;
   e->clock.offset += (long long)e->eng().state.ticks;  // keep the virtual clock monotonic across reset
   e->reset();
+  e->add_example_bots();
 }
 
 int ref_env_take_actions(void *h, const float *dxdy, const int *act, int n) {

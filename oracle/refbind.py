@@ -30,6 +30,8 @@ def lib():
         L = C.CDLL(REF_SO)
         L.ref_env_create.restype = C.c_void_p
         L.ref_env_create.argtypes = [C.c_int] * 11
+        L.ref_env_create_ex.restype = C.c_void_p
+        L.ref_env_create_ex.argtypes = [C.c_int] * 12
         L.ref_env_destroy.argtypes = [C.c_void_p]
         L.ref_env_seed.argtypes = [C.c_void_p, C.c_uint]
         L.ref_env_reset.argtypes = [C.c_void_p, C.c_int]
@@ -59,12 +61,12 @@ class RefEnv:
     """One reference arena (BaseEnvironment<false> + Engine<false>)."""
 
     def __init__(self, num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True, num_pellets=1000,
-                 num_viruses=0, num_bots=0, reward_type=1, c_death=0, mode=0, dt=1.0 / 30):
+                 num_viruses=0, num_bots=0, reward_type=1, c_death=0, mode=0, dt=1.0 / 30, example_bots=0):
         self.L = lib()
         self.num_agents = num_agents
         self.dt = dt
-        self.h = self.L.ref_env_create(num_agents, ticks_per_step, arena_size, int(pellet_regen), num_pellets,
-                                       num_viruses, num_bots, int(reward_type), c_death, mode, recomb_ticks_for(dt))
+        self.h = self.L.ref_env_create_ex(num_agents, ticks_per_step, arena_size, int(pellet_regen), num_pellets,
+                                       num_viruses, num_bots, int(reward_type), c_death, mode, recomb_ticks_for(dt), int(example_bots))
         if not self.h:
             raise RuntimeError("reference env construction failed")
         self._buf = np.zeros(BLOB_CAP, dtype=np.uint32)
@@ -106,7 +108,7 @@ class RefEnv:
     def dones(self):
         out = np.zeros(max(self.num_agents, 1), dtype=np.uint8)
         self.L.ref_env_dones(self.h, out.ctypes.data)
-        return out.astype(bool)
+        return out[:self.num_agents].astype(bool)
 
     def pids(self):
         out = np.zeros(64, dtype=np.int32)

@@ -16,5 +16,5 @@ prev = None
 for t in range(40):
     eng.set_actions(dxdy, act); eng.step()
     ar, pl = eng.arena_words(0); w = pl[0]
-    cur = (int(w[9]), int(w[19]), int(w[22]), float(np.int32(ar[31]).view(np.float32)), float(np.int32(w[17]).view(np.float32)), float(np.int32(w[20]).view(np.float32)))
+    cur = (int(w[9]), int(w[19]), int(w[22]), float(np.int32(ar[47]).view(np.float32)), float(np.int32(w[17]).view(np.float32)), float(np.int32(w[20]).view(np.float32)))
     if cur != prev: print(t, "eaten %d passes %d cidx %d slack %.3f safe_x %.2f cand_x %.2f" % cur, "fused", int(eng.L.agarcl_debug_fused(eng.h)), "work", eng.work()); prev = cur

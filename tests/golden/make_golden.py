@@ -136,6 +136,17 @@ def main():
            400, seed=5, sticky=8, checkpoints=[0, 399])
     record("roll_mode9_bot_s2", dict(num_agents=1, ticks_per_step=4, arena_size=200, num_pellets=500, num_viruses=5, num_bots=1, mode=9), 300, seed=2, sticky=8)
 
+    # ---- bench/main.cpp's Tick population (bench/main.cpp:14-38): N ExampleBots (agario/bots/ExampleBot.hpp:45-51) on the default 250 x 250
+    # engine, no Player at all; and the same bots as prey of a random-policy agent (they get eaten and respawn: mode 0)
+    tick = dict(ticks_per_step=4, arena_size=250, num_pellets=500, num_viruses=10, mode=0)
+    record("fb_tick30_examplebots", dict(tick, num_agents=0, example_bots=30), 300, seed=42, checkpoints=[0, 149, 299],
+           note="Tick/30: 30 ExampleBots, nobody else; 1200 engine ticks")
+    record("fb_tick5_examplebots", dict(tick, num_agents=0, example_bots=5), 150, seed=43, checkpoints=[0, 149], note="Tick/5")
+    record("fb_agent_among_20_examplebots", dict(tick, num_agents=1, example_bots=20), 400, seed=44, sticky=8, checkpoints=[0, 199, 399],
+           note="one random-policy agent among 20 ExampleBots: cell-eats-cell, respawns, the 13 -> 29 rehash of the players map")
+    record("fb_mode6_agent_among_30_examplebots", dict(tick, num_agents=1, example_bots=30, mode=6, arena_size=300), 300, seed=45, sticky=8, checkpoints=[0, 299],
+           note="a mass-1000 agent among 30 ExampleBots (31 players: the 29 -> 59 rehash)")
+
     # ---- F1: reset / spawn as standalone vectors: seeds {0, 1, 42} x the four (W, N_p, N_v) shapes -> every position and id
     for W, n_p, n_v in ((250, 500, 10), (1000, 1000, 0), (1000, 1000, 25), (350, 500, 0)):
         for sd in (0, 1, 42):

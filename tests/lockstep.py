@@ -198,7 +198,7 @@ def golden_files(gpu_capable_only=False):
             continue
         if gpu_capable_only:
             cfg = json.loads(str(np.load(p)["cfg"]))
-            if cfg.get("num_agents", 1) + cfg.get("num_bots", 0) > 16:
+            if cfg.get("num_agents", 1) + cfg.get("num_bots", 0) + cfg.get("example_bots", 0) > 32:    # agar_types.h AG_MAX_PLAYERS
                 continue
         out.append(p)
     return out

@@ -94,5 +94,10 @@ def test_bench_line_as_the_driver_runs_it_gpu():
         if v["traffic"] is not None:
             assert abs(v["frac_hbm_traffic"] - v["frac"]) < 1e-12
     assert b["ranks"][0]["rank"] == 0 and b["obs_gather_ran"] is False
+    # bench/main.cpp's own population (Tick/N: N ExampleBots, no Player) batched, the reference engine's rate beside it
+    tick = b["bench_main_cpp_tick"]
+    assert set(tick) == {"Tick/%d@4096" % n for n in (0, 5, 10, 20, 30)}
+    for v in tick.values():
+        assert "error" not in v and v["gpu_env_steps_per_s"] > 0 and v["cpu_ticks_per_s_1core"] > 0 and v["cpu_kind"] in ("reference", "port")
     assert full["mid@4096"]["mean_counts_pellets_viruses_foods_cells"][3] > 1.5      # the agents have grown and split
     assert b["capacity_flags_raised"] == 0

@@ -21,6 +21,9 @@ CASES = [
     (dict(num_agents=1, arena_size=200, num_pellets=500, num_viruses=5, num_bots=1, mode=10), 300, 8),
     (dict(num_agents=14, arena_size=300, num_pellets=300, num_viruses=5, mode=0), 60, 8),   # 14th insert rehashes the player map
     (dict(num_agents=2, arena_size=150, num_pellets=300, num_viruses=3, num_bots=3, mode=0, reward_type=0), 400, 8),
+    # ExampleBots (bench/main.cpp's population): 31 players in one arena, and the four bot kinds beside them
+    (dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, mode=6, example_bots=30), 200, 8),
+    (dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0, example_bots=12), 300, 4),
 ]
 
 

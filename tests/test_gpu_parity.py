@@ -39,6 +39,10 @@ def test_hip_matches_reference_golden(hip_engine_cls, path):
     (dict(num_agents=1, arena_size=200, num_pellets=500, num_viruses=5, num_bots=1, mode=10), 300, 8),
     (dict(num_agents=14, arena_size=300, num_pellets=300, num_viruses=5, mode=0), 60, 8),
     (dict(num_agents=2, arena_size=150, num_pellets=300, num_viruses=3, num_bots=3, mode=0, reward_type=0), 400, 8),
+    # bench/main.cpp's ExampleBots: 21 and 31 players per arena (players-map rehashes 13 -> 29 -> 59), and beside the four scripted kinds
+    (dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, mode=0, example_bots=20), 300, 4),
+    (dict(num_agents=1, arena_size=300, num_pellets=500, num_viruses=10, mode=6, example_bots=30), 200, 8),
+    (dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0, example_bots=12), 300, 4),
 ])
 def test_hip_vs_oracle_lockstep(hip_engine_cls, oracle_lib, cfg, steps, sticky):
     A = 16

@@ -68,9 +68,8 @@ def check_observation_shape(mod):
 
 
 def check_actions_step_state(mod):
-    # the fixture's SetUp (:96-105) is 4 agents + 25 bots; the fixed layouts of this build hold AG_MAX_PLAYERS = 16 players per arena
-    # (agar_types.h), so the bot count is 12 here -- none of the fixture's assertions depends on it
-    env = mod.GridEnvironment(4, 4, 1000, True, 1000, 25, 12, True, 0, 0)
+    # the fixture's SetUp (:96-105): 4 agents + 25 bots = 29 players per arena (AG_MAX_PLAYERS is 32, agar_types.h)
+    env = mod.GridEnvironment(4, 4, 1000, True, 1000, 25, 25, True, 0, 0)
     env.configure_observation(dict(num_frames=2, grid_size=128, observe_cells=True, observe_others=True, observe_viruses=True, observe_pellets=True))
     none = (0.0, 0.0, 0)
     env.take_actions([none] * 4)                             # TakeActions

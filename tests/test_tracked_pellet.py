@@ -9,7 +9,7 @@ import pytest
 from oracle import blob
 
 CFG = dict(num_agents=1, ticks_per_step=1, arena_size=1000, num_pellets=1000, num_viruses=0, mode=3, pellet_regen=False)   # mode 3: no decay
-PL_FOOD_EATEN, PL_PASSES, PL_CAND_IDX, AR_SAFE = 9, 19, 22, 31   # agar_types.h
+PL_FOOD_EATEN, PL_PASSES, PL_CAND_IDX, AR_SAFE = 9, 19, 22, 47   # agar_types.h
 
 
 def arena_with(o, cell_xy, pellets, mass=25):
