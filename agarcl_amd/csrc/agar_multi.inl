@@ -154,7 +154,7 @@ template <int NS, bool AV> AG_DEV AG_GLOBAL int32_t *g_rnd(const AgCtx<NS, AV> &
 // R: GameState.hpp:44-46,61-67 (clear() keeps the bucket array), Engine.hpp:70-83.
 template <int NS, bool AV> AG_DEV void compute_player_order(AgCtx<NS, AV> &c) {
   int P = c.P;
-  if (P == 1) { SW(c, AR_ORDER0, 0); return; }
+  if (P <= 1) { if (P == 1) SW(c, AR_ORDER0, 0); return; }   // (P == 0: bench/main.cpp's Tick/0 -- an engine without players; the map is untouched)
   auto scr = g_scratch(c);
   int bc = SR(c, AR_HM_BUCKETS), nr = SR(c, AR_HM_RESIZE);
   int *T = L_I(c, L_TMP);

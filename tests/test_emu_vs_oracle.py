@@ -24,6 +24,8 @@ CASES = [
     # ExampleBots (bench/main.cpp's population): 31 players in one arena, and the four bot kinds beside them
     (dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, mode=6, example_bots=30), 200, 8),
     (dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0, example_bots=12), 300, 4),
+    (dict(num_agents=0, arena_size=250, num_pellets=500, num_viruses=10, mode=0, example_bots=0), 100, 4),      # Tick/0: an engine without players
+    (dict(num_agents=0, arena_size=250, num_pellets=500, num_viruses=10, mode=0, example_bots=5), 100, 4),      # Tick/5
 ]
 
 

@@ -43,6 +43,8 @@ def test_hip_matches_reference_golden(hip_engine_cls, path):
     (dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, mode=0, example_bots=20), 300, 4),
     (dict(num_agents=1, arena_size=300, num_pellets=500, num_viruses=10, mode=6, example_bots=30), 200, 8),
     (dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0, example_bots=12), 300, 4),
+    (dict(num_agents=0, arena_size=250, num_pellets=500, num_viruses=10, mode=0, example_bots=0), 100, 4),      # Tick/0: an engine without players
+    (dict(num_agents=0, arena_size=250, num_pellets=500, num_viruses=10, mode=0, example_bots=30), 150, 4),     # Tick/30
 ])
 def test_hip_vs_oracle_lockstep(hip_engine_cls, oracle_lib, cfg, steps, sticky):
     A = 16

@@ -21,6 +21,7 @@ CASES = [
     (dict(num_agents=14, arena_size=300, num_pellets=300, num_viruses=5, mode=0), 300, 8),  # 14th insert rehashes the player map
     # bench/main.cpp's population: the reference's ExampleBot (agario/bots/ExampleBot.hpp) -- alone, and as prey of agents (29 -> 59 rehash at 30+)
     (dict(num_agents=0, arena_size=250, num_pellets=500, num_viruses=10, mode=0, example_bots=30), 1500, 4),
+    (dict(num_agents=0, arena_size=250, num_pellets=500, num_viruses=10, mode=0, example_bots=0), 600, 4),     # Tick/0: nobody at all
     (dict(num_agents=2, arena_size=250, num_pellets=500, num_viruses=10, mode=6, example_bots=20), 1500, 8),
     (dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0, example_bots=10, dt=1.0 / 60), 1500, 4),
 ]
