@@ -630,7 +630,8 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   s.food_x = alloc<float>(e, A * d.FC); s.food_y = alloc<float>(e, A * d.FC); s.food_vx = alloc<float>(e, A * d.FC); s.food_vy = alloc<float>(e, A * d.FC); s.food_id = alloc<int32_t>(e, A * d.FC);
   const int ag_ts_lg = d.ts_lg;
   const size_t At = AG_TILE_ARENAS(A);  // the tile-transposed arrays hold whole tiles
-  e->stage_words = (size_t)d.P * CF_ALL * AG_CC; e->d_stage = alloc<uint32_t>(e, e->stage_words);
+  e->stage_words = (size_t)d.P * CF_ALL * AG_CC; if (e->stage_words < 256) e->stage_words = 256;   // (also holds one arena's AR block when there are no players)
+  e->d_stage = alloc<uint32_t>(e, e->stage_words);
   s.cells = alloc<uint32_t>(e, At * d.P * CF_ALL * AG_CC);
   s.pl = alloc<int32_t>(e, At * d.P * PL_WORDS); s.vticks = alloc<int32_t>(e, A * d.P * AG_VT_CAP); s.ar = alloc<int32_t>(e, At * AR_WORDS);
   s.mt = alloc<uint64_t>(e, A * 312); s.rnd = alloc<int32_t>(e, A * 35);

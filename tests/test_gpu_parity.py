@@ -606,7 +606,7 @@ def test_error_paths(hip_engine_cls):
     with pytest.raises(AgarclError):
         hip_engine_cls(1, mode=11)                      # Engine.hpp:413-414 "Invalid mode number"
     with pytest.raises(AgarclError):
-        hip_engine_cls(1, num_agents=12, num_bots=8, mode=0)   # more than 16 players per arena: loud, not a silent fallback
+        hip_engine_cls(1, num_agents=12, num_bots=8, example_bots=13, mode=0)   # more than 32 players per arena: loud, not a silent fallback
     with pytest.raises(AgarclError):
         hip_engine_cls(1, num_pellets=5000)             # beyond the pellet register file
     e = hip_engine_cls(2, **C2)
