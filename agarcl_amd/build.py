@@ -75,6 +75,38 @@ def build(force=False, verbose=False, extra=(), out=OUT, single=False, jobs=None
     return out
 
 
+def resource_table(path):
+    """hipcc -Rpass-analysis=kernel-resource-usage over the SAME seventeen units with the SAME flags as build() (device code only), condensed
+    into one line per kernel: profiles/rNN_kernel_resource_usage.txt"""
+    import re
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    base = [hipcc()] + [f for f in FLAGS if f != "-shared"] + ["-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", SRC]
+    with tempfile.TemporaryDirectory(prefix="agarcl_res_") as tmp:
+        units = [base + ["-DAG_SPLIT_BUILD", "-o", os.path.join(tmp, "main.o")]]
+        for ns, av, kind in PARTS:
+            units.append(base + (STEP_FLAGS if kind == 0 else []) + ["-DAG_PART_NS=%d" % ns, "-DAG_PART_AV=%d" % av, "-DAG_PART_KIND=%d" % kind,
+                                                                     "-o", os.path.join(tmp, "p%d_%d_%d.o" % (ns, av, kind))])
+        with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 1)) as pool:
+            texts = list(pool.map(lambda u: subprocess.run(u, capture_output=True, text=True, check=True).stderr, units))
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(HERE, "csrc", "*"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    out = ["# hipcc -Rpass-analysis=kernel-resource-usage of agarcl_amd/csrc/agar_engine.hip, unit by unit with the flags of agarcl_amd/build.py "
+           "(step units: %s), source sha %s" % (" ".join(STEP_FLAGS), h.hexdigest()[:16]),
+           "# kernel | VGPRs | AGPRs | SGPRs | scratch bytes/lane | VGPR spills | SGPR spills | occupancy waves/SIMD | LDS bytes/block"]
+    rows = {}
+    for t in texts:
+        for b in re.split(r"remark: [^\n]*Function Name: ", t)[1:]:
+            g = lambda k: re.search(k + r": (\d+)", b).group(1)
+            rows[b.split()[0]] = " | ".join([b.split()[0], g("VGPRs"), g("AGPRs"), g("SGPRs"), g(r"ScratchSize \[bytes/lane\]"), g("VGPRs Spill"), g("SGPRs Spill"),
+                                              g(r"Occupancy \[waves/SIMD\]"), g(r"LDS Size \[bytes/block\]")])
+    out += [rows[k] for k in sorted(rows)]
+    open(path, "w").write("\n".join(out) + "\n")
+    return len(rows)
+
+
 def pybind_out():
     import sysconfig
     return os.path.join(HERE, "..", "agarcl" + sysconfig.get_config_var("EXT_SUFFIX"))
@@ -98,6 +130,8 @@ if __name__ == "__main__":
     if "--profile" in sys.argv:
         os.makedirs(os.path.join(HERE, "..", "build_variants"), exist_ok=True)
         print(build(True, "-v" in sys.argv, ["-DAGAR_PROFILE"], os.path.join(HERE, "..", "build_variants", "lib_PROF.so")))
+    elif "--resources" in sys.argv:
+        print(resource_table(sys.argv[sys.argv.index("--resources") + 1]), "kernels")
     elif "--pybind" in sys.argv:
         print(build_pybind(True))
     else:

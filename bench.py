@@ -385,15 +385,16 @@ def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, 
 
 def obs_bytes(res, A, cfg, with_obs, with_screen, with_ram):
     """(requested, streaming-model) observation bytes per step.  Streaming model: the whole tensor is written once per step.
-    Requested by this implementation: the grid tensor is persistent (agarcl_grid_obs on_device = 2), so a step rewrites the dense
-    out-of-bounds channel and, per word scattered, clears the old one and writes the new one plus their undo-list entries (16 B; the view
-    covers at most (300 / arena)^2 of the arena's pellets and viruses)"""
+    Requested by this implementation: the grid tensor is persistent (agarcl_grid_obs on_device = 2), so per word scattered a step clears
+    the old one and writes the new one plus their undo-list entries (16 B; the view covers at most (300 / arena)^2 of the arena's pellets
+    and viruses), reads and writes the out-of-bounds channel's row / column signature (2 x 2 x 128 B) and stores the rows / columns of that
+    channel whose signature byte changed (round 4; not counted: a few 512-byte rows per agent near a wall, none elsewhere)"""
     model_extra = (A * 8 * 128 * 128 * 4 if with_obs else 0) + (A * 84 * 84 * 3 if with_screen else 0) + (A * cfg["num_agents"] * 152 * 4 if with_ram else 0)
     extra = model_extra
     if with_obs:
         n_pel, n_vir, n_food, n_cells = res["counts"]
         vis = min(1.0, (300.0 / cfg["arena_size"]) ** 2)
-        extra = A * (128 * 128 * 4 + 16.0 * (vis * 2 * (n_pel + n_vir) + 3 * n_cells))
+        extra = A * (512.0 + 16.0 * (vis * 2 * (n_pel + n_vir) + 3 * n_cells))
     kernel = None
     if with_obs: kernel = "k_step + k_grid_obs (persistent tensor: incremental clear)"
     if with_screen: kernel = "k_step + k_screen_obs"

@@ -17,7 +17,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-STEP_KERNELS = ("k_fused", "k_quiet", "k_step", "k_grid_zero", "k_grid_obs", "k_screen_obs", "k_ram_obs")
+STEP_KERNELS = ("k_fused", "k_quiet", "k_step", "k_order", "k_grid_zero", "k_grid_obs", "k_screen_obs", "k_ram_obs")
 
 
 def main():

@@ -6,8 +6,8 @@
 # gpurun_out/profiles_<tag>/ : <tag>_<run>_kernel_stats.csv, <tag>_<run>_bench.json and <tag>_pmc_traffic.json -- copy
 # those into profiles/ and commit them.
 set -u
-TAG=${1:-r03}; shift
-RUNS=${@:-"C2:4096:400 C2:65536:200 C2:262144:100 C3m6:4096:200 mid:4096:200 C5:4096:100 C5s:4096:100 C1:4096:200 C1r:4096:200"}
+TAG=${1:-r04}; shift
+RUNS=${@:-"C2:4096:400 C2:65536:200 C2:262144:100 C3m6:4096:200 C3m6:32768:60 mid:4096:200 C5:4096:100 C5s:4096:100 C1:4096:200 C1r:4096:200"}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
