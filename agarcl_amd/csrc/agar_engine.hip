@@ -99,6 +99,7 @@ struct agarcl_env {
   long step_no, front_runs, stat_req_front, stat_last_front; int32_t stat_last_total;
   int parity;     // launch parity of the k_quiet / k_step pair (selects the unfinished-arena counter)
   int sched_parity; // launch parity of k_step (selects its work counter: see k_step)
+  int kstep_grid;   // workgroups of a k_step launch over the whole batch (4096; AGARCL_KSTEP_GRID caps it for tests)
   long order_age; bool order_ready, no_order;   // k_order: k_step launches over the whole batch so far / order[] holds a permutation / AGARCL_NO_ORDER=1 (A/B timing)
   bool no_front;  // AGARCL_NO_FRONT=1 in the environment: skip k_quiet (diagnostics / A-B timing only)
   bool few_unfinished; // adaptive: the front part leaves < 64 arenas per step to k_step (see launch_step)
@@ -453,7 +454,7 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
 #define CALL(N, V) hipLaunchKernelGGL((k_step<N, V, T>), dim3(kgrid), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, use_q, e->parity, e->sched_parity, order)
   // grid of k_step: every arena (grid-stride from 4096 workgroups on), or -- working off a list the statistics say is short --
   // 256 workgroups, which dispatch faster (the loop still visits every listed arena if the list is long after all)
-  const int kfull = e->d.A < 4096 ? e->d.A : 4096, kgrid = use_q && e->few_unfinished && kfull > AG_KSTEP_SMALL_GRID ? AG_KSTEP_SMALL_GRID : kfull;
+  const int kfull = e->d.A < e->kstep_grid ? e->d.A : e->kstep_grid, kgrid = use_q && e->few_unfinished && kfull > AG_KSTEP_SMALL_GRID ? AG_KSTEP_SMALL_GRID : kfull;
   // a batch beyond the grid visiting every arena: expensive arenas first (k_order over the cycle counts of their last visits, refreshed
   // every 8th step -- the same arenas are expensive step after step)
   const int32_t *order = nullptr;
@@ -651,6 +652,9 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   s.sched = alloc<int32_t>(e, 2); e->sched_parity = 0;
   s.cost = alloc<uint32_t>(e, (size_t)d.A); s.order = alloc<int32_t>(e, (size_t)d.A); e->order_age = 0; e->order_ready = false;
   { const char *no = getenv("AGARCL_NO_ORDER"); e->no_order = no && no[0] == '1'; }
+  // k_step's grid: 4096 single-wave workgroups is what stays resident (4 per SIMD).  AGARCL_KSTEP_GRID=<n> caps it lower: soaks and tests use it to
+  // put small batches through the several-items-per-workgroup path (work counter, cost order)
+  e->kstep_grid = 4096; { const char *kg = getenv("AGARCL_KSTEP_GRID"); if (kg) { int v = atoi(kg); if (v >= 1 && v <= 4096) e->kstep_grid = v; } }
   s.qlist = alloc<int32_t>(e, 2 * (size_t)d.A);
   { const char *nf = getenv("AGARCL_NO_FRONT"); e->no_front = nf && nf[0] == '1'; }
   // modes 0-4 start agents at mass 25 (quiet-dominated); 5 and 6 start at mass 1000 (general path every step)

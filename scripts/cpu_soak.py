@@ -25,6 +25,7 @@ def trial(args):
     if os.environ.get("SOAK_MANY"):   # crowded arenas: up to 6 agents and 6 bots (mode 0)
         cfg["mode"] = int(rng.choice([0, 0, 0, 4, 6])); cfg["num_agents"] = int(rng.randint(1, 7)); cfg["num_bots"] = int(rng.randint(0, 7)) if cfg["mode"] == 0 else 0
         cfg["arena_size"] = int(rng.choice([150, 250, 400]))
+        if rng.rand() < 0.4: cfg["example_bots"] = int(rng.randint(1, 20))     # the reference's ExampleBots beside them: up to 32 players per arena
     engine_level = bool(os.environ.get("SOAK_ENGINE")) and rng.rand() < 0.7   # bench/main.cpp's path: Engine::tick at dt = 1/60, respawns
     if engine_level: cfg["dt"] = 1.0 / 60
     os.environ["AGARCL_TILE_LG"] = str(rng.choice([0, 6]))

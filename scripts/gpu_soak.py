@@ -24,7 +24,9 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     if os.environ.get("SOAK_MANY"):
         cfg["mode"] = int(rng.choice([0, 0, 0, 4, 6])); cfg["num_agents"] = int(rng.randint(1, 7)); cfg["num_bots"] = int(rng.randint(0, 7)) if cfg["mode"] == 0 else 0
         cfg["arena_size"] = int(rng.choice([150, 250, 400]))
-    pins = dict(AGARCL_TILE_LG=str(rng.choice([0, 6])), AGARCL_FUSED=str(rng.choice([0, 1])), AGARCL_FUSED_QG=str(rng.choice([1, 2, 4, 8, 16, 16])), AGARCL_QUIET_QG=str(rng.choice([1, 2, 4, 8, 16])))
+        if rng.rand() < 0.4: cfg["example_bots"] = int(rng.randint(1, 20))     # the reference's ExampleBots beside them: up to 32 players per arena
+    pins = dict(AGARCL_TILE_LG=str(rng.choice([0, 6])), AGARCL_FUSED=str(rng.choice([0, 1])), AGARCL_FUSED_QG=str(rng.choice([1, 2, 4, 8, 16, 16])), AGARCL_QUIET_QG=str(rng.choice([1, 2, 4, 8, 16])),
+                AGARCL_KSTEP_GRID=str(rng.choice([4096, 4096, 7, 32])), AGARCL_NO_ORDER=str(rng.choice([0, 0, 1])))     # (a small grid: several arenas per workgroup -- work counter, cost order)
     if os.environ.get('SOAK_NOPINS'): pins = {k: '' for k in pins}
     if os.environ.get('SOAK_TILE') is not None: pins['AGARCL_TILE_LG'] = os.environ['SOAK_TILE']
     for k_ in list(pins):

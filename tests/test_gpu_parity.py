@@ -55,6 +55,59 @@ def test_hip_vs_oracle_lockstep(hip_engine_cls, oracle_lib, cfg, steps, sticky):
     assert ok, "%s: %s" % (cfg, msg)
 
 
+@pytest.mark.parametrize("pins", [dict(AGARCL_KSTEP_GRID="5"), dict(AGARCL_KSTEP_GRID="3", AGARCL_NO_ORDER="1"), dict(AGARCL_KSTEP_GRID="7", AGARCL_TILE_LG="6")],
+                         ids=["grid5-order", "grid3-index", "grid7-tiled"])
+@pytest.mark.parametrize("cfg", [C3M6, dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0)], ids=["mode6", "c1"])
+def test_several_arenas_per_workgroup(hip_engine_cls, oracle_lib, monkeypatch, cfg, pins):
+    """k_step with fewer workgroups than arenas (AGARCL_KSTEP_GRID caps the grid: what batches beyond 4096 arenas do): arenas beyond the grid are
+    drawn from the work counter, by descending cost of their last visit once k_order has run (every 8th step), or in index order -- every arena
+    against the oracle, 60 steps."""
+    for k, v in pins.items():
+        monkeypatch.setenv(k, v)
+    A = 29
+    eng = hip_engine_cls(A, **cfg)
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    ok, msg = run_batched_lockstep(eng, oras, 60, seeds=np.arange(900, 900 + A), sticky=8, every=3)
+    eng.close()
+    assert ok, "%s %s: %s" % (cfg, pins, msg)
+
+
+def test_every_arena_equal_across_launch_forms_8192(hip_engine_cls, oracle_lib, monkeypatch):
+    """8192 arenas of the full rule set (two items per workgroup): the per-arena digest (counts, masses, rewards, flags) after 16 steps is the
+    same for the default launch, for index order, for a small grid and for the tiled layout -- EVERY arena, not a sample (a real-call form of
+    the quiet run once passed six sampled arenas while ~3000 of 8192 differed: DESIGN.md section 5) -- and 48 sampled arenas equal the oracle."""
+    from oracle import blob
+    A, steps = 8192, 16
+    rng = np.random.RandomState(4)
+    acts = [(rng.uniform(-1, 1, (A, 1, 2)).astype(np.float32), rng.randint(0, 3, (A, 1)).astype(np.int32)) for _ in range(steps)]
+
+    def run(pins, sample=()):
+        for k in ("AGARCL_KSTEP_GRID", "AGARCL_NO_ORDER", "AGARCL_TILE_LG"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in pins.items():
+            monkeypatch.setenv(k, v)
+        eng = hip_engine_cls(A, **C3M6)
+        eng.seed(None, 52000); eng.reset(reset_ids=True)
+        for d, a in acts:
+            eng.set_actions(d, a); eng.step()
+        dig = np.concatenate([eng.counts(), eng.masses().reshape(A, -1), eng.rewards().reshape(A, -1).astype(np.int64), eng.flags().reshape(A, 1).astype(np.int64)], axis=1)
+        dumps = {a: eng.dump(a) for a in sample}
+        eng.close()
+        return dig, dumps
+    sample = [int(x) for x in np.random.RandomState(1).choice(A, 48, replace=False)]
+    ref, dumps = run({}, sample)
+    assert not ref[:, -1].any()
+    for pins in (dict(AGARCL_NO_ORDER="1"), dict(AGARCL_KSTEP_GRID="1024"), dict(AGARCL_TILE_LG="6")):
+        got, _ = run(pins)
+        bad = np.nonzero((got != ref).any(axis=1))[0]
+        assert len(bad) == 0, "%s: %d arenas differ from the default launch, first %s" % (pins, len(bad), bad[:8])
+    for a in sample:
+        o = oracle_lib.OraEnv(**C3M6); o.seed(52000 + a); o.reset(True)
+        for d, ac in acts:
+            o.take_actions(d[a], ac[a]); o.step()
+        assert blob.diff(o.dump(), dumps[a]) is None, "arena %d" % a
+
+
 @pytest.mark.parametrize("A", [1, 5, 7, 67])
 def test_front_kernel_odd_arena_counts_long_quiet_rollout(hip_engine_cls, oracle_lib, A):
     """The lean front kernel (agar_quiet.inl) packs 4 arenas per wavefront: arena counts that are not a multiple of
