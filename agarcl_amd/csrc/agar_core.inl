@@ -197,7 +197,13 @@ struct Cells {  // LDS arrays of one player
 // diagnostic build only (-DAGAR_PROFILE): per-phase shader-clock accumulation, summed into gs->prof
 #if defined(AGAR_PROFILE) && !defined(AGAR_CPU_EMU)
 #define AG_NPROF 16
-#define AG_T(c, k) do { unsigned t_ = (unsigned)__builtin_readcyclecounter(); (c).tacc[k] += t_ - (c).tlast; (c).tlast = t_; } while (0)
+// (volatile asm with a memory clobber: __builtin_readcyclecounter may be scheduled across the phase it is meant to close)
+__device__ __forceinline__ unsigned ag_clock32() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory"); return (unsigned)t; }
+#ifdef AGAR_PROFILE_LEVELS   // slots 13..15 count relaxation levels visited / with a touching pair / touch-bit passes instead (their phases go to 12)
+#define AG_T(c, k) do { unsigned t_ = ag_clock32(); (c).tacc[(k) >= 13 ? 12 : (k)] += t_ - (c).tlast; (c).tlast = t_; } while (0)
+#else
+#define AG_T(c, k) do { unsigned t_ = ag_clock32(); (c).tacc[k] += t_ - (c).tlast; (c).tlast = t_; } while (0)
+#endif
 #else
 #define AG_T(c, k) do { } while (0)
 #endif
@@ -928,18 +934,46 @@ template <int NS, bool AV> AG_DEV void self_collisions(AgCtx<NS, AV> &c, const C
 #else
   // this lane's pairs of the first 128 (all of them up to 16 cells), decoded once per call -- NOT once per pass: arenas with 12+ cells,
   // whose second round decoded on the fly, ran 1.5x longer than the others, and a launch lasts as long as its slowest arena
-  int a_l, b_l, a_l2 = 0, b_l2 = 0; decode(AG_LANE, a_l, b_l);
-  if (NP > 64) decode(AG_LANE + 64, a_l2, b_l2);
+  int a_l = 0, b_l = 0, a_l2 = 0, b_l2 = 0;
+  // Up to 16 cells (NP <= 120, every local level below 32) the pair bookkeeping is branch-free: the rows are walked with a wave-uniform
+  // counter (no per-lane loop), a lane without a pair gets the pair (0, 0) with an empty level bit, and the touch pass below is straight-line
+  // code -- the relaxation of a dense clump is one dependent chain, and every taken branch in it is an instruction-fetch stall.
+  const bool few = n <= 16;
+  unsigned lb1 = 0u, lb2 = 0u;   // this lane's level bits 1 << (a + b) (0: no pair)
+  if (few) {
+    int st1 = 0, st2 = 0;
+    for (int r = 0, st = 0, row = n - 1; r < n - 1; st += row, row--, r++) {
+      if (AG_LANE >= st) { a_l = r; st1 = st; }
+      if (AG_LANE + 64 >= st) { a_l2 = r; st2 = st; }
+    }
+    b_l = a_l + 1 + (AG_LANE - st1); b_l2 = a_l2 + 1 + (AG_LANE + 64 - st2);
+    if (AG_LANE < NP) lb1 = 1u << (a_l + b_l); else { a_l = 0; b_l = 0; }
+    if (AG_LANE + 64 < NP) lb2 = 1u << (a_l2 + b_l2); else { a_l2 = 0; b_l2 = 0; }
+  } else {
+    decode(AG_LANE, a_l, b_l);
+    if (NP > 64) decode(AG_LANE + 64, a_l2, b_l2);
+  }
   auto pair_of = [&](int k, int &a, int &b) { if (k < 64) { a = a_l; b = b_l; } else if (k < 128) { a = a_l2; b = b_l2; } else decode(k, a, b); };
 #endif
   const int LL = 2 * n - 3;                  // local levels 1 .. LL (<= 61 at 32 cells)
   unsigned long long H = 0ull;               // bit L: some pair with a + b == L touches at the current positions
   auto level_hits = [&]() {
+#ifndef AGAR_CPU_EMU
+    if (few) {
+      unsigned bits = touches(s.x[a_l], s.y[a_l], s.crad[a_l], s.x[b_l], s.y[b_l], s.crad[b_l]) ? lb1 : 0u;
+      if (NP > 64) bits |= touches(s.x[a_l2], s.y[a_l2], s.crad[a_l2], s.x[b_l2], s.y[b_l2], s.crad[b_l2]) ? lb2 : 0u;
+      H = wred_or(bits);
+#ifdef AGAR_PROFILE_LEVELS
+      c.tacc[15]++;
+#endif
+      return;
+    }
+#endif
     const unsigned lo = wave_or(NP, [&](int k) -> unsigned { int a, b; pair_of(k, a, b); const int L = a + b; return (L < 32 && touches(s.x[a], s.y[a], s.crad[a], s.x[b], s.y[b], s.crad[b])) ? 1u << L : 0u; });
     const unsigned hi = LL < 32 ? 0u : wave_or(NP, [&](int k) -> unsigned { int a, b; pair_of(k, a, b); const int L = a + b; return (L >= 32 && touches(s.x[a], s.y[a], s.crad[a], s.x[b], s.y[b], s.crad[b])) ? 1u << (L - 32) : 0u; });
     H = ((unsigned long long)hi << 32) | lo;
 #if defined(AGAR_PROFILE_LEVELS) && !defined(AGAR_CPU_EMU)
-    AG_SERIAL { atomicAdd(c.gs->qstat + 12, 1); }
+    c.tacc[15]++;
 #endif
   };
   level_hits();
@@ -969,7 +1003,7 @@ template <int NS, bool AV> AG_DEV void self_collisions(AgCtx<NS, AV> &c, const C
       // pairs of a local level L: a = a0 .. (L - 1) / 2, b = L - a
       const int a0O = LO - (n - 1) > 0 ? LO - (n - 1) : 0, wO = validO ? (LO - 1) / 2 - a0O + 1 : 0;
       const int a0N = LN - (n - 1) > 0 ? LN - (n - 1) : 0, wN = (LN - 1) / 2 - a0N + 1;
-      bool he = false, ho = false;
+      bool he = false, ho = false, hn = false, hold = false;   // hn / hold: the newer / the older sweep has visited a touching pair at this level-time
 #if defined(AGAR_CPU_EMU) && defined(AGAR_STATS_LEVELS)
       // could this level-time and the next one (LN + 1 / LO + 1) have been visited together?  Yes iff the pairs of both that touch at the
       // positions BEFORE this visit share no cell; a misspeculation is a pair of the next level-time that touches only after this one moved
@@ -1010,12 +1044,13 @@ template <int NS, bool AV> AG_DEV void self_collisions(AgCtx<NS, AV> &c, const C
         return true;
       };
       for (int j = 0; j < wO + wN; j++) { int sw = 0; if (visit(j, sw)) { if (sw & 1) ho = true; else he = true; } }
+      hn = (sN & 1) ? ho : he; hold = (sN & 1) ? he : ho;   // he / ho are by sweep parity: the newer sweep's, the older sweep's
 #else
       {  // four lanes per pair (q_visit): lane = 4 * pair + 2 * cell + component
         const int lane = AG_LANE, j = lane >> 2; int sw = 0; bool t0 = false;
         if (j < wO + wN) {
-          int a, b;
-          if (j < wO) { a = a0O + j; b = LO - a; sw = sO; } else { a = a0N + (j - wO); b = LN - a; sw = sN; }
+          const bool older = j < wO;   // (selects, not a branch: measured 423 -> 416 us on mode 6)
+          const int a = older ? a0O + j : a0N + (j - wO), b = (older ? LO : LN) - a; sw = older ? sO : sN;
           QuadK q; q.cB = (lane & 2) != 0; q.kY = (lane & 1) != 0; q.W = W; q.dt = dt; q.tk = q.kY ? ty : tx;
           const int self = q.cB ? b : a;
           float *pp = (q.kY ? s.y : s.x) + self, *vp = (q.kY ? s.vy : s.vx) + self;
@@ -1027,7 +1062,9 @@ template <int NS, bool AV> AG_DEV void self_collisions(AgCtx<NS, AV> &c, const C
             if (t0) { *pp = p; *vp = v; }
           }
         }
-        he = __ballot(t0 && !(sw & 1)) != 0ull; ho = __ballot(t0 && (sw & 1)) != 0ull;
+        // (one ballot: the older sweep's quads are the first wO, so its hits are the low 4 wO bits)
+        const unsigned long long hit = __ballot(t0), mO = wO >= 16 ? ~0ull : (1ull << (4 * wO)) - 1ull;
+        hold = (hit & mO) != 0ull; hn = (hit & ~mO) != 0ull;
       }
 #endif
       ag_lds_order();
@@ -1046,10 +1083,10 @@ template <int NS, bool AV> AG_DEV void self_collisions(AgCtx<NS, AV> &c, const C
       }
 #endif
 #if defined(AGAR_PROFILE_LEVELS) && !defined(AGAR_CPU_EMU)
-      AG_SERIAL { atomicAdd(c.gs->qstat + 2, 1); if (he || ho) atomicAdd(c.gs->qstat + 3, 1); }   // diagnostic build: levels visited / with a touching pair
+      c.tacc[13]++; if (hn || hold) c.tacc[14]++;   // diagnostic build: levels visited / with a touching pair
 #endif
-      if (he || ho) {
-        const bool hn = (sN & 1) ? ho : he, hold = (sN & 1) ? he : ho;   // he / ho are by sweep parity: the newer sweep's, the older sweep's
+      (void)he; (void)ho;
+      if (hn || hold) {
         touched |= (hn ? 1u << sN : 0u) | ((hold && sN >= 1) ? 1u << sO : 0u);
         level_hits();   // cells have moved: the touch bits are taken again
       }

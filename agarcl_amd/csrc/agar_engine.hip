@@ -185,7 +185,7 @@ template <int NS, bool AV, int TSLG> __global__ void __launch_bounds__(64) AG_KS
     c.ts_lg = TSLG;   // (== gs->d.ts_lg, as a constant: the array strides fold into the address arithmetic)
 #ifdef AGAR_PROFILE
     for (int i = 0; i < AG_NPROF; i++) c.tacc[i] = 0;
-    c.tlast = (unsigned)__builtin_readcyclecounter();
+    c.tlast = ag_clock32();
 #endif
     arena_load(c, true);   // a general tick is (almost) certain: the pellets join the first round trip
     AG_T(c, 0);

@@ -69,6 +69,35 @@ def test_grid_obs_device_buffer_4096(hip_engine_cls):
 
 
 @pytest.mark.gpu
+def test_grid_obs_4096_sampled_arenas_vs_oracle(hip_engine_cls, oracle_lib):
+    """Config 5 at full size, on the full rule set: 4096 mode-6 arenas stepped 40 times with random moves / feeds / splits; the persistent
+    device tensor (undo-list path, rewritten every step) of sampled arenas -- first, last, tile edges -- equals the oracle's frame of the
+    same arena advanced alone with the same seed and actions, every 10th step, word for word."""
+    import torch
+    A, G, steps = 4096, 128, 40
+    cfg = dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode=6)
+    sample = [0, 1, 63, 64, 1000, 2047, 2048, 4094, 4095]
+    eng = hip_engine_cls(A, **cfg)
+    eng.seed(None, 10000); eng.reset(reset_ids=True)
+    oras = {a: oracle_lib.OraEnv(**cfg) for a in sample}
+    for a, o in oras.items():
+        o.seed(10000 + a); o.reset(True)
+    out = torch.zeros((A, 1, 8, G, G), dtype=torch.int32, device="cuda")
+    rng = np.random.RandomState(77)
+    for t in range(steps):
+        dxdy = rng.uniform(-1, 1, size=(A, 1, 2)).astype(np.float32); act = rng.randint(0, 3, size=(A, 1)).astype(np.int32)
+        eng.set_actions(dxdy, act); eng.step()
+        assert eng.grid_obs(G, out_ptr=out.data_ptr(), persistent=True) == 8
+        for a, o in oras.items():
+            o.take_actions(dxdy[a], act[a]); o.step()
+        if t % 10 == 9:
+            eng.sync()
+            for a, o in oras.items():
+                assert np.array_equal(out[a, 0].cpu().numpy(), o.grid_obs(0, G, True, True, True, True)), (t, a)
+    eng.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode=6),
                                  dict(num_agents=2, arena_size=250, num_pellets=500, num_viruses=10, num_bots=3, mode=0)])
 def test_grid_obs_persistent_buffer(hip_engine_cls, cfg):
