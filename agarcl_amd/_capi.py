@@ -87,6 +87,7 @@ SYMBOLS = [
     ("agarcl_debug_prof_raw", C.c_int, [C.c_void_p, C.c_void_p]),
     ("agarcl_debug_work", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     ("agarcl_debug_qstat", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("agarcl_debug_sqrt_check", C.c_int, [C.c_void_p, C.c_void_p]),
 ]
 
 
@@ -247,6 +248,12 @@ class BatchedEngine:
         v = C.c_uint32(0)
         self._chk(self.L.agarcl_poll_flags(self.h, C.byref(v)))
         return int(v.value)
+
+    def sqrt_check(self):
+        """self-test: (patterns, lowest pattern) for which the relaxation's short square root differs from sqrtf, over all 2^32 floats"""
+        out = np.zeros(2, dtype=np.uint64)
+        self._chk(self.L.agarcl_debug_sqrt_check(self.h, _ptr(out)))
+        return int(out[0]), int(out[1])
 
     def work(self, reset=False):
         """diagnostics: [arena-steps finished by the front part, arena-steps through the general engine, pellet-array

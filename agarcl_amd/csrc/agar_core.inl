@@ -36,6 +36,7 @@ AG_DEV float ag_unif(float v) { return v; }
 AG_DEV void ag_mem_fence() {}
 AG_DEV void ag_lds_order() {}
 AG_DEV float ag_sqrtf(float x) { return sqrtf(x); }
+AG_DEV float ag_sqrtf_lean(float x) { return sqrtf(x); }
 AG_DEV float ag_divf(float a, float b) { return a / b; }
 AG_DEV void ag_atomic_or(int32_t *p, int v) { *p |= v; }
 AG_DEV bool ag_any(bool p) { return p; }
@@ -63,6 +64,25 @@ AG_DEV float ag_sqrtf(float x) { return __builtin_sqrtf(x); }
 AG_DEV float ag_divf(float a, float b) { return a / b; }
 AG_DEV void ag_atomic_or(int32_t *p, int v) { (void)__hip_atomic_fetch_or((__attribute__((address_space(1))) int32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // (p is HBM: a global, not a flat, atomic)
 AG_DEV bool ag_any(bool p) { return __ballot(p) != 0ull; }   // does any ACTIVE lane of the wave want it?
+// The same correctly rounded square root in 9 instead of 22 instructions, for the relaxation's dependent chain (three per pair visit).
+// The compiler's expansion of sqrtf is: scale x by 2^32 when x < 2^-96, v_sqrt_f32 (1 ulp), two residual tests (one ulp down / up, each an
+// FMA), undo the scaling, pass +-0 / +inf through.  Without the scaling the residual FMAs are still exact for x >= 2^-96, and 0, +inf and
+// NaN come out of the two tests unchanged (NaN residuals compare false) -- so only 0 < |x| < 2^-96 needs the long form, and a squared
+// distance between two cells never is (but a loaded snapshot may hold anything): wave-uniform fallback.  agarcl_debug_sqrt_check runs all
+// 2^32 bit patterns through both.
+AG_DEV float ag_sqrtf_lean(float x) {
+#ifdef AG_NO_LEAN_SQRT
+  return __builtin_sqrtf(x);
+#else
+  if (__builtin_expect(ag_any(fabsf(x) < 0x1p-96f && x != 0.0f), 0)) return __builtin_sqrtf(x);   // (v_sqrt_f32 takes a denormal for a zero)
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float dn = __int_as_float(__float_as_int(s) - 1), up = __int_as_float(__float_as_int(s) + 1);
+  const float rdn = __builtin_fmaf(-dn, s, x), rup = __builtin_fmaf(-up, s, x);
+  float r = (0.0f >= rdn) ? dn : s;
+  r = (0.0f < rup) ? up : r;
+  return r;
+#endif
+}
 #endif
 
 #include "agar_libm.inl"
@@ -819,7 +839,7 @@ AG_DEV float q_boundary(float p, float r, float W) { return smaxf(0.0f, clampf(p
 AG_DEV void q_push(const QuadK &q, bool want, bool small, float r, float ro, unsigned m, unsigned mo, float &p, float &v) {
   const float po = q_cell(p);
   const float d = (q.cB ? p : po) - (q.cB ? po : p);        // B - A, this component (operands selected, not the sign flipped: x - x must stay +0)
-  const float sq = d * d, dist = ag_sqrtf(sq + q_comp(sq));
+  const float sq = d * d, dist = ag_sqrtf_lean(sq + q_comp(sq));
   const float target = r + ro;
   const bool go = want && !(dist > target);
   const float ad = fabsf(d), den = ad + q_comp(ad);
@@ -849,7 +869,7 @@ AG_DEV void q_visit(const QuadK &q, bool t0, bool stat, float r, float ro, unsig
   if (stat) { q_push(q, t0, true, r, ro, m, mo, p, v); return; }   // (wave-uniform except where sweeps 4 and 5 share a level)
   const float po = q_cell(p);
   const float d = (q.cB ? p : po) - (q.cB ? po : p);
-  const float sq = d * d, dist = ag_sqrtf(sq + q_comp(sq));
+  const float sq = d * d, dist = ag_sqrtf_lean(sq + q_comp(sq));
   const float target = r + ro;
   const bool go = t0 && !(dist > target);
   float u = v + sv, t = u * q.dt;
@@ -1047,21 +1067,20 @@ template <int NS, bool AV> AG_DEV void self_collisions(AgCtx<NS, AV> &c, const C
       hn = (sN & 1) ? ho : he; hold = (sN & 1) ? he : ho;   // he / ho are by sweep parity: the newer sweep's, the older sweep's
 #else
       {  // four lanes per pair (q_visit): lane = 4 * pair + 2 * cell + component
-        const int lane = AG_LANE, j = lane >> 2; int sw = 0; bool t0 = false;
-        if (j < wO + wN) {
-          const bool older = j < wO;   // (selects, not a branch: measured 423 -> 416 us on mode 6)
-          const int a = older ? a0O + j : a0N + (j - wO), b = (older ? LO : LN) - a; sw = older ? sO : sN;
-          QuadK q; q.cB = (lane & 2) != 0; q.kY = (lane & 1) != 0; q.W = W; q.dt = dt; q.tk = q.kY ? ty : tx;
-          const int self = q.cB ? b : a;
-          float *pp = (q.kY ? s.y : s.x) + self, *vp = (q.kY ? s.vy : s.vx) + self;
-          float p = *pp; const float r = s.crad[self], ro = q_cell(r);
-          { const float dk = fabsf(p - q_cell(p)), s2 = dk * dk; const float rs = r + ro, rr = rs * rs; t0 = rr >= (s2 + q_comp(s2)) + 0.0f; }
-          if (ag_any(t0)) {
-            float v = *vp; const float sv = (q.kY ? s.sy : s.sx)[self]; const unsigned m = s.m[self], mo = q_cellu(m);
-            q_visit(q, t0, sw >= 5, r, ro, m, mo, sv, p, v);
-            if (t0) { *pp = p; *vp = v; }
-          }
-        }
+        // Straight-line: a quad without a pair takes the pair (0, 0) with its touch bit forced off, and the visit is not guarded by "does any
+        // pair of this level touch" -- the level was picked from H, so one does.  (A visit of a pair that does not touch changes nothing.)
+        const int lane = AG_LANE, j = lane >> 2;
+        const bool has = j < wO + wN, older = j < wO;   // (selects, not branches: measured 423 -> 416 us on mode 6)
+        const int a = has ? (older ? a0O + j : a0N + (j - wO)) : 0, b = has ? (older ? LO : LN) - a : 0, sw = older ? sO : sN;
+        QuadK q; q.cB = (lane & 2) != 0; q.kY = (lane & 1) != 0; q.W = W; q.dt = dt; q.tk = q.kY ? ty : tx;
+        const int self = q.cB ? b : a;
+        float *pp = (q.kY ? s.y : s.x) + self, *vp = (q.kY ? s.vy : s.vx) + self;
+        // everything a visit reads in ONE LDS round trip
+        float p = *pp, v = *vp; const float r = s.crad[self], ro = q_cell(r), sv = (q.kY ? s.sy : s.sx)[self]; const unsigned m = s.m[self], mo = q_cellu(m);
+        bool t0;
+        { const float dk = fabsf(p - q_cell(p)), s2 = dk * dk; const float rs = r + ro, rr = rs * rs; t0 = has && rr >= (s2 + q_comp(s2)) + 0.0f; }
+        q_visit(q, t0, sw >= 5, r, ro, m, mo, sv, p, v);
+        if (t0) { *pp = p; *vp = v; }
         // (one ballot: the older sweep's quads are the first wO, so its hits are the low 4 wO bits)
         const unsigned long long hit = __ballot(t0), mO = wO >= 16 ? ~0ull : (1ull << (4 * wO)) - 1ull;
         hold = (hit & mO) != 0ull; hn = (hit & ~mO) != 0ull;

@@ -1007,6 +1007,31 @@ extern "C" int agarcl_debug_qstat(agarcl_env *e, int32_t *out16) {  // raw stati
   if (!e || !out16) return AGARCL_E_INVALID;
   return d2h(out16, e->s.qstat, 64, e->stream) ? AGARCL_E_HIP : AGARCL_OK;
 }
+// Exhaustive check of the relaxation's short square root (agar_core.inl ag_sqrtf_lean) against the compiler's correctly rounded sqrtf: all
+// 2^32 bit patterns, compared bit for bit.  out2[0] = patterns that differ, out2[1] = the lowest such pattern (valid when out2[0] != 0).
+#ifndef AGAR_CPU_EMU
+__global__ void k_sqrt_check(unsigned long long *out) {
+  unsigned long long bad = 0ull; unsigned first = 0xffffffffu;
+  const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;   // (nth divides 2^32: every wave makes the same number of rounds)
+  for (unsigned long long i = tid; i < (1ull << 32); i += nth) {
+    const float x = __int_as_float((int)(unsigned)i);
+    const unsigned a = (unsigned)__float_as_int(ag_sqrtf_lean(x)), b = (unsigned)__float_as_int(__builtin_sqrtf(x));
+    if (a != b) { bad++; if ((unsigned)i < first) first = (unsigned)i; }
+  }
+  if (bad) { atomicAdd(out, bad); atomicMin(out + 1, (unsigned long long)first); }
+}
+#endif
+extern "C" int agarcl_debug_sqrt_check(agarcl_env *e, unsigned long long *out2) {
+  if (!e || !out2) return AGARCL_E_INVALID;
+  out2[0] = 0ull; out2[1] = ~0ull;
+#ifndef AGAR_CPU_EMU   // (the host emulation has one square root only)
+  unsigned long long *d = alloc<unsigned long long>(e, 2);
+  if (!d || h2d(d, out2, 16, e->stream)) return fail(AGARCL_E_HIP, "sqrt check: allocation failed");
+  hipLaunchKernelGGL(k_sqrt_check, dim3(4096), dim3(256), 0, e->stream, d);
+  if (d2h(out2, d, 16, e->stream)) return fail(AGARCL_E_HIP, "sqrt check failed");
+#endif
+  return AGARCL_OK;
+}
 extern "C" int agarcl_num_arenas(agarcl_env *e) { return e ? e->d.A : 0; }
 extern "C" int agarcl_players_per_arena(agarcl_env *e) { return e ? e->d.P : 0; }
 

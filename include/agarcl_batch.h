@@ -248,6 +248,9 @@ int agarcl_debug_work(agarcl_env *env, int64_t *out4, int reset);
  * only: [2] / [3] levels walked / levels with a touching pair in the self-collision relaxation (-DAGAR_PROFILE_LEVELS), [4..11] why
  * the front part stopped (-DAGAR_PROFILE_REASONS, agar_core.inl AG_WHY) */
 int agarcl_debug_qstat(agarcl_env *env, int32_t *out16);
+/* self-test of the self-collision relaxation's short square root against the correctly rounded sqrtf on all 2^32 float bit patterns
+ * (runs a kernel, waits for it): out2[0] = patterns whose results differ in any bit, out2[1] = the lowest of them */
+int agarcl_debug_sqrt_check(agarcl_env *env, unsigned long long *out2);
 
 #ifdef __cplusplus
 }

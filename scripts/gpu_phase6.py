@@ -4,8 +4,9 @@ sys.path.insert(0, '.')
 import numpy as np
 from agarcl_amd import _capi
 import os
+os.environ.setdefault('AGARCL_NO_FRONT', '1')   # (the front kernel's profile stamps share slots 4 / 5 / 7)
 lib = _capi.bind(C.CDLL(os.environ.get('PROF_SO', 'build_variants/lib_PROF.so')))
-names = ['load', 'tick_pre', 'pl_load/bots', 'kinematics', 'virus', 'pellets', 'stats/food', 'emit/split/add', 'recomb/decay/store', 'regen/end', 'env_post', 'store', 'selfcol(+rendezvous)', 'remove', 'sort', 'plcol/foods']
+names = ['load', 'tick_pre', 'pl_load/bots', 'selfcol (relaxation)', 'virus', 'pellets', 'stats/food', 'emit/split/add', 'recomb/decay/store', 'regen/end', 'env_post', 'store', 'move', 'remove', 'sort', 'plcol/foods']
 def run(A, K=100, ticks=4, **cfg):
     eng = _capi.BatchedEngine(A, lib=lib, **cfg)
     na = cfg.get('num_agents', 1)

@@ -57,3 +57,12 @@ def test_dense_clumps_of_many_cells_emulated(emu_lib, oracle_lib):
 @pytest.mark.gpu
 def test_dense_clumps_of_many_cells_hip(hip_engine_cls, oracle_lib):
     run_clumps(hip_engine_cls, oracle_lib, ticks=40)
+
+
+@pytest.mark.gpu
+def test_short_square_root_is_sqrtf_on_every_float(hip_engine_cls):
+    """The pair visit's 9-instruction square root (agar_core.inl ag_sqrtf_lean) equals the compiler's correctly rounded sqrtf bit for bit on
+    all 2^32 bit patterns (zeros, denormals, the < 2^-96 range that falls back to the long form, infinities, NaNs)."""
+    eng = hip_engine_cls(1, arena_size=100, num_pellets=10, num_viruses=0)
+    assert eng.sqrt_check() == (0, 2 ** 64 - 1)
+    eng.close()
