@@ -152,6 +152,7 @@ struct UBlock { int w[64]; };
 AG_DEV int ub_get(const UBlock &b, int k) { return b.w[k]; }
 AG_DEV void ub_set(UBlock &b, int k, int v) { b.w[k] = v; }
 template <class PT> AG_DEV void ub_load(UBlock &b, PT src, int n) { for (int i = 0; i < 64; i++) b.w[i] = i < n ? src[i] : 0; }
+template <class F> AG_DEV void ub_fill(UBlock &b, F f) { for (int i = 0; i < 64; i++) b.w[i] = f(i); }   // word i = f(i)
 template <class PT> AG_DEV void ub_store(const UBlock &b, PT dst, int n) { for (int i = 0; i < n; i++) dst[i] = b.w[i]; }
 template <class PT> AG_DEV void ub_load_t(UBlock &b, PT src, int n, int ag_ts_lg) { for (int i = 0; i < 64; i++) b.w[i] = i < n ? src[AG_TW(i)] : 0; }   // tile-transposed source
 template <class PT> AG_DEV void ub_store_t(const UBlock &b, PT dst, int n, int ag_ts_lg) { for (int i = 0; i < n; i++) dst[AG_TW(i)] = b.w[i]; }
@@ -160,6 +161,7 @@ struct UBlock { int v; };
 AG_DEV int ub_get(const UBlock &b, int k) { return __builtin_amdgcn_readlane(b.v, k); }
 AG_DEV void ub_set(UBlock &b, int k, int v) { b.v = (AG_LANE == k) ? v : b.v; }
 template <class PT> AG_DEV void ub_load(UBlock &b, PT src, int n) { int l = AG_LANE; b.v = l < n ? src[l] : 0; }
+template <class F> AG_DEV void ub_fill(UBlock &b, F f) { b.v = f(AG_LANE); }   // word i = f(i)
 template <class PT> AG_DEV void ub_store(const UBlock &b, PT dst, int n) { int l = AG_LANE; if (l < n) dst[l] = b.v; }
 template <class PT> AG_DEV void ub_load_t(UBlock &b, PT src, int n, int ag_ts_lg) { int l = AG_LANE; b.v = l < n ? src[AG_TW(l)] : 0; }   // tile-transposed source
 template <class PT> AG_DEV void ub_store_t(const UBlock &b, PT dst, int n, int ag_ts_lg) { int l = AG_LANE; if (l < n) dst[AG_TW(l)] = b.v; }
@@ -1003,13 +1005,17 @@ template <int NS, bool AV> AG_DEV void self_collisions(AgCtx<NS, AV> &c, const C
   const int D = n < LL ? n : LL;
   auto levels_1_to = [](int k) -> unsigned long long { return ((1ull << (k + 1)) - 1ull) & ~1ull; };   // bits 1 .. k (k <= 62)
   unsigned touched = 0u;   // bit s: sweep s has visited a touching pair
+  // the pairs of a local level L are a = a0 .. (L - 1) / 2, b = L - a: (a0 | count << 8) per level in a uniform block (one v_readlane per
+  // look-up instead of a dozen scalar instructions in every step of the walk); word 0 = "no level"
+  UBlock LD; ub_fill(LD, [&](int L) -> int { if (L < 1 || L > LL) return 0; const int a0 = L > n - 1 ? L - (n - 1) : 0; return a0 | ((((L - 1) >> 1) - a0 + 1) << 8); });
   for (int sN = 0; sN <= 5; sN++) {
     const int sO = sN - 1, plen = sN < 5 ? D : LL;
     const int eo = sN >= 1 ? LL - D : 0;   // the level of this phase at which the older sweep completes (0: it has no level here)
+    const unsigned long long mN = levels_1_to(plen), mO = eo >= 1 ? levels_1_to(eo) : 0ull;
     bool done = false;
     for (int LN = 0;;) {
       // levels of this phase after LN at which something touches: the newer sweep's LN, the older sweep's LN + D
-      const unsigned long long M = (H & levels_1_to(plen)) | (eo >= 1 ? (H >> D) & levels_1_to(eo) : 0ull);
+      const unsigned long long M = (H & mN) | ((H >> D) & mO);
       const unsigned long long R = M >> (LN + 1);
       const int Lhit = R ? LN + 1 + (int)__builtin_ctzll(R) : 1000;
       if (eo > LN && eo < Lhit) {   // the older sweep completes before anything else touches
@@ -1019,10 +1025,9 @@ template <int NS, bool AV> AG_DEV void self_collisions(AgCtx<NS, AV> &c, const C
       if (Lhit > plen) break;
       LN = Lhit;
       const int LO = LN + D;
-      const bool validO = sN >= 1 && LO <= LL;
-      // pairs of a local level L: a = a0 .. (L - 1) / 2, b = L - a
-      const int a0O = LO - (n - 1) > 0 ? LO - (n - 1) : 0, wO = validO ? (LO - 1) / 2 - a0O + 1 : 0;
-      const int a0N = LN - (n - 1) > 0 ? LN - (n - 1) : 0, wN = (LN - 1) / 2 - a0N + 1;
+      const bool validO = LN <= eo;   // <=> sN >= 1 && LO <= LL  (eo = LL - D from the second phase on, 0 in the first)
+      const int dO = ub_get(LD, validO ? LO : 0), dN = ub_get(LD, LN);
+      const int a0O = dO & 255, wO = dO >> 8, a0N = dN & 255, wN = dN >> 8;
       bool he = false, ho = false, hn = false, hold = false;   // hn / hold: the newer / the older sweep has visited a touching pair at this level-time
 #if defined(AGAR_CPU_EMU) && defined(AGAR_STATS_LEVELS)
       // could this level-time and the next one (LN + 1 / LO + 1) have been visited together?  Yes iff the pairs of both that touch at the
