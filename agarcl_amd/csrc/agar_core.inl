@@ -1075,15 +1075,17 @@ template <int NS, bool AV> AG_DEV void self_collisions(AgCtx<NS, AV> &c, const C
         // Straight-line: a quad without a pair takes the pair (0, 0) with its touch bit forced off, and the visit is not guarded by "does any
         // pair of this level touch" -- the level was picked from H, so one does.  (A visit of a pair that does not touch changes nothing.)
         const int lane = AG_LANE, j = lane >> 2;
-        const bool has = j < wO + wN, older = j < wO;   // (selects, not branches: measured 423 -> 416 us on mode 6)
-        const int a = has ? (older ? a0O + j : a0N + (j - wO)) : 0, b = has ? (older ? LO : LN) - a : 0, sw = older ? sO : sN;
+        // (selects between wave-uniform values, not branches: measured 423 -> 416 us on mode 6)
+        const bool has = j < wO + wN, older = j < wO;
+        const int offs = older ? a0O : a0N - wO, Lsel = older ? LO : LN, sw = older ? sO : sN;
+        const int a = has ? j + offs : 0, b = has ? Lsel - a : 0;
         QuadK q; q.cB = (lane & 2) != 0; q.kY = (lane & 1) != 0; q.W = W; q.dt = dt; q.tk = q.kY ? ty : tx;
         const int self = q.cB ? b : a;
         float *pp = (q.kY ? s.y : s.x) + self, *vp = (q.kY ? s.vy : s.vx) + self;
         // everything a visit reads in ONE LDS round trip
         float p = *pp, v = *vp; const float r = s.crad[self], ro = q_cell(r), sv = (q.kY ? s.sy : s.sx)[self]; const unsigned m = s.m[self], mo = q_cellu(m);
         bool t0;
-        { const float dk = fabsf(p - q_cell(p)), s2 = dk * dk; const float rs = r + ro, rr = rs * rs; t0 = has && rr >= (s2 + q_comp(s2)) + 0.0f; }
+        { const float dk = fabsf(p - q_cell(p)), s2 = dk * dk; const float rs = r + ro, rr = rs * rs; const bool tt = rr >= (s2 + q_comp(s2)) + 0.0f; t0 = has & tt; }
         q_visit(q, t0, sw >= 5, r, ro, m, mo, sv, p, v);
         if (t0) { *pp = p; *vp = v; }
         // (one ballot: the older sweep's quads are the first wO, so its hits are the low 4 wO bits)
