@@ -187,7 +187,14 @@ template <int NS, bool AV, int TSLG> __global__ void __launch_bounds__(64) AG_KS
     for (int i = 0; i < AG_NPROF; i++) c.tacc[i] = 0;
     c.tlast = ag_clock32();
 #endif
-    arena_load(c, true);   // a general tick is (almost) certain: the pellets join the first round trip
+    // The pellets are NOT part of this load although a general tick is certain: a launch starts with every wavefront of the device loading at
+    // once, which is a bandwidth burst (45 MB at 4096 arenas), not a latency -- so the 8 KB of pellets are requested by the first tick
+    // (ensure_pellets) and stream in behind its kinematics, relaxation and virus test, none of which reads them; the compiler's wait sits in
+    // front of the first pellet scan.  Measured against "everything in one round trip": mid-game 67.7 -> 65.2 us, mode 6 357 -> 352, C1 208.8 -> 205.6.
+#ifndef AG_KSTEP_WANT_PELLETS
+#define AG_KSTEP_WANT_PELLETS false   // (measurement switch)
+#endif
+    arena_load(c, AG_KSTEP_WANT_PELLETS);
     AG_T(c, 0);
     env_step<NS, AV, false>(c, ticks, with_env != 0, q_done, q_before);   // (general ticks only: see env_step)
     AG_T(c, 10);
