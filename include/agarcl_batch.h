@@ -245,8 +245,8 @@ int agarcl_debug_prof_raw(agarcl_env *env, unsigned long long *out_host);
  * out[2] = pellet passes (each reads the arena's whole pellet array), out[3] = general ticks executed */
 int agarcl_debug_work(agarcl_env *env, int64_t *out4, int reset);
 /* the 16 raw running statistics words: [0] arena-steps the front part left unfinished, [1] OR of raised flags; diagnostic builds
- * only: [2] / [3] levels walked / levels with a touching pair in the self-collision relaxation (-DAGAR_PROFILE_LEVELS), [4..11] why
- * the front part stopped (-DAGAR_PROFILE_REASONS, agar_core.inl AG_WHY) */
+ * only: [4..11] why the front part stopped (-DAGAR_PROFILE_REASONS, agar_core.inl AG_WHY).  (-DAGAR_PROFILE -DAGAR_PROFILE_LEVELS counts
+ * the relaxation's visited levels / levels with a touching pair / touch passes per arena in slots 13 / 14 / 15 of agarcl_debug_prof.) */
 int agarcl_debug_qstat(agarcl_env *env, int32_t *out16);
 /* self-test of the self-collision relaxation's short square root against the correctly rounded sqrtf on all 2^32 float bit patterns
  * (runs a kernel, waits for it): out2[0] = patterns whose results differ in any bit, out2[1] = the lowest of them */

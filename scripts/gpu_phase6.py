@@ -25,8 +25,6 @@ def run(A, K=100, ticks=4, **cfg):
     print('A=%d cfg=%s: cycles per wave per launch (%d ticks): total %.0f, wall %.1f us/launch (incl. host action upload)' % (A, cfg, ticks, per.sum(), wall))
     for n, v in zip(names, per): print('   %-24s %9.0f  %5.1f%%' % (n, v, 100 * v / per.sum()))
     print('   mean counts (pellets, viruses, foods, cells):', eng.counts().mean(axis=0))
-    q = np.zeros(16, np.int32); lib.agarcl_debug_qstat(eng.h, q.ctypes.data)
-    print('   relaxation levels walked / with a touching pair / touch-bit passes, per arena-tick over the whole run (LEVELS build only): %.1f / %.1f / %.1f' % (q[2] / (A * (K + 200) * ticks), q[3] / (A * (K + 200) * ticks), q[12] / (A * (K + 200) * ticks)))
     eng.close()
 run(4096, arena_size=1000, num_pellets=1000, num_viruses=25, mode=6)
 run(4096, num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0, dt=1.0 / 60)
