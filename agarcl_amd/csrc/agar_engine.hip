@@ -1181,7 +1181,10 @@ extern "C" int64_t agarcl_state_bytes(agarcl_env *e) {
 }
 
 #ifndef AGAR_CPU_EMU
-__global__ void __launch_bounds__(256) k_grid_obs(const AgState *__restrict__ gs, AgObsCfg o, int32_t *out, int zero_fill, AgObsUndo un) {
+#ifndef AG_GRID_WAVES
+#define AG_GRID_WAVES 6   // (waves per SIMD the register budget is cut for: 80 VGPRs, no spills; 8 -- all that LDS admits -- spills 20 registers for the same time, the uncapped 111 VGPRs leave 4 waves and cost 6 us)
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AG_GRID_WAVES, AG_GRID_WAVES))) k_grid_obs(const AgState *__restrict__ gs, AgObsCfg o, int32_t *out, int zero_fill, AgObsUndo un) {
   int b = (int)blockIdx.x, na = gs->d.n_agents;
   grid_obs_agent(gs, b / na, b % na, o, out + (size_t)b * obs_channels(o) * o.G * o.G, zero_fill != 0, un, b);
 }

@@ -20,12 +20,17 @@
 #define OBS_DEV static inline
 #define OBS_FOR(k, n) for (int k = 0; k < (n); ++k)
 #define OBS_BARRIER()
+#define OBS_BARRIER_LDS()
 #define OBS_THREAD0 true
 #define OBS_ATOMIC_ADD(p, v) (*(p) += (v))
 #else
 #define OBS_DEV __device__ __forceinline__
 #define OBS_FOR(k, n) for (int k = (int)threadIdx.x; k < (n); k += (int)blockDim.x)
 #define OBS_BARRIER() __syncthreads()
+// a barrier for data exchanged through LDS only: __syncthreads() also waits for every global store / atomic of the wave to be acknowledged
+// (vmcnt counts stores on gfx9) -- a round trip per barrier behind a phase that scattered into the frame.  The one barrier that must be a
+// full one is between undoing the previous frame's words and scattering the new ones (two threads may write the same word).
+#define OBS_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define OBS_THREAD0 (threadIdx.x == 0)
 #define OBS_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #endif
@@ -77,20 +82,48 @@ OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o,
 #ifndef AGAR_CPU_EMU
   __shared__ int un_cnt;
   int32_t *ul = un.list ? un.list + (size_t)frame * un.cap : nullptr;
+  // Everything this frame reads has an address known from (arena, agent, thread): the counts, the first 512 undo entries, the first 1024
+  // pellets, the viruses, the agent's cell slots and the mask signature are requested HERE, together -- a frame used to make about ten
+  // dependent round trips (count, then list; cell count, then cells; pellet count, then pellets; ...), and with two rounds of workgroups
+  // per CU that chain was the kernel's time.  Slots behind a count hold valid memory (capacities), so nothing waits for a count to load.
+  const int tid = (int)threadIdx.x, ag_ts_lg0 = gs->d.ts_lg;
+  const bool undo = ul && un.clear;
+  int pf_nprev = 0, pf_ul0 = 0, pf_ul1 = 0;
+  if (undo) { pf_nprev = un.count[frame]; if (tid < un.cap) pf_ul0 = ul[tid]; if (tid + 256 < un.cap) pf_ul1 = ul[tid + 256]; }
+  int pf_np, pf_nv, pf_nown;
+  { const int ag_ts_lg = ag_ts_lg0; const int32_t *arw0 = AG_AR_PTR(gs, arena); pf_np = arw0[AG_TW(AR_NPEL)]; pf_nv = arw0[AG_TW(AR_NVIR)]; pf_nown = AG_PL_PTR(gs, arena, agent)[AG_TW(PL_NCELLS)]; }
+  const int PCp = gs->d.PC;
+  const float *pxy0 = gs->pel_xy + (size_t)arena * PCp * 2;
+  float pf_px[4], pf_py[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) { const int k = tid + 256 * j; pf_px[j] = 0.0f; pf_py[j] = 0.0f; if (o.pellets && k < PCp) { pf_px[j] = pxy0[2 * k]; pf_py[j] = pxy0[2 * k + 1]; } }
+  float pf_vx = 0.0f, pf_vy = 0.0f; int pf_vm = 0;
+  { const size_t vo0 = (size_t)arena * gs->d.VC; if (o.viruses && tid < gs->d.VC) { pf_vx = gs->vir_x[vo0 + tid]; pf_vy = gs->vir_y[vo0 + tid]; pf_vm = gs->vir_mass[vo0 + tid]; } }
+  uint8_t pf_sx = 0, pf_sy = 0;
+  if (undo && un.sig && tid < o.G) { const uint8_t *sg0 = un.sig + (size_t)frame * 2 * o.G; pf_sx = sg0[tid]; pf_sy = sg0[o.G + tid]; }
+  __shared__ float own_x[AG_CC], own_y[AG_CC]; __shared__ unsigned own_m[AG_CC];
+  if (tid < AG_CC) { const int ag_ts_lg = ag_ts_lg0; const uint32_t *Co = AG_CELLS_PTR(gs, arena, agent); union { uint32_t u; float f; } x, y; x.u = Co[AG_CELL_W(CF_X, tid)]; y.u = Co[AG_CELL_W(CF_Y, tid)]; own_x[tid] = x.f; own_y[tid] = y.f; own_m[tid] = Co[AG_CELL_W(CF_M, tid)]; }
   if (ul) {
     if (un.clear) {   // undo the previous observation's scattered writes
-      const int n_prev = un.count[frame];   // (block-uniform)
-      if (n_prev == OBS_UNDO_OVERFLOW) zero_fill = true; else OBS_FOR(k, n_prev) out[ul[k]] = 0;
+      const int n_prev = pf_nprev;   // (block-uniform)
+      if (n_prev == OBS_UNDO_OVERFLOW) zero_fill = true;
+      else { if (tid < n_prev) out[pf_ul0] = 0; if (tid + 256 < n_prev) out[pf_ul1] = 0; for (int k = tid + 512; k < n_prev; k += 256) out[ul[k]] = 0; }
     }
     if (threadIdx.x == 0) un_cnt = 0;
   }
   auto rec = [&](int off) { if (ul) { const int p_ = atomicAdd(&un_cnt, 1); if (p_ < un.cap) ul[p_] = off; } };
+  OBS_BARRIER_LDS();   // the agent's cells are in LDS
+  // (Player::x / y / mass: sequential fp32 sums in cell order, obs_player's arithmetic on the staged slots)
+  float px, py; unsigned mass;
+  { float sx = 0.0f, sy = 0.0f; unsigned tm = 0;
+    for (int i = 0; i < pf_nown; i++) { const unsigned m = own_m[i]; const float fm = (float)m; float t = own_x[i] * fm; sx += t; t = own_y[i] * fm; sy += t; tm += m; }
+    px = sx / (float)tm; py = sy / (float)tm; mass = tm; }
 #else
   (void)un; (void)frame;
   auto rec = [&](int) {};
-#endif
   float px, py; unsigned mass;
   obs_player(gs, arena, agent, px, py, mass);
+#endif
   float view = obs_smaxf(obs_sminf((float)(2u * mass), 300.0f), 100.0f);  // clamp<float>(2*mass, 100, 300), :251-254
   float centering = (float)(G / 2.0);
   float W = gs->g.W;
@@ -107,7 +140,7 @@ OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o,
     float lx = px + t, ly = py + t;
     inx[i] = (0 <= lx && lx < W) ? 1 : 0; iny[i] = (0 <= ly && ly < W) ? 1 : 0;
   }
-  OBS_BARRIER();
+  OBS_BARRIER_LDS();
   auto oob = [&](int k) -> int32_t { int i = k / G, j = k - i * G; return (inx[i] & iny[j]) ? 0 : -1; };
 #ifndef AGAR_CPU_EMU
   // persistent tensor (the undo list of the previous call is valid): channel 0 still holds the previous mask.  Only the rows whose x byte and
@@ -119,12 +152,16 @@ OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o,
     const bool incremental = un.clear && !zero_fill;   // (block-uniform; zero_fill here means "the list overflowed": everything is rewritten)
     if (incremental) {
       if (threadIdx.x == 0) { n_rows = 0; n_cols = 0; }
-      __syncthreads();
-      OBS_FOR(i, G) {
+      OBS_BARRIER_LDS();
+      if (tid < G) {   // (G <= 256 rows / columns: the prefetched bytes; larger grids read theirs here)
+        if (pf_sx != inx[tid]) ch_rows[atomicAdd(&n_rows, 1)] = (uint16_t)tid;
+        if (pf_sy != iny[tid]) ch_cols[atomicAdd(&n_cols, 1)] = (uint16_t)tid;
+      }
+      for (int i = tid + 256; i < G; i += 256) {
         if (sg[i] != inx[i]) ch_rows[atomicAdd(&n_rows, 1)] = (uint16_t)i;
         if (sg[G + i] != iny[i]) ch_cols[atomicAdd(&n_cols, 1)] = (uint16_t)i;
       }
-      __syncthreads();
+      OBS_BARRIER_LDS();
       const int nr = n_rows, nc = n_cols;
       OBS_FOR(k, nr * G) { const int i = ch_rows[k / G], j = k % G; out[i * G + j] = (inx[i] & iny[j]) ? 0 : -1; }
       OBS_FOR(k, nc * G) { const int j = ch_cols[k / G], i = k % G; out[i * G + j] = (inx[i] & iny[j]) ? 0 : -1; }
@@ -158,9 +195,17 @@ OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o,
   const int ag_ts_lg = gs->d.ts_lg;
   int ch = 0;
   if (o.pellets) {  // ch+1: "at least one" (= mass 1), ch+2: count
-    const float *pxy = gs->pel_xy + (size_t)arena * gs->d.PC * 2; int np = AG_AR_PTR(gs, arena)[AG_TW(AR_NPEL)];
     int32_t *a1 = out + (size_t)(ch + 1) * GG, *a2 = out + (size_t)(ch + 2) * GG;
-    OBS_FOR(k, np) { int gx, gy; if (w2g(pxy[2 * k], pxy[2 * k + 1], gx, gy)) { a1[gx * G + gy] = 1; OBS_ATOMIC_ADD(&a2[gx * G + gy], 1); rec((ch + 1) * GG + gx * G + gy); rec((ch + 2) * GG + gx * G + gy); } }
+    auto pellet = [&](float qx, float qy) { int gx, gy; if (w2g(qx, qy, gx, gy)) { a1[gx * G + gy] = 1; OBS_ATOMIC_ADD(&a2[gx * G + gy], 1); rec((ch + 1) * GG + gx * G + gy); rec((ch + 2) * GG + gx * G + gy); } };
+#ifndef AGAR_CPU_EMU
+    const int np = pf_np;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { if (tid + 256 * j < np) pellet(pf_px[j], pf_py[j]); }
+    for (int k = tid + 1024; k < np; k += 256) pellet(pxy0[2 * k], pxy0[2 * k + 1]);
+#else
+    const float *pxy = gs->pel_xy + (size_t)arena * gs->d.PC * 2; int np = AG_AR_PTR(gs, arena)[AG_TW(AR_NPEL)];
+    OBS_FOR(k, np) pellet(pxy[2 * k], pxy[2 * k + 1]);
+#endif
     ch += 2;
   }
   // Viruses and cells: the reference applies them one after the other (GridEnvironment.hpp:222-229: "at least one"
@@ -173,7 +218,11 @@ OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o,
   __shared__ int32_t e_idx[OBS_ECAP], e_mass[OBS_ECAP], e_kind[OBS_ECAP];
 #endif
   const int32_t *arw = AG_AR_PTR(gs, arena);
+#ifndef AGAR_CPU_EMU
+  const int P = gs->d.P, nv = o.viruses ? pf_nv : 0;
+#else
   const int P = gs->d.P, nv = o.viruses ? arw[AG_TW(AR_NVIR)] : 0;
+#endif
   int c2 = o.pellets ? 2 : 0;
   int32_t *v1 = out + (size_t)(c2 + 1) * GG, *v2 = out + (size_t)(c2 + 2) * GG; if (o.viruses) c2 += 2;
   int32_t *cown = out + (size_t)(c2 + 1) * GG; if (o.cells) c2 += 1;
@@ -181,12 +230,25 @@ OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o,
   int E = nv;
   {  // viruses: kind 0, in vector order
     size_t vo = (size_t)arena * gs->d.VC;
+#ifndef AGAR_CPU_EMU
+    if (tid < nv) { int gx, gy; bool in = w2g(pf_vx, pf_vy, gx, gy); e_idx[tid] = in ? gx * G + gy : -1; e_mass[tid] = pf_vm; e_kind[tid] = 0; }
+    for (int k = tid + 256; k < nv; k += 256) { if (k < OBS_ECAP) { int gx, gy; bool in = w2g(gs->vir_x[vo + k], gs->vir_y[vo + k], gx, gy); e_idx[k] = in ? gx * G + gy : -1; e_mass[k] = gs->vir_mass[vo + k]; e_kind[k] = 0; } }
+#else
     OBS_FOR(k, nv) { if (k < OBS_ECAP) { int gx, gy; bool in = w2g(gs->vir_x[vo + k], gs->vir_y[vo + k], gx, gy); e_idx[k] = in ? gx * G + gy : -1; e_mass[k] = gs->vir_mass[vo + k]; e_kind[k] = 0; } }
+#endif
   }
   for (int k = -1; k < P; k++) {  // own cells (kind 1), then the other players in the engine's iteration order (kind 2)
     if (k < 0 ? !o.cells : !o.others) continue;
     const int p = k < 0 ? agent : arw[AG_TW(AR_ORDER0 + k)];
     if (k >= 0 && p == agent) continue;
+#ifndef AGAR_CPU_EMU
+    if (k < 0) {   // the agent's own cells are staged already
+      const int n = pf_nown;
+      if (tid < n && E + tid < OBS_ECAP) { int gx, gy; bool in = w2g(own_x[tid], own_y[tid], gx, gy); e_idx[E + tid] = in ? gx * G + gy : -1; e_mass[E + tid] = (int32_t)own_m[tid]; e_kind[E + tid] = 1; }
+      E += n;
+      continue;
+    }
+#endif
     const int32_t *pl = AG_PL_PTR(gs, arena, p);
     const uint32_t *Cc = AG_CELLS_PTR(gs, arena, p);
     const int n = pl[AG_TW(PL_NCELLS)];
@@ -200,7 +262,7 @@ OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o,
     E += n;
   }
   if (E > OBS_ECAP) E = OBS_ECAP;
-  OBS_BARRIER();
+  OBS_BARRIER_LDS();
   OBS_FOR(k, E) {
     const int idx = e_idx[k], kind = e_kind[k];
     if (idx < 0) continue;
@@ -217,6 +279,6 @@ OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o,
     else { omin[idx] = mn; omax[idx] = mx; rec((int)(omin - out) + idx); rec((int)(omax - out) + idx); }
   }
 #ifndef AGAR_CPU_EMU
-  if (ul) { OBS_BARRIER(); if (threadIdx.x == 0) un.count[frame] = un_cnt <= un.cap ? un_cnt : OBS_UNDO_OVERFLOW; }
+  if (ul) { OBS_BARRIER_LDS(); if (threadIdx.x == 0) un.count[frame] = un_cnt <= un.cap ? un_cnt : OBS_UNDO_OVERFLOW; }
 #endif
 }
