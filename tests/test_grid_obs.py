@@ -10,6 +10,7 @@ CFGS = [
     dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode=6),
     dict(arena_size=250, num_pellets=500, num_viruses=10, mode=6),
     dict(arena_size=60, num_pellets=200, num_viruses=0, mode=0),   # tiny arena: large out-of-bounds band
+    dict(arena_size=1000, num_pellets=1300, num_viruses=300, mode=6),   # more pellets / viruses than the kernel's up-front loads cover (1024 / 256)
 ]
 
 

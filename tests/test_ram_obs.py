@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
     dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0, dt=1.0 / 60),   # BASELINE configs[0]'s population
     dict(num_agents=1, arena_size=1000, num_pellets=1000, num_viruses=25, mode=6),
     dict(num_agents=3, arena_size=250, num_pellets=300, num_viruses=5, mode=6),
-], ids=["c1_bots", "c3m6", "multi3"])
+    dict(num_agents=1, arena_size=1000, num_pellets=1300, num_viruses=40, mode=0),   # more than 1024 pellets: the selection's general form
+], ids=["c1_bots", "c3m6", "multi3", "many_pellets"])
 def test_ram_obs_matches_host_restatement(hip_engine_cls, cfg):
     from oracle import ram_oracle
     A = 6
