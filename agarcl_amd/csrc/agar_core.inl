@@ -274,6 +274,9 @@ template <int NS, bool AV> struct AgCtx {
   UBlock S;    // arena words (AR_*): register-resident for the whole launch
   UBlock PB;   // current player's words (PL_*): valid inside tick_player only; LDS PLS is its home
   int ncreated;
+  // end-of-tick table check (arena_tick): lut_risk = some cell had at least half the table size when its player moved this tick (an exact
+  // per-cell test folded into move_player's pass); mass_sum = the players' total masses of this tick (they cannot wrap while lut_risk is off)
+  bool lut_risk; unsigned mass_sum;
   bool pel_dirty, pel_loaded;   // pel_dirty: some slot is marked in pel.dirty
   bool pel_all;                 // every slot is dirty (reset): the store skips the per-slot tests
 };
@@ -1141,14 +1144,17 @@ AG_DEV void move_one(float &x, float &y, float &vx, float &vy, float &svx, float
 template <int NS, bool AV> AG_DEV void move_player(AgCtx<NS, AV> &c, const Cells &s, int n) {
   float tx = PRF(c, PL_TX), ty = PRF(c, PL_TY), dt = c.gs->g.dt, W = c.gs->g.W;
   auto lut_r = g_lut_r(c); auto lut_ms = g_lut_ms(c);
+  bool big = false;
   AG_LANES(i, n) {
     float x = s.x[i], y = s.y[i], svx = s.sx[i], svy = s.sy[i]; unsigned m = s.m[i];
+    big = big | (m >= (unsigned)AG_LUT_SIZE / 2u);
     if (s.cmc[i] != m) { s.cmc[i] = m; s.crad[i] = lut(lut_r, m); s.cms[i] = lut(lut_ms, m); }  // refresh the cache on mass change
     float hi = s.cms[i], r = s.crad[i], vx, vy;
     move_one(x, y, vx, vy, svx, svy, hi, r, tx, ty, dt, W);
     s.x[i] = x; s.y[i] = y; s.vx[i] = vx; s.vy[i] = vy; s.sx[i] = svx; s.sy[i] = svy;
   }
   ag_lds_order();
+  if (AG_RARE(ag_any(big))) c.lut_risk = true;
   unsigned mn = n == 1 ? ag_uniu(s.m[0]) : wave_min(n, [&](int i) { return s.m[i]; });
   PW(c, PL_MIN_MASS, (int)mn);
   AG_T(c, 12);
@@ -1533,11 +1539,14 @@ template <int NS, bool AV> AG_DEV void decay(AgCtx<NS, AV> &c, const Cells &s, i
   }
   if (elapsed - PR(c, PL_LAST_DECAY) >= 60) {
     double rate = (double)PRF(c, PL_ANTI_TEAM);
+    bool big = false;   // (a negative factor wraps the mass around 2^32, d2u_x86: the one way a cell grows that arena_tick's mass bound does not see)
     AG_LANES(i, n) {
       double nm = (double)s.m[i] * (1 - 0.002 * rate);
       unsigned um = d2u_x86(nm);
       s.m[i] = um > AG_CELL_MIN_SIZE ? um : AG_CELL_MIN_SIZE;
+      big = big | (um >= (unsigned)AG_LUT_SIZE / 2u);
     }
+    if (AG_RARE(ag_any(big))) c.lut_risk = true;
     PW(c, PL_LAST_DECAY, elapsed);
     ag_lds_order();
   }
@@ -1578,6 +1587,7 @@ template <int NS, bool AV> AG_DEV void tick_player(AgCtx<NS, AV> &c, int p) {
 #endif
   AG_T(c, 5);
   unsigned total = n == 1 ? ag_uniu(s.m[0]) : (unsigned)wave_sum(n, [&](int i) { return (int)s.m[i]; });
+  c.mass_sum += total;
   if (ate) PW(c, PL_FOOD_EATEN, PR(c, PL_FOOD_EATEN) + ate);
   if ((unsigned)PR(c, PL_HIGHEST_MASS) < total) PW(c, PL_HIGHEST_MASS, (int)total);
   // per-cell: auto split (mass >= 22500) then eat ejected food.  R: Engine.hpp:520-525, 592-601
@@ -2071,6 +2081,7 @@ template <int NS, bool AV> AG_DEV void arena_tick(AgCtx<NS, AV> &c) {
   SW(c, AR_SAFE, 0);  // the out-of-reach budget is only maintained by quiet_run
   if (c.P == 1) { AG_SERIAL { PLS(c, 0)[PL_CAND_IDX] = -1; } ag_lds_order(); }   // ... and the tracked pellet goes with the disc (no stale index may outlive it)
   SW(c, AR_NEVP, 0); SW(c, AR_NEVV, 0);
+  c.lut_risk = false; c.mass_sum = 0u;
   AG_T(c, 1);
   for (int k = 0; k < c.P; k++) tick_player(c, SR(c, AR_ORDER0 + k));
   remove_pellets(c);
@@ -2095,11 +2106,16 @@ template <int NS, bool AV> AG_DEV void arena_tick(AgCtx<NS, AV> &c) {
   SW(c, AR_TICKS, ticks + 1); SW(c, AR_CLOCK, SR(c, AR_CLOCK) + 1);
   // a mass beyond the radius / speed tables (2^19 entries; the reference computes them from the mass, without a limit): every
   // table look-up clamps, so the arena has left the reference -- say so (AGARCL_F_MASS_LUT_OVERFLOW) instead of diverging silently
-  for (int p = 0; p < c.P; p++) {
-    const int n = ag_uni(PLS(c, p)[PL_NCELLS]);
-    if (n == 0) continue;
-    Cells s = cells_of(c, p);
-    if (AG_RARE(wave_any(n, [&](int i) { return s.m[i] >= (unsigned)AG_LUT_SIZE; }))) flag(c, 32u);
+  // (Two round trips to LDS per player, every tick, for a flag that is never raised: so the per-cell test runs only when a cell COULD have
+  // reached the table size -- one had half of it when it moved (lut_risk), or all the mass of the arena plus everything a tick can add
+  // (ejected foods eaten, a respawn per player) would.  Otherwise no cell can, and the loop would find nothing.)
+  if (AG_RARE(c.lut_risk || c.mass_sum + 10u * (unsigned)c.FC + 4096u * (unsigned)c.P + 65536u >= (unsigned)AG_LUT_SIZE)) {
+    for (int p = 0; p < c.P; p++) {
+      const int n = ag_uni(PLS(c, p)[PL_NCELLS]);
+      if (n == 0) continue;
+      Cells s = cells_of(c, p);
+      if (AG_RARE(wave_any(n, [&](int i) { return s.m[i] >= (unsigned)AG_LUT_SIZE; }))) flag(c, 32u);
+    }
   }
   AG_T(c, 9);
 }
