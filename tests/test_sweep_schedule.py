@@ -40,3 +40,39 @@ def test_level_enumeration_matches_the_schedule():
                 a0 = max(LN - (n - 1), 0)
                 got |= {(sN, a, LN - a) for a in range(a0, (LN - 1) // 2 + 1)}
             assert got == want.get(lev, set()), (n, lev)
+
+
+def test_branch_free_pair_bookkeeping_up_to_16_cells():
+    """agar_core.inl self_collisions, the straight-line forms used up to 16 cells: (1) the wave-uniform row walk gives lane k (and k + 64)
+    the pair the row-major decode gives; (2) the packed level descriptor (first a | pair count << 8, one v_readlane per look-up) describes
+    exactly the pairs (a, L - a) of local level L; (3) the quad -> pair mapping by selects (older sweep's pairs first) enumerates the
+    level-time's pairs; (4) a lane's level bit 1 << (a + b) stays below 32."""
+    for n in range(2, 17):
+        NP = n * (n - 1) // 2; LL = 2 * n - 3
+        pairs = [(a, b) for a in range(n) for b in range(a + 1, n)]            # row-major: the reference's loop order
+        for k in range(min(NP, 128)):
+            a = st_k = 0; st = 0; row = n - 1
+            for r in range(n - 1):                                             # the uniform walk: lane k keeps the last row whose start it has reached
+                if k >= st: a, st_k = r, st
+                st += row; row -= 1
+            b = a + 1 + (k - st_k)
+            assert (a, b) == pairs[k], (n, k)
+            assert a + b < 32
+        for L in range(1, LL + 1):
+            a0 = L - (n - 1) if L > n - 1 else 0
+            desc = a0 | ((((L - 1) >> 1) - a0 + 1) << 8)
+            a0_, w = desc & 255, desc >> 8
+            assert {(a, L - a) for a in range(a0_, a0_ + w)} == {(a, b) for (a, b) in pairs if a + b == L}, (n, L)
+        D = min(n, LL)
+        for LN in range(1, LL + 1):                                            # a level-time of a phase: newer sweep's LN, older sweep's LN + D
+            LO = LN + D; validO = LO <= LL
+            d = lambda L: ((L - (n - 1) if L > n - 1 else 0), ((L - 1) >> 1) - (L - (n - 1) if L > n - 1 else 0) + 1)
+            (a0O, wO), (a0N, wN) = (d(LO) if validO else (0, 0)), d(LN)
+            got = []
+            for j in range(16):
+                has, older = j < wO + wN, j < wO
+                offs, Lsel = (a0O if older else a0N - wO), (LO if older else LN)
+                a = j + offs if has else 0; b = Lsel - a if has else 0
+                if has: got.append((older, a, b))
+            want = [(True, a, LO - a) for a in range(a0O, a0O + wO)] + [(False, a, LN - a) for a in range(a0N, a0N + wN)]
+            assert got == want and wO + wN <= 16, (n, LN)
