@@ -277,6 +277,7 @@ template <int NS, bool AV> struct AgCtx {
   // end-of-tick table check (arena_tick): lut_risk = some cell had at least half the table size when its player moved this tick (an exact
   // per-cell test folded into move_player's pass); mass_sum = the players' total masses of this tick (they cannot wrap while lut_risk is off)
   bool lut_risk; unsigned mass_sum;
+  bool moved_all;   // this tick's kinematics of ALL players have been done in one lane-parallel pass (move_all_players)
   bool pel_dirty, pel_loaded;   // pel_dirty: some slot is marked in pel.dirty
   bool pel_all;                 // every slot is dirty (reset): the store skips the per-slot tests
 };
@@ -1141,20 +1142,49 @@ AG_DEV void move_one(float &x, float &y, float &vx, float &vy, float &svx, float
   if (!(svx == 0.0f && svy == 0.0f)) v_decelerate(svx, svy, AG_SPLIT_DECEL, dt);
   boundary(W, x, y, r);
 }
-template <int NS, bool AV> AG_DEV void move_player(AgCtx<NS, AV> &c, const Cells &s, int n) {
-  float tx = PRF(c, PL_TX), ty = PRF(c, PL_TY), dt = c.gs->g.dt, W = c.gs->g.W;
-  auto lut_r = g_lut_r(c); auto lut_ms = g_lut_ms(c);
+// one cell's kinematics out of / into its player's LDS arrays (Engine::move_player's loop body); returns "its mass is at least half the tables"
+template <int NS, bool AV> AG_DEV bool move_cell(const AgCtx<NS, AV> &c, const Cells &s, int i, float tx, float ty, float dt, float W) {
+  float x = s.x[i], y = s.y[i], svx = s.sx[i], svy = s.sy[i]; unsigned m = s.m[i];
+  if (s.cmc[i] != m) { s.cmc[i] = m; s.crad[i] = lut(g_lut_r(c), m); s.cms[i] = lut(g_lut_ms(c), m); }  // refresh the cache on mass change
+  float hi = s.cms[i], r = s.crad[i], vx, vy;
+  move_one(x, y, vx, vy, svx, svy, hi, r, tx, ty, dt, W);
+  s.x[i] = x; s.y[i] = y; s.vx[i] = vx; s.vy[i] = vy; s.sx[i] = svx; s.sy[i] = svy;
+  return m >= (unsigned)AG_LUT_SIZE / 2u;
+}
+// The kinematics of ALL players' cells in one pass, a lane per live cell.  Engine::tick moves player B after player A's whole turn, but B's
+// move reads only B's cells and B's target, and nothing in A's turn writes those (A's turn changes A's cells, the shared pellets, viruses and
+// foods) -- EXCEPT on the ticks on which bots choose their targets (every 10th, Engine.hpp:498-499): a shy / aggressive bot looks at the
+// other players' cells as they are at that moment.  So: every tick that is not a bot tick.  A five-player arena (C1) pays the ~150
+// instructions of move_one once instead of five times one after the other, each for a single active lane.
+template <int NS, bool AV> AG_DEV void move_all_players(AgCtx<NS, AV> &c) {
+  const float dt = c.gs->g.dt, W = c.gs->g.W;
   bool big = false;
-  AG_LANES(i, n) {
-    float x = s.x[i], y = s.y[i], svx = s.sx[i], svy = s.sy[i]; unsigned m = s.m[i];
-    big = big | (m >= (unsigned)AG_LUT_SIZE / 2u);
-    if (s.cmc[i] != m) { s.cmc[i] = m; s.crad[i] = lut(lut_r, m); s.cms[i] = lut(lut_ms, m); }  // refresh the cache on mass change
-    float hi = s.cms[i], r = s.crad[i], vx, vy;
-    move_one(x, y, vx, vy, svx, svy, hi, r, tx, ty, dt, W);
-    s.x[i] = x; s.y[i] = y; s.vx[i] = vx; s.vy[i] = vy; s.sx[i] = svx; s.sy[i] = svy;
+#ifdef AGAR_CPU_EMU
+  for (int p = 0; p < c.P; p++) {
+    const int *PLp = PLS(c, p); const int n = PLp[PL_NCELLS]; Cells s = cells_of(c, p);
+    for (int i = 0; i < n; i++) big = big | move_cell(c, s, i, u2f(PLp[PL_TX]), u2f(PLp[PL_TY]), dt, W);
   }
+#else
+  const int ncl = AG_LANE < c.P ? PLS(c, AG_LANE)[PL_NCELLS] : 0;   // (P <= 32 players: a lane each)
+  for (int base = 0;; base += 64) {
+    const int t = base + AG_LANE; int p = -1, i = 0, st = 0;
+    for (int q = 0; q < c.P; q++) { const int nq = __builtin_amdgcn_readlane(ncl, q); if (t >= st && t < st + nq) { p = q; i = t - st; } st += nq; }
+    if (p >= 0) { const int *PLp = PLS(c, p); Cells s = cells_of(c, p); big = big | move_cell(c, s, i, u2f(PLp[PL_TX]), u2f(PLp[PL_TY]), dt, W); }
+    if (base + 64 >= st) break;
+  }
+#endif
   ag_lds_order();
   if (AG_RARE(ag_any(big))) c.lut_risk = true;
+  c.moved_all = true;
+}
+template <int NS, bool AV> AG_DEV void move_player(AgCtx<NS, AV> &c, const Cells &s, int n) {
+  float tx = PRF(c, PL_TX), ty = PRF(c, PL_TY), dt = c.gs->g.dt, W = c.gs->g.W;
+  if (!c.moved_all) {
+    bool big = false;
+    AG_LANES(i, n) { big = big | move_cell(c, s, i, tx, ty, dt, W); }
+    ag_lds_order();
+    if (AG_RARE(ag_any(big))) c.lut_risk = true;
+  }
   unsigned mn = n == 1 ? ag_uniu(s.m[0]) : wave_min(n, [&](int i) { return s.m[i]; });
   PW(c, PL_MIN_MASS, (int)mn);
   AG_T(c, 12);
@@ -2081,7 +2111,10 @@ template <int NS, bool AV> AG_DEV void arena_tick(AgCtx<NS, AV> &c) {
   SW(c, AR_SAFE, 0);  // the out-of-reach budget is only maintained by quiet_run
   if (c.P == 1) { AG_SERIAL { PLS(c, 0)[PL_CAND_IDX] = -1; } ag_lds_order(); }   // ... and the tracked pellet goes with the disc (no stale index may outlive it)
   SW(c, AR_NEVP, 0); SW(c, AR_NEVV, 0);
-  c.lut_risk = false; c.mass_sum = 0u;
+  c.lut_risk = false; c.mass_sum = 0u; c.moved_all = false;
+#ifndef AG_NO_MOVE_ALL
+  if (c.P > 1 && SR(c, AR_TICKS) % 10 != 0) move_all_players(c);
+#endif
   AG_T(c, 1);
   for (int k = 0; k < c.P; k++) tick_player(c, SR(c, AR_ORDER0 + k));
   remove_pellets(c);
