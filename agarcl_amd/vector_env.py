@@ -21,6 +21,10 @@ same `step()` on the device (agarcl_reset_device with the done mask: no host rou
 observation of its next episode; reward and terminated of that row belong to the episode that ended.  The last observation of the ended
 episode is not kept (it would double the observation traffic of every step).
 
+`info` carries the episode statistics gymnasium's RecordEpisodeStatistics wrapper would keep, as device tensors: "episode_steps" and
+"episode_return" of the running episodes, "ended" (the arenas whose episode ended in this step) and, valid for those rows, "final_return" /
+"final_length" of the episode that ended.
+
 Returned tensors are CUDA tensors owned by the environment and rewritten in place by the next `step()` -- copy what must outlive it (a
 rollout buffer does that anyway).  With one agent per arena the agent axis is dropped: obs [N, ...], reward [N]; with several agents
 [N, num_agents, ...].
@@ -67,6 +71,11 @@ class AgarioVectorEnv:
             self._obs_args = {}
         N, n = self.num_envs, self.num_agents
         self._steps = torch.zeros(N, dtype=torch.int32, device=self.device)       # steps played in the current episode, per arena
+        # episode statistics, kept on the device (what gymnasium's RecordEpisodeStatistics wrapper keeps per env on the host): the running
+        # return of the current episode, and -- rewritten only for the arenas whose episode ended in a step -- the return and length of it
+        self._ep_return = torch.zeros((N, n), dtype=torch.float32, device=self.device)
+        self._final_return = torch.zeros((N, n), dtype=torch.float32, device=self.device)
+        self._final_length = torch.zeros(N, dtype=torch.int32, device=self.device)
         self._reward = torch.zeros((N, n), dtype=torch.float32, device=self.device)
         self._done = torch.zeros((N, n), dtype=torch.bool, device=self.device)
         self._trunc = torch.zeros((N, n), dtype=torch.bool, device=self.device)   # never set: the cut-off is a `done` (see the module text)
@@ -117,7 +126,7 @@ class AgarioVectorEnv:
             else:
                 self.env.seed(np.asarray(seed, dtype=np.uint32))
         self.env.reset()
-        self._steps.zero_()
+        self._steps.zero_(); self._ep_return.zero_()
         self._started = True
         return self._observe(), {}
 
@@ -146,9 +155,18 @@ class AgarioVectorEnv:
         # same-step auto-reset: arenas whose episode ended (any agent) start the next one now, on the device
         torch.any(self._done, dim=1, out=self._mask.view(torch.bool))
         self.env.reset(mask=self._mask)
-        self._steps.masked_fill_(self._mask.view(torch.bool), 0)
+        ended = self._mask.view(torch.bool)
+        self._ep_return += self._reward
+        torch.where(ended.unsqueeze(1), self._ep_return, self._final_return, out=self._final_return)
+        torch.where(ended, self._steps, self._final_length, out=self._final_length)
+        self._ep_return.masked_fill_(ended.unsqueeze(1), 0.0)
+        self._steps.masked_fill_(ended, 0)
         obs = self._observe()
-        info = {"episode_steps": self._steps}
+        # "ended": the arenas whose episode ended in this step (and were reset); for those rows "final_return" / "final_length" are the
+        # finished episode's return and length (they keep their last value otherwise); "episode_return" / "episode_steps" run with the
+        # current episode.  All CUDA tensors owned by the env, like the observations.
+        info = {"episode_steps": self._steps, "episode_return": self._agents(self._ep_return), "ended": ended,
+                "final_return": self._agents(self._final_return), "final_length": self._final_length}
         return obs, self._agents(self._reward), self._agents(self._done), self._agents(self._trunc), info
 
     def close(self):

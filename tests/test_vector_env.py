@@ -37,6 +37,7 @@ def test_vector_env_equals_single_envs_step_for_step(hip_engine_cls, kw):
         assert np.array_equal(got[a], e.get_state()[0]), "reset observation of arena %d" % a
     rng = np.random.RandomState(3)
     played = np.zeros(N, np.int64); resets = 0
+    ret = np.zeros(N, np.float32); fin_ret = np.zeros(N, np.float32); fin_len = np.zeros(N, np.int64)   # the episode statistics, redone on the host
     for t in range(steps):
         move = rng.uniform(-1, 1, size=(N, 2)).astype(np.float32); kind = rng.randint(0, 3, size=N).astype(np.int32)
         obs, rew, term, trunc, info = venv.step((torch.as_tensor(move, device="cuda"), torch.as_tensor(kind, device="cuda")))
@@ -48,10 +49,14 @@ def test_vector_env_equals_single_envs_step_for_step(hip_engine_cls, kw):
             want_d = bool(e.dones()[0]) or played[a] >= kw["number_steps"]        # AgarioEnv.py:111-112, compared before the step is counted
             played[a] += 1
             assert r[a] == np.float32(want_r) and bool(d[a]) == want_d, (t, a, r[a], want_r, d[a], want_d)
+            ret[a] = np.float32(ret[a] + np.float32(want_r))
             if want_d:                                                            # what a user of the single env does next
-                e.reset(); played[a] = 0; resets += 1
+                fin_ret[a], fin_len[a] = ret[a], played[a]
+                e.reset(); played[a] = 0; resets += 1; ret[a] = 0
             assert np.array_equal(got[a], e.get_state()[0]), "step %d arena %d" % (t, a)
         assert np.array_equal(info["episode_steps"].cpu().numpy(), played)
+        assert np.array_equal(info["episode_return"].cpu().numpy(), ret) and np.array_equal(info["ended"].cpu().numpy(), d)
+        assert np.array_equal(info["final_return"].cpu().numpy(), fin_ret) and np.array_equal(info["final_length"].cpu().numpy(), fin_len)
     assert resets >= (N if kw["number_steps"] < steps else 0)                     # the auto-reset path ran
     for e in singles:
         e.close()
