@@ -42,6 +42,19 @@ PARTS = [(ns, av, kind) for ns in (16, 32, 8, 4) for av in (1, 0) for kind in (0
 STEP_FLAGS = ["-mllvm", "-disable-machine-licm"]
 
 
+VEC_SRC = os.path.join(HERE, "csrc_vec", "agar_vecpost.hip")
+VEC_OUT = os.path.join(HERE, "libagarcl_vec.so")
+
+
+def build_vecpost(force=False):
+    """hipcc -> agarcl_amd/libagarcl_vec.so: the vector env's episode bookkeeping kernel (include/agarcl_vec.h), a library of its own"""
+    deps = [VEC_SRC, os.path.join(HERE, "..", "include", "agarcl_vec.h")]
+    if not force and os.path.exists(VEC_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(VEC_OUT) for d in deps):
+        return VEC_OUT
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", VEC_SRC, "-o", VEC_OUT])
+    return VEC_OUT
+
+
 def _compile(args):
     subprocess.check_call(args)
     return args[-1]

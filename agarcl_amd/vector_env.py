@@ -29,10 +29,27 @@ Returned tensors are CUDA tensors owned by the environment and rewritten in plac
 rollout buffer does that anyway).  With one agent per arena the agent axis is dropped: obs [N, ...], reward [N]; with several agents
 [N, num_agents, ...].
 """
+import ctypes
+import os
+
 import numpy as np
 
 from . import gym_agario as _single
 from .vec_env import VecEnvironment
+
+
+def _load_vecpost():
+    """agarcl_amd/libagarcl_vec.so (include/agarcl_vec.h): the episode bookkeeping as ONE launch per step.  There is no torch fall-back: the
+    library is built in-tree by agarcl_amd/build.py (build_vecpost) and a missing one is an error."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libagarcl_vec.so")
+    if not os.path.exists(path):
+        from . import build as _build
+        _build.build_vecpost()
+    lib = ctypes.CDLL(path)
+    f = lib.agarcl_vec_post
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 7
+    return f
 
 
 class AgarioVectorEnv:
@@ -80,10 +97,10 @@ class AgarioVectorEnv:
         self._done = torch.zeros((N, n), dtype=torch.bool, device=self.device)
         self._trunc = torch.zeros((N, n), dtype=torch.bool, device=self.device)   # never set: the cut-off is a `done` (see the module text)
         self._mask = torch.zeros(N, dtype=torch.uint8, device=self.device)
-        self._move = torch.zeros((N, n, 2), dtype=torch.float32, device=self.device)
-        self._kind = torch.zeros((N, n), dtype=torch.int32, device=self.device)
         self._started = False
         self.single_observation_shape = None      # set by the first observation
+        self._vec_post = _load_vecpost()
+        self._post_args = None                    # (pointers of the tensors above: they never move)
 
     # ---- helpers ------------------------------------------------------------------------------------------------------------------
     def _agents(self, t):
@@ -139,28 +156,24 @@ class AgarioVectorEnv:
         torch = self.torch
         N, n = self.num_envs, self.num_agents
         move, kind = actions
-        self._move.copy_(self._as_device(move, torch.float32, (N, n, 2)))
-        self._kind.copy_(self._as_device(kind, torch.int32, (N, n)))
-        self.env.take_actions(self._move, self._kind)
+        # (CUDA tensors of the right type are handed to the engine as they are -- the step below reads them in stream order; anything else
+        # is converted / uploaded first)
+        self.env.take_actions(self._as_device(move, torch.float32, (N, n, 2)), self._as_device(kind, torch.int32, (N, n)))
         self.env.step()
-        # episode bookkeeping on the device: the cut-off is compared BEFORE this step is counted (AgarioEnv.py:111-112)
-        done_eng = self.env.dones_u8 != 0                                              # [N, n]; the engine reports the arena's flag on agent 0
-        if self.env_type == 0:
-            timeout = (self._steps >= self.number_of_steps).unsqueeze(1)
-            torch.logical_or(done_eng, timeout, out=self._done)                         # a timed-out arena ends for every agent
-        else:
-            self._done.copy_(done_eng)
-        self._steps += 1
-        self._reward.copy_(self.env.rewards)                                            # f64 -> f32
+        # episode bookkeeping on the device, one launch (include/agarcl_vec.h): done = the engine's flag or the episodic cut-off -- compared
+        # BEFORE this step is counted, AgarioEnv.py:111-112 --, the step counters, f64 -> f32 rewards, the episode statistics and the mask
+        # of the arenas that start their next episode now
+        if self._post_args is None:
+            e = self.env
+            self._post_args = (e.dones_u8.data_ptr(), e.rewards.data_ptr(), N, n, int(self.number_of_steps), 1 if self.env_type == 0 else 0,
+                               self._steps.data_ptr(), self._reward.data_ptr(), self._done.data_ptr(), self._mask.data_ptr(),
+                               self._ep_return.data_ptr(), self._final_return.data_ptr(), self._final_length.data_ptr())
+        rc = self._vec_post(torch.cuda.current_stream(self.device).cuda_stream, *self._post_args)
+        if rc != 0:
+            raise RuntimeError("agarcl_vec_post failed (%d)" % rc)
         # same-step auto-reset: arenas whose episode ended (any agent) start the next one now, on the device
-        torch.any(self._done, dim=1, out=self._mask.view(torch.bool))
         self.env.reset(mask=self._mask)
         ended = self._mask.view(torch.bool)
-        self._ep_return += self._reward
-        torch.where(ended.unsqueeze(1), self._ep_return, self._final_return, out=self._final_return)
-        torch.where(ended, self._steps, self._final_length, out=self._final_length)
-        self._ep_return.masked_fill_(ended.unsqueeze(1), 0.0)
-        self._steps.masked_fill_(ended, 0)
         obs = self._observe()
         # "ended": the arenas whose episode ended in this step (and were reset); for those rows "final_return" / "final_length" are the
         # finished episode's return and length (they keep their last value otherwise); "episode_return" / "episode_steps" run with the

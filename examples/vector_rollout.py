@@ -1,0 +1,45 @@
+"""A rollout loop through the batched user surface (agarcl_amd/vector_env.py: AgarioVectorEnv): N arenas, a random policy on the device,
+T steps collected into a rollout buffer -- the shape of a PPO / IMPALA actor -- with nothing inside the loop that waits for the GPU.
+
+    python examples/vector_rollout.py [--envs 4096] [--steps 256] [--obs grid|ram|screen|none] [--difficulty normal]
+
+Prints env-steps per second of the whole loop (engine step + observation + Python), which is what a learner sees; `bench.py` times the
+engine alone."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # (run from a checkout: the package is in-tree)
+import torch
+from agarcl_amd.vector_env import AgarioVectorEnv
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--envs", type=int, default=4096); ap.add_argument("--steps", type=int, default=256)
+ap.add_argument("--obs", default="ram"); ap.add_argument("--difficulty", default="normal"); ap.add_argument("--number-steps", type=int, default=500)
+ap.add_argument("--bare", action="store_true", help="time venv.step alone: one fixed action batch, no rollout buffer")
+a = ap.parse_args()
+venv = AgarioVectorEnv(a.envs, obs_type=a.obs, difficulty=a.difficulty, number_steps=a.number_steps, env_type=0)
+dev = venv.device
+obs, _ = venv.reset(seed=1)
+g = torch.Generator(device=dev); g.manual_seed(0)
+buf_obs = None if obs is None else torch.empty((a.steps,) + tuple(obs.shape), dtype=obs.dtype, device=dev)
+buf_rew = torch.empty((a.steps, a.envs), dtype=torch.float32, device=dev)
+buf_done = torch.empty((a.steps, a.envs), dtype=torch.bool, device=dev)
+def policy():   # uniform moves, action kind ~ U{none, feed, split}
+    return torch.rand((a.envs, 2), generator=g, device=dev) * 2 - 1, torch.randint(0, 3, (a.envs,), generator=g, device=dev, dtype=torch.int32)
+for _ in range(8): venv.step(policy())                      # warm-up
+if a.bare:
+    act = policy(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for t in range(a.steps): venv.step(act)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("%d envs x %d steps, obs=%s, step() alone: %.3g env-steps/s (%.1f us per vector step)" % (a.envs, a.steps, a.obs, a.envs * a.steps / dt, dt / a.steps * 1e6))
+    venv.close(); sys.exit(0)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+episodes = torch.zeros((), dtype=torch.int64, device=dev); ret_sum = torch.zeros((), dtype=torch.float32, device=dev)
+for t in range(a.steps):
+    obs, rew, term, trunc, info = venv.step(policy())
+    if buf_obs is not None: buf_obs[t].copy_(obs)           # (the env rewrites its tensors in place: a rollout buffer copies them)
+    buf_rew[t].copy_(rew); buf_done[t].copy_(term)
+    episodes += info["ended"].sum(); ret_sum += (info["final_return"] * info["ended"]).sum()
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+n = int(episodes.item())
+print("%d envs x %d steps, obs=%s: %.3g env-steps/s through AgarioVectorEnv.step (%.1f us per vector step); %d episodes ended, mean return %.1f"
+      % (a.envs, a.steps, a.obs, a.envs * a.steps / dt, dt / a.steps * 1e6, n, float(ret_sum.item()) / max(n, 1)))
+venv.close()

@@ -51,3 +51,15 @@ def test_product_never_imports_oracle():
                 assert "import oracle" not in txt and "from oracle" not in txt, f
                 assert "libagarcl_emu" not in txt or f == "agar_engine.hip", f
                 assert "libagar_oracle" not in txt and "libagar_ref" not in txt, f
+
+
+def test_vec_library_exports_its_header():
+    """include/agarcl_vec.h -> agarcl_amd/libagarcl_vec.so (the vector env's bookkeeping launch): builds, loads, exports the symbol"""
+    import ctypes
+    from agarcl_amd import build
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "agarcl_vec.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(agarcl_[a-z_0-9]+)\s*\(", src)))
+    assert names == ["agarcl_vec_post"]
+    lib = ctypes.CDLL(build.build_vecpost())
+    for name in names:
+        assert hasattr(lib, name), name
