@@ -122,3 +122,19 @@ def test_vec_environment_observation_tensors(hip_engine_cls):
     with pytest.raises(ValueError):
         env.grid_obs(32, out=torch.empty((A, 1, 8, 16, 16), dtype=torch.int32, device="cuda"))
     env.close()
+
+
+@pytest.mark.gpu
+def test_rollout_example_runs(hip_engine_cls):
+    """examples/vector_rollout.py end to end on a small batch (its own process, as a user would run it): with short episodes the auto-reset
+    and the episode statistics are exercised, and the bare mode times step() alone"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "vector_rollout.py"), "--envs", "64", "--steps", "30", "--obs", "ram", "--number-steps", "10"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = out.stdout.strip().splitlines()[-1]
+    assert "env-steps/s through AgarioVectorEnv.step" in line and " episodes ended" in line
+    assert int(line.split(";")[1].split()[0]) >= 64 * 2      # 30 steps of 10-step episodes: every arena ended at least twice
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "vector_rollout.py"), "--envs", "64", "--steps", "10", "--obs", "none", "--bare"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "step() alone" in out.stdout, out.stderr[-2000:]
