@@ -30,10 +30,12 @@ class VecEnvironment:
         self.engine = _capi.BatchedEngine(num_arenas, num_agents, ticks_per_step, arena_size, pellet_regen, num_pellets,
                                           num_viruses, num_bots, reward_type, c_death, mode_number, dt, device, **caps)
         self._torch_stream = bool(use_torch_stream)
+        self.stream_handle = None   # the hipStream_t the engine launches on, when it is torch's (None: a stream of the engine's own)
         if use_torch_stream:
             # launch on torch's current stream so torch events / collectives order against the engine
             with torch.cuda.device(self.device):
-                self.engine.set_stream(torch.cuda.current_stream().cuda_stream)
+                self.stream_handle = torch.cuda.current_stream().cuda_stream
+                self.engine.set_stream(self.stream_handle)
         p = self.engine.device_ptrs()
         A, n = num_arenas, num_agents
         self.rewards = torch.as_tensor(_DevArray(p["rewards"], (A, n), "<f8"), device=self.device)

@@ -168,7 +168,7 @@ class AgarioVectorEnv:
             self._post_args = (e.dones_u8.data_ptr(), e.rewards.data_ptr(), N, n, int(self.number_of_steps), 1 if self.env_type == 0 else 0,
                                self._steps.data_ptr(), self._reward.data_ptr(), self._done.data_ptr(), self._mask.data_ptr(),
                                self._ep_return.data_ptr(), self._final_return.data_ptr(), self._final_length.data_ptr())
-        rc = self._vec_post(torch.cuda.current_stream(self.device).cuda_stream, *self._post_args)
+        rc = self._vec_post(self.env.stream_handle, *self._post_args)   # (the stream the engine was bound to: the launch sits between its step and its reset)
         if rc != 0:
             raise RuntimeError("agarcl_vec_post failed (%d)" % rc)
         # same-step auto-reset: arenas whose episode ended (any agent) start the next one now, on the device
