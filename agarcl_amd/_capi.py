@@ -81,6 +81,17 @@ SYMBOLS = [
     ("agarcl_num_arenas", C.c_int, [C.c_void_p]),
     ("agarcl_players_per_arena", C.c_int, [C.c_void_p]),
     ("agarcl_state_bytes", C.c_int64, [C.c_void_p]),
+    ("agarcl_get_stream", C.c_void_p, [C.c_void_p]),
+    ("agarcl_stream_wait", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("agarcl_stream_signal", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("agarcl_pipe_create", C.c_int, [C.POINTER(Config), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    ("agarcl_pipe_destroy", C.c_int, [C.c_void_p]),
+    ("agarcl_pipe_sub_batches", C.c_int, [C.c_void_p]),
+    ("agarcl_pipe_env", C.c_void_p, [C.c_void_p, C.c_int32]),
+    ("agarcl_pipe_range", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("agarcl_pipe_seed", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    ("agarcl_pipe_concurrent", C.c_int, [C.c_void_p]),
+    ("agarcl_pipe_sync", C.c_int, [C.c_void_p]),
     ("agarcl_debug_fused", C.c_int, [C.c_void_p]),
     ("agarcl_debug_qinfo", C.c_int, [C.c_void_p, C.c_void_p]),
     ("agarcl_debug_prof", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
@@ -91,9 +102,28 @@ SYMBOLS = [
 ]
 
 
+# ---- include/agarcl_vec.h: one host call per step of the batched RL surface -------------------------------------------------------
+OBS_NONE, OBS_GRID, OBS_SCREEN, OBS_RAM = 0, 1, 2, 3
+
+
+class VecSpec(C.Structure):
+    _fields_ = [("number_steps", C.c_int32), ("episodic", C.c_int32), ("reset_ids", C.c_int32), ("obs_kind", C.c_int32), ("obs_arg", C.c_int32 * 6),
+                ("ticks", C.c_int32), ("reserved", C.c_int32 * 5)]
+
+
+class VecBuffers(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("steps", "reward", "done", "truncated", "ended", "ep_return", "final_return", "final_length", "obs")]
+
+
+VEC_SYMBOLS = [
+    ("agarcl_vec_reset", C.c_int, [C.c_void_p, C.POINTER(VecSpec), C.POINTER(VecBuffers)]),
+    ("agarcl_vec_step", C.c_int, [C.c_void_p, C.POINTER(VecSpec), C.POINTER(VecBuffers), C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
+]
+
+
 def bind(cdll):
-    """Attach prototypes for every declared symbol; raises AttributeError if one is missing."""
-    for name, res, args in SYMBOLS:
+    """Attach prototypes for every declared symbol (both headers); raises AttributeError if one is missing."""
+    for name, res, args in SYMBOLS + VEC_SYMBOLS:
         fn = getattr(cdll, name)
         fn.restype = res
         fn.argtypes = args
@@ -133,7 +163,7 @@ class BatchedEngine:
 
     def __init__(self, num_arenas, num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True,
                  num_pellets=1000, num_viruses=0, num_bots=0, reward_type=1, c_death=0, mode=0, dt=1.0 / 30,
-                 device=0, cap_cells=0, cap_viruses=0, cap_foods=0, screen_respawn=False, example_bots=0, lib=None):
+                 device=0, cap_cells=0, cap_viruses=0, cap_foods=0, screen_respawn=False, example_bots=0, lib=None, _adopt=None):
         self.L = lib if lib is not None else hip_lib()
         self.cfg = Config(num_agents, ticks_per_step, arena_size, int(bool(pellet_regen)), num_pellets, num_viruses,
                           num_bots, int(reward_type), c_death, mode, dt, cap_cells, cap_viruses, cap_foods, int(bool(screen_respawn)), int(example_bots))
@@ -141,7 +171,11 @@ class BatchedEngine:
         self.num_arenas = num_arenas
         self.num_agents = num_agents
         self.dt = dt
-        self._chk(self.L.agarcl_create(C.byref(self.cfg), num_arenas, device, C.byref(self.h)))
+        self._owner = _adopt          # a PipelinedEngine: the handle is one of its sub-batches and dies with it
+        if _adopt is not None:
+            self.h = C.c_void_p(_adopt[1])
+        else:
+            self._chk(self.L.agarcl_create(C.byref(self.cfg), num_arenas, device, C.byref(self.h)))
         self.players = self.L.agarcl_players_per_arena(self.h)
         self._blob = np.zeros(1 << 16, dtype=np.uint32)
 
@@ -151,7 +185,8 @@ class BatchedEngine:
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:
-            self.L.agarcl_destroy(self.h)
+            if getattr(self, "_owner", None) is None:
+                self.L.agarcl_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):
@@ -166,6 +201,18 @@ class BatchedEngine:
 
     def sync(self):
         self._chk(self.L.agarcl_sync(self.h))
+
+    def stream(self):
+        """the hipStream_t (int) the engine launches on"""
+        return int(self.L.agarcl_get_stream(self.h) or 0)
+
+    def stream_wait(self, producer_stream):
+        """the engine's stream waits, on the device, for everything enqueued so far on `producer_stream` (a hipStream_t as int; 0 = the legacy default stream)"""
+        self._chk(self.L.agarcl_stream_wait(self.h, C.c_void_p(int(producer_stream))))
+
+    def stream_signal(self, consumer_stream):
+        """`consumer_stream` waits, on the device, for everything the engine has enqueued so far"""
+        self._chk(self.L.agarcl_stream_signal(self.h, C.c_void_p(int(consumer_stream))))
 
     def seed(self, seeds=None, base_seed=0):
         if seeds is not None:
@@ -364,3 +411,61 @@ class BatchedEngine:
     def load(self, blob, arena=0):
         blob = np.ascontiguousarray(blob, dtype=np.uint32)
         self._chk(self.L.agarcl_load_arena(self.h, arena, _ptr(blob), len(blob)))
+
+
+class PipelinedEngine:
+    """k sub-batches of one job (include/agarcl_batch.h agarcl_pipe_*): contiguous arena ranges, each a BatchedEngine on a HIP stream of its
+    own that was verified to execute concurrently with the others.  parts[j] is used like any BatchedEngine; ranges[j] = (first arena, count)."""
+
+    def __init__(self, num_arenas, sub_batches=2, num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True, num_pellets=1000, num_viruses=0,
+                 num_bots=0, reward_type=1, c_death=0, mode=0, dt=1.0 / 30, device=0, cap_cells=0, cap_viruses=0, cap_foods=0, screen_respawn=False,
+                 example_bots=0, lib=None):
+        self.L = lib if lib is not None else hip_lib()
+        self.cfg = Config(num_agents, ticks_per_step, arena_size, int(bool(pellet_regen)), num_pellets, num_viruses,
+                          num_bots, int(reward_type), c_death, mode, dt, cap_cells, cap_viruses, cap_foods, int(bool(screen_respawn)), int(example_bots))
+        self.p = C.c_void_p()
+        self.num_arenas, self.num_agents, self.sub_batches = num_arenas, num_agents, sub_batches
+        rc = self.L.agarcl_pipe_create(C.byref(self.cfg), num_arenas, sub_batches, device, C.byref(self.p))
+        if rc != 0:
+            raise AgarclError(rc, (self.L.agarcl_last_error() or b"").decode())
+        kw = dict(num_agents=num_agents, ticks_per_step=ticks_per_step, arena_size=arena_size, pellet_regen=pellet_regen, num_pellets=num_pellets,
+                  num_viruses=num_viruses, num_bots=num_bots, reward_type=reward_type, c_death=c_death, mode=mode, dt=dt, device=device,
+                  cap_cells=cap_cells, cap_viruses=cap_viruses, cap_foods=cap_foods, screen_respawn=screen_respawn, example_bots=example_bots, lib=self.L)
+        self.parts, self.ranges = [], []
+        for j in range(sub_batches):
+            lo, n = C.c_int32(0), C.c_int32(0)
+            self.L.agarcl_pipe_range(self.p, j, C.byref(lo), C.byref(n))
+            self.ranges.append((int(lo.value), int(n.value)))
+            self.parts.append(BatchedEngine(int(n.value), _adopt=(self, int(self.L.agarcl_pipe_env(self.p, j))), **kw))
+        self.concurrent = int(self.L.agarcl_pipe_concurrent(self.p))
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise AgarclError(rc, (self.L.agarcl_last_error() or b"").decode())
+
+    def seed(self, seeds=None, base_seed=0):
+        """seeds by GLOBAL arena index: uint32 [num_arenas], or arena i gets base_seed + i"""
+        if seeds is not None:
+            seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+            assert seeds.shape == (self.num_arenas,)
+        self._chk(self.L.agarcl_pipe_seed(self.p, _ptr(seeds), base_seed))
+
+    def reset(self, reset_ids=False):
+        for e in self.parts:
+            e.reset(None, reset_ids)
+
+    def sync(self):
+        self._chk(self.L.agarcl_pipe_sync(self.p))
+
+    def close(self):
+        if getattr(self, "p", None) and self.p.value:
+            for e in self.parts:
+                e.close()
+            self.L.agarcl_pipe_destroy(self.p)
+            self.p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

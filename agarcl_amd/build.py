@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "agar_engine.hip")
 import glob
 # every file under csrc/ is a dependency (one translation unit that #includes the .inl / .h files)
-DEPS = sorted(glob.glob(os.path.join(HERE, "csrc", "*"))) + [os.path.join(HERE, "..", "include", "agarcl_batch.h")]
+DEPS = sorted(glob.glob(os.path.join(HERE, "csrc", "*"))) + [os.path.join(HERE, "..", "include", h) for h in ("agarcl_batch.h", "agarcl_vec.h")]
 OUT = os.path.join(HERE, "libagarcl_hip.so")
 
 FLAGS = [
@@ -40,19 +40,6 @@ PARTS = [(ns, av, kind) for ns in (16, 32, 8, 4) for av in (1, 0) for kind in (0
 # C1 208.6 / 207.3; k_step's WRITE_SIZE per 4096-arena launch 57.1 -> 28.8 MB, scratch 460 -> 276 bytes per lane.  (The front kernels keep
 # it: C2 at 4096 arenas 8.94 / 9.05.)
 STEP_FLAGS = ["-mllvm", "-disable-machine-licm"]
-
-
-VEC_SRC = os.path.join(HERE, "csrc_vec", "agar_vecpost.hip")
-VEC_OUT = os.path.join(HERE, "libagarcl_vec.so")
-
-
-def build_vecpost(force=False):
-    """hipcc -> agarcl_amd/libagarcl_vec.so: the vector env's episode bookkeeping kernel (include/agarcl_vec.h), a library of its own"""
-    deps = [VEC_SRC, os.path.join(HERE, "..", "include", "agarcl_vec.h")]
-    if not force and os.path.exists(VEC_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(VEC_OUT) for d in deps):
-        return VEC_OUT
-    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", VEC_SRC, "-o", VEC_OUT])
-    return VEC_OUT
 
 
 def _compile(args):

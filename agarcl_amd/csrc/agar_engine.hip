@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/agarcl_batch.h"
+#include "../../include/agarcl_vec.h"
 #include "agar_core.inl"
 #include "agar_quiet.inl"
 #ifndef AG_PART_NS   // (split build: the observation kernels live in the main unit only)
@@ -80,6 +81,7 @@ struct agarcl_env {
   float *d_act_dxdy; int32_t *d_act;  // env-owned action buffers (host-copy path)
   float *lut_r, *lut_ms, *lut_ss, *lut_anti;
   void *timer_ev[2];               // agarcl_timer_mark / agarcl_timer_elapsed_ms
+  void *order_ev[2];               // agarcl_stream_wait / agarcl_stream_signal (created on first use)
   int32_t *obs_buf; size_t obs_cap;  // staging for host-side grid observations
   int32_t *undo_list, *undo_count; const int32_t *undo_out; int undo_key;  // incremental clearing of the grid observation (AgObsUndo)
   uint8_t *undo_sig; int undo_sig_g;   // ... and the out-of-bounds channel's row / column signature of the previous call ([frames][2 G] bytes)
@@ -105,6 +107,35 @@ struct agarcl_env {
   bool few_unfinished; // adaptive: the front part leaves < 64 arenas per step to k_step (see launch_step)
   bool front_off; // adaptive: the front part finishes (almost) no arena-step, so the two-kernel step runs k_step alone
 };
+
+// ---- episode bookkeeping of the vector surface (include/agarcl_vec.h) ---------------------------------------------------------------
+// What AgarioEnv.step does per env on the host after the engine's step (/root/reference/gym_agario/AgarioEnv.py:105-123): done = the
+// engine's done flag or, for an episodic env, number_steps played -- compared BEFORE this step is counted (:111-112) --, the step counter,
+// f64 -> f32 rewards, plus the episode statistics; returns whether the arena's episode ended (it is then reset by the caller).
+struct AgVecPost {
+  const uint8_t *dones; const double *rewards; int n, number_steps, episodic;
+  int32_t *steps; float *reward; uint8_t *done, *trunc, *ended; float *ep_return, *final_return; int32_t *final_length;
+};
+AG_DEV bool ag_vec_post_arena(const AgVecPost &v, int a) {
+  const int n = v.n, played = v.steps[a];
+  const bool timeout = v.episodic != 0 && played >= v.number_steps;
+  bool any = timeout;
+  for (int i = 0; i < n; i++) any = any || v.dones[(size_t)a * n + i] != 0;
+  for (int i = 0; i < n; i++) {
+    const size_t k = (size_t)a * n + i;
+    const bool d = v.dones[k] != 0 || timeout;
+    v.done[k] = d ? 1 : 0;
+    v.trunc[k] = (any && !d) ? 1 : 0;   // the arena is reset under an agent that was not done: its episode is cut, not finished
+    const float r = (float)v.rewards[k];
+    v.reward[k] = r;
+    const float e = v.ep_return[k] + r;
+    if (any) { v.final_return[k] = e; v.ep_return[k] = 0.0f; } else v.ep_return[k] = e;
+  }
+  if (any) v.final_length[a] = played + 1;
+  v.steps[a] = any ? 0 : played + 1;
+  v.ended[a] = any ? 1 : 0;
+  return any;
+}
 
 // ---- kernels ----------------------------------------------------------------------------------------
 // NS = pellet register slots per lane (64 pellets per slot): 4 / 8 / 16 / 32 <=> up to 256 / 512 / 1024 / 2048 pellets
@@ -266,6 +297,18 @@ template <int NS, bool AV, int QG, int TSLG> __global__ void __launch_bounds__(2
     general_arena_step<NS, AV, TSLG>(gs, ar, lds, act_dxdy, act, slot, ticks, with_env, qd, qb);
   }
 }
+// a workgroup (one wavefront) per arena: lane 0 settles the arena's episode; the wavefront resets the arena if the episode ended and leaves
+// at once otherwise -- bookkeeping and same-step auto-reset of agarcl_vec_step in ONE launch
+template <int NS, bool AV> __global__ void __launch_bounds__(64) k_vec_post_reset(const AgState *__restrict__ gs, const AgVecPost v, int reset_ids) {
+  int any = 0;
+  if (threadIdx.x == 0) any = ag_vec_post_arena(v, (int)blockIdx.x) ? 1 : 0;
+  if (!__builtin_amdgcn_readfirstlane(any)) return;
+  const float *act_dxdy = nullptr; const int32_t *act = nullptr;
+  AG_KERNEL_PROLOGUE
+  arena_load(c);
+  env_reset(c, reset_ids);
+  arena_store(c);
+}
 template <int NS, bool AV> __global__ void __launch_bounds__(64) k_reset(const AgState *__restrict__ gs, const uint8_t *mask, int reset_ids) {
   if (mask && !mask[blockIdx.x]) {
     // the flag watch word (qstat[1]) was zeroed in front of this launch (agarcl_reset / agarcl_reset_device): arenas that are NOT reset
@@ -332,7 +375,8 @@ __global__ void k_tile_scatter(uint32_t *dst, const uint32_t *src, int R, int ag
 #define AG_INST_FRONTS(X, N, V, T) AG_INST_FRONT(X, N, V, 1, T) AG_INST_FRONT(X, N, V, 2, T) AG_INST_FRONT(X, N, V, 4, T) AG_INST_FRONT(X, N, V, 8, T) AG_INST_FRONT(X, N, V, 16, T)
 #define AG_INST_KIND0(X, N, V) AG_INST_STEP(X, N, V, 0) AG_INST_STEP(X, N, V, 6) \
   X template __global__ void k_reset<N, V>(const AgState *__restrict__, const uint8_t *, int); \
-  X template __global__ void k_respawn<N, V>(const AgState *__restrict__);
+  X template __global__ void k_respawn<N, V>(const AgState *__restrict__); \
+  X template __global__ void k_vec_post_reset<N, V>(const AgState *__restrict__, const AgVecPost, int);
 #define AG_INST_KIND1(X, N, V) AG_INST_FRONTS(X, N, V, 0) AG_INST_FRONTS(X, N, V, 6)
 #ifdef AG_PART_NS
 #if AG_PART_KIND == 0
@@ -562,6 +606,7 @@ extern "C" int agarcl_destroy(agarcl_env *e) {
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
   if (e->stat_ev) (void)hipEventDestroy((hipEvent_t)e->stat_ev);
   for (int i = 0; i < 2; i++) if (e->timer_ev[i]) (void)hipEventDestroy((hipEvent_t)e->timer_ev[i]);
+  for (int i = 0; i < 2; i++) if (e->order_ev[i]) (void)hipEventDestroy((hipEvent_t)e->order_ev[i]);
   if (e->h_stat) (void)hipHostFree(e->h_stat);
 #endif
   for (void *p : e->allocs) dfree(p);
@@ -572,7 +617,8 @@ extern "C" int agarcl_destroy(agarcl_env *e) {
   return AGARCL_OK;
 }
 
-extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32_t device, agarcl_env **out) {
+// (base_seed: arena i starts with seed base_seed + i; agarcl_create passes 5489, a pipe's sub-batch 5489 + its first arena)
+static int create_env(const agarcl_config *cfg, int32_t num_arenas, int32_t device, uint32_t base_seed, agarcl_env **out) {
   if (!cfg || !out || num_arenas <= 0) return fail(AGARCL_E_INVALID, "agarcl_create: bad arguments");
   if (cfg->num_agents < 0 || cfg->example_bots < 0 || cfg->ticks_per_step < 1 || cfg->arena_size < 8 || cfg->num_pellets < 0 || cfg->num_viruses < 0 || cfg->num_bots < 0)
     return fail(AGARCL_E_INVALID, "agarcl_create: invalid environment arguments");
@@ -586,7 +632,7 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
 #endif
   agarcl_env *e = new agarcl_env();
   e->cfg = *cfg; e->device = device; e->own_stream = true; e->d_act_dxdy = nullptr; e->d_act = nullptr;
-  e->slot = 0; e->d_state = nullptr; e->act_dxdy = nullptr; e->act = nullptr; e->timer_ev[0] = e->timer_ev[1] = nullptr; e->obs_buf = nullptr; e->obs_cap = 0; e->undo_sig = nullptr; e->undo_sig_g = 0; e->undo_list = e->undo_count = nullptr; e->undo_out = nullptr; e->undo_key = -1;
+  e->slot = 0; e->d_state = nullptr; e->act_dxdy = nullptr; e->act = nullptr; e->timer_ev[0] = e->timer_ev[1] = nullptr; e->order_ev[0] = e->order_ev[1] = nullptr; e->obs_buf = nullptr; e->obs_cap = 0; e->undo_sig = nullptr; e->undo_sig_g = 0; e->undo_list = e->undo_count = nullptr; e->undo_out = nullptr; e->undo_key = -1;
 #ifdef AGAR_CPU_EMU
   e->stream = nullptr;
 #else
@@ -727,11 +773,12 @@ extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32
   }
   *out = e;
   // the reference constructor resets once (BaseEnvironment.hpp:66)
-  int rc = agarcl_seed(e, nullptr, 5489u);
+  int rc = agarcl_seed(e, nullptr, base_seed);
   if (rc == 0) rc = agarcl_reset(e, nullptr, 1);
   if (rc != 0) { agarcl_destroy(e); *out = nullptr; return rc; }
   return AGARCL_OK;
 }
+extern "C" int agarcl_create(const agarcl_config *cfg, int32_t num_arenas, int32_t device, agarcl_env **out) { return create_env(cfg, num_arenas, device, 5489u, out); }
 
 extern "C" int agarcl_set_stream(agarcl_env *e, void *hip_stream) {
   if (!e) return fail(AGARCL_E_INVALID, "null env");
@@ -1355,5 +1402,193 @@ extern "C" int agarcl_grid_obs(agarcl_env *e, int32_t G, int32_t cells, int32_t 
   if (!on_device && d2h(out, dst, words * 4, e->stream)) return fail(AGARCL_E_HIP, "agarcl_grid_obs: copy failed");
   return AGARCL_OK;
 #endif
+}
+
+// ---- stream ordering (include/agarcl_batch.h) ---------------------------------------------------------------------------------------
+extern "C" void *agarcl_get_stream(agarcl_env *e) { return e ? (void *)e->stream : nullptr; }
+#ifndef AGAR_CPU_EMU
+// everything enqueued so far on `from` happens before whatever is enqueued on `to` from now on (one event per env and direction, re-recorded:
+// a wait captures the record that precedes it)
+static int order_streams(agarcl_env *e, int which, hipStream_t from, hipStream_t to) {
+  if (from == to) return AGARCL_OK;
+  HIPCHK(hipSetDevice(e->device));
+  if (!e->order_ev[which]) { hipEvent_t ev = nullptr; HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); e->order_ev[which] = (void *)ev; }
+  HIPCHK(hipEventRecord((hipEvent_t)e->order_ev[which], from));
+  HIPCHK(hipStreamWaitEvent(to, (hipEvent_t)e->order_ev[which], 0));
+  return AGARCL_OK;
+}
+#endif
+extern "C" int agarcl_stream_wait(agarcl_env *e, void *producer_stream) {
+  if (!e) return fail(AGARCL_E_INVALID, "null env");
+#ifdef AGAR_CPU_EMU
+  (void)producer_stream; return AGARCL_OK;
+#else
+  return order_streams(e, 0, (hipStream_t)producer_stream, e->stream);
+#endif
+}
+extern "C" int agarcl_stream_signal(agarcl_env *e, void *consumer_stream) {
+  if (!e) return fail(AGARCL_E_INVALID, "null env");
+#ifdef AGAR_CPU_EMU
+  (void)consumer_stream; return AGARCL_OK;
+#else
+  return order_streams(e, 1, e->stream, (hipStream_t)consumer_stream);
+#endif
+}
+
+// ---- one host call per vector step (include/agarcl_vec.h) ---------------------------------------------------------------------------
+static int vec_args(agarcl_env *e, const agarcl_vec_spec *sp, const agarcl_vec_buffers *b, AgVecPost &v, const char *who) {
+  if (!e || !sp || !b) return fail(AGARCL_E_INVALID, std::string(who) + ": null pointer");
+  if (e->d.n_agents < 1) return fail(AGARCL_E_INVALID, std::string(who) + ": the env has no agents");
+  if (!b->steps || !b->reward || !b->done || !b->truncated || !b->ended || !b->ep_return || !b->final_return || !b->final_length)
+    return fail(AGARCL_E_INVALID, std::string(who) + ": a bookkeeping buffer is null");
+  if (sp->obs_kind < AGARCL_OBS_NONE || sp->obs_kind > AGARCL_OBS_RAM || (sp->obs_kind != AGARCL_OBS_NONE && !b->obs))
+    return fail(AGARCL_E_INVALID, std::string(who) + ": bad observation kind / null observation buffer");
+  v.dones = e->s.dones; v.rewards = e->s.rewards; v.n = e->d.n_agents; v.number_steps = sp->number_steps; v.episodic = sp->episodic;
+  v.steps = b->steps; v.reward = b->reward; v.done = b->done; v.trunc = b->truncated; v.ended = b->ended;
+  v.ep_return = b->ep_return; v.final_return = b->final_return; v.final_length = b->final_length;
+  return AGARCL_OK;
+}
+static int vec_observe(agarcl_env *e, const agarcl_vec_spec *sp, const agarcl_vec_buffers *b) {
+  const int32_t *a = sp->obs_arg; int32_t q = 0;
+  switch (sp->obs_kind) {
+    case AGARCL_OBS_GRID: return agarcl_grid_obs(e, a[0], a[1], a[2], a[3], a[4], (int32_t *)b->obs, 2, &q);
+    case AGARCL_OBS_SCREEN: return agarcl_screen_obs(e, a[0], a[1], a[2], (uint8_t *)b->obs, 1);
+    case AGARCL_OBS_RAM: return agarcl_ram_obs(e, a[0], a[1], a[2], a[3], (float *)b->obs, 1, &q);
+    default: return AGARCL_OK;
+  }
+}
+extern "C" int agarcl_vec_reset(agarcl_env *e, const agarcl_vec_spec *sp, const agarcl_vec_buffers *b) {
+  AgVecPost v; int rc = vec_args(e, sp, b, v, "agarcl_vec_reset");
+  if (rc) return rc;
+  if ((rc = agarcl_reset(e, nullptr, sp->reset_ids)) != 0) return rc;
+  const size_t A = (size_t)e->d.A, n = (size_t)e->d.n_agents;
+#ifdef AGAR_CPU_EMU
+  memset(b->steps, 0, A * 4); memset(b->final_length, 0, A * 4); memset(b->ended, 0, A);
+  memset(b->reward, 0, A * n * 4); memset(b->ep_return, 0, A * n * 4); memset(b->final_return, 0, A * n * 4); memset(b->done, 0, A * n); memset(b->truncated, 0, A * n);
+#else
+  HIPCHK(hipMemsetAsync(b->steps, 0, A * 4, e->stream)); HIPCHK(hipMemsetAsync(b->final_length, 0, A * 4, e->stream)); HIPCHK(hipMemsetAsync(b->ended, 0, A, e->stream));
+  HIPCHK(hipMemsetAsync(b->reward, 0, A * n * 4, e->stream)); HIPCHK(hipMemsetAsync(b->ep_return, 0, A * n * 4, e->stream)); HIPCHK(hipMemsetAsync(b->final_return, 0, A * n * 4, e->stream));
+  HIPCHK(hipMemsetAsync(b->done, 0, A * n, e->stream)); HIPCHK(hipMemsetAsync(b->truncated, 0, A * n, e->stream));
+#endif
+  return vec_observe(e, sp, b);
+}
+extern "C" int agarcl_vec_step(agarcl_env *e, const agarcl_vec_spec *sp, const agarcl_vec_buffers *b, const float *dxdy_dev, const int32_t *act_dev, uint32_t *flags_seen) {
+  AgVecPost v; int rc = vec_args(e, sp, b, v, "agarcl_vec_step");
+  if (rc) return rc;
+  if (!dxdy_dev || !act_dev) return fail(AGARCL_E_INVALID, "agarcl_vec_step: null action pointer");
+#ifndef AGAR_CPU_EMU
+  HIPCHK(hipSetDevice(e->device));
+#endif
+  e->act_dxdy = dxdy_dev; e->act = act_dev;
+  rc = launch_step(e, sp->ticks > 0 ? sp->ticks : e->cfg.ticks_per_step, 1);
+  e->slot = (e->slot + 1) % AG_PACKED_SLOTS;
+  if (rc) return rc;
+#ifdef AGAR_CPU_EMU
+  { std::vector<uint8_t> mask((size_t)e->d.A, 0); bool some = false;
+    for (int a = 0; a < e->d.A; a++) if (ag_vec_post_arena(v, a)) { mask[(size_t)a] = 1; some = true; }
+    if (some) { const int32_t keep = e->s.qstat[1]; rc = launch_reset(e, nullptr, mask.data(), sp->reset_ids); e->s.qstat[1] |= keep; if (rc) return rc; } }
+#else
+#define CALL(N, V) hipLaunchKernelGGL((k_vec_post_reset<N, V>), dim3(e->d.A), dim3(64), e->lds_bytes, e->stream, e->d_state, v, (int)sp->reset_ids)
+  AG_DISPATCH_NS(e->ns, CALL);
+#undef CALL
+  HIPCHK(hipGetLastError());
+#endif
+  if ((rc = vec_observe(e, sp, b)) != 0) return rc;
+  if (flags_seen) return agarcl_poll_flags(e, flags_seen);
+  return AGARCL_OK;
+}
+
+// ---- sub-batch pipelining (include/agarcl_batch.h) ------------------------------------------------------------------------------------
+struct agarcl_pipe { std::vector<agarcl_env *> envs; std::vector<int32_t> first; int32_t A; int device; int concurrent; };
+#ifndef AGAR_CPU_EMU
+// Do two streams execute concurrently?  The runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) and two
+// streams that share a queue run one after the other whatever the API says -- measured on MI355X: two 2048-arena sub-batches on streams that
+// happened to share a queue took 590 us per step instead of 313 (scripts/gpu_pipe_probe.py).  The probe: a one-lane kernel on `a` waits (at most
+// `ticks` of the 100 MHz wall clock) for a flag that a kernel on `b` sets; it sees the flag iff `b`'s kernel ran while it was waiting.
+__global__ void k_pipe_wait(int *flag, int *seen, long long ticks) {
+  const long long t0 = (long long)wall_clock64(); int f;
+  do { f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!f && (long long)wall_clock64() - t0 < ticks);
+  *seen = f;
+}
+__global__ void k_pipe_set(int *flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static int streams_concurrent(hipStream_t a, hipStream_t b, int *d_two) {   // 1 yes, 0 no, -1 error
+  if (a == b) return 0;
+  if (hipMemsetAsync(d_two, 0, 8, a) != hipSuccess || hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1;
+  hipLaunchKernelGGL(k_pipe_wait, dim3(1), dim3(1), 0, a, d_two, d_two + 1, 200000LL);   // <= 2 ms
+  hipLaunchKernelGGL(k_pipe_set, dim3(1), dim3(1), 0, b, d_two);
+  int seen = 0;
+  if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess || hipMemcpy(&seen, d_two + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return seen ? 1 : 0;
+}
+#endif
+extern "C" int agarcl_pipe_destroy(agarcl_pipe *p) {
+  if (!p) return AGARCL_OK;
+  for (agarcl_env *e : p->envs) agarcl_destroy(e);
+  delete p;
+  return AGARCL_OK;
+}
+extern "C" int agarcl_pipe_create(const agarcl_config *cfg, int32_t num_arenas, int32_t sub_batches, int32_t device, agarcl_pipe **out) {
+  if (!cfg || !out || num_arenas <= 0 || sub_batches < 1 || sub_batches > num_arenas || sub_batches > 64) return fail(AGARCL_E_INVALID, "agarcl_pipe_create: bad arguments (1 <= sub_batches <= min(num_arenas, 64))");
+  agarcl_pipe *p = new agarcl_pipe(); p->A = num_arenas; p->device = device; p->concurrent = 1;
+  const int32_t base = num_arenas / sub_batches, rem = num_arenas % sub_batches;   // contiguous ranges, the first ones take the remainder (agarcl_amd/dist.py shard_bounds)
+  for (int32_t j = 0; j < sub_batches; j++) {
+    const int32_t lo = j * base + (j < rem ? j : rem), n = base + (j < rem ? 1 : 0);
+    agarcl_env *e = nullptr;
+    // one engine over all arenas gives arena i the default seed 5489 + i (agarcl_create): so do the sub-batches, by global index
+    int rc = create_env(cfg, n, device, 5489u + (uint32_t)lo, &e);
+    if (rc != 0) { if (e) agarcl_destroy(e); agarcl_pipe_destroy(p); return rc; }
+    p->envs.push_back(e); p->first.push_back(lo);
+  }
+#ifndef AGAR_CPU_EMU
+  if (sub_batches > 1) {
+    // every sub-batch stream must run concurrently with the ones before it; a stream that shares a hardware queue with one of them is
+    // replaced (the rejected candidates stay alive until the end, so that the runtime does not hand the same queue out again)
+    int *d_two = nullptr; std::vector<hipStream_t> rejected;
+    if (hipMalloc((void **)&d_two, 8) != hipSuccess) { agarcl_pipe_destroy(p); return fail(AGARCL_E_NOMEM, "agarcl_pipe_create: allocation failed"); }
+    for (int32_t j = 1; j < sub_batches; j++) {
+      agarcl_env *e = p->envs[(size_t)j];
+      bool ok = false;
+      for (int attempt = 0; attempt < 12 && !ok; attempt++) {
+        ok = true;
+        for (int32_t i = 0; i < j && ok; i++) ok = streams_concurrent(p->envs[(size_t)i]->stream, e->stream, d_two) == 1;
+        if (!ok && attempt < 11) {
+          hipStream_t ns = nullptr;
+          if (hipStreamCreateWithFlags(&ns, hipStreamNonBlocking) != hipSuccess) break;
+          (void)hipStreamSynchronize(e->stream);
+          rejected.push_back(e->stream); e->stream = ns;
+        }
+      }
+      if (ok) p->concurrent++;
+    }
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    (void)hipFree(d_two);
+  }
+#else
+  p->concurrent = sub_batches;
+#endif
+  *out = p;
+  return AGARCL_OK;
+}
+extern "C" int agarcl_pipe_sub_batches(agarcl_pipe *p) { return p ? (int)p->envs.size() : 0; }
+extern "C" agarcl_env *agarcl_pipe_env(agarcl_pipe *p, int32_t j) { return p && j >= 0 && (size_t)j < p->envs.size() ? p->envs[(size_t)j] : nullptr; }
+extern "C" int agarcl_pipe_range(agarcl_pipe *p, int32_t j, int32_t *first_arena, int32_t *count) {
+  if (!p || j < 0 || (size_t)j >= p->envs.size()) return fail(AGARCL_E_INVALID, "agarcl_pipe_range: bad arguments");
+  if (first_arena) *first_arena = p->first[(size_t)j];
+  if (count) *count = p->envs[(size_t)j]->d.A;
+  return AGARCL_OK;
+}
+extern "C" int agarcl_pipe_seed(agarcl_pipe *p, const uint32_t *seeds_host, uint32_t base_seed) {
+  if (!p) return fail(AGARCL_E_INVALID, "null pipe");
+  for (size_t j = 0; j < p->envs.size(); j++) {
+    const int rc = agarcl_seed(p->envs[j], seeds_host ? seeds_host + p->first[j] : nullptr, base_seed + (uint32_t)p->first[j]);
+    if (rc) return rc;
+  }
+  return AGARCL_OK;
+}
+extern "C" int agarcl_pipe_concurrent(agarcl_pipe *p) { return p ? p->concurrent : 0; }
+extern "C" int agarcl_pipe_sync(agarcl_pipe *p) {
+  if (!p) return fail(AGARCL_E_INVALID, "null pipe");
+  for (agarcl_env *e : p->envs) { const int rc = agarcl_sync(e); if (rc) return rc; }
+  return AGARCL_OK;
 }
 #endif  // AG_PART_NS

@@ -25,8 +25,12 @@ class ResultGatherer:
     """Double-buffered asynchronous gather of (reward, done) rows to rank 0.
 
     pack(k, rewards, dones) copies this step's results into slot k % depth on the current stream and
-    starts a gather; the collective overlaps the next step's kernel.  Buffers are float32 [A_local, 2].
-    Works with any torch.distributed backend (nccl == RCCL on ROCm, gloo on CPU)."""
+    starts a gather; the collective overlaps the next step's kernel.  Buffers are float32 [rows, 2].
+    Works with any torch.distributed backend (nccl == RCCL on ROCm, gloo on CPU).
+
+    Unequal shards (shard_bounds() hands the first ranks one arena more when total % world != 0): dist.gather needs equally sized
+    contributions, so every rank sends `n_max` rows -- the largest shard -- and rank 0 drops the padding rows again in gathered().  A rank
+    whose shard is the largest sends zero-copy; a smaller one goes through its padded staging buffer (one small device copy)."""
 
     def __init__(self, n_local, device, depth=2, group=None):
         import torch
@@ -35,20 +39,18 @@ class ResultGatherer:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.depth = depth
-        self.send = [torch.zeros((n_local, 2), dtype=torch.float32, device=device) for _ in range(depth)]
+        self.n_local = int(n_local)
+        sizes = [None] * self.world
+        dist.all_gather_object(sizes, self.n_local, group=group)
+        self.sizes = [int(x) for x in sizes]
+        self.n_max = max(self.sizes)
+        self.send = [torch.zeros((self.n_max, 2), dtype=torch.float32, device=device) for _ in range(depth)]
         self.recv = None
         if self.rank == 0:
-            self.recv = [[torch.zeros((n_local, 2), dtype=torch.float32, device=device) for _ in range(self.world)]
+            self.recv = [[torch.zeros((self.n_max, 2), dtype=torch.float32, device=device) for _ in range(self.world)]
                          for _ in range(depth)]
         self.work = [None] * depth
-        self.n_local = n_local
         self.reset_stats()
-        # dist.gather needs equally sized contributions: shard_bounds() gives unequal blocks when total % world != 0,
-        # so such a job must pad its shards to the largest one (or pick a divisible arena count).  Fail at construction.
-        sizes = [None] * self.world
-        dist.all_gather_object(sizes, int(n_local), group=group)
-        if any(s != sizes[0] for s in sizes):
-            raise ValueError("ResultGatherer: every rank must contribute the same number of rows, got %s" % (sizes,))
 
     def reset_stats(self):
         """diagnostics: host seconds spent waiting for collectives, collectives started, payload bytes this rank sent"""
@@ -66,21 +68,24 @@ class ResultGatherer:
         if self.work[s] is not None:
             self._wait(s)
         buf = self.send[s]
-        buf[:, 0].copy_(rewards.reshape(-1))
-        buf[:, 1].copy_(dones.reshape(-1))
+        buf[:self.n_local, 0].copy_(rewards.reshape(-1))
+        buf[:self.n_local, 1].copy_(dones.reshape(-1))
         self.work[s] = self.dist.gather(buf, self.recv[s] if self.rank == 0 else None, dst=0, group=self.group,
                                         async_op=True)
-        self.calls += 1; self.bytes_sent += buf.numel() * buf.element_size()
+        self.calls += 1; self.bytes_sent += self.n_local * 2 * buf.element_size()
         return s
 
     def gather_packed(self, slot, packed):
-        """Zero-copy variant: `packed` is the engine's own ping-pong buffer of step parity `slot` ([A_local, 2] f32,
+        """Zero-copy variant: `packed` is the engine's own ping-pong buffer of step parity `slot` ([n_local, 2] f32,
         agarcl_packed_dev).  wait_slot(slot) must be called before the engine overwrites that parity again.  A gather still
-        in flight on this buffer is waited for first."""
+        in flight on this buffer is waited for first.  (A shard smaller than the largest one is staged into its padded buffer.)"""
         self.wait_slot(slot)
+        if packed.shape[0] != self.n_max:
+            self.send[slot][:packed.shape[0]].copy_(packed)
+            packed = self.send[slot]
         self.work[slot] = self.dist.gather(packed, self.recv[slot] if self.rank == 0 else None, dst=0, group=self.group,
                                            async_op=True)
-        self.calls += 1; self.bytes_sent += packed.numel() * packed.element_size()
+        self.calls += 1; self.bytes_sent += self.n_local * 2 * packed.element_size()
 
     def wait_slot(self, slot):
         if self.work[slot] is not None:
@@ -92,10 +97,10 @@ class ResultGatherer:
                 self._wait(i)
 
     def gathered(self, slot):
-        """rank 0: float32 [world * n_local, 2] of the given slot (after its work completed)."""
+        """rank 0: float32 [sum of the shards' rows, 2] of the given slot (after its work completed), padding rows dropped."""
         if self.rank != 0:
             return None
-        return self.torch.cat(self.recv[slot], dim=0)
+        return self.torch.cat([r[:n] for r, n in zip(self.recv[slot], self.sizes)], dim=0)
 
 
 class TensorGatherer:

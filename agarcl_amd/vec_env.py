@@ -22,20 +22,21 @@ class _DevArray:
 class VecEnvironment:
     def __init__(self, num_arenas, num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True,
                  num_pellets=1000, num_viruses=0, num_bots=0, reward_type=1, c_death=0, mode_number=0,
-                 device=0, dt=1.0 / 30, use_torch_stream=True, strict_flags=True, **caps):
+                 device=0, dt=1.0 / 30, use_torch_stream=True, strict_flags=True, engine=None, **caps):
+        """engine: an existing _capi.BatchedEngine to wrap instead of creating one (a sub-batch of a PipelinedVecEnvironment: it keeps its
+        own, verified-concurrent stream, so use_torch_stream must be False for it)"""
         import torch
         self.torch = torch
         self.device = torch.device("cuda", device)
         self.num_arenas, self.num_agents, self.ticks_per_step = num_arenas, num_agents, ticks_per_step
-        self.engine = _capi.BatchedEngine(num_arenas, num_agents, ticks_per_step, arena_size, pellet_regen, num_pellets,
-                                          num_viruses, num_bots, reward_type, c_death, mode_number, dt, device, **caps)
+        self.engine = engine if engine is not None else _capi.BatchedEngine(num_arenas, num_agents, ticks_per_step, arena_size, pellet_regen, num_pellets,
+                                                                            num_viruses, num_bots, reward_type, c_death, mode_number, dt, device, **caps)
         self._torch_stream = bool(use_torch_stream)
-        self.stream_handle = None   # the hipStream_t the engine launches on, when it is torch's (None: a stream of the engine's own)
         if use_torch_stream:
             # launch on torch's current stream so torch events / collectives order against the engine
             with torch.cuda.device(self.device):
-                self.stream_handle = torch.cuda.current_stream().cuda_stream
-                self.engine.set_stream(self.stream_handle)
+                self.engine.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.stream_handle = self.engine.stream()   # the hipStream_t (int) the engine launches on: torch's at construction, or its own
         p = self.engine.device_ptrs()
         A, n = num_arenas, num_agents
         self.rewards = torch.as_tensor(_DevArray(p["rewards"], (A, n), "<f8"), device=self.device)
@@ -56,8 +57,8 @@ class VecEnvironment:
     def reset(self, mask=None, reset_ids=False):
         """mask: None (all arenas), a host uint8/bool array, or a CUDA uint8 tensor [A] such as self.dones_u8[:, 0] made
         contiguous -- the device form is a pure stream-ordered launch (no copy, no synchronisation) when the engine runs on torch's
-        stream (use_torch_stream=True, the default).  With an engine-owned stream the mask's producer (torch's current stream) is
-        waited for first: nothing else orders the cast below against the reset kernel.
+        stream (use_torch_stream=True, the default).  With another stream current, the engine's stream first waits -- on the device -- for it
+        (agarcl_stream_wait): nothing else orders the cast below against the reset kernel.
         Every reset also restarts the capacity-flag watch (strict_flags): after reset(mask) only arenas that are still flagged count."""
         torch = self.torch
         if isinstance(mask, torch.Tensor) and mask.is_cuda:
@@ -65,8 +66,7 @@ class VecEnvironment:
             if m.numel() != self.num_arenas:
                 raise ValueError("mask must have one entry per arena")
             self._mask_keep = m
-            if not self._torch_stream:
-                torch.cuda.current_stream(self.device).synchronize()
+            self.order_after_current()        # (the cast above ran on torch's current stream; a no-op when that is the engine's stream)
             self.engine.reset_device(m.data_ptr(), reset_ids)
         else:
             self.engine.reset(None if mask is None else np.asarray(mask), reset_ids)
@@ -168,8 +168,83 @@ class VecEnvironment:
     def dones(self):
         return self.dones_u8.bool()
 
+    def torch_stream(self):
+        """the engine's stream as a torch stream object (`with torch.cuda.stream(env.torch_stream()):` runs torch ops in order with the engine)"""
+        if self.stream_handle == 0:
+            return self.torch.cuda.default_stream(self.device)
+        return self.torch.cuda.ExternalStream(self.stream_handle, device=self.device)
+
+    def order_after_current(self):
+        """the engine's next launches come after everything enqueued so far on torch's CURRENT stream (no-op when that is the engine's stream)"""
+        cur = self.torch.cuda.current_stream(self.device).cuda_stream
+        if cur != self.stream_handle:
+            self.engine.stream_wait(cur)
+
+    def order_current_after(self):
+        """torch's CURRENT stream waits, on the device, for everything the engine has enqueued so far"""
+        cur = self.torch.cuda.current_stream(self.device).cuda_stream
+        if cur != self.stream_handle:
+            self.engine.stream_signal(cur)
+
     def sync(self):
         self.engine.sync()
 
     def close(self):
         self.engine.close()
+
+
+class PipelinedVecEnvironment:
+    """`num_arenas` arenas as `sub_batches` independent sub-batches (include/agarcl_batch.h agarcl_pipe_*): contiguous arena ranges, each a
+    VecEnvironment (`parts[j]`, arenas `ranges[j] = (first, count)`) on a HIP stream of its own that was verified to run concurrently with
+    the others.  The reference's vectorised runner lets every engine run ahead on its own pool thread and waits once at the end
+    (/root/reference/agario/bots/benchmark.cpp:149-167); here a sub-batch's step does not wait for the slowest arena of another, and one
+    sub-batch's observation kernel runs under another's step.
+
+        send(j, dxdy_j, act_j)   enqueue take_actions + step of sub-batch j (after whatever produced the tensors on the current stream)
+        recv(j)                  the current stream waits (on the device) for sub-batch j; returns parts[j] (rewards / dones_u8 / masses / *_obs)
+        step(dxdy, act)          all sub-batches with full-batch tensors [A, n, ..]: send each, then recv each
+
+    Arena first_j + a computes exactly what arena first_j + a of one VecEnvironment over all arenas computes (seeds by global index)."""
+
+    def __init__(self, num_arenas, sub_batches=2, num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True, num_pellets=1000,
+                 num_viruses=0, num_bots=0, reward_type=1, c_death=0, mode_number=0, device=0, dt=1.0 / 30, strict_flags=True, **caps):
+        import torch
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        self.num_arenas, self.num_agents, self.sub_batches = num_arenas, num_agents, sub_batches
+        self.pipe = _capi.PipelinedEngine(num_arenas, sub_batches, num_agents, ticks_per_step, arena_size, pellet_regen, num_pellets, num_viruses,
+                                          num_bots, reward_type, c_death, mode_number, dt, device, **caps)
+        self.ranges = list(self.pipe.ranges)
+        self.concurrent = self.pipe.concurrent     # sub-batch streams verified to overlap (== sub_batches unless hardware queues ran out)
+        self.parts = [VecEnvironment(n, num_agents, ticks_per_step, arena_size, pellet_regen, num_pellets, num_viruses, num_bots, reward_type, c_death,
+                                     mode_number, device, dt, use_torch_stream=False, strict_flags=strict_flags, engine=self.pipe.parts[j])
+                      for j, (lo, n) in enumerate(self.ranges)]
+
+    def seed(self, seeds=None, base_seed=0):
+        self.pipe.seed(seeds, base_seed)
+
+    def reset(self, reset_ids=False):
+        for p in self.parts:
+            p.reset(None, reset_ids)
+
+    def send(self, j, dxdy, act, ticks=0):
+        p = self.parts[j]
+        p.order_after_current()
+        p.take_actions(dxdy, act)
+        p.step(ticks)
+
+    def recv(self, j):
+        p = self.parts[j]
+        p.order_current_after()
+        return p
+
+    def step(self, dxdy, act, ticks=0):
+        for j, (lo, n) in enumerate(self.ranges):
+            self.send(j, dxdy[lo:lo + n], act[lo:lo + n], ticks)
+        return [self.recv(j) for j in range(self.sub_batches)]
+
+    def sync(self):
+        self.pipe.sync()
+
+    def close(self):
+        self.pipe.close()

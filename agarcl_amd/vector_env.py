@@ -1,6 +1,6 @@
 """AgarioVectorEnv: the batched user surface -- `num_envs` arenas behind ONE `reset()` / `step()` pair, shaped like
-gymnasium.vector.VectorEnv (batched observations / rewards / terminated / truncated, auto-reset of finished episodes), with every tensor
-resident in HBM and nothing inside `step()` that waits for the GPU.
+gymnasium.vector.VectorEnv (batched observations / rewards / terminated / truncated, spaces, auto-reset of finished episodes), with every
+tensor resident in HBM, nothing inside `step()` that waits for the GPU, and ONE host call into the library per step and sub-batch.
 
 `gym.make("agario-*-v0")` (agarcl_amd/gym_agario.py, the counterpart of /root/reference/gym_agario/AgarioEnv.py:85-132) is the N = 1 case:
 one arena per object, Python lists and host arrays.  This class keeps its meaning per arena --
@@ -11,55 +11,61 @@ one arena per object, Python lists and host arrays.  This class keeps its meanin
       sets done, never truncated; the comparison happens before the step is counted);
     * a finished arena is reset as `env.reset()` resets it (BaseEnvironment::reset: the arena's own random stream continues)
 
--- and runs all arenas in one launch per call:
+-- and runs all arenas in one call of `agarcl_vec_step` (include/agarcl_vec.h: step kernel, one bookkeeping + masked-reset launch, the
+observation kernel):
 
     obs, info = venv.reset(seed=123)
     obs, reward, terminated, truncated, info = venv.step((move, kind))     # move f32 [N, 2] in [-1, 1], kind int [N] in {0, 1, 2}
 
 Auto-reset is "same step" (gymnasium.vector.AutoresetMode.SAME_STEP): when an arena's episode ends in a step, that arena is reset inside the
-same `step()` on the device (agarcl_reset_device with the done mask: no host round trip) and the returned observation row is the FIRST
-observation of its next episode; reward and terminated of that row belong to the episode that ended.  The last observation of the ended
-episode is not kept (it would double the observation traffic of every step).
+same `step()` on the device and the returned observation row is the FIRST observation of its next episode; reward and terminated of that
+row belong to the episode that ended.  The last observation of the ended episode is not kept (it would double the observation traffic of
+every step).  With several agents per arena the arena ends -- and is reset -- as soon as ANY agent is done: the rows of the agents that were
+not done get truncated = True for that step (their episode was cut by the reset; a learner must not bootstrap across it as if nothing
+happened), every row of the arena gets its "final_return".
+
+Spaces: `single_observation_space`, `single_action_space`, `observation_space`, `action_space` (gymnasium.spaces objects when gymnasium is
+importable, agarcl_amd/spaces.py's equivalents otherwise) and `num_envs`, as gymnasium.vector.VectorEnv carries them; the reference's
+per-env spaces are AgarioEnv.py:55-62 and :232-264.
 
 `info` carries the episode statistics gymnasium's RecordEpisodeStatistics wrapper would keep, as device tensors: "episode_steps" and
 "episode_return" of the running episodes, "ended" (the arenas whose episode ended in this step) and, valid for those rows, "final_return" /
 "final_length" of the episode that ended.
+
+Sub-batches (`sub_batches=k`): the arenas are split into k contiguous ranges that run on HIP streams of their own (include/agarcl_batch.h
+agarcl_pipe_*), so a range never waits for the slowest arena of another and one range's observation kernel runs under another's step --
+the reference's vectorised runner works that way (every engine on its own pool thread, /root/reference/agario/bots/benchmark.cpp:149-167).
+`step()` still takes and returns full-batch tensors (each range writes its rows of them).  The two halves are also available on their own, for
+double-buffered sampling (the policy works on range j's observations while the other ranges step):
+
+    venv.async_reset(seed=0)
+    for j in cycle(range(k)):
+        obs_j, reward_j, term_j, trunc_j, info_j = venv.recv(j)       # rows of range j (views of the full tensors)
+        venv.send(policy(obs_j), j)
 
 Returned tensors are CUDA tensors owned by the environment and rewritten in place by the next `step()` -- copy what must outlive it (a
 rollout buffer does that anyway).  With one agent per arena the agent axis is dropped: obs [N, ...], reward [N]; with several agents
 [N, num_agents, ...].
 """
 import ctypes
-import os
 
 import numpy as np
 
+from . import _capi
 from . import gym_agario as _single
-from .vec_env import VecEnvironment
-
-
-def _load_vecpost():
-    """agarcl_amd/libagarcl_vec.so (include/agarcl_vec.h): the episode bookkeeping as ONE launch per step.  There is no torch fall-back: the
-    library is built in-tree by agarcl_amd/build.py (build_vecpost) and a missing one is an error."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libagarcl_vec.so")
-    if not os.path.exists(path):
-        from . import build as _build
-        _build.build_vecpost()
-    lib = ctypes.CDLL(path)
-    f = lib.agarcl_vec_post
-    f.restype = ctypes.c_int
-    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 7
-    return f
+from . import spaces as _spaces
+from .vec_env import PipelinedVecEnvironment, VecEnvironment
 
 
 class AgarioVectorEnv:
     metadata = {"render_modes": [], "autoreset_mode": "same_step"}
 
-    def __init__(self, num_envs, obs_type="grid", device=0, channels_last=False, **kwargs):
+    def __init__(self, num_envs, obs_type="grid", device=0, channels_last=False, sub_batches=1, **kwargs):
         """num_envs arenas; obs_type "grid" | "screen" | "ram" | "gobigger" | "none"; channels_last: grid observations as a [.., G, G, C]
-        VIEW (what AgarioEnv hands out per arena) instead of the engine's channel-first layout; every other keyword as AgarioEnv takes it
-        (difficulty, ticks_per_step, arena_size, num_pellets, num_viruses, num_bots, pellet_regen, reward_type, c_death, mode, num_agents,
-        number_steps, env_type, grid_size, observe_*, screen_len, agent_view, k_cells / k_pellets / k_viruses / k_others)."""
+        VIEW (what AgarioEnv hands out per arena) instead of the engine's channel-first layout; sub_batches: see the module text; every other
+        keyword as AgarioEnv takes it (difficulty, ticks_per_step, arena_size, num_pellets, num_viruses, num_bots, pellet_regen, reward_type,
+        c_death, mode, num_agents, number_steps, env_type, grid_size, observe_*, screen_len, agent_view, k_cells / k_pellets / k_viruses /
+        k_others)."""
         import torch
         if obs_type not in _single.OBS_TYPES + ("none",):
             raise ValueError("obs_type must be one of %s, got %r" % (_single.OBS_TYPES + ("none",), obs_type))
@@ -69,118 +75,203 @@ class AgarioVectorEnv:
         self.num_agents, self.multi_agent = o["num_agents"], o["multi_agent"]
         self.number_of_steps, self.env_type = o["number_steps"], o["env_type"]
         self.channels_last = bool(channels_last)
-        self.env = VecEnvironment(self.num_envs, num_agents=o["num_agents"], ticks_per_step=o["ticks_per_step"], arena_size=o["arena_size"],
-                                  pellet_regen=o["pellet_regen"], num_pellets=o["num_pellets"], num_viruses=o["num_viruses"],
-                                  num_bots=o["num_bots"], reward_type=o["reward_type"], c_death=o["c_death"], mode_number=o["mode"],
-                                  device=device, **{k: kwargs[k] for k in ("strict_flags", "dt") if k in kwargs})
-        self.device = self.env.device
+        self.sub_batches = int(sub_batches)
+        if self.sub_batches < 1 or self.sub_batches > self.num_envs:
+            raise ValueError("sub_batches must be in [1, num_envs]")
+        if obs_type == "gobigger" and self.sub_batches > 1:
+            raise ValueError("the GoBigger observation (five padded tensors per call) is available with sub_batches=1 only")
+        eng = dict(num_agents=o["num_agents"], ticks_per_step=o["ticks_per_step"], arena_size=o["arena_size"], pellet_regen=o["pellet_regen"],
+                   num_pellets=o["num_pellets"], num_viruses=o["num_viruses"], num_bots=o["num_bots"], reward_type=o["reward_type"], c_death=o["c_death"],
+                   mode_number=o["mode"], device=device, **{k: kwargs[k] for k in ("strict_flags", "dt", "cap_foods", "cap_viruses") if k in kwargs})
+        if self.sub_batches == 1:
+            self.env = VecEnvironment(self.num_envs, **eng)
+            self.pipe, self._parts, self._ranges = None, [self.env], [(0, self.num_envs)]
+        else:
+            self.pipe = PipelinedVecEnvironment(self.num_envs, self.sub_batches, **eng)
+            self.env, self._parts, self._ranges = None, self.pipe.parts, self.pipe.ranges
+        self.concurrent_sub_batches = self.pipe.concurrent if self.pipe is not None else 1
+        self.strict_flags = bool(kwargs.get("strict_flags", True))
+        self.device = self._parts[0].device
+        N, n = self.num_envs, self.num_agents
+        # ---- the observation: its configuration, per-agent shape, and ONE tensor for all arenas (each sub-batch writes its rows) -------------
+        spec_kind, arg, shape, dtype = _capi.OBS_NONE, [0] * 6, None, None
         if obs_type == "grid":
-            self._obs_args = dict(grid_size=kwargs.get("grid_size", 128), cells=kwargs.get("observe_cells", True), others=kwargs.get("observe_others", True),
-                                  viruses=kwargs.get("observe_viruses", True), pellets=kwargs.get("observe_pellets", True))
+            a = dict(grid_size=int(kwargs.get("grid_size", 128)), cells=bool(kwargs.get("observe_cells", True)), others=bool(kwargs.get("observe_others", True)),
+                     viruses=bool(kwargs.get("observe_viruses", True)), pellets=bool(kwargs.get("observe_pellets", True)))
+            C = 1 + int(a["cells"]) + 2 * (int(a["others"]) + int(a["viruses"]) + int(a["pellets"]))
+            spec_kind, arg[:5], shape, dtype = _capi.OBS_GRID, [a["grid_size"], a["cells"], a["others"], a["viruses"], a["pellets"]], (C, a["grid_size"], a["grid_size"]), torch.int32
+            self._obs_args = a
         elif obs_type == "screen":
-            side = kwargs.get("screen_len", 84)
+            side = int(kwargs.get("screen_len", 84))
+            spec_kind, arg[:3], shape, dtype = _capi.OBS_SCREEN, [side, side, int(bool(o["agent_view"]))], (side, side, 4 if o["agent_view"] else 3), torch.uint8
             self._obs_args = dict(width=side, height=side, agent_view=o["agent_view"])
         elif obs_type == "ram":
-            self._obs_args = {k: kwargs[k] for k in ("k_cells", "k_pellets", "k_viruses", "k_others") if k in kwargs}
-        elif obs_type == "gobigger":
-            self._obs_args = {k: kwargs[k] for k in ("grid_size", "cap_food", "cap_virus", "cap_spore", "cap_clone") if k in kwargs}
+            k = [int(kwargs.get(key, dflt)) for key, dflt in (("k_cells", 16), ("k_pellets", 16), ("k_viruses", 8), ("k_others", 16))]
+            spec_kind, arg[:4], shape, dtype = _capi.OBS_RAM, k, (4 + 3 * k[0] + 2 * k[1] + 3 * k[2] + 3 * k[3],), torch.float32
+            self._obs_args = dict(zip(("k_cells", "k_pellets", "k_viruses", "k_others"), k))
         else:
-            self._obs_args = {}
-        N, n = self.num_envs, self.num_agents
+            self._obs_args = {k: kwargs[k] for k in ("grid_size", "cap_food", "cap_virus", "cap_spore", "cap_clone") if k in kwargs}
+        self._obs = torch.zeros((N, n) + shape, dtype=dtype, device=self.device) if shape is not None else None
+        self._obs_row_bytes = (int(np.prod(shape)) * n * self._obs.element_size()) if shape is not None else 0
+        # ---- bookkeeping tensors (include/agarcl_vec.h agarcl_vec_buffers), one allocation each for all arenas -------------------------------
         self._steps = torch.zeros(N, dtype=torch.int32, device=self.device)       # steps played in the current episode, per arena
-        # episode statistics, kept on the device (what gymnasium's RecordEpisodeStatistics wrapper keeps per env on the host): the running
-        # return of the current episode, and -- rewritten only for the arenas whose episode ended in a step -- the return and length of it
         self._ep_return = torch.zeros((N, n), dtype=torch.float32, device=self.device)
         self._final_return = torch.zeros((N, n), dtype=torch.float32, device=self.device)
         self._final_length = torch.zeros(N, dtype=torch.int32, device=self.device)
         self._reward = torch.zeros((N, n), dtype=torch.float32, device=self.device)
         self._done = torch.zeros((N, n), dtype=torch.bool, device=self.device)
-        self._trunc = torch.zeros((N, n), dtype=torch.bool, device=self.device)   # never set: the cut-off is a `done` (see the module text)
-        self._mask = torch.zeros(N, dtype=torch.uint8, device=self.device)
+        self._trunc = torch.zeros((N, n), dtype=torch.bool, device=self.device)   # several agents only: reset under an agent that was not done
+        self._mask = torch.zeros(N, dtype=torch.uint8, device=self.device)        # "ended"
         self._started = False
-        self.single_observation_shape = None      # set by the first observation
-        self._vec_post = _load_vecpost()
-        self._post_args = None                    # (pointers of the tensors above: they never move)
+        self._L = self._parts[0].engine.L
+        self._spec = _capi.VecSpec(int(self.number_of_steps), 1 if self.env_type == 0 else 0, 0, spec_kind, (ctypes.c_int32 * 6)(*[int(x) for x in arg]), 0)
+        self._bufs = []
+        for lo, cnt in self._ranges:
+            off = lambda t, per_row: t.data_ptr() + lo * per_row
+            self._bufs.append(_capi.VecBuffers(off(self._steps, 4), off(self._reward, 4 * n), off(self._done, n), off(self._trunc, n), off(self._mask, 1),
+                                               off(self._ep_return, 4 * n), off(self._final_return, 4 * n), off(self._final_length, 4),
+                                               (self._obs.data_ptr() + lo * self._obs_row_bytes) if self._obs is not None else None))
+        self._flags = ctypes.c_uint32(0)
+        self._act_keep = [None] * self.sub_batches
+        # ---- spaces -----------------------------------------------------------------------------------------------------------------------------
+        self.single_observation_shape = self._single_obs_shape(shape)
+        self.single_action_space = _spaces.single_action_space(n, self.multi_agent)
+        self.action_space = _spaces.batched_action_space(N, n, self.multi_agent)
+        if self.single_observation_shape is not None and obs_type in _spaces.OBS_BOUNDS:
+            self.single_observation_space = _spaces.observation_space(obs_type, self.single_observation_shape)
+            self.observation_space = _spaces.observation_space(obs_type, (N,) + self.single_observation_shape)
+        else:       # "none", and the GoBigger observation (a dict of padded tensors per player: no single Box describes it)
+            self.single_observation_space = self.observation_space = None
 
     # ---- helpers ------------------------------------------------------------------------------------------------------------------
+    def _single_obs_shape(self, shape):
+        if shape is None:
+            return None
+        if self.obs_type == "grid" and self.channels_last:
+            shape = (shape[1], shape[2], shape[0])
+        return ((self.num_agents,) + tuple(shape)) if self.multi_agent else tuple(shape)
+
     def _agents(self, t):
         """[N, num_agents, ...] -> [N, ...] for single-agent envs"""
         return t if self.multi_agent else t[:, 0]
 
-    def _observe(self):
-        k = self.obs_type
-        if k == "none":
+    def _obs_view(self, lo=0, hi=None):
+        if self.obs_type == "none":
             return None
-        if k == "gobigger":
+        if self.obs_type == "gobigger":
             return self.env.gobigger_obs(**self._obs_args)        # rows per PLAYER (agents and bots), see VecEnvironment.gobigger_obs
-        if k == "grid":
-            t = self.env.grid_obs(**self._obs_args)
-            t = self._agents(t)
-            if self.channels_last:
-                t = t.movedim(-3, -1)
-        elif k == "screen":
-            t = self._agents(self.env.screen_obs(**self._obs_args))
-        else:
-            t = self._agents(self.env.ram_obs(**self._obs_args))
-        self.single_observation_shape = tuple(t.shape[1:])
+        t = self._agents(self._obs[lo:hi])
+        if self.obs_type == "grid" and self.channels_last:
+            t = t.movedim(-3, -1)
         return t
 
     def _as_device(self, x, dtype, shape):
         torch = self.torch
+        if isinstance(x, torch.Tensor) and x.dtype == dtype and x.is_cuda and x.is_contiguous() and x.numel() == int(np.prod(shape)):
+            return x                                              # the policy's own tensor, handed through
         if not isinstance(x, torch.Tensor):
             x = torch.as_tensor(np.asarray(x), device=self.device)
         if x.numel() != int(np.prod(shape)):
-            raise ValueError("actions for %d arenas x %d agents expected, got a tensor of shape %s" % (self.num_envs, self.num_agents, tuple(x.shape)))
-        return x.to(device=self.device, dtype=dtype).reshape(shape)
+            raise ValueError("actions for %d arenas x %d agents expected, got a tensor of shape %s" % (shape[0], self.num_agents, tuple(x.shape)))
+        return x.to(device=self.device, dtype=dtype).reshape(shape).contiguous()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise _capi.AgarclError(rc, (self._L.agarcl_last_error() or b"").decode())
+
+    def _check_flags(self):
+        if self.strict_flags and self._flags.value:
+            raise _capi.AgarclError(-6, "capacity flags 0x%x were raised in at least one arena (it has diverged from the reference's unbounded "
+                                        "containers): read engine.flags() and reset those arenas" % self._flags.value)
+
+    def _info(self, lo=0, hi=None):
+        # "ended": the arenas whose episode ended in this step (and were reset); for those rows "final_return" / "final_length" are the finished
+        # episode's return and length (they keep their last value otherwise); "episode_return" / "episode_steps" run with the current episode
+        return {"episode_steps": self._steps[lo:hi], "episode_return": self._agents(self._ep_return[lo:hi]), "ended": self._mask[lo:hi].view(self.torch.bool),
+                "final_return": self._agents(self._final_return[lo:hi]), "final_length": self._final_length[lo:hi]}
+
+    def _seed(self, seed):
+        if seed is None:
+            return
+        if self.pipe is not None:
+            self.pipe.seed(None, int(seed)) if np.isscalar(seed) else self.pipe.seed(np.asarray(seed, dtype=np.uint32))
+        elif np.isscalar(seed):
+            self.env.seed(base_seed=int(seed))
+        else:
+            self.env.seed(np.asarray(seed, dtype=np.uint32))
+
+    def _reset_part(self, j):
+        p = self._parts[j]
+        p.order_after_current()
+        self._chk(self._L.agarcl_vec_reset(p.engine.h, ctypes.byref(self._spec), ctypes.byref(self._bufs[j])))
+
+    def _step_part(self, j, move, kind):
+        """one host call: the step, the episode bookkeeping with the same-step auto-reset, and the observation of sub-batch j"""
+        p = self._parts[j]
+        self._act_keep[j] = (move, kind)                         # (read when the step kernel executes)
+        p.order_after_current()                                   # the actions were produced on the current stream (no-op when that is the engine's)
+        rc = self._L.agarcl_vec_step(p.engine.h, ctypes.byref(self._spec), ctypes.byref(self._bufs[j]), move.data_ptr(), kind.data_ptr(), ctypes.byref(self._flags))
+        if rc != 0:
+            self._chk(rc)
+        if self._flags.value:
+            self._check_flags()
 
     # ---- the vector-env surface -------------------------------------------------------------------------------------------------
     def reset(self, seed=None, options=None):
         """all arenas start a new episode.  seed: None (the arenas' random streams continue), an int s (arena a gets seed s + a, as
         num_envs separate `env.seed(s + a)` calls would give), or a sequence of num_envs seeds."""
-        if seed is not None:
-            if np.isscalar(seed):
-                self.env.seed(base_seed=int(seed))
-            else:
-                self.env.seed(np.asarray(seed, dtype=np.uint32))
-        self.env.reset()
-        self._steps.zero_(); self._ep_return.zero_()
-        self._started = True
-        return self._observe(), {}
+        self.async_reset(seed)
+        for p in self._parts:
+            p.order_current_after()
+        return self._obs_view(), {}
 
     def step(self, actions):
         """actions = (move, kind): move f32 [N, 2] (or [N, num_agents, 2]) in [-1, 1]^2, kind int [N] (or [N, num_agents]) in {0 none, 1 feed,
-        2 split}; CUDA tensors are used in place, host arrays are uploaded.  Everything below is enqueued on the current CUDA stream; nothing
-        waits for it.  (Values are not range-checked here -- that would need them on the host; the engine clamps nothing either, as the
-        reference's take_action: BaseEnvironment.hpp:162-176.)"""
+        2 split}; CUDA tensors of the right type are used in place, anything else is converted / uploaded.  Everything is enqueued -- on the
+        current CUDA stream, or on the sub-batches' own streams ordered against it -- and nothing waits for it.  (Values are not range-checked
+        here -- that would need them on the host; the engine clamps nothing either, as the reference's take_action: BaseEnvironment.hpp:162-176.)"""
         assert self._started, "reset() must be called before the first step()"
         torch = self.torch
         N, n = self.num_envs, self.num_agents
-        move, kind = actions
-        # (CUDA tensors of the right type are handed to the engine as they are -- the step below reads them in stream order; anything else
-        # is converted / uploaded first)
-        self.env.take_actions(self._as_device(move, torch.float32, (N, n, 2)), self._as_device(kind, torch.int32, (N, n)))
-        self.env.step()
-        # episode bookkeeping on the device, one launch (include/agarcl_vec.h): done = the engine's flag or the episodic cut-off -- compared
-        # BEFORE this step is counted, AgarioEnv.py:111-112 --, the step counters, f64 -> f32 rewards, the episode statistics and the mask
-        # of the arenas that start their next episode now
-        if self._post_args is None:
-            e = self.env
-            self._post_args = (e.dones_u8.data_ptr(), e.rewards.data_ptr(), N, n, int(self.number_of_steps), 1 if self.env_type == 0 else 0,
-                               self._steps.data_ptr(), self._reward.data_ptr(), self._done.data_ptr(), self._mask.data_ptr(),
-                               self._ep_return.data_ptr(), self._final_return.data_ptr(), self._final_length.data_ptr())
-        rc = self._vec_post(self.env.stream_handle, *self._post_args)   # (the stream the engine was bound to: the launch sits between its step and its reset)
-        if rc != 0:
-            raise RuntimeError("agarcl_vec_post failed (%d)" % rc)
-        # same-step auto-reset: arenas whose episode ended (any agent) start the next one now, on the device
-        self.env.reset(mask=self._mask)
-        ended = self._mask.view(torch.bool)
-        obs = self._observe()
-        # "ended": the arenas whose episode ended in this step (and were reset); for those rows "final_return" / "final_length" are the
-        # finished episode's return and length (they keep their last value otherwise); "episode_return" / "episode_steps" run with the
-        # current episode.  All CUDA tensors owned by the env, like the observations.
-        info = {"episode_steps": self._steps, "episode_return": self._agents(self._ep_return), "ended": ended,
-                "final_return": self._agents(self._final_return), "final_length": self._final_length}
-        return obs, self._agents(self._reward), self._agents(self._done), self._agents(self._trunc), info
+        move = self._as_device(actions[0], torch.float32, (N, n, 2)); kind = self._as_device(actions[1], torch.int32, (N, n))
+        if self.sub_batches == 1:
+            self._step_part(0, move, kind)
+            self._parts[0].order_current_after()
+        else:
+            move, kind = move.reshape(N, n, 2), kind.reshape(N, n)
+            for j, (lo, cnt) in enumerate(self._ranges):
+                self._step_part(j, move[lo:lo + cnt], kind[lo:lo + cnt])
+            for p in self._parts:
+                p.order_current_after()
+        return self._obs_view(), self._agents(self._reward), self._agents(self._done), self._agents(self._trunc), self._info()
+
+    # ---- the two halves, per sub-batch (double-buffered sampling) ---------------------------------------------------------------------
+    def async_reset(self, seed=None):
+        """reset() without the wait of the current stream: follow with recv(j) per sub-batch"""
+        self._seed(seed)
+        for j in range(self.sub_batches):
+            self._reset_part(j)
+        self._started = True
+
+    def send(self, actions, j=0):
+        """enqueue the step of sub-batch j: actions = (move [n_j, 2], kind [n_j]) for ITS arenas (ranges[j])"""
+        assert self._started, "reset() / async_reset() must be called before the first send()"
+        lo, cnt = self._ranges[j]
+        n = self.num_agents
+        self._step_part(j, self._as_device(actions[0], self.torch.float32, (cnt, n, 2)), self._as_device(actions[1], self.torch.int32, (cnt, n)))
+
+    def recv(self, j=0):
+        """the current stream waits (on the device) for sub-batch j's last reset / step; returns its rows (views of the full tensors):
+        obs, reward, terminated, truncated, info"""
+        lo, cnt = self._ranges[j]
+        self._parts[j].order_current_after()
+        hi = lo + cnt
+        return self._obs_view(lo, hi), self._agents(self._reward[lo:hi]), self._agents(self._done[lo:hi]), self._agents(self._trunc[lo:hi]), self._info(lo, hi)
+
+    @property
+    def ranges(self):
+        """[(first arena, count)] per sub-batch"""
+        return list(self._ranges)
 
     def close(self):
-        self.env.close()
+        (self.pipe if self.pipe is not None else self.env).close()

@@ -247,22 +247,33 @@ def spawn_ranks(n):
 
 
 def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, Wm, cfg, rand_act, with_obs, with_screen,
-                 gather_mode, gather_obs, gather_block=32, start_mass=0, with_ram=False):
-    """Builds the env, runs Wm untimed + K timed steps, returns the measurements of this rank."""
+                 gather_mode, gather_obs, gather_block=32, start_mass=0, with_ram=False, sub_batches=1, screen=(84, 84, False)):
+    """Builds the env, runs Wm untimed + K timed steps, returns the measurements of this rank.
+    sub_batches > 1: the rank's arenas as that many independent sub-batches on HIP streams of their own (agarcl_pipe_*): every step enqueues
+    all of them, none waits for another's slowest arena, one's observation kernel runs under another's step.  Same arenas, same results."""
     import torch.distributed as dist
     lo, hi = rank * A, (rank + 1) * A  # weak scaling: every GPU owns `A` arenas
-    env = env_cls(A, device=dev_index, strict_flags=False, **cfg)
-    env.seed(agdist.arena_seeds(10000, lo, hi))
-    env.reset(reset_ids=True)
+    if sub_batches > 1:
+        from agarcl_amd.vec_env import PipelinedVecEnvironment
+        penv = PipelinedVecEnvironment(A, sub_batches, device=dev_index, strict_flags=False, **cfg)
+        penv.seed(agdist.arena_seeds(10000, lo, hi)); penv.reset(reset_ids=True)
+        parts, ranges, env = penv.parts, penv.ranges, penv.parts[0]
+    else:
+        penv = None
+        env = env_cls(A, device=dev_index, strict_flags=False, **cfg)
+        env.seed(agdist.arena_seeds(10000, lo, hi))
+        env.reset(reset_ids=True)
+        parts, ranges = [env], [(0, A)]
     if start_mass:   # grown agents, through the product's own snapshot path (the reference's JSON wire format, agarcl_amd/snapshot.py)
         from agarcl_amd import snapshot
         sn = snapshot.save_arena(env.engine, 0, cfg)   # one start state for every arena (seeds and actions differ): enough for a timing
         for pl in sn["players"]:
             for cell in pl["cells"]:
                 cell["mass"] = int(start_mass)
-        for a in range(A):
-            sn["seed"] = 10000 + lo + a
-            snapshot.load_arena(env.engine, a, sn, reset_ids=True)
+        for p_, (l_, n_) in zip(parts, ranges):
+            for a in range(n_):
+                sn["seed"] = 10000 + lo + l_ + a
+                snapshot.load_arena(p_.engine, a, sn, reset_ids=True)
     # synthetic random policy, resident in HBM before the timed region: counter-based per (arena, step)
     g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
     na = cfg["num_agents"]
@@ -272,8 +283,10 @@ def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, 
         act = torch.randint(0, 3, (K + Wm, A, na), generator=g, device=dev, dtype=torch.int32)
     obs = torch.empty((A, 8, 128, 128), dtype=torch.int32, device=dev) if with_obs else None
     want_screen = with_screen or (world > 1 and gather_obs == "screen")
-    scr = torch.empty((A, 84, 84, 3), dtype=torch.uint8, device=dev) if want_screen else None
+    sw, sh, sav = screen
+    scr = torch.empty((A, sh, sw, 4 if sav else 3), dtype=torch.uint8, device=dev) if want_screen else None
     ram = torch.empty((A, na, 152), dtype=torch.float32, device=dev) if with_ram else None
+    torch.cuda.synchronize()                    # (sub-batches run on streams of their own: the policy tensors are complete before they start)
     # Multi-GPU result path (the only exchange there is: arenas never interact).
     #   block: (reward, done) of 32 (--gather-block) consecutive steps -- one contiguous block of the engine's 64-slot result
     #          ring, zero copy -- per asynchronous RCCL gather, double-buffered by ring half: a rollout chunk, as an n-step learner
@@ -284,90 +297,119 @@ def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, 
     SLOTS = 64                                  # agarcl_batch.h AGARCL_PACKED_SLOTS
     assert SLOTS % (2 * BLK) == 0
     eng = env.engine
-    gather = obs_gather = None
+    engs = [p_.engine for p_ in parts]
+    gathers = obs_gather = None
     if world > 1:
-        gather = agdist.ResultGatherer(BLK * A * na if gather_mode == "block" else A * na, dev, depth=2)
+        # one gatherer per sub-batch (its (reward, done) ring is its own engine's memory: zero copy)
+        gathers = [agdist.ResultGatherer(BLK * n_ * na if gather_mode == "block" else n_ * na, dev, depth=2) for (_, n_) in ranges]
         if gather_obs == "screen":
-            obs_gather = agdist.TensorGatherer((A, 84, 84, 3), torch.uint8, dev)
+            obs_gather = agdist.TensorGatherer((A, sh, sw, 4 if sav else 3), torch.uint8, dev)
 
-    # raw pointers of the pre-generated policy output, one pair per step (no tensor indexing inside the timed loop)
-    dx_ptr = [dxdy[k].data_ptr() for k in range(K + Wm)]
-    ac_ptr = [act[k].data_ptr() for k in range(K + Wm)]
+    # raw pointers of the pre-generated policy output, one pair per step and sub-batch (no tensor indexing inside the timed loop)
+    dx_ptr = [[dxdy[k].data_ptr() + l_ * na * 8 for (l_, _) in ranges] for k in range(K + Wm)]
+    ac_ptr = [[act[k].data_ptr() + l_ * na * 4 for (l_, _) in ranges] for k in range(K + Wm)]
+    obs_ptr = [obs.data_ptr() + l_ * 8 * 128 * 128 * 4 for (l_, _) in ranges] if obs is not None else None
+    scr_ptr = [scr.data_ptr() + l_ * sh * sw * (4 if sav else 3) for (l_, _) in ranges] if scr is not None else None
+    ram_ptr = [ram.data_ptr() + l_ * na * 152 * 4 for (l_, _) in ranges] if ram is not None else None
     tps = cfg["ticks_per_step"]
-    slot_of = lambda k: (first_slot + k) % SLOTS   # the ring slot step k writes (the engine's slot counter advances by one per step)
+    slot_of = lambda k: (first_slot + k) % SLOTS   # the ring slot step k writes (every engine's slot counter advances by one per step)
     first_slot = (eng.last_slot() + 1) % SLOTS
+    piped = penv is not None
 
     def one_step(k):
-        if gather is not None and gather_mode == "block":
+        if gathers is not None and gather_mode == "block":
             nxt = slot_of(k)
             if nxt % BLK == 0:
-                gather.wait_slot((nxt // BLK) & 1)   # the engine is about to write this block: the gather that last used its buffer has left
-        eng.step_actions(dx_ptr[k], ac_ptr[k], tps)   # take_actions + step: one host call
-        if obs is not None:
-            eng.grid_obs(128, True, True, True, True, out_ptr=obs.data_ptr(), persistent=True)   # the same tensor every step
-        if ram is not None:
-            eng.ram_obs(16, 16, 8, 16, out_ptr=ram.data_ptr())
-        if scr is not None:
-            if obs_gather is not None:
-                obs_gather.wait()               # the previous step's frames have left before they are overwritten
-            eng.screen_obs(84, 84, out_ptr=scr.data_ptr())
-            if obs_gather is not None:
-                obs_gather.gather(scr)
-        if gather is not None:
+                for g_ in gathers:
+                    g_.wait_slot((nxt // BLK) & 1)   # the engine is about to write this block: the gather that last used its buffer has left
+        for j, e_ in enumerate(engs):
+            e_.step_actions(dx_ptr[k][j], ac_ptr[k][j], tps)   # take_actions + step: one host call
+            if obs is not None:
+                e_.grid_obs(128, True, True, True, True, out_ptr=obs_ptr[j], persistent=True)   # the same tensor every step
+            if ram is not None:
+                e_.ram_obs(16, 16, 8, 16, out_ptr=ram_ptr[j])
+            if scr is not None:
+                if obs_gather is not None and j == 0:
+                    obs_gather.wait()           # the previous step's frames have left before they are overwritten
+                    if piped:
+                        for p_ in parts: p_.order_after_current()
+                e_.screen_obs(sw, sh, out_ptr=scr_ptr[j], agent_view=sav)
+        if obs_gather is not None:
+            if piped:
+                for p_ in parts: p_.order_current_after()
+            obs_gather.gather(scr)
+        if gathers is not None:
             s_ = slot_of(k)
-            if gather_mode == "step":
-                gather.wait_slot(s_ & 1)
-                gather.gather_packed(s_ & 1, env.packed_ring[s_])
-            elif s_ % BLK == BLK - 1:           # RCCL gather of one block of steps of (reward, done) straight from engine memory
-                h_ = s_ // BLK
-                gather.gather_packed(h_ & 1, env.packed_ring[h_ * BLK:(h_ + 1) * BLK].reshape(-1, 2))
+            for j, g_ in enumerate(gathers):
+                ring = parts[j].packed_ring
+                if gather_mode == "step":
+                    g_.wait_slot(s_ & 1)
+                    if piped: parts[j].order_current_after()
+                    g_.gather_packed(s_ & 1, ring[s_])
+                elif s_ % BLK == BLK - 1:           # RCCL gather of one block of steps of (reward, done) straight from engine memory
+                    h_ = s_ // BLK
+                    if piped: parts[j].order_current_after()
+                    g_.gather_packed(h_ & 1, ring[h_ * BLK:(h_ + 1) * BLK].reshape(-1, 2))
 
     def flush():                                # results of a partial last block still go to rank 0
         s_ = eng.last_slot()
-        if gather is not None and gather_mode == "block" and s_ % BLK != BLK - 1:
+        if gathers is not None and gather_mode == "block" and s_ % BLK != BLK - 1:
             h_ = s_ // BLK
-            gather.wait_slot(h_ & 1)
-            gather.gather_packed(h_ & 1, env.packed_ring[h_ * BLK:(h_ + 1) * BLK].reshape(-1, 2))
+            for j, g_ in enumerate(gathers):
+                g_.wait_slot(h_ & 1)
+                if piped: parts[j].order_current_after()
+                g_.gather_packed(h_ & 1, parts[j].packed_ring[h_ * BLK:(h_ + 1) * BLK].reshape(-1, 2))
 
     def drain():
-        if gather is not None:
-            gather.wait_all()
+        for g_ in (gathers or []):
+            g_.wait_all()
         if obs_gather is not None:
             obs_gather.wait()
+
+    def sync_all():
+        for e_ in engs:
+            e_.sync()
+        torch.cuda.synchronize()
 
     for k in range(Wm):
         one_step(k)
     flush(); drain()
-    eng.work(reset=True)                        # (synchronising) the kernels' work counters restart with the timed region
-    for g_ in (gather, obs_gather):
+    for e_ in engs:
+        e_.work(reset=True)                     # (synchronising) the kernels' work counters restart with the timed region
+    for g_ in (gathers or []) + [obs_gather]:
         if g_ is not None:
             g_.reset_stats()
-    # HIP events on the launch stream (the engine's own pair: created once, recorded without the system-scope fence of an ordinary
+    # HIP events on the launch stream(s) (the engine's own pair: created once, recorded without the system-scope fence of an ordinary
     # event record); marking them once here creates them outside the timed region
-    eng.timer_mark(0); eng.timer_mark(1)
-    torch.cuda.synchronize()
+    for e_ in engs:
+        e_.timer_mark(0); e_.timer_mark(1)
+    sync_all()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync_all()
     t0 = time.perf_counter()
-    eng.timer_mark(0)
+    for e_ in engs:
+        e_.timer_mark(0)
     for k in range(Wm, Wm + K):
         one_step(k)
     flush()
-    eng.timer_mark(1)
+    for e_ in engs:
+        e_.timer_mark(1)
     drain()
-    torch.cuda.synchronize()
+    sync_all()
     elapsed_own = time.perf_counter() - t0     # this rank's own time, before it waits for the others
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = eng.timer_elapsed_ms() / K    # HIP events on the launch stream (the engine adopts torch's current stream): avg per step
+    # HIP events on the launch stream (the engine adopts torch's current stream; a sub-batch has its own): avg per step, the slowest sub-batch
+    kernel_ms = max(e_.timer_elapsed_ms() for e_ in engs) / K
     # per-rank record (so that a poor scaling curve can be read off the line): this rank's own wall time and step time by HIP events,
     # the host time it spent waiting for collectives, the payload bytes it contributed
+    gl = gathers or []
     rank_info = {"rank": rank, "ms_per_step": elapsed_own / K * 1e3, "kernel_ms_per_step": kernel_ms,
-                 "gather_wait_ms_total": (gather.wait_s if gather is not None else 0.0) * 1e3 + (obs_gather.wait_s if obs_gather is not None else 0.0) * 1e3,
-                 "result_collectives": gather.calls if gather is not None else 0, "result_bytes_sent": gather.bytes_sent if gather is not None else 0,
+                 "gather_wait_ms_total": sum(g_.wait_s for g_ in gl) * 1e3 + (obs_gather.wait_s if obs_gather is not None else 0.0) * 1e3,
+                 "result_collectives": sum(g_.calls for g_ in gl), "result_bytes_sent": sum(g_.bytes_sent for g_ in gl),
                  "obs_collectives": obs_gather.calls if obs_gather is not None else 0, "obs_bytes_sent": obs_gather.bytes_sent if obs_gather is not None else 0}
     ranks = [rank_info]
     if world > 1:
@@ -376,10 +418,11 @@ def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, 
         elapsed = float(tmax.item())
         ranks = [None] * world
         dist.all_gather_object(ranks, rank_info)
-    res = dict(elapsed=elapsed, kernel_ms=kernel_ms, ranks=ranks, work=eng.work(), flags=eng.flags(),
-               counts=eng.counts().astype(np.float64).mean(axis=0), players=eng.players, fused=int(eng.L.agarcl_debug_fused(eng.h)),
-               pellet_cap=(cfg["num_pellets"] + 63) // 64 * 64)
-    env.close()
+    counts = sum(e_.counts().astype(np.float64).sum(axis=0) for e_ in engs) / float(A)
+    res = dict(elapsed=elapsed, kernel_ms=kernel_ms, ranks=ranks, work=sum(e_.work() for e_ in engs), flags=np.concatenate([e_.flags() for e_ in engs]),
+               counts=counts, players=eng.players, fused=int(eng.L.agarcl_debug_fused(eng.h)),
+               pellet_cap=(cfg["num_pellets"] + 63) // 64 * 64, sub_batches=len(engs), concurrent=(penv.concurrent if penv is not None else 1))
+    (penv if penv is not None else env).close()
     return res
 
 

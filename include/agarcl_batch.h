@@ -232,6 +232,42 @@ int agarcl_players_per_arena(agarcl_env *env);
 int64_t agarcl_state_bytes(agarcl_env *env);
 
 
+/* ---- stream ordering (the env's launches against work of the caller's own streams) --------------------------------------- */
+/* the hipStream_t the env currently launches on (its private non-blocking stream until agarcl_set_stream adopts another) */
+void *agarcl_get_stream(agarcl_env *env);
+/* the env's stream waits (on the device; the host does not block) for everything enqueued so far on `producer_stream` -- e.g. the policy's
+ * kernels that wrote the action tensors of the next agarcl_step_actions.  NULL = the legacy default stream. */
+int agarcl_stream_wait(agarcl_env *env, void *producer_stream);
+/* `consumer_stream` waits (on the device) for everything the env has enqueued so far -- e.g. before a learner reads rewards / observations */
+int agarcl_stream_signal(agarcl_env *env, void *consumer_stream);
+
+/* ---- sub-batch pipelining ------------------------------------------------------------------------------------------------
+ * replaces: the reference's vectorised runner, which lets every engine run ahead on its own pool thread and waits once at the end
+ * (/root/reference/agario/bots/benchmark.cpp:149-167: pool.schedule per game, one pool.wait()).  An agarcl_env steps ALL its arenas in one
+ * launch, so every step lasts as long as its slowest arena while the wave slots of the finished ones stand empty.  A pipe splits
+ * `num_arenas` into `sub_batches` contiguous arena ranges, each a complete agarcl_env (agarcl_pipe_env: use it with every call of this
+ * header) on a HIP stream of its own; the streams are checked at creation to really execute concurrently (distinct hardware queues:
+ * agarcl_pipe_concurrent), so sub-batch B's launch fills the SIMDs during A's tail and A's observation kernel runs under B's step.
+ * Arenas never interact and seeds go by the GLOBAL arena index (agarcl_pipe_seed), so arena `first_j + a` of the pipe computes exactly
+ * what arena `first_j + a` of one agarcl_env over all arenas computes -- only the waiting differs.
+ * The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them the legacy default stream's):
+ * more than 3 concurrent sub-batches need that variable raised in the process environment before the first HIP call. */
+typedef struct agarcl_pipe agarcl_pipe;
+int agarcl_pipe_create(const agarcl_config *cfg, int32_t num_arenas, int32_t sub_batches, int32_t device, agarcl_pipe **out);
+int agarcl_pipe_destroy(agarcl_pipe *pipe);
+int agarcl_pipe_sub_batches(agarcl_pipe *pipe);
+/* the j-th sub-batch: an agarcl_env over the arenas [first, first + count) of the pipe (agarcl_pipe_range); owned by the pipe */
+agarcl_env *agarcl_pipe_env(agarcl_pipe *pipe, int32_t j);
+int agarcl_pipe_range(agarcl_pipe *pipe, int32_t j, int32_t *first_arena, int32_t *count);
+/* agarcl_seed over the whole pipe: seeds_host[num_arenas] by global arena index; NULL -> arena i gets base_seed + i */
+int agarcl_pipe_seed(agarcl_pipe *pipe, const uint32_t *seeds_host, uint32_t base_seed);
+/* how many of the sub-batch streams were verified at creation to execute concurrently with each other (== sub_batches unless the
+ * runtime ran out of hardware queues; a smaller number only costs overlap, never results) */
+int agarcl_pipe_concurrent(agarcl_pipe *pipe);
+/* waits for every sub-batch's stream (the reference's single pool.wait()) */
+int agarcl_pipe_sync(agarcl_pipe *pipe);
+
+
 /* ---- diagnostics (not part of the drop-in surface; used by tests/ and scripts/) --------------------------------------- */
 /* 1 = the single-launch fused step is in use, 0 = the two-kernel step (the choice never changes results) */
 int agarcl_debug_fused(agarcl_env *env);

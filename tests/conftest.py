@@ -53,6 +53,6 @@ def hip_engine_cls():
     (hipcc, ~1.5 min); a missing library or GPU makes every -m gpu test fail loudly -- there is nothing to fall back to."""
     from agarcl_amd import _capi, build as hip_build
     if not os.path.exists(_capi.HIP_SO):
-        hip_build.build(); hip_build.build_vecpost()
+        hip_build.build()
     _capi.hip_lib()
     return _capi.BatchedEngine

@@ -53,13 +53,19 @@ def test_product_never_imports_oracle():
                 assert "libagar_oracle" not in txt and "libagar_ref" not in txt, f
 
 
-def test_vec_library_exports_its_header():
-    """include/agarcl_vec.h -> agarcl_amd/libagarcl_vec.so (the vector env's bookkeeping launch): builds, loads, exports the symbol"""
+def test_vec_header_and_binding_agree():
+    """include/agarcl_vec.h (one host call per vector step) is implemented by the same library: header, binding and exports agree"""
     import ctypes
-    from agarcl_amd import build
+    from agarcl_amd import _capi, build
     src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "agarcl_vec.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(agarcl_[a-z_0-9]+)\s*\(", src)))
-    assert names == ["agarcl_vec_post"]
-    lib = ctypes.CDLL(build.build_vecpost())
+    assert names == sorted(n for n, _, _ in _capi.VEC_SYMBOLS) == ["agarcl_vec_reset", "agarcl_vec_step"]
+    build.build()
+    lib = ctypes.CDLL(_capi.HIP_SO)
     for name in names:
         assert hasattr(lib, name), name
+    # the structures the binding passes are the header's: field for field
+    fields = lambda body: [f.split()[-1].lstrip("*").split("[")[0] for f in re.findall(r"([^;{}]+);", body)]
+    for cname, cls in (("agarcl_vec_spec", _capi.VecSpec), ("agarcl_vec_buffers", _capi.VecBuffers)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, flags=re.S).group(1)
+        assert fields(body) == [f[0] for f in cls._fields_], cname

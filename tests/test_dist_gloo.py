@@ -127,12 +127,23 @@ def _worker(rank, world, port, q):
             got = tg.gathered().reshape(world, A, 6, 6, 3)
             for r in range(world):
                 ok = ok and bool((got[r] == 10 * r + step).all())
-    # unequal shards are refused at construction (dist.gather needs equal contributions)
-    try:
-        agdist.ResultGatherer(3 + rank, torch.device("cpu"))
-        ok = False
-    except ValueError:
-        pass
+    # unequal shards (shard_bounds hands the first ranks one arena more): padded to the largest one, the padding dropped on rank 0
+    total = 2 * 4 + 1
+    lo, hi = agdist.shard_bounds(total, world, rank)
+    gu = agdist.ResultGatherer(hi - lo, torch.device("cpu"), depth=2)
+    ok = ok and gu.n_max == 5 and gu.sizes == [5, 4]
+    for k in range(4):
+        rewards = torch.arange(lo, hi, dtype=torch.float64) * 3 + k
+        slot = gu.pack(k, rewards, torch.zeros(hi - lo, dtype=torch.uint8))
+        gu.wait_all()
+        if rank == 0:
+            got = gu.gathered(slot)
+            ok = ok and tuple(got.shape) == (total, 2) and torch.equal(got[:, 0], torch.arange(0, total, dtype=torch.float32) * 3 + k)
+        own = torch.stack([torch.arange(lo, hi, dtype=torch.float32) + 100 * k, torch.ones(hi - lo)], dim=1)     # the zero-copy entry point
+        gu.gather_packed(k & 1, own); gu.wait_slot(k & 1)
+        if rank == 0:
+            got = gu.gathered(k & 1)
+            ok = ok and torch.equal(got[:, 0], torch.arange(0, total, dtype=torch.float32) + 100 * k) and bool((got[:, 1] == 1).all())
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
