@@ -92,6 +92,8 @@ SYMBOLS = [
     ("agarcl_pipe_seed", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     ("agarcl_pipe_concurrent", C.c_int, [C.c_void_p]),
     ("agarcl_pipe_sync", C.c_int, [C.c_void_p]),
+    ("agarcl_pipe_fork", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("agarcl_pipe_join", C.c_int, [C.c_void_p, C.c_void_p]),
     ("agarcl_debug_fused", C.c_int, [C.c_void_p]),
     ("agarcl_debug_qinfo", C.c_int, [C.c_void_p, C.c_void_p]),
     ("agarcl_debug_prof", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
@@ -456,6 +458,14 @@ class PipelinedEngine:
 
     def sync(self):
         self._chk(self.L.agarcl_pipe_sync(self.p))
+
+    def fork(self, producer_stream):
+        """every sub-batch's stream waits, on the device, for everything enqueued so far on `producer_stream` (hipStream_t as int): one call"""
+        self._chk(self.L.agarcl_pipe_fork(self.p, C.c_void_p(int(producer_stream))))
+
+    def join(self, consumer_stream):
+        """`consumer_stream` waits, on the device, for everything every sub-batch has enqueued so far: one call"""
+        self._chk(self.L.agarcl_pipe_join(self.p, C.c_void_p(int(consumer_stream))))
 
     def close(self):
         if getattr(self, "p", None) and self.p.value:

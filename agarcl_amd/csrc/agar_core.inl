@@ -87,6 +87,17 @@ AG_DEV float ag_sqrtf_lean(float x) {
 
 #include "agar_libm.inl"
 
+#if defined(AGAR_CPU_EMU) && defined(AG_DEBUG_FLAG8)
+#define AG_DBG8(what, a, b) fprintf(stderr, "flag 8: %s %d > %d\n", what, (int)(a), (int)(b))
+#else
+#define AG_DBG8(what, a, b) do { } while (0)
+#endif
+#if defined(AGAR_CPU_EMU) && defined(AG_DEBUG_FLAG8)
+static int ag_dbg8_max = 0;
+#define AG_DBG8MAX(v) do { if ((int)(v) > ag_dbg8_max) { ag_dbg8_max = (int)(v); if (ag_dbg8_max > 256) fprintf(stderr, "max events %d\n", ag_dbg8_max); } } while (0)
+#else
+#define AG_DBG8MAX(v) do { } while (0)
+#endif
 #define AG_RARE(x) __builtin_expect(!!(x), 0)  // keeps rare branches out of the hot instruction stream
 
 // Pointers fetched from the HBM-resident descriptor are generic to the compiler (flat_load/flat_store); every
@@ -188,10 +199,8 @@ AG_DEV unsigned d2u_x86(double v) { return (unsigned)(long long)v; }
 AG_DEV unsigned clamp_mass(unsigned m) { return m > AG_CELL_MIN_SIZE ? m : AG_CELL_MIN_SIZE; }  // R: Entities.hpp:171-177
 
 // ---- LDS layout (bytes).  Everything but the pellet base is a compile-time constant for P == 1 -----
-#define L_EVP 0                                   // int[AG_EV_CAP]   pellet eat events of the tick
-#define L_EVV (L_EVP + 4 * AG_EV_CAP)             // int[AG_EVV_CAP]
-#define L_CAND (L_EVV + 4 * AG_EVV_CAP)           // unsigned[AG_CAND_CAP] ordered-replay keys
-#define L_TMP (L_CAND + 4 * AG_CAND_CAP)          // int[128] mailbox / scratch
+#define L_EVV 0                                    // int[AG_EVV_CAP]  virus eat events of the tick
+#define L_TMP (L_EVV + 4 * AG_EVV_CAP)             // int[128] mailbox / scratch
 #define L_NEW (L_TMP + 4 * 128)                    // created cells [CF_FIELDS][AG_CC]; also the RNG draw buffer (128 x u64)
 #define L_PLS (L_NEW + 4 * CF_FIELDS * AG_CC)     // int[P][PL_WORDS]
 #define CELL_STRIDE (4 * (CF_FIELDS + 3) * AG_CC) // per player: 9 fields + (cached-for mass, radius, max speed)
@@ -201,14 +210,21 @@ static inline
 __host__ __device__ inline
 #endif
 // behind the cells: the arena's viruses (x, y, radius, mass: a read cache, see stage_viruses) and ejected foods (x, y, vx, vy: the working
-// copy of a launch, see Foods) -- VC and FC entries each (AgDims)
-size_t ag_lds_layout(int P, int VC, int FC, int *cells_off, int *vir_off = nullptr, int *food_off = nullptr) {
+// copy of a launch, see Foods) -- VC and FC entries each (AgDims) --, then the two arrays whose size follows the arena's pellet DENSITY
+// (AgDims::EC / KC): the pellet eat events of the tick (int[EC]) and the candidate records of one cell's ordered replay (2 words x KC; also the 64
+// (x, y) pairs staged by add_pellets).  The reference's containers are unbounded (Engine.hpp:976-1009: pellets_to_remove); a mass-1000 cell
+// in an 80 x 80 arena with 1300 pellets has 200 of them within its radius and a handful of such cells exceeded the 256 events these arrays
+// held at fixed offsets until round 4 -- 3-5 % of the soak's default draw ended flagged.  At the end of the block their size costs the
+// default arenas nothing (EC = 256 as before) and the dense ones LDS, not correctness.
+size_t ag_lds_layout(int P, int VC, int FC, int EC, int KC, int *cells_off, int *vir_off = nullptr, int *food_off = nullptr, int *evp_off = nullptr, int *cand_off = nullptr) {
   int co = L_PLS + 4 * P * PL_WORDS;
   if (cells_off) *cells_off = co;
-  int vo = co + P * CELL_STRIDE, fo = vo + 16 * VC;
+  int vo = co + P * CELL_STRIDE, fo = vo + 16 * VC, eo = fo + 16 * FC, ko = eo + 4 * EC;
   if (vir_off) *vir_off = vo;
   if (food_off) *food_off = fo;
-  return (size_t)fo + (size_t)16 * (size_t)FC;
+  if (evp_off) *evp_off = eo;
+  if (cand_off) *cand_off = ko;
+  return (size_t)ko + (size_t)8 * (size_t)KC;
 }
 
 struct Cells {  // LDS arrays of one player
@@ -283,6 +299,11 @@ template <int NS, bool AV> struct AgCtx {
 };
 
 template <int NS, bool AV> AG_DEV int *L_I(const AgCtx<NS, AV> &c, int off) { return (int *)(c.lds + off); }
+// the two density-sized arrays behind the foods (ag_lds_layout): formed where they are used -- rare paths -- instead of living in the context
+template <int NS, bool AV> AG_DEV int ag_evp_off(const AgCtx<NS, AV> &c) { return c.food_off + 16 * c.FC; }
+template <int NS, bool AV> AG_DEV int ag_cand_off(const AgCtx<NS, AV> &c) { return c.food_off + 16 * c.FC + 4 * c.gs->d.EC; }
+// the arena's event list in HBM: [0, EC) = the LDS events as arena_store exports them (agarcl_get_events), [EC, EC + EX) = the spill area
+template <int NS, bool AV> AG_DEV AG_GLOBAL int32_t *g_evp(const AgCtx<NS, AV> &c) { return (AG_GLOBAL int32_t *)(c.gs->ev_p + (size_t)c.arena * (size_t)(c.gs->d.EC + c.gs->d.EX)); }
 template <int NS, bool AV> AG_DEV int *PLS(const AgCtx<NS, AV> &c, int p) { return (int *)(c.lds + L_PLS) + p * PL_WORDS; }
 template <int NS, bool AV> AG_DEV Cells cells_of(const AgCtx<NS, AV> &c, int p) {
   float *b = (float *)(c.lds + c.cells_off + p * CELL_STRIDE);
@@ -518,7 +539,7 @@ template <int NS, bool AV> AG_DEV void arena_store(AgCtx<NS, AV> &c) {
   auto gpl = g_pl(c);
   AG_LANES(i, c.P * PL_WORDS) gpl[AG_TW(i)] = PLS(c, 0)[i];
   int nevp = SR(c, AR_NEVP), nevv = SR(c, AR_NEVV);
-  if (nevp > 0) { auto ge = (AG_GLOBAL int32_t *)(c.gs->ev_p + (size_t)c.arena * AG_EV_CAP); int lim = nevp < AG_EV_CAP ? nevp : AG_EV_CAP; AG_LANES(i, lim) ge[i] = L_I(c, L_EVP)[i]; }
+  if (nevp > 0) { const int EC = c.gs->d.EC; auto ge = g_evp(c); int lim = nevp < EC ? nevp : EC; AG_LANES(i, lim) ge[i] = L_I(c, ag_evp_off(c))[i]; }
   if (nevv > 0) { auto ge = (AG_GLOBAL int32_t *)(c.gs->ev_v + (size_t)c.arena * AG_EVV_CAP); int lim = nevv < AG_EVV_CAP ? nevv : AG_EVV_CAP; AG_LANES(i, lim) ge[i] = L_I(c, L_EVV)[i]; }
   int nv = SR(c, AR_NVIR), nf = SR(c, AR_NFOOD);
   AG_SERIAL { auto cn = (AG_GLOBAL int32_t *)(c.gs->counts + (size_t)c.arena * 4); cn[0] = np; cn[1] = nv; cn[2] = nf; cn[3] = total_cells; }
@@ -609,7 +630,7 @@ template <int NS, bool AV> AG_DEV void add_pellets(AgCtx<NS, AV> &c, int n) {
   if (np + n > c.PC) { flag(c, 64u); n = c.PC - np; if (n <= 0) return; }
   float r = radius_of(c, AG_PELLET_MASS);
   auto gid = g_pid(c);
-  float *stage = (float *)L_I(c, L_CAND);  // 64 (x,y) pairs; the candidate list is idle during regen
+  float *stage = (float *)L_I(c, ag_cand_off(c));  // 64 (x,y) pairs; the candidate list is idle during regen
   float two_r = 2.0f * r; float span = c.gs->g.W - two_r;
   const uint64_t *rb = (const uint64_t *)(c.lds + L_NEW);
   for (int done = 0; done < n; done += 64) {  // random_location(r) x n in sequence.  R: Engine.hpp:143-148, 418-424
@@ -1286,7 +1307,7 @@ template <int NS, bool AV> AG_DEV bool virus_collisions(AgCtx<NS, AV> &c, const 
       SW(c, AR_IDC, idc + num_new); c.ncreated = nc0 + num_new;
     }
     int ne = SR(c, AR_NEVV);
-    if (ne < AG_EVV_CAP) { AG_SERIAL { L_I(c, L_EVV)[ne] = vi; } } else flag(c, 8u);
+    if (ne < AG_EVV_CAP) { AG_SERIAL { L_I(c, L_EVV)[ne] = vi; } } else { flag(c, 8u); AG_DBG8("virus events", ne, AG_EVV_CAP); }
     SW(c, AR_NEVV, ne + 1);
     ag_lds_order();
     return true;
@@ -1331,24 +1352,25 @@ template <int NS, bool AV> AG_DEV int pellets_eat(AgCtx<NS, AV> &c, const Cells 
       if (cK <= K) break;
       K = cK;
     }
-    if (K > AG_CAND_CAP / 2) { flag(c, 8u); }
+    const int EC = c.gs->d.EC, KC = c.gs->d.KC, EX = c.gs->d.EX;
+    if (K > KC) { flag(c, 8u); AG_DBG8("cands", K, KC); }
     // candidate records (key, squared distance to the cell) in LDS, ascending index; key = (bucket visit rank) * capacity + index.  The cell
     // does not move while it eats -- only its radius grows -- so the distance the replay compares is the one computed here (the same fp32
     // operations on the same operands as sqr_dist in the replay would be), and the index is the key's low bits: 8 bytes per candidate
     const unsigned PC = (unsigned)c.PC;   // NS * 64: a power of two
-    unsigned *cand = (unsigned *)L_I(c, L_CAND);
+    unsigned *cand = (unsigned *)L_I(c, ag_cand_off(c));
     pel_launder(c);
     int ncand = pel_compact(c, [&](float qx, float qy, int) { return hit(qx, qy, rrK); }, [&](float qx, float qy, int i, int rank) {
-      if (rank < AG_CAND_CAP / 2) {
+      if (rank < KC) {
         int ddx = f2i(qx) / AG_PELLET_GRID - gx, ddy = f2i(qy) / AG_PELLET_GRID - gy;
         cand[2 * rank] = (unsigned)((ddx + 1) * 3 + (ddy + 1)) * PC + (unsigned)i;
         cand[2 * rank + 1] = (unsigned)f2u(sqr_dist(x, y, qx, qy));
       }
     });
-    if (ncand > AG_CAND_CAP / 2) ncand = AG_CAND_CAP / 2;
+    if (ncand > KC) ncand = KC;
     ag_lds_order();
     int ne0 = SR(c, AR_NEVP);
-    int *T = L_I(c, L_TMP); int *evp = L_I(c, L_EVP);
+    int *T = L_I(c, L_TMP); int *evp = L_I(c, ag_evp_off(c)); auto gsp = g_evp(c) + EC;
     auto lut_r = g_lut_r(c);
     AG_SERIAL {
       for (int a = 1; a < ncand; a++) {  // insertion sort of the 2-word records by key
@@ -1360,7 +1382,10 @@ template <int NS, bool AV> AG_DEV int pellets_eat(AgCtx<NS, AV> &c, const Cells 
       for (int a = 0; a < ncand; a++) {
         float rc = lut(lut_r, mc); float rrc = rc * rc;
         if (rrc >= u2f((int)cand[2 * a + 1])) {
-          if (ne < AG_EV_CAP) evp[ne] = (int)(cand[2 * a] & (PC - 1u));
+          // (the reference's pellets_to_remove is unbounded and holds one entry per EAT, not per pellet: a pellet under k overlapping cells is
+          // eaten k times in a tick -- the stale-index quirk -- so a mass-1000 agent split into 13 cells in an 80 x 80 arena with 1300 pellets
+          // produced 16 861 events in one tick (4 players: 37 821).  Beyond the LDS list they go to the arena's spill area in HBM, where one exists)
+          if (ne < EC) evp[ne] = (int)(cand[2 * a] & (PC - 1u)); else if (ne - EC < EX) gsp[ne - EC] = (int)(cand[2 * a] & (PC - 1u));
           ne++; mc = clamp_mass(mc + AG_PELLET_MASS);
         }
       }
@@ -1368,7 +1393,8 @@ template <int NS, bool AV> AG_DEV int pellets_eat(AgCtx<NS, AV> &c, const Cells 
     }
     ag_lds_order();
     int ne1 = ag_uni(T[0]);
-    if (ne1 > AG_EV_CAP) flag(c, 8u);
+    if (ne1 > EC + EX) { flag(c, 8u); AG_DBG8("events", ne1, EC + EX); }
+    AG_DBG8MAX(ne1);
     SW(c, AR_NEVP, ne1);
     eaten_total += ne1 - ne0;
   }
@@ -1686,15 +1712,76 @@ template <int NS, bool AV> AG_DEV void tick_player(AgCtx<NS, AV> &c, int p) {
   AG_T(c, 8);
 }
 
+// ---- the turns of all "simple" players at once (several players per arena, non-bot ticks) -----------------------------------------------------
+// A player's turn (tick_player) is a chain of small steps -- load its words, virus test, pellet scan, totals, food test, eject / split
+// cooldowns, recombine, decay, store -- each a few instructions for one to three active lanes behind an LDS round trip: ~3000 cycles per
+// player and tick, one player after the other (scripts/gpu_phase_multi.py: 30 single-cell players = 365 k of 589 k cycles per 4-tick launch).
+// For most players on most ticks every one of those steps is a no-op: ONE cell, below the mass a virus can be eaten at (or no virus), no pellet
+// within its radius, no eject / split due, no ejected food anywhere, not a decay tick.  Such a turn only counts: elapsed + 1, the cooldowns - 1,
+// the min / highest mass of the cell, the arena's mass sum.  It reads and writes nothing but the player's own words and cell and nothing another
+// player's turn looks at (the kinematics have been done for everybody by move_all_players: this runs on non-bot ticks only), so all such turns
+// are performed here, a lane per player, whatever their place in the iteration order; dead players (no turn at all) are ticked off too.
+// Returns the mask, by player slot, of the players arena_tick need not visit.  Every predicate is the one tick_player's own steps test
+// (pellets_eat's fast path, virus_collisions' mass bound, maybe_emit_food / maybe_split, decay), on the same values.
+template <int NS, bool AV> AG_DEV unsigned simple_turns(AgCtx<NS, AV> &c) {
+  const int P = c.P;
+  if (SR(c, AR_NFOOD) != 0) return 0u;   // ejected food somewhere: the per-player food test decides (Engine.hpp:520-525)
+  const int nv = SR(c, AR_NVIR), np = SR(c, AR_NPEL);
+  const bool decays = c.gs->g.mass_decay != 0;
+  unsigned dead = 0u;
+  UBlock bx, by, br;
+  ub_fill(bx, [&](int l) { return l < P ? f2u(cells_of(c, l).x[0]) : 0; });
+  ub_fill(by, [&](int l) { return l < P ? f2u(cells_of(c, l).y[0]) : 0; });
+  ub_fill(br, [&](int l) { if (l >= P) return 0; const Cells s = cells_of(c, l); return f2u(cell_rad(c, s, 0)); });
+  unsigned cand = wave_or(P, [&](int p) -> unsigned {
+    const int *PL = PLS(c, p); const int n = PL[PL_NCELLS];
+    if (n != 1) return 0u;
+    const unsigned m = cells_of(c, p).m[0];
+    const int el = PL[PL_ELAPSED] + 1, fcd = PL[PL_FEED_CD], scd = PL[PL_SPLIT_CD], act = PL[PL_ACTION];
+    const bool ok = m < AG_MAX_MASS && (nv == 0 || m < 111u) && !(decays && el % 60 == 0) &&
+                    !(act == 1 && (fcd > 0 ? fcd - 1 : fcd) == 0) && !(act == 2 && (scd > 0 ? scd - 1 : scd) == 0);
+    return ok ? 1u << p : 0u;
+  });
+  dead = wave_or(P, [&](int p) -> unsigned { return PLS(c, p)[PL_NCELLS] == 0 ? 1u << p : 0u; });
+  if (np > 0) {
+    for (unsigned todo = cand; todo; todo &= todo - 1u) {   // pellets_eat's fast path for the player's one cell: nothing inside the current radius
+      const int p = __builtin_ctz(todo);
+      const float x = u2f(ub_get(bx, p)), y = u2f(ub_get(by, p)), r0 = u2f(ub_get(br, p)); const float rr0 = r0 * r0;
+      const int gx = f2i(x) / AG_PELLET_GRID, gy = f2i(y) / AG_PELLET_GRID;
+      const bool hit = pel_any(c, [&](float qx, float qy, int) {
+        bool ok = rr0 >= sqr_dist(x, y, qx, qy);
+        if constexpr (!AV) { int ddx = f2i(qx) / AG_PELLET_GRID - gx, ddy = f2i(qy) / AG_PELLET_GRID - gy; ok = ok && ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1; }
+        return ok;
+      });
+      if (hit) cand &= ~(1u << p);
+      (void)gx; (void)gy;
+    }
+  }
+  if (cand) {
+    AG_LANES(p, P) {
+      if ((cand >> p) & 1u) {
+        int *PL = PLS(c, p); const unsigned m = cells_of(c, p).m[0];
+        PL[PL_ELAPSED] += 1; PL[PL_MIN_MASS] = (int)m;
+        if ((unsigned)PL[PL_HIGHEST_MASS] < m) PL[PL_HIGHEST_MASS] = (int)m;
+        const int fcd = PL[PL_FEED_CD], scd = PL[PL_SPLIT_CD];
+        if (fcd > 0) PL[PL_FEED_CD] = fcd - 1;
+        if (scd > 0) PL[PL_SPLIT_CD] = scd - 1;
+      }
+    }
+    c.mass_sum += (unsigned)wave_sum(P, [&](int p) { return ((cand >> p) & 1u) ? (int)cells_of(c, p).m[0] : 0; });
+    ag_lds_order();
+  }
+  return cand | dead;
+}
+
 // ---- end-of-tick bookkeeping.  R: Engine.hpp:1002-1009, 1253-1260, 150-200 ------------------------------------
 template <int NS, bool AV> AG_DEV void remove_pellets(AgCtx<NS, AV> &c) {
   int ne = SR(c, AR_NEVP);
   if (ne == 0) return;
   int n = SR(c, AR_NPEL);
-  const int *evp = L_I(c, L_EVP); auto gid = g_pid(c);
-  int lim = ne < AG_EV_CAP ? ne : AG_EV_CAP;
-  for (int e = 0; e < lim; e++) {  // wave-level replay of the stale-index swap-pop
-    int idx = ag_uni(evp[e]);
+  const int *evp = L_I(c, ag_evp_off(c)); auto gid = g_pid(c);
+  const int EC = c.gs->d.EC; int lim = ne < EC ? ne : EC;
+  auto pop = [&](int idx) {   // wave-level replay of the stale-index swap-pop
     if (n > 1 && idx < n - 1) {  // std::swap(p[idx], p.back()): the half parked at the back is popped and never read again
       int b = n - 1;
       pel_move(c, idx, b);
@@ -1702,6 +1789,21 @@ template <int NS, bool AV> AG_DEV void remove_pellets(AgCtx<NS, AV> &c) {
       ag_mem_fence();
     }
     if (n >= 1) n--;
+  };
+  for (int e = 0; e < lim; e++) pop(ag_uni(evp[e]));
+  if (AG_RARE(ne > EC)) {   // the tick's further events, from the arena's spill area in HBM (dense arenas only): 64 at a time, a lane each
+    const int EX = c.gs->d.EX, tot = ne < EC + EX ? ne : EC + EX;
+    auto gsp = g_evp(c) + EC;
+    ag_mem_fence();
+    for (int base = EC; base < tot; base += 64) {
+      const int cnt = tot - base < 64 ? tot - base : 64;
+#ifdef AGAR_CPU_EMU
+      for (int j = 0; j < cnt; j++) pop(gsp[base - EC + j]);
+#else
+      const int mine = AG_LANE < cnt ? gsp[base - EC + AG_LANE] : 0;
+      for (int j = 0; j < cnt; j++) pop(__builtin_amdgcn_readlane(mine, j));
+#endif
+    }
   }
   // keep the padding invariant: everything at index >= n is a sentinel again
   int n0 = SR(c, AR_NPEL);
@@ -2087,7 +2189,7 @@ template <int NS, bool AV> AG_DEV int quiet_run(AgCtx<NS, AV> &c, int max_ticks)
   RegPel<NS, AV> pel{c};
   quiet_ticks<AV>(q, c.gs->g, g_lut_r(c), g_lut_ms(c), (const AG_GLOBAL uint64_t *)g_mt(c), pel, max_ticks);
   if (q.done == 0) return 0;
-  int *evp = L_I(c, L_EVP);
+  int *evp = L_I(c, ag_evp_off(c));
   AG_SERIAL {
     s.x[0] = q.x; s.y[0] = q.y; s.vx[0] = q.vx; s.vy[0] = q.vy; s.sx[0] = q.svx; s.sy[0] = q.svy;
     s.m[0] = q.m; s.cmc[0] = q.m; s.crad[0] = q.r; s.cms[0] = q.hi;
@@ -2116,7 +2218,9 @@ template <int NS, bool AV> AG_DEV void arena_tick(AgCtx<NS, AV> &c) {
   if (c.P > 1 && SR(c, AR_TICKS) % 10 != 0) move_all_players(c);
 #endif
   AG_T(c, 1);
-  for (int k = 0; k < c.P; k++) tick_player(c, SR(c, AR_ORDER0 + k));
+  // (several players, kinematics done: the turns that are pure bookkeeping are performed for all such players at once -- simple_turns)
+  const unsigned done_ = c.moved_all ? simple_turns(c) : 0u;
+  for (int k = 0; k < c.P; k++) { const int p_ = SR(c, AR_ORDER0 + k); if (!((done_ >> p_) & 1u)) tick_player(c, p_); }
   remove_pellets(c);
   remove_viruses(c);
   AG_T(c, 13);

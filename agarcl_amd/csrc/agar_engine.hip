@@ -144,7 +144,7 @@ template <int NS, bool AV> AG_DEV void ag_ctx_init(AgCtx<NS, AV> &c, const AgSta
   c.gs = gs; c.arena = arena; c.lds = lds; c.act_dxdy = (const AG_GLOBAL float *)act_dxdy; c.act = (const AG_GLOBAL int32_t *)act;
   c.P = gs->d.P; c.PC = gs->d.PC; c.ts_lg = gs->d.ts_lg;
   c.VC = gs->d.VC; c.FC = gs->d.FC;
-  ag_lds_layout(c.P, c.VC, c.FC, &c.cells_off, &c.vir_off, &c.food_off);
+  ag_lds_layout(c.P, c.VC, c.FC, gs->d.EC, gs->d.KC, &c.cells_off, &c.vir_off, &c.food_off);
   c.food_dirty = false;
   c.ncreated = 0; c.pel_dirty = false; c.pel_loaded = false; c.pel_all = false; PEL_CLEAN(c);
 }
@@ -667,8 +667,21 @@ static int create_env(const agarcl_config *cfg, int32_t num_arenas, int32_t devi
   { const char *t = getenv("AGARCL_TILE_LG"); if (t && (t[0] == '0' || t[0] == '6') && !t[1]) d.ts_lg = t[0] - '0'; }
   if (d.P > AG_MAX_PLAYERS) { agarcl_destroy(e); return fail(AGARCL_E_UNSUPPORTED, "too many players per arena"); }
   if (cfg->cap_cells != 0 && cfg->cap_cells != AG_CC) { agarcl_destroy(e); return fail(AGARCL_E_INVALID, "cap_cells is fixed at 32 in this build"); }
+  // Pellet eat events of a tick (the reference's pellets_to_remove, Engine.hpp:976-1009: unbounded, one entry per EAT) and the candidate records
+  // of one cell's ordered replay.  LDS holds 256 events and 256 candidates -- for every arena with <= 0.016 pellets per unit area (the
+  // 1000 x 1000 / 1000-pellet default: 0.001; C1: 0.008) that is all there is, as before.  A DENSE arena (the gym "trivial" preset 50 x 50 / 200:
+  // 0.08; the soak's 80 x 80 / 1300 corner: 0.2) gets candidates up to its pellet capacity (one cell cannot reach more pellets than exist) and a
+  // spill area in HBM for the events beyond 256: a pellet under k overlapping cells is eaten k times in one tick (the stale-index quirk) -- a
+  // mass-1000 agent split into 13 cells produced 16 861 events in ONE tick of an 80 x 80 / 1300 arena, four players 37 821 (measured on the
+  // emulation).  Spill = 64 eats per pellet slot, at most 65 536 entries (256 KB per arena, only there).
+  { const double dens = (double)npel / ((double)g.W * (double)g.W); const bool dense = dens > 0.016;
+    const int pc = d.PC <= 256 ? 256 : d.PC <= 512 ? 512 : d.PC <= 1024 ? 1024 : 2048;
+    d.EC = AG_EV_MIN; d.KC = dense ? pc : AG_EV_MIN; d.EX = dense ? (64 * pc < 65536 ? 64 * pc : 65536) : 0; }
+  // ejected foods live in LDS during a launch, 16 bytes each: 128 keep the single-player layout within the 10 KB per wavefront that 16 resident
+  // wavefronts per CU leave (nominal play: <= ~60 in 20k-tick mode-6 roll-outs); arenas with many players feed more: 16 per player
+  if (cfg->cap_foods <= 0 && d.P * 16 > d.FC) d.FC = d.P * 16;
   e->d = d; e->g = g;
-  e->lds_bytes = ag_lds_layout(d.P, d.VC, d.FC, nullptr);
+  e->lds_bytes = ag_lds_layout(d.P, d.VC, d.FC, d.EC, d.KC, nullptr);
   e->all_vis = g.pgw <= 2 && g.pgh <= 2;
   e->ns = d.PC <= 256 ? 4 : d.PC <= 512 ? 8 : d.PC <= 1024 ? 16 : 32;
   int pc_needed = d.PC;
@@ -693,7 +706,7 @@ static int create_env(const agarcl_config *cfg, int32_t num_arenas, int32_t devi
   if (d.P > 1 && !s.scratch) { agarcl_destroy(e); return fail(AGARCL_E_NOMEM, "device allocation failed"); }
   s.rewards = alloc<double>(e, A * d.n_agents); s.dones = alloc<uint8_t>(e, A * d.n_agents); s.masses = alloc<int32_t>(e, A * d.n_agents);
   s.packed = alloc<float>(e, (size_t)AG_PACKED_SLOTS * A * d.n_agents * 2);
-  s.counts = alloc<int32_t>(e, A * 4); s.ev_p = alloc<int32_t>(e, A * AG_EV_CAP); s.ev_v = alloc<int32_t>(e, A * AG_EVV_CAP);
+  s.counts = alloc<int32_t>(e, A * 4); s.ev_p = alloc<int32_t>(e, A * (size_t)(d.EC + d.EX)); s.ev_v = alloc<int32_t>(e, A * AG_EVV_CAP);
   e->d_act_dxdy = alloc<float>(e, A * d.n_agents * 2); e->d_act = alloc<int32_t>(e, A * d.n_agents);
   e->lut_r = alloc<float>(e, AG_LUT_SIZE); e->lut_ms = alloc<float>(e, AG_LUT_SIZE); e->lut_ss = alloc<float>(e, AG_LUT_SIZE); e->lut_anti = alloc<float>(e, AG_ANTI_LUT);
   if (!e->lut_anti || !s.ev_v || !s.mt || !s.cells || !s.pel_xy) { agarcl_destroy(e); return fail(AGARCL_E_NOMEM, "device allocation failed"); }
@@ -1010,13 +1023,14 @@ extern "C" int agarcl_poll_flags(agarcl_env *e, uint32_t *out) {
 extern "C" int agarcl_get_events(agarcl_env *e, int32_t *n_events_host, int32_t *pellet_idx_host, int32_t cap, int32_t *virus_idx_host, int32_t cap_v) {
   if (!e || !n_events_host) return fail(AGARCL_E_INVALID, "agarcl_get_events: null pointer");
   size_t A = (size_t)e->d.A; const int ag_ts_lg = e->d.ts_lg;
-  std::vector<int32_t> ar(AG_TILE_ARENAS(A) * AR_WORDS), evp(A * AG_EV_CAP), evv(A * AG_EVV_CAP);
+  const size_t EC = (size_t)(e->d.EC + e->d.EX);   // (the arena's stride: exported LDS events, then the spill area)
+  std::vector<int32_t> ar(AG_TILE_ARENAS(A) * AR_WORDS), evp(A * EC), evv(A * AG_EVV_CAP);
   if (d2h(ar.data(), e->s.ar, ar.size() * 4, e->stream) || d2h(evp.data(), e->s.ev_p, evp.size() * 4, e->stream) || d2h(evv.data(), e->s.ev_v, evv.size() * 4, e->stream))
     return fail(AGARCL_E_HIP, "copy failed");
   for (size_t a = 0; a < A; a++) {
     int np = ar[tix(ag_ts_lg, a, AR_WORDS, AR_NEVP)], nv = ar[tix(ag_ts_lg, a, AR_WORDS, AR_NEVV)];
     n_events_host[2 * a] = np; n_events_host[2 * a + 1] = nv;
-    if (pellet_idx_host) for (int i = 0; i < np && i < cap && i < AG_EV_CAP; i++) pellet_idx_host[a * cap + i] = evp[a * AG_EV_CAP + i];
+    if (pellet_idx_host) for (int i = 0; i < np && i < cap && i < (int)EC; i++) pellet_idx_host[a * cap + i] = evp[a * EC + i];
     if (virus_idx_host) for (int i = 0; i < nv && i < cap_v && i < AG_EVV_CAP; i++) virus_idx_host[a * cap_v + i] = evv[a * AG_EVV_CAP + i];
   }
   return AGARCL_OK;
@@ -1079,10 +1093,12 @@ extern "C" int agarcl_debug_sqrt_check(agarcl_env *e, unsigned long long *out2) 
   if (!e || !out2) return AGARCL_E_INVALID;
   out2[0] = 0ull; out2[1] = ~0ull;
 #ifndef AGAR_CPU_EMU   // (the host emulation has one square root only)
-  unsigned long long *d = alloc<unsigned long long>(e, 2);
-  if (!d || h2d(d, out2, 16, e->stream)) return fail(AGARCL_E_HIP, "sqrt check: allocation failed");
+  unsigned long long *d = (unsigned long long *)dmalloc(16, e->stream);   // (freed below: repeated calls must not grow the env's allocation list)
+  if (!d || h2d(d, out2, 16, e->stream)) { dfree(d); return fail(AGARCL_E_HIP, "sqrt check: allocation failed"); }
   hipLaunchKernelGGL(k_sqrt_check, dim3(4096), dim3(256), 0, e->stream, d);
-  if (d2h(out2, d, 16, e->stream)) return fail(AGARCL_E_HIP, "sqrt check failed");
+  const int rc_ = d2h(out2, d, 16, e->stream);
+  dfree(d);
+  if (rc_) return fail(AGARCL_E_HIP, "sqrt check failed");
 #endif
   return AGARCL_OK;
 }
@@ -1412,7 +1428,9 @@ extern "C" void *agarcl_get_stream(agarcl_env *e) { return e ? (void *)e->stream
 static int order_streams(agarcl_env *e, int which, hipStream_t from, hipStream_t to) {
   if (from == to) return AGARCL_OK;
   HIPCHK(hipSetDevice(e->device));
-  if (!e->order_ev[which]) { hipEvent_t ev = nullptr; HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); e->order_ev[which] = (void *)ev; }
+  // (no timing, and no system-scope fence when the event completes: producer and consumer are streams of ONE device, an agent-scope release is what
+  // they need -- with the default flags every record flushed the caches to system scope: 147 us per quiet 4096-arena step instead of 15)
+  if (!e->order_ev[which]) { hipEvent_t ev = nullptr; HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence)); e->order_ev[which] = (void *)ev; }
   HIPCHK(hipEventRecord((hipEvent_t)e->order_ev[which], from));
   HIPCHK(hipStreamWaitEvent(to, (hipEvent_t)e->order_ev[which], 0));
   return AGARCL_OK;
@@ -1499,7 +1517,7 @@ extern "C" int agarcl_vec_step(agarcl_env *e, const agarcl_vec_spec *sp, const a
 }
 
 // ---- sub-batch pipelining (include/agarcl_batch.h) ------------------------------------------------------------------------------------
-struct agarcl_pipe { std::vector<agarcl_env *> envs; std::vector<int32_t> first; int32_t A; int device; int concurrent; };
+struct agarcl_pipe { std::vector<agarcl_env *> envs; std::vector<int32_t> first; int32_t A; int device; int concurrent; void *fork_ev; };
 #ifndef AGAR_CPU_EMU
 // Do two streams execute concurrently?  The runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) and two
 // streams that share a queue run one after the other whatever the API says -- measured on MI355X: two 2048-arena sub-batches on streams that
@@ -1523,13 +1541,16 @@ static int streams_concurrent(hipStream_t a, hipStream_t b, int *d_two) {   // 1
 #endif
 extern "C" int agarcl_pipe_destroy(agarcl_pipe *p) {
   if (!p) return AGARCL_OK;
+#ifndef AGAR_CPU_EMU
+  if (p->fork_ev) (void)hipEventDestroy((hipEvent_t)p->fork_ev);
+#endif
   for (agarcl_env *e : p->envs) agarcl_destroy(e);
   delete p;
   return AGARCL_OK;
 }
 extern "C" int agarcl_pipe_create(const agarcl_config *cfg, int32_t num_arenas, int32_t sub_batches, int32_t device, agarcl_pipe **out) {
   if (!cfg || !out || num_arenas <= 0 || sub_batches < 1 || sub_batches > num_arenas || sub_batches > 64) return fail(AGARCL_E_INVALID, "agarcl_pipe_create: bad arguments (1 <= sub_batches <= min(num_arenas, 64))");
-  agarcl_pipe *p = new agarcl_pipe(); p->A = num_arenas; p->device = device; p->concurrent = 1;
+  agarcl_pipe *p = new agarcl_pipe(); p->A = num_arenas; p->device = device; p->concurrent = 1; p->fork_ev = nullptr;
   const int32_t base = num_arenas / sub_batches, rem = num_arenas % sub_batches;   // contiguous ranges, the first ones take the remainder (agarcl_amd/dist.py shard_bounds)
   for (int32_t j = 0; j < sub_batches; j++) {
     const int32_t lo = j * base + (j < rem ? j : rem), n = base + (j < rem ? 1 : 0);
@@ -1586,6 +1607,23 @@ extern "C" int agarcl_pipe_seed(agarcl_pipe *p, const uint32_t *seeds_host, uint
   return AGARCL_OK;
 }
 extern "C" int agarcl_pipe_concurrent(agarcl_pipe *p) { return p ? p->concurrent : 0; }
+extern "C" int agarcl_pipe_fork(agarcl_pipe *p, void *producer_stream) {
+  if (!p) return fail(AGARCL_E_INVALID, "null pipe");
+#ifndef AGAR_CPU_EMU
+  HIPCHK(hipSetDevice(p->device));
+  if (!p->fork_ev) { hipEvent_t ev = nullptr; HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence)); p->fork_ev = (void *)ev; }
+  HIPCHK(hipEventRecord((hipEvent_t)p->fork_ev, (hipStream_t)producer_stream));
+  for (agarcl_env *e : p->envs) if (e->stream != (hipStream_t)producer_stream) HIPCHK(hipStreamWaitEvent(e->stream, (hipEvent_t)p->fork_ev, 0));
+#else
+  (void)producer_stream;
+#endif
+  return AGARCL_OK;
+}
+extern "C" int agarcl_pipe_join(agarcl_pipe *p, void *consumer_stream) {
+  if (!p) return fail(AGARCL_E_INVALID, "null pipe");
+  for (agarcl_env *e : p->envs) { const int rc = agarcl_stream_signal(e, consumer_stream); if (rc) return rc; }
+  return AGARCL_OK;
+}
 extern "C" int agarcl_pipe_sync(agarcl_pipe *p) {
   if (!p) return fail(AGARCL_E_INVALID, "null pipe");
   for (agarcl_env *e : p->envs) { const int rc = agarcl_sync(e); if (rc) return rc; }

@@ -182,13 +182,63 @@ template <int NS, bool AV> AG_DEV void players_collision(AgCtx<NS, AV> &c) {
   // [P+1] prefix of cell counts and the slot of each order position, in LDS: lanes index them with lane-varying
   // subscripts (the register-resident uniform block can only be read with a wave-uniform index)
   int *off = L_I(c, L_TMP) + 52, *ordl = L_I(c, L_TMP) + 85;   // (33 and 32 words: up to AG_MAX_PLAYERS = 32 players; words 20 .. 51 belong to env_step)
-  { int acc = 0; for (int k = 0; k < P; k++) { int slot = SR(c, AR_ORDER0 + k); AG_SERIAL { off[k] = acc; ordl[k] = slot; } acc += ag_uni(PLS(c, slot)[PL_NCELLS]); } AG_SERIAL { off[P] = acc; } }
-  ag_lds_order();
-  int T = ag_uni(off[P]);
-  if (T == 0) return;
+  auto build_tables = [&]() -> int {
+    int acc = 0; for (int k = 0; k < P; k++) { int slot = SR(c, AR_ORDER0 + k); AG_SERIAL { off[k] = acc; ordl[k] = slot; } acc += ag_uni(PLS(c, slot)[PL_NCELLS]); } AG_SERIAL { off[P] = acc; }
+    ag_lds_order();
+    return acc;
+  };
   auto locate = [&](int g, int &p, int &i) { int k = 0; while (g >= off[k + 1]) k++; p = ordl[k]; i = g - off[k]; };
   // wave-parallel necessary condition: solve() can only report (collides && can_eat) pairs of different players
-  bool any = wave_any(T * T, [&](int q) {
+  bool any; int T;
+#ifndef AGAR_CPU_EMU
+  {
+    // Lane k < P holds order position k (its player slot and cell count, one parallel LDS read); every lane then finds its own cell of the flat
+    // list by walking the P counts with v_readlane -- no LDS round trip per player.  Up to 64 cells in the arena (the usual case: bench/main.cpp's
+    // Tick/30 has 30) lane g HOLDS cell g -- loaded and its radius looked up once -- and the eaten candidate b is broadcast with v_readlane: T
+    // iterations of some twenty instructions.  The generic form walks T * T (eater, eaten) pairs with two searches through LDS tables, eight
+    // LDS reads and two table look-ups EACH, behind a table build of one dependent LDS round trip per player: at 30 players that pre-test alone
+    // was 44 % of the tick (plcol/foods 395 k of 907 k cycles per 4-tick launch, scripts/gpu_phase_multi.py).
+    const int lane = AG_LANE;
+    const int myslot = __builtin_amdgcn_ds_bpermute((AR_ORDER0 + (lane < P ? lane : 0)) << 2, c.S.v);     // word AR_ORDER0 + lane of the arena block
+    const int mycnt = lane < P ? PLS(c, myslot)[PL_NCELLS] : 0;
+    int acc = 0, pa = 0, ia = 0;
+    for (int k = 0; k < P; k++) {
+      const int nk = __builtin_amdgcn_readlane(mycnt, k), sk = __builtin_amdgcn_readlane(myslot, k);
+      const bool mine = lane >= acc && lane < acc + nk;
+      pa = mine ? sk : pa; ia = mine ? lane - acc : ia;
+      acc += nk;
+    }
+    T = acc;
+    if (T == 0) return;
+    if (T <= 64) {
+      const bool act = lane < T;
+      const Cells A = cells_of(c, pa);
+      const unsigned ma = act ? A.m[ia] : 0u; const float xa = act ? A.x[ia] : 0.0f, ya = act ? A.y[ia] : 0.0f; const float ra = act ? radius_of(c, ma) : 0.0f;
+      // can_eat(a, b) = a > 25 && (double)a > (double)b * 1.1 (Entities.hpp:148-151, Ball.hpp:45-47): the victim's side of it once per lane
+      const double eat_thr = (double)ma * 1.1; const bool eater = act && ma > 25u; const double dma = (double)ma;
+      const int tlo = (int)(unsigned)(__builtin_bit_cast(unsigned long long, eat_thr) & 0xffffffffull), thi = (int)(unsigned)(__builtin_bit_cast(unsigned long long, eat_thr) >> 32);
+      bool hit = false;
+      for (int b = 0; b < T; b++) {
+        const int pb = __builtin_amdgcn_readlane(pa, b);
+        const float xb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xa), b)), yb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ya), b));
+        const float rb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra), b));
+        const unsigned long long tb = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(thi, b) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readlane(tlo, b);
+        hit = hit | (eater && pa != pb && dma > __builtin_bit_cast(double, tb) && collides(xa, ya, ra, xb, yb, rb));
+      }
+      any = ag_any(hit);
+      if (!any) return;
+      (void)build_tables();      // the rare path below reads the LDS tables
+    } else {
+      (void)build_tables();
+      any = true;                // (more than 64 cells: the generic pre-test below decides)
+    }
+  }
+  if (T > 64)
+#else
+  T = build_tables();
+  if (T == 0) return;
+#endif
+  any = wave_any(T * T, [&](int q) {
     int a = q / T, b = q - a * T, pa, ia, pb, ib; locate(a, pa, ia); locate(b, pb, ib);
     if (pa == pb) return false;
     Cells A = cells_of(c, pa), B = cells_of(c, pb);

@@ -218,7 +218,7 @@ template <int NS, bool AV, int QG, int TSLG> AG_DEV QHandOver quiet_arena(const 
       P[PL_FOOD_EATEN] = q.food_eaten; P[PL_LAST_DECAY] = q.last_decay; P[PL_SAFE_X] = f2u(q.sx0); P[PL_SAFE_Y] = f2u(q.sy0); P[PL_PASSES] = q.passes;
       P[PL_CAND_X] = f2u(q.cx); P[PL_CAND_Y] = f2u(q.cy); P[PL_CAND_IDX] = q.cidx;
       S[AR_NEVP] = (q.last_ev >= 0 ? 1 : 0) + (q.last_ev2 >= 0 ? 1 : 0); S[AR_NEVV] = 0; S[AR_NPEL] = q.np; S[AR_TICKS] = q.ticks; S[AR_CLOCK] = clock + q.done; S[AR_SAFE] = f2u(q.slack); S[AR_MTIDX] = q.mtidx; S[AR_IDC] = q.idc;
-      if (q.last_ev >= 0) { auto ge = (AG_GLOBAL int32_t *)(gs->ev_p + (size_t)arena * AG_EV_CAP); ge[0] = q.last_ev; if (q.last_ev2 >= 0) ge[1] = q.last_ev2; }
+      if (q.last_ev >= 0) { auto ge = (AG_GLOBAL int32_t *)(gs->ev_p + (size_t)arena * (size_t)(gs->d.EC + gs->d.EX)); ge[0] = q.last_ev; if (q.last_ev2 >= 0) ge[1] = q.last_ev2; }
       auto cn = (AG_GLOBAL int32_t *)(gs->counts + (size_t)arena * 4);
       cn[0] = q.np; cn[1] = q.nv; cn[2] = 0; cn[3] = 1;
     }

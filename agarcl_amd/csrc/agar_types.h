@@ -43,9 +43,8 @@ enum {
 #define AG_MAX_PLAYERS 32   // (bench/main.cpp's Tick/30: 30 ExampleBots in one arena)
 #define AG_PACKED_SLOTS 64  // ring of packed (reward, done) result buffers: step k of an env writes slot k % 64
 #define AG_CC 32        // cell capacity per player (reference: unbounded vector, nominal limit 14)
-#define AG_EV_CAP 256   // pellet eat events per arena-tick
-#define AG_EVV_CAP 16   // virus eat events per arena-tick (<= players)
-#define AG_CAND_CAP 512  // words of the ordered-replay candidate list: 256 records of (key, squared distance); also the 64 (x, y) pairs staged by add_pellets
+#define AG_EV_MIN 256   // pellet eat events per arena-tick (AgDims::EC) and candidate records of one cell's replay (AgDims::KC): at least this; dense small arenas get more (agarcl_create)
+#define AG_EVV_CAP 32   // virus eat events per arena-tick (at most one per player and tick in practice; AG_MAX_PLAYERS of them fit)
 #define AG_VT_CAP 256   // virus_eaten_ticks kept per player (the reference vector is unbounded; > 256 virus meals inside 3600 ticks raises a flag)
 #define AG_LUT_SIZE (1 << 19)
 #define AG_ANTI_LUT 256
@@ -86,6 +85,9 @@ struct AgDims {
   int PC;        // pellet capacity per arena (multiple of 64)
   int VC;        // virus capacity
   int FC;        // food capacity
+  int EC;        // pellet eat events per arena-tick kept in LDS (behind the foods): AG_EV_MIN
+  int KC;        // candidate records of ONE cell's ordered replay (LDS, behind the events): >= AG_EV_MIN, <= pellet capacity (a cell cannot reach more)
+  int EX;        // further eat events of the tick spill to HBM (ev_p, behind the first EC of each arena): 0 except in dense arenas (agarcl_create)
   int ts_lg;     // log2 of the tile size of the transposed word arrays (0: arena-major, 6: tiles of 64 arenas)
 };
 
@@ -129,7 +131,7 @@ struct AgState {
   int32_t *masses;        // [A][n_agents]
   float *packed;          // [AG_PACKED_SLOTS][A][n_agents][2] (reward, done) as f32, ring indexed by step number: what gets gathered across GPUs
   int32_t *counts;        // [A][4]
-  int32_t *ev_p;          // [A][AG_EV_CAP]
+  int32_t *ev_p;          // [A][EC + EX]: the tick's pellet eat events -- the first EC exported from LDS by arena_store, the rest written directly (spill)
   int32_t *ev_v;          // [A][AG_EVV_CAP]
   // read-only tables (mass -> fp32), host generated (Engine.hpp:1296-1302, core/utils.hpp:8-11)
   const float *lut_r, *lut_ms, *lut_ss, *lut_anti;

@@ -8,7 +8,7 @@ The implementation is this repository's own: options live in one table, every ob
 validated in one vectorised check, and recorded agent-view frames are coloured by a palette look-up on a per-pixel class index.
 
 gymnasium is optional (it is not installed in the build image): when importable the class derives from gymnasium.Env and carries
-real spaces.  There is no OpenGL window on a GPU server: render mode "human" shows nothing and returns None; "rgb_array" returns
+gymnasium's spaces; otherwise `action_space` / `observation_space` are the same-shaped stand-ins of agarcl_amd/spaces.py.  There is no OpenGL window on a GPU server: render mode "human" shows nothing and returns None; "rgb_array" returns
 the screen observation, or the engine's 512 x 512 frame for the grid / GoBigger observations.
 """
 import os
@@ -36,12 +36,11 @@ agarcl = _binding()
 
 try:  # optional
     import gymnasium as _gym
-    from gymnasium import spaces as _spaces
     _Base = _gym.Env
 except Exception:  # pragma: no cover - gymnasium is not installed in the build image
     _gym = None
-    _spaces = None
     _Base = object
+from . import spaces as _spaces   # gymnasium's spaces when importable, same-shaped stand-ins otherwise
 
 OBS_TYPES = ("ram", "screen", "grid", "gobigger")
 
@@ -150,11 +149,9 @@ class AgarioEnv(_Base):
         self.steps = None                     # None until the first reset()
         self.video_recorder, self.video_recorder_enabled = [], False
         self._seed = None
-        if _spaces is not None:
-            self.action_space = _spaces.Tuple((_spaces.Box(low=-1, high=1, shape=(2,)), _spaces.Discrete(3)))
-            lo, hi, dt = {"grid": (-1, np.iinfo(np.int32).max, np.int32), "screen": (0, 255, np.uint8),
-                          "ram": (-np.inf, np.inf, np.float32), "gobigger": (0, 255, np.float32)}[obs_type]
-            self.observation_space = _spaces.Box(low=lo, high=hi, shape=self.observation_shape, dtype=dt)
+        # the counterpart's spaces (AgarioEnv.py:55-62, 232-264): always present -- gymnasium's objects when it is importable
+        self.action_space = _spaces.single_action_space()
+        self.observation_space = _spaces.observation_space(obs_type, self.observation_shape)
 
     # ---- actions ------------------------------------------------------------------------------------------------------------
     def _checked_actions(self, actions):

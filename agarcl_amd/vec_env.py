@@ -174,15 +174,21 @@ class VecEnvironment:
             return self.torch.cuda.default_stream(self.device)
         return self.torch.cuda.ExternalStream(self.stream_handle, device=self.device)
 
+    def _current_raw_stream(self):
+        try:       # (the raw handle without building a Stream object: this sits in the per-step path)
+            return self.torch._C._cuda_getCurrentRawStream(self.device.index)
+        except AttributeError:
+            return self.torch.cuda.current_stream(self.device).cuda_stream
+
     def order_after_current(self):
         """the engine's next launches come after everything enqueued so far on torch's CURRENT stream (no-op when that is the engine's stream)"""
-        cur = self.torch.cuda.current_stream(self.device).cuda_stream
+        cur = self._current_raw_stream()
         if cur != self.stream_handle:
             self.engine.stream_wait(cur)
 
     def order_current_after(self):
         """torch's CURRENT stream waits, on the device, for everything the engine has enqueued so far"""
-        cur = self.torch.cuda.current_stream(self.device).cuda_stream
+        cur = self._current_raw_stream()
         if cur != self.stream_handle:
             self.engine.stream_signal(cur)
 
@@ -239,9 +245,14 @@ class PipelinedVecEnvironment:
         return p
 
     def step(self, dxdy, act, ticks=0):
+        cur = self.parts[0]._current_raw_stream()
+        self.pipe.fork(cur)                                   # one event on the current stream, every sub-batch waits for it (one host call)
         for j, (lo, n) in enumerate(self.ranges):
-            self.send(j, dxdy[lo:lo + n], act[lo:lo + n], ticks)
-        return [self.recv(j) for j in range(self.sub_batches)]
+            p = self.parts[j]
+            p.take_actions(dxdy[lo:lo + n], act[lo:lo + n])
+            p.step(ticks)
+        self.pipe.join(cur)
+        return list(self.parts)
 
     def sync(self):
         self.pipe.sync()

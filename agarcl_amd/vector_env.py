@@ -83,6 +83,10 @@ class AgarioVectorEnv:
         eng = dict(num_agents=o["num_agents"], ticks_per_step=o["ticks_per_step"], arena_size=o["arena_size"], pellet_regen=o["pellet_regen"],
                    num_pellets=o["num_pellets"], num_viruses=o["num_viruses"], num_bots=o["num_bots"], reward_type=o["reward_type"], c_death=o["c_death"],
                    mode_number=o["mode"], device=device, **{k: kwargs[k] for k in ("strict_flags", "dt", "cap_foods", "cap_viruses") if k in kwargs})
+        if obs_type == "screen":
+            # the screen env respawns a dead agent right after the ticks of a step in every mode and adds c_death to that step's reward
+            # (/root/reference/environment/envs/ScreenEnvironment.hpp:233-243): what agarcl.ScreenEnvironment -- the N = 1 case -- does too
+            eng["screen_respawn"] = True
         if self.sub_batches == 1:
             self.env = VecEnvironment(self.num_envs, **eng)
             self.pipe, self._parts, self._ranges = None, [self.env], [(0, self.num_envs)]
@@ -133,6 +137,13 @@ class AgarioVectorEnv:
                                                (self._obs.data_ptr() + lo * self._obs_row_bytes) if self._obs is not None else None))
         self._flags = ctypes.c_uint32(0)
         self._act_keep = [None] * self.sub_batches
+        # what step() / recv(j) hand out: views of the tensors above, built ONCE (slicing a tensor costs microseconds, and step() is a per-step path)
+        self._ret_full = None if obs_type == "gobigger" else self._make_ret(0, None)
+        self._ret_part = [None if obs_type == "gobigger" else self._make_ret(lo, lo + cnt) for lo, cnt in self._ranges]
+        self._byref = [(ctypes.byref(self._spec), ctypes.byref(b)) for b in self._bufs]
+        self._flags_ref = ctypes.byref(self._flags)
+        self._vec_step = self._L.agarcl_vec_step
+        self._handles = [p.engine.h for p in self._parts]
         # ---- spaces -----------------------------------------------------------------------------------------------------------------------------
         self.single_observation_shape = self._single_obs_shape(shape)
         self.single_action_space = _spaces.single_action_space(n, self.multi_agent)
@@ -200,17 +211,23 @@ class AgarioVectorEnv:
         else:
             self.env.seed(np.asarray(seed, dtype=np.uint32))
 
+    def _make_ret(self, lo, hi):
+        return (self._obs_view(lo, hi), self._agents(self._reward[lo:hi]), self._agents(self._done[lo:hi]), self._agents(self._trunc[lo:hi]), self._info(lo, hi))
+
+    def _ret(self, j=None):
+        if self.obs_type == "gobigger":                           # (five tensors per call: built per step, sub_batches == 1 only)
+            return self._make_ret(0, None)
+        return self._ret_full if j is None else self._ret_part[j]
+
     def _reset_part(self, j):
         p = self._parts[j]
         p.order_after_current()
         self._chk(self._L.agarcl_vec_reset(p.engine.h, ctypes.byref(self._spec), ctypes.byref(self._bufs[j])))
 
-    def _step_part(self, j, move, kind):
+    def _step_part(self, j, move_ptr, kind_ptr):
         """one host call: the step, the episode bookkeeping with the same-step auto-reset, and the observation of sub-batch j"""
-        p = self._parts[j]
-        self._act_keep[j] = (move, kind)                         # (read when the step kernel executes)
-        p.order_after_current()                                   # the actions were produced on the current stream (no-op when that is the engine's)
-        rc = self._L.agarcl_vec_step(p.engine.h, ctypes.byref(self._spec), ctypes.byref(self._bufs[j]), move.data_ptr(), kind.data_ptr(), ctypes.byref(self._flags))
+        sp, bf = self._byref[j]
+        rc = self._vec_step(self._handles[j], sp, bf, move_ptr, kind_ptr, self._flags_ref)
         if rc != 0:
             self._chk(rc)
         if self._flags.value:
@@ -223,7 +240,7 @@ class AgarioVectorEnv:
         self.async_reset(seed)
         for p in self._parts:
             p.order_current_after()
-        return self._obs_view(), {}
+        return self._ret()[0], {}
 
     def step(self, actions):
         """actions = (move, kind): move f32 [N, 2] (or [N, num_agents, 2]) in [-1, 1]^2, kind int [N] (or [N, num_agents]) in {0 none, 1 feed,
@@ -234,16 +251,23 @@ class AgarioVectorEnv:
         torch = self.torch
         N, n = self.num_envs, self.num_agents
         move = self._as_device(actions[0], torch.float32, (N, n, 2)); kind = self._as_device(actions[1], torch.int32, (N, n))
-        if self.sub_batches == 1:
-            self._step_part(0, move, kind)
-            self._parts[0].order_current_after()
+        self._act_keep[0] = (move, kind)                           # (read when the step kernel executes)
+        mp, kp = move.data_ptr(), kind.data_ptr()
+        if self.pipe is None:
+            p = self._parts[0]
+            cur = p._current_raw_stream()
+            if cur != p.stream_handle:                             # (stepping under another torch stream than the one the engine was bound to)
+                p.engine.stream_wait(cur)
+            self._step_part(0, mp, kp)
+            if cur != p.stream_handle:
+                p.engine.stream_signal(cur)
         else:
-            move, kind = move.reshape(N, n, 2), kind.reshape(N, n)
+            cur = self._parts[0]._current_raw_stream()
+            self.pipe.pipe.fork(cur)                               # the actions were produced on the current stream: one event, every sub-batch waits for it
             for j, (lo, cnt) in enumerate(self._ranges):
-                self._step_part(j, move[lo:lo + cnt], kind[lo:lo + cnt])
-            for p in self._parts:
-                p.order_current_after()
-        return self._obs_view(), self._agents(self._reward), self._agents(self._done), self._agents(self._trunc), self._info()
+                self._step_part(j, mp + lo * n * 8, kp + lo * n * 4)
+            self.pipe.pipe.join(cur)
+        return self._ret()
 
     # ---- the two halves, per sub-batch (double-buffered sampling) ---------------------------------------------------------------------
     def async_reset(self, seed=None):
@@ -258,15 +282,16 @@ class AgarioVectorEnv:
         assert self._started, "reset() / async_reset() must be called before the first send()"
         lo, cnt = self._ranges[j]
         n = self.num_agents
-        self._step_part(j, self._as_device(actions[0], self.torch.float32, (cnt, n, 2)), self._as_device(actions[1], self.torch.int32, (cnt, n)))
+        move = self._as_device(actions[0], self.torch.float32, (cnt, n, 2)); kind = self._as_device(actions[1], self.torch.int32, (cnt, n))
+        self._act_keep[j] = (move, kind)
+        self._parts[j].order_after_current()                      # the actions were produced on the current stream (no-op when that is the engine's)
+        self._step_part(j, move.data_ptr(), kind.data_ptr())
 
     def recv(self, j=0):
         """the current stream waits (on the device) for sub-batch j's last reset / step; returns its rows (views of the full tensors):
         obs, reward, terminated, truncated, info"""
-        lo, cnt = self._ranges[j]
         self._parts[j].order_current_after()
-        hi = lo + cnt
-        return self._obs_view(lo, hi), self._agents(self._reward[lo:hi]), self._agents(self._done[lo:hi]), self._agents(self._trunc[lo:hi]), self._info(lo, hi)
+        return self._ret(j)
 
     @property
     def ranges(self):

@@ -51,8 +51,31 @@ WORKLOADS = {
     "C1r": dict(arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, dt=1.0 / 60, rand_act=True, ram_obs=True,
                 desc="C1 batched + ram observation: %d arenas/GPU x (1 agent + 4 bots), 250x250, 500 pellets, 10 viruses, mode 0, dt 1/60 s, 4 ticks/step, f32 [A][1][152] written once per step"),
 }
-TRAFFIC_FILE = "r04_pmc_traffic.json"   # PMC FETCH_SIZE / WRITE_SIZE per step of the bench workloads, recorded by scripts/profile_round.sh
+TRAFFIC_FILE = "r05_pmc_traffic.json"   # PMC FETCH_SIZE / WRITE_SIZE (+ one SQ pass) per step of the bench workloads, recorded by scripts/profile_round.sh
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
+GUIDE_COPY_GBS = 6300.0   # the achievable device copy rate the guide quotes (MI355X_MICROARCH.md), beside the copy timed in this process
+PIPE_K = 2                # sub-batches of the "<workload>/pipe2" entries (agarcl_pipe_*: independent arena ranges on streams of their own)
+TASKS_FIXTURE = os.path.join(ROOT, "tests", "golden", "paper_tasks.json")   # values of the reference's bench/tasks_configs/mode_{1..10}.json
+
+
+def paper_tasks():
+    """{m: config values} of the reference's ten RL tasks (tests/golden/make_tasks_fixture.py wrote them from /root/reference/bench/tasks_configs)"""
+    try:
+        return {int(k): v for k, v in json.load(open(TASKS_FIXTURE))["tasks"].items()}
+    except Exception:
+        return {}
+
+
+def task_workload(m):
+    """bench workload of task m: the engine arguments + the 128 x 128 agent-view frame written every step (obs_type "screen": the screen env's
+    respawn hook is on, ScreenEnvironment.hpp:233-243)"""
+    t = paper_tasks()[m]
+    cfg = dict(num_agents=1, ticks_per_step=t["ticks_per_step"], arena_size=t["arena_size"], pellet_regen=bool(t["pellet_regen"]), num_pellets=t["num_pellets"],
+               num_viruses=t["num_viruses"], num_bots=t["num_bots"], reward_type=t["reward_type"], c_death=t["c_death"], mode_number=t["mode"], screen_respawn=True)
+    desc = ("task %d (bench/tasks_configs/mode_%d.json): %%d arenas/GPU, %dx%d arena, %d pellets, %d viruses, %d bot(s), mode %d, %d ticks/step, action ~ U{0,1,2}, "
+            "uint8 agent-view frame [%%d][%d][%d][4] written every step" % (m, m, t["arena_size"], t["arena_size"], t["num_pellets"], t["num_viruses"], t["num_bots"],
+                                                                               t["mode"], t["ticks_per_step"], t["screen_len"], t["screen_len"]))
+    return cfg, (t["screen_len"], t["screen_len"], bool(t["agent_view"])), desc
 
 
 def source_sha():
@@ -426,13 +449,13 @@ def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, 
     return res
 
 
-def obs_bytes(res, A, cfg, with_obs, with_screen, with_ram):
+def obs_bytes(res, A, cfg, with_obs, with_screen, with_ram, screen=(84, 84, False)):
     """(requested, streaming-model) observation bytes per step.  Streaming model: the whole tensor is written once per step.
     Requested by this implementation: the grid tensor is persistent (agarcl_grid_obs on_device = 2), so per word scattered a step clears
     the old one and writes the new one plus their undo-list entries (16 B; the view covers at most (300 / arena)^2 of the arena's pellets
     and viruses), reads and writes the out-of-bounds channel's row / column signature (2 x 2 x 128 B) and stores the rows / columns of that
     channel whose signature byte changed (round 4; not counted: a few 512-byte rows per agent near a wall, none elsewhere)"""
-    model_extra = (A * 8 * 128 * 128 * 4 if with_obs else 0) + (A * 84 * 84 * 3 if with_screen else 0) + (A * cfg["num_agents"] * 152 * 4 if with_ram else 0)
+    model_extra = (A * 8 * 128 * 128 * 4 if with_obs else 0) + (A * screen[0] * screen[1] * (4 if screen[2] else 3) if with_screen else 0) + (A * cfg["num_agents"] * 152 * 4 if with_ram else 0)
     extra = model_extra
     if with_obs:
         n_pel, n_vir, n_food, n_cells = res["counts"]
@@ -454,12 +477,13 @@ def roofline_block(res, A, K, ticks, cfg, workload, extra_bytes=0.0, kernel=None
     # SURVEY 8(d) streaming model (every live entity once per tick): 8 N_p + 12 N_v + 72 N_c + 40 N_f + 112 P + 24 A
     b_tick = 8 * n_pel + 12 * n_vir + 72 * n_cells + 40 * n_food + 112 * P + 24 * na
     model = b_tick * A * ticks + (extra_bytes if model_extra is None else model_extra)
-    traffic = tag = None
+    traffic = tag = issue = None
     try:  # HBM bytes per step from the PMC counters, recorded separately by scripts/profile_round.sh on THIS kernel source
         tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
         ent = tj["runs"].get("%s@%d" % (workload, A))
-        if ent and tj.get("source_sha") == source_sha():
+        if ent and tj.get("source_sha") == source_sha() and res.get("sub_batches", 1) == 1:
             traffic, tag = ent["traffic_bytes_per_step"], "%s, source %s" % (tj.get("recorded", "?"), tj["source_sha"])
+            issue = ent.get("issue")   # scripts/collect_profiles.py: the dominant kernel's SQ counters condensed (see "issue" below)
     except Exception:
         pass
     moved = traffic if traffic else req
@@ -482,6 +506,84 @@ def roofline_block(res, A, K, ticks, cfg, workload, extra_bytes=0.0, kernel=None
            "model_speedup": model / t / 1e9 / HBM_PEAK_GBS,
            "work_per_step": {"front_finished_arena_steps": float(res["work"][0]) / K, "general_engine_arena_steps": float(res["work"][1]) / K,
                              "pellet_array_transfers": float(res["work"][2]) / K}}
+    # The roofline that binds the general engine is not HBM but instruction issue and the dependent chain of the slowest arena.  From one SQ
+    # pass of rocprofv3 over this workload on this kernel source (profiles/, sha-gated like `traffic`):
+    #   frac_valu_issue     = SQ_INSTS_VALU x 2 cycles / (kernel time x measured clock x 1024 SIMDs): share of the VALU issue slots used
+    #   mean_wave_residency = mean time a wavefront is resident / the launch's duration: 1 - this = wave slots standing empty while the launch
+    #                         waits for its slowest arenas
+    #   clock_ghz           = SQ_BUSY_CYCLES / 32 / kernel time: the shader clock under this load (nominal 2.4 GHz)
+    if issue:
+        out["frac_valu_issue"] = issue.get("frac_valu_issue"); out["mean_wave_residency"] = issue.get("mean_wave_residency")
+        out["clock_ghz_measured"] = issue.get("clock_ghz"); out["issue_kernel"] = issue.get("kernel")
+    else:
+        out["frac_valu_issue"] = out["mean_wave_residency"] = out["clock_ghz_measured"] = None
+    if res.get("sub_batches", 1) > 1:
+        out["sub_batches"] = res["sub_batches"]; out["sub_batches_concurrent"] = res.get("concurrent")
+    return out
+
+
+def compact(rf, value, ms, cpu=None, cpu_cores=None):
+    """one row of roofline.by_workload: [ms_per_step, env_steps_per_s, frac_hbm_traffic, traffic / requested, frac_valu_issue,
+    mean_wave_residency, cpu_reference_env_steps_per_s, cpu_reference_cores]"""
+    tr = rf.get("traffic")
+    return [ms, value, rf.get("frac_hbm_traffic"), (tr / rf["requested_bytes_per_step"]) if tr else None, rf.get("frac_valu_issue"),
+            rf.get("mean_wave_residency"), cpu, cpu_cores]
+
+
+BY_WORKLOAD_COLUMNS = ["ms_per_step", "env_steps_per_s", "frac_hbm_traffic", "traffic_over_requested", "frac_valu_issue", "mean_wave_residency",
+                       "cpu_reference_env_steps_per_s", "cpu_reference_cores"]
+
+
+def reference_rate(cfg, seconds=0.5, dt=1.0 / 30):
+    """the reference engine (oracle/_ref, kind "reference"; else the C port) on ONE host core on this env configuration, random policy:
+    engine ticks per second over a bounded sample"""
+    kw = dict(num_agents=cfg["num_agents"], ticks_per_step=cfg["ticks_per_step"], arena_size=cfg["arena_size"], pellet_regen=cfg["pellet_regen"],
+              num_pellets=cfg["num_pellets"], num_viruses=cfg["num_viruses"], num_bots=cfg["num_bots"], reward_type=cfg["reward_type"], c_death=cfg["c_death"],
+              mode=cfg["mode_number"], dt=cfg.get("dt", dt))
+    try:
+        from oracle import refbind as B
+        if not B.available():
+            raise ImportError
+        env, kind = B.RefEnv(**kw), "reference"
+    except Exception:
+        from oracle import orabind as B
+        if not B.available():
+            B.build()
+        env, kind = B.OraEnv(**kw), "port"
+    if cfg.get("screen_respawn"):
+        env.set_screen_hook(True)
+    env.seed(42); env.reset(True)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        n += env.run_random(400, policy_seed=n + 1, allow_actions=True)
+    rate = n / (time.perf_counter() - t0)
+    env.close()
+    return rate, kind
+
+
+def vector_surface(torch, A, K, Wm, dev_index, sub_batches=1):
+    """The RL surface itself (agarcl_amd/vector_env.py AgarioVectorEnv = gym.make's N > 1 case, one agarcl_vec_step per step): gym "normal"
+    preset (= C2's arena), a fixed device action batch, K steps.  host_us_per_step: what step() costs the host (enqueue only, nothing
+    waits); gym_vector_steps_per_s: arena-steps per second through the surface, GPU time included."""
+    from agarcl_amd.vector_env import AgarioVectorEnv
+    out = {}
+    for tag, obs, kw in (("no_obs", "none", {}), ("ram_obs", "ram", {}), ("screen_obs_84", "screen", dict(screen_len=84))):
+        venv = AgarioVectorEnv(A, obs_type=obs, device=dev_index, difficulty="normal", strict_flags=False, sub_batches=sub_batches, **kw)
+        venv.reset(seed=10000)
+        dev = venv.device
+        move = torch.rand((A, 2), device=dev) * 2 - 1; kind = torch.zeros(A, dtype=torch.int32, device=dev)
+        for _ in range(Wm):
+            venv.step((move, kind))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            venv.step((move, kind))
+        host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        total = time.perf_counter() - t0
+        out[tag] = {"host_us_per_step": host / K * 1e6, "us_per_step": total / K * 1e6, "gym_vector_steps_per_s": A * K / total,
+                    "env_steps_per_s": A * K * venv.options["ticks_per_step"] / total}
+        venv.close()
     return out
 
 
@@ -493,9 +595,11 @@ def main():
     ap.add_argument("--arenas", type=int, default=ARENAS_PER_GPU, help="arenas per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large", action="store_true", help="skip the %d-arena roofline_large run" % LARGE_ARENAS)
-    ap.add_argument("--no-full", action="store_true", help="skip the roofline_full runs (C3 / mode 6 and the mid-game workload)")
-    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS) + ["tick%d" % n for n in TICK_BOTS],
-                    help="C2 = the headline metric's configuration; tickN = bench/main.cpp's Tick/N population (N ExampleBots, no Player), batched")
+    ap.add_argument("--no-full", action="store_true", help="skip the other workloads of roofline.by_workload (full rule set, mid-game, C1, observations, pipelined forms, tasks, Tick/N, the vector surface)")
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS) + ["tick%d" % n for n in TICK_BOTS] + ["task%d" % m for m in range(1, 11)],
+                    help="C2 = the headline metric's configuration; tickN = bench/main.cpp's Tick/N population (N ExampleBots, no Player), batched; "
+                         "taskM = the reference's RL task M (bench/tasks_configs/mode_M.json) with its 128 x 128 agent-view frame every step")
+    ap.add_argument("--sub-batches", type=int, default=1, help="the rank's arenas as this many independent sub-batches on HIP streams of their own (agarcl_pipe_*)")
     ap.add_argument("--gather", default="block", choices=["block", "step"], help="multi-GPU: how (reward, done) reaches rank 0")
     ap.add_argument("--gather-block", type=int, default=32, choices=[8, 16, 32], help="multi-GPU, --gather block: steps per collective")
     ap.add_argument("--gather-obs", default="none", choices=["none", "screen"], help="multi-GPU: also gather every step's uint8 frames")
@@ -522,12 +626,21 @@ def main():
             out["cpu_baseline"] = {"value": rate, "unit": "env-steps/s", "cores": 1, "kind": kind, "sample": "2 s of Engine::tick at dt 1/60 s on the same population, one core"}
         print(json.dumps(out))
         return
-    wl = dict(WORKLOADS[args.workload])
-    desc, rand_act, with_obs, with_screen = wl.pop("desc"), wl.pop("rand_act", False), wl.pop("grid_obs", False), wl.pop("screen_obs", False)
-    start_mass = wl.pop("start_mass", 0)
-    with_ram = wl.pop("ram_obs", False)
-    cfg = dict(CFG); cfg.update(wl)
+    screen = (84, 84, False)
+    if args.workload.startswith("task"):
+        cfg, screen, desc = task_workload(int(args.workload[4:]))
+        rand_act, with_obs, with_screen, with_ram, start_mass = True, False, True, False, 0
+        desc = desc.replace("%%", "%")
+    else:
+        wl = dict(WORKLOADS[args.workload])
+        desc, rand_act, with_obs, with_screen = wl.pop("desc"), wl.pop("rand_act", False), wl.pop("grid_obs", False), wl.pop("screen_obs", False)
+        start_mass = wl.pop("start_mass", 0)
+        with_ram = wl.pop("ram_obs", False)
+        cfg = dict(CFG); cfg.update(wl)
 
+    # more hardware queues than the runtime's default 4, so that sub-batch streams (agarcl_pipe_*) find queues of their own beside torch's
+    # streams; must be in the environment before the first HIP call (read by the HIP runtime, nothing else)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import numpy as np
     rank = int(os.environ.get("RANK", "0"))
@@ -562,7 +675,7 @@ def main():
     A, K, Wm = args.arenas, args.steps, args.warmup
     ticks = cfg["ticks_per_step"]
     res = run_workload(torch, np, VecEnvironment, agdist, dev, dev_index, rank, world, A, K, Wm, cfg, rand_act, with_obs, with_screen,
-                       args.gather, args.gather_obs, args.gather_block, start_mass, with_ram)
+                       args.gather, args.gather_obs, args.gather_block, start_mass, with_ram, sub_batches=args.sub_batches, screen=screen)
     devs = [None] * world   # which device every rank ran on: lets the driver see "RCCL saw N ranks on N GPUs"
     if world > 1:
         dist.all_gather_object(devs, "%s:%d" % (os.uname().nodename, dev_index))
@@ -570,26 +683,27 @@ def main():
         devs = ["%s:%d" % (os.uname().nodename, dev_index)]
     value = world * A * ticks * K / res["elapsed"]
     if rank == 0:
-        extra, model_extra, kernel = obs_bytes(res, A, cfg, with_obs, with_screen, with_ram)
+        extra, model_extra, kernel = obs_bytes(res, A, cfg, with_obs, with_screen, with_ram, screen)
         roof = roofline_block(res, A, K, ticks, cfg, args.workload, float(extra), kernel, float(model_extra))
         roof["note"] = ("achieved = HBM bytes one env step moves (PMC FETCH_SIZE x2 + WRITE_SIZE of the same kernel source when profiles/ "
                         "holds them -> `traffic`; otherwise the bytes the kernels request, counted by the kernels themselves) / the step's "
-                        "HIP-event time; frac <= 1 by construction.  model_speedup = SURVEY 8(d)'s streaming-model bytes over the same time: "
+                        "HIP-event time; frac <= 1 by construction.  frac_streaming_model = SURVEY 8(d)'s streaming-model bytes over the same time: "
                         "it exceeds 1 because the engine does not stream (state stays in registers across the ticks of a step, pellets are "
-                        "read only when a cell leaves its pellet-free disc): it is reported as frac_streaming_model and is not a bound.  "
-                        "frac == frac_hbm_traffic when PMC data of this kernel source is committed.  `regime` says which side of the "
-                        "latency / bandwidth turn this size is on; see roofline_large / roofline_xlarge for the bandwidth regime")
+                        "read only when a cell leaves its pellet-free disc): not a bound.  frac == frac_hbm_traffic when PMC data of this kernel "
+                        "source is committed.  by_workload: every other workload measured in this run on the same clock, one row each "
+                        "(by_workload_columns); '<w>/pipe%d' = the same arenas as %d independent sub-batches on streams of their own" % (PIPE_K, PIPE_K))
         if world > 1:
-            par = "arena-sharded x%d; every step's (reward, done) gathered to rank 0 %s%s" % (
+            par = "arena-sharded x%d; every step's (reward, done) gathered to rank 0 %s%s%s" % (
                 world, "in asynchronous blocks of %d steps" % args.gather_block if args.gather == "block" else "by one collective per step",
-                ", plus every step's uint8 screen frames" if args.gather_obs == "screen" else "")
+                ", plus every step's uint8 screen frames" if args.gather_obs == "screen" else "",
+                ", %d sub-batches per rank" % args.sub_batches if args.sub_batches > 1 else "")
         else:
-            par = "single GPU"
+            par = "single GPU" + (", %d sub-batches on streams of their own" % args.sub_batches if args.sub_batches > 1 else "")
         out = {
             "metric": "env-steps/sec (arenas x ticks/s)", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": K, "warmup": Wm, "ms_per_step": res["elapsed"] / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc % A, "arenas_total": world * A, "ticks_per_step": ticks, "parallelism": par},
+            "config": {"workload": desc % ((A, A) if desc.count("%d") == 2 else A), "arenas_total": world * A, "ticks_per_step": ticks, "parallelism": par},
             "gym_steps_per_s": value / ticks,
             "world_size": world, "backend": (backend if world > 1 else None), "rank_devices": devs,
             # one entry per rank: its own wall / HIP-event step time, host time spent waiting for collectives, collectives and bytes it sent
@@ -597,55 +711,62 @@ def main():
             "roofline": roof,
             "capacity_flags_raised": int((res["flags"] != 0).sum()),
         }
-        if world == 1 and not args.no_large and args.workload == "C2" and A != LARGE_ARENAS:
-            # the same kernel where it is bandwidth- rather than latency-bound: >= 50 k arenas (north star), short run
+        headline = args.workload == "C2" and world == 1 and args.sub_batches == 1
+        by = {}                      # roofline.by_workload: one compact row per other workload measured in this run (BY_WORKLOAD_COLUMNS)
+        detail = {}                  # the full roofline blocks of the same runs (top-level `roofline_full`, as in earlier rounds)
+        cpu = cpu_baseline() if (headline and not args.no_cpu_baseline) else None
+        ncores = cpu["cores"] if cpu else None
+
+        def measure(name, wcfg, a_, k_, w_, ra=False, wo=False, ws=False, wr=False, sm=0, sub=1, scr=(84, 84, False), cpu_rate=None, cpu_cores=None, label=None):
+            key = "%s@%d%s" % (name, a_, "/pipe%d" % sub if sub > 1 else "")
             try:
-                big = run_workload(torch, np, VecEnvironment, agdist, dev, dev_index, 0, 1, LARGE_ARENAS, 200, 40, cfg, rand_act, False, False, "block", "none")
-                rl = roofline_block(big, LARGE_ARENAS, 200, ticks, cfg, args.workload)
-                rl["value_env_steps_per_s"] = LARGE_ARENAS * ticks * 200 / big["elapsed"]
-                rl["ms_per_step"] = big["elapsed"] / 200 * 1e3
-                out["roofline_large"] = rl
+                r2 = run_workload(torch, np, VecEnvironment, agdist, dev, dev_index, 0, 1, a_, k_, w_, wcfg, ra, wo, ws, "block", "none", 32, sm, wr, sub_batches=sub, screen=scr)
+                ex, mex, kern = obs_bytes(r2, a_, wcfg, wo, ws, wr, scr)
+                rf = roofline_block(r2, a_, k_, wcfg["ticks_per_step"], wcfg, name, ex, kern, mex)
+                v_ = a_ * wcfg["ticks_per_step"] * k_ / r2["elapsed"]; ms_ = r2["elapsed"] / k_ * 1e3
+                rf["value_env_steps_per_s"] = v_; rf["ms_per_step"] = ms_
+                rf["mean_counts_pellets_viruses_foods_cells"] = [float(x) for x in r2["counts"]]
+                if label:
+                    rf["workload"] = label
+                by[key] = compact(rf, v_, ms_, cpu_rate, cpu_cores)
+                detail[key] = rf
+                return rf
             except Exception as ex:  # the headline line must not depend on it
-                out["roofline_large"] = {"error": str(ex)}
-            try:
-                xl = run_workload(torch, np, VecEnvironment, agdist, dev, dev_index, 0, 1, XLARGE_ARENAS, 100, 20, cfg, rand_act, False, False, "block", "none")
-                rx = roofline_block(xl, XLARGE_ARENAS, 100, ticks, cfg, args.workload)
-                rx["value_env_steps_per_s"] = XLARGE_ARENAS * ticks * 100 / xl["elapsed"]
-                rx["ms_per_step"] = xl["elapsed"] / 100 * 1e3
-                out["roofline_xlarge"] = rx
-            except Exception as ex:
-                out["roofline_xlarge"] = {"error": str(ex)}
-            # between and beside them: where the step turns from latency- to bandwidth-bound (compact entries, same accounting)
-            sweep = []
-            for a_ in SWEEP_ARENAS:
-                try:
-                    r_ = run_workload(torch, np, VecEnvironment, agdist, dev, dev_index, 0, 1, a_, 100, 20, cfg, rand_act, False, False, "block", "none")
-                    b_ = roofline_block(r_, a_, 100, ticks, cfg, args.workload)
-                    sweep.append({"arenas": a_, "ms_per_step": r_["elapsed"] / 100 * 1e3, "value_env_steps_per_s": a_ * ticks * 100 / r_["elapsed"],
-                                  "achieved": b_["achieved"], "frac": b_["frac"], "unit": b_["unit"]})
-                except Exception as ex:
-                    sweep.append({"arenas": a_, "error": str(ex)})
-            out["roofline_sweep"] = sweep
-        if world == 1 and not args.no_full and args.workload == "C2":
-            # the other two regimes in the same run: the full rule set at mass 1000 (BASELINE configs[2]) and a learning agent's mid-game
-            # ... and BASELINE configs[0] (the bench/main.cpp population, batched) and configs[4] (grid / screen observation on top of the
-            # full rule set): every BASELINE config has a figure on the driver's clock
-            full = {}
-            for name, fk, fw in (("C3m6", 100, 20), ("mid", 150, 400), ("C1", 100, 20), ("C5", 60, 20), ("C5s", 60, 20)):
-                try:
-                    w2 = dict(WORKLOADS[name]); w2.pop("desc"); ra = w2.pop("rand_act", False); sm = w2.pop("start_mass", 0)
-                    wo, ws, wr = w2.pop("grid_obs", False), w2.pop("screen_obs", False), w2.pop("ram_obs", False)
-                    c2 = dict(CFG); c2.update(w2)
-                    r2 = run_workload(torch, np, VecEnvironment, agdist, dev, dev_index, 0, 1, A, fk, fw, c2, ra, wo, ws, "block", "none", 32, sm, wr)
-                    ex, mex, kern = obs_bytes(r2, A, c2, wo, ws, wr)
-                    rf = roofline_block(r2, A, fk, ticks, c2, name, ex, kern, mex)
-                    rf["value_env_steps_per_s"] = A * ticks * fk / r2["elapsed"]; rf["ms_per_step"] = r2["elapsed"] / fk * 1e3
-                    rf["mean_counts_pellets_viruses_foods_cells"] = [float(x) for x in r2["counts"]]
-                    rf["workload"] = WORKLOADS[name]["desc"] % A
-                    full["%s@%d" % (name, A)] = rf
-                except Exception as ex:
-                    full["%s@%d" % (name, A)] = {"error": str(ex)}
-            out["roofline_full"] = full
+                by[key] = {"error": str(ex)}; detail[key] = {"error": str(ex)}
+                return None
+
+        def wl_args(name):
+            w2 = dict(WORKLOADS[name]); lab = w2.pop("desc")
+            kw = dict(ra=w2.pop("rand_act", False), sm=w2.pop("start_mass", 0), wo=w2.pop("grid_obs", False), ws=w2.pop("screen_obs", False), wr=w2.pop("ram_obs", False))
+            c2 = dict(CFG); c2.update(w2)
+            return c2, kw, lab
+
+        if headline and not args.no_large:
+            # the same kernels where they are bandwidth- rather than latency-bound: >= 50 k arenas (north star), short runs
+            c2cpu = (cpu["value"], ncores) if cpu else (None, None)
+            by["C2@%d" % A] = compact(roof, value, out["ms_per_step"], *c2cpu)
+            for a_, k_, w_, top in ((16384, 100, 20, None), (LARGE_ARENAS, 200, 40, "roofline_large"), (131072, 100, 20, None), (XLARGE_ARENAS, 100, 20, "roofline_xlarge")):
+                rf = measure("C2", cfg, a_, k_, w_, ra=rand_act, cpu_rate=c2cpu[0], cpu_cores=c2cpu[1])
+                if top:
+                    out[top] = rf if rf is not None else {"error": by["C2@%d" % a_].get("error")}
+            out["roofline_sweep"] = [{"arenas": a_, "ms_per_step": detail["C2@%d" % a_].get("ms_per_step"), "value_env_steps_per_s": detail["C2@%d" % a_].get("value_env_steps_per_s"),
+                                      "achieved": detail["C2@%d" % a_].get("achieved"), "frac": detail["C2@%d" % a_].get("frac"), "unit": "GB/s"} for a_ in SWEEP_ARENAS]
+        if headline and not args.no_full:
+            # every other BASELINE config on the same clock: the full rule set at mass 1000 (configs[2]), a learning agent's mid-game, configs[0]
+            # (the bench/main.cpp population, batched), configs[4] (grid / screen observation on top of the full rule set) -- each also as
+            # PIPE_K independent sub-batches --, and the full rule set at 32768 arenas on one GPU (configs[3]'s per-node size / 8)
+            c6cpu = (cpu["c3m6_value"], ncores) if cpu else (None, None)
+            c1cpu = (cpu["c1_ticks_per_s_1core"], 1) if cpu else (None, None)
+            for name, fk, fw, cr in (("C3m6", 100, 20, c6cpu), ("mid", 150, 400, (None, None)), ("C1", 100, 20, c1cpu), ("C5", 60, 20, c6cpu), ("C5s", 60, 20, c6cpu)):
+                c2, kw, lab = wl_args(name)
+                rf = measure(name, c2, A, fk, fw, cpu_rate=cr[0], cpu_cores=cr[1], label=lab % A, **kw)
+                if name == "C1" and rf is not None and cpu:
+                    rf["cpu_reference_ticks_per_s_1core"] = cpu["c1_ticks_per_s_1core"]
+                measure(name, c2, A, fk, fw, sub=PIPE_K, cpu_rate=cr[0], cpu_cores=cr[1], label=(lab % A) + " -- as %d sub-batches" % PIPE_K, **kw)
+                if name in ("C3m6", "mid"):      # ... and as four (GPU_MAX_HW_QUEUES was raised above: four queues beside torch's streams)
+                    measure(name, c2, A, fk, fw, sub=4, cpu_rate=cr[0], cpu_cores=cr[1], label=(lab % A) + " -- as 4 sub-batches", **kw)
+            c2, kw, lab = wl_args("C3m6")
+            measure("C3m6", c2, 32768, 40, 10, cpu_rate=c6cpu[0], cpu_cores=c6cpu[1], label=lab % 32768, **kw)
         if world == 1:  # measured roofline next to the nominal one: device stream copy and fill of 1 GiB
             try:
                 src = torch.empty(1 << 28, dtype=torch.int32, device=dev); dst = torch.empty_like(src)
@@ -660,31 +781,62 @@ def main():
                 copy_gbs = _bw(lambda: dst.copy_(src), 2 * src.numel() * 4)
                 fill_gbs = _bw(lambda: dst.fill_(1), src.numel() * 4)
                 del src, dst
-                for r in [out["roofline"], out.get("roofline_large"), out.get("roofline_xlarge")] + list(out.get("roofline_full", {}).values()):
-                    if r and "achieved" in r:
-                        r["measured_copy_GBs"] = copy_gbs; r["measured_fill_GBs"] = fill_gbs
-                        r["frac_of_measured_copy"] = r["achieved"] / copy_gbs
+                for r in [roof] + [v for v in detail.values() if v and "achieved" in v]:
+                    r["measured_copy_GBs"] = copy_gbs; r["measured_fill_GBs"] = fill_gbs
+                    r["frac_of_measured_copy"] = r["achieved"] / copy_gbs
+                    r["guide_copy_GBs"] = GUIDE_COPY_GBS; r["frac_of_guide_copy"] = r["achieved"] / GUIDE_COPY_GBS
             except Exception:
                 pass
-        if world == 1 and not args.no_full and args.workload == "C2":
+        if headline and not args.no_full:
             # bench/main.cpp:14-38 literally: Tick/{0,5,10,20,30} -- N ExampleBots and no Player on the default engine -- batched at this arena
             # count, with the reference engine's own rate on one host core beside each
             table = {}
             for nb in TICK_BOTS:
+                key = "Tick/%d@%d" % (nb, A)
                 try:
-                    r3, _ = run_tick_workload(nb, A, 50, 10, dev_index)
+                    r3, c3 = run_tick_workload(nb, A, 50, 10, dev_index)
                     ent = {"gpu_env_steps_per_s": A * 4 * 50 / r3["elapsed"], "gpu_us_per_4_ticks": r3["kernel_ms"] * 1e3}
                     if not args.no_cpu_baseline:
                         ent["cpu_ticks_per_s_1core"], ent["cpu_kind"] = tick_reference_rate(nb)
-                    table["Tick/%d@%d" % (nb, A)] = ent
+                    table[key] = ent
+                    rf = roofline_block(r3, A, 50, 4, c3, "tick%d" % nb, kernel="k_step (agarcl_tick)")
+                    by[key] = compact(rf, ent["gpu_env_steps_per_s"], r3["elapsed"] / 50 * 1e3, ent.get("cpu_ticks_per_s_1core"), 1 if "cpu_ticks_per_s_1core" in ent else None)
                 except Exception as ex:
-                    table["Tick/%d@%d" % (nb, A)] = {"error": str(ex)}
+                    table[key] = {"error": str(ex)}; by[key] = {"error": str(ex)}
             out["bench_main_cpp_tick"] = table
-        if world == 1 and not args.no_cpu_baseline and args.workload == "C2":
-            out["cpu_baseline"] = cpu_baseline()
-            c1 = out.get("roofline_full", {}).get("C1@%d" % A)
-            if c1 and "error" not in c1:   # the reference engine on the same population (bench/main.cpp:14-38), one host core
-                c1["cpu_reference_ticks_per_s_1core"] = out["cpu_baseline"]["c1_ticks_per_s_1core"]
+            # the reference's ten RL tasks (bench/tasks_configs/mode_{1..10}.json), each with its 128 x 128 agent-view frame written every step
+            tasks = {}
+            for m in sorted(paper_tasks()):
+                tcfg, tscr, tdesc = task_workload(m)
+                cr = (None, None)
+                if not args.no_cpu_baseline:
+                    try:
+                        cr = (reference_rate(tcfg, 0.4)[0], 1)
+                    except Exception:
+                        pass
+                rf = measure("task%d" % m, tcfg, A, 40, 10, ra=True, ws=True, scr=tscr, cpu_rate=cr[0], cpu_cores=cr[1], label=tdesc.replace("%%", "%") % (A, A))
+                if rf is not None:
+                    tasks["task%d" % m] = by["task%d@%d" % (m, A)]
+            roof["tasks"] = {"columns": BY_WORKLOAD_COLUMNS, "rows": tasks,
+                             "what": "the reference's bench/tasks_configs/mode_{1..10}.json at %d arenas: k_step (+ k_quiet / k_fused) + k_screen_obs 128x128x4 per step" % A}
+            try:   # the RL surface itself: AgarioVectorEnv.step = ONE agarcl_vec_step (step + bookkeeping / auto-reset + observation)
+                vs = vector_surface(torch, A, 200, 30, dev_index)
+                roof["gym_vector"] = vs
+                out["gym_vector_steps_per_s"] = vs["no_obs"]["gym_vector_steps_per_s"]
+                roof["gym_vector_pipe%d" % PIPE_K] = vector_surface(torch, A, 200, 30, dev_index, sub_batches=PIPE_K)
+            except Exception as ex:
+                roof["gym_vector"] = {"error": str(ex)}
+        if headline and not args.no_full:
+            out["roofline_full"] = {k: v for k, v in detail.items() if not k.startswith("C2@")}
+        for r in [v for v in detail.values() if v and "achieved" in v and "guide_copy_GBs" not in v]:   # (blocks measured after the copy was timed)
+            if "measured_copy_GBs" in roof:
+                r["measured_copy_GBs"] = roof["measured_copy_GBs"]; r["measured_fill_GBs"] = roof["measured_fill_GBs"]; r["frac_of_measured_copy"] = r["achieved"] / roof["measured_copy_GBs"]
+            r["guide_copy_GBs"] = GUIDE_COPY_GBS; r["frac_of_guide_copy"] = r["achieved"] / GUIDE_COPY_GBS
+        if by:
+            roof["by_workload_columns"] = BY_WORKLOAD_COLUMNS
+            roof["by_workload"] = by
+        if cpu:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -1,7 +1,11 @@
 """A rollout loop through the batched user surface (agarcl_amd/vector_env.py: AgarioVectorEnv): N arenas, a random policy on the device,
 T steps collected into a rollout buffer -- the shape of a PPO / IMPALA actor -- with nothing inside the loop that waits for the GPU.
 
-    python examples/vector_rollout.py [--envs 4096] [--steps 256] [--obs grid|ram|screen|none] [--difficulty normal]
+    python examples/vector_rollout.py [--envs 4096] [--steps 256] [--obs grid|ram|screen|none] [--difficulty normal] [--sub-batches 2 [--halves]]
+
+--sub-batches k: the arenas as k independent ranges on HIP streams of their own (a range never waits for the slowest arena of another, one
+range's observation kernel runs under another's step); --halves: double-buffered sampling through recv(j) / send(actions_j, j) -- the policy
+works on range j's observations while the other ranges step.
 
 Prints env-steps per second of the whole loop (engine step + observation + Python), which is what a learner sees; `bench.py` times the
 engine alone."""
@@ -14,8 +18,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--envs", type=int, default=4096); ap.add_argument("--steps", type=int, default=256)
 ap.add_argument("--obs", default="ram"); ap.add_argument("--difficulty", default="normal"); ap.add_argument("--number-steps", type=int, default=500)
 ap.add_argument("--bare", action="store_true", help="time venv.step alone: one fixed action batch, no rollout buffer")
+ap.add_argument("--sub-batches", type=int, default=1); ap.add_argument("--halves", action="store_true", help="recv / send per sub-batch instead of full-batch step()")
+ap.add_argument("--mode", type=int, default=0)
 a = ap.parse_args()
-venv = AgarioVectorEnv(a.envs, obs_type=a.obs, difficulty=a.difficulty, number_steps=a.number_steps, env_type=0)
+venv = AgarioVectorEnv(a.envs, obs_type=a.obs, difficulty=a.difficulty, number_steps=a.number_steps, env_type=0, sub_batches=a.sub_batches, mode=a.mode,
+                       **({"num_viruses": 25} if a.mode else {}))
 dev = venv.device
 obs, _ = venv.reset(seed=1)
 g = torch.Generator(device=dev); g.manual_seed(0)
@@ -30,6 +37,24 @@ if a.bare:
     for t in range(a.steps): venv.step(act)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print("%d envs x %d steps, obs=%s, step() alone: %.3g env-steps/s (%.1f us per vector step)" % (a.envs, a.steps, a.obs, a.envs * a.steps / dt, dt / a.steps * 1e6))
+    venv.close(); sys.exit(0)
+if a.halves:   # every range on its own: range j's policy output is computed from range j's observation while the other ranges step
+    k = venv.sub_batches
+    def policy_j(n):
+        return torch.rand((n, 2), generator=g, device=dev) * 2 - 1, torch.randint(0, 3, (n,), generator=g, device=dev, dtype=torch.int32)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    episodes = torch.zeros((), dtype=torch.int64, device=dev)
+    for t in range(a.steps):
+        for j in range(k):
+            obs_j, rew_j, term_j, trunc_j, info_j = venv.recv(j)      # the current stream now waits for range j only
+            lo, cnt = venv.ranges[j]
+            if buf_obs is not None: buf_obs[t, lo:lo + cnt].copy_(obs_j)
+            buf_rew[t, lo:lo + cnt].copy_(rew_j); buf_done[t, lo:lo + cnt].copy_(term_j)
+            episodes += info_j["ended"].sum()
+            venv.send(policy_j(cnt), j)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("%d envs x %d steps as %d ranges (recv / send halves), obs=%s: %.3g env-steps/s (%.1f us per vector step); %d episodes ended"
+          % (a.envs, a.steps, k, a.obs, a.envs * a.steps / dt, dt / a.steps * 1e6, int(episodes.item())))
     venv.close(); sys.exit(0)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 episodes = torch.zeros((), dtype=torch.int64, device=dev); ret_sum = torch.zeros((), dtype=torch.float32, device=dev)

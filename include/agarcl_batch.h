@@ -33,7 +33,7 @@ extern "C" {
 #define AGARCL_F_CELLS_OVERFLOW 1u
 #define AGARCL_F_FOODS_OVERFLOW 2u
 #define AGARCL_F_VIRUSES_OVERFLOW 4u
-#define AGARCL_F_EVENTS_OVERFLOW 8u
+#define AGARCL_F_EVENTS_OVERFLOW 8u   /* more eat events in one tick than the arena holds: 256 (+ a spill area of 64 per pellet slot in dense arenas) */
 #define AGARCL_F_VTICKS_OVERFLOW 16u
 #define AGARCL_F_MASS_LUT_OVERFLOW 32u
 #define AGARCL_F_PELLETS_OVERFLOW 64u
@@ -54,7 +54,7 @@ typedef struct agarcl_config {
   double dt;              /* seconds per tick; 0 -> DEFAULT_DT = 1/30 (BaseEnvironment.hpp:14) */
   int32_t cap_cells;      /* cells per player, 0 -> 32 (reference: unbounded vector, nominal limit 14) */
   int32_t cap_viruses;    /* 0 -> num_viruses + 64 */
-  int32_t cap_foods;      /* 0 -> 128 (ejected foods live in LDS during a launch: 16 bytes each) */
+  int32_t cap_foods;      /* 0 -> max(128, 16 per player) (ejected foods live in LDS during a launch: 16 bytes each) */
   /* ScreenEnvironment semantics (environment/envs/ScreenEnvironment.hpp:233-243): a dead agent is respawned right
    * after the ticks of a step in EVERY mode, and that step's rewards get + c_death (BaseEnvironment.hpp:116-120) */
   int32_t screen_respawn;
@@ -266,6 +266,10 @@ int agarcl_pipe_seed(agarcl_pipe *pipe, const uint32_t *seeds_host, uint32_t bas
 int agarcl_pipe_concurrent(agarcl_pipe *pipe);
 /* waits for every sub-batch's stream (the reference's single pool.wait()) */
 int agarcl_pipe_sync(agarcl_pipe *pipe);
+/* agarcl_stream_wait for all sub-batches at once: ONE event recorded on `producer_stream`, every sub-batch's stream waits for it (device-side) */
+int agarcl_pipe_fork(agarcl_pipe *pipe, void *producer_stream);
+/* agarcl_stream_signal for all sub-batches at once: `consumer_stream` waits (device-side) for everything every sub-batch has enqueued so far */
+int agarcl_pipe_join(agarcl_pipe *pipe, void *consumer_stream);
 
 
 /* ---- diagnostics (not part of the drop-in surface; used by tests/ and scripts/) --------------------------------------- */

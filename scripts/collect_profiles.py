@@ -78,6 +78,22 @@ def main():
                 if cnt.get("SQ_ACTIVE_INST_VALU"):
                     cnt["thread_cycles_per_active_valu_cycle"] = cnt.get("SQ_THREAD_CYCLES_VALU", 0.0) / cnt["SQ_ACTIVE_INST_VALU"]   # raw ratio (both in the counters' own units)
             ent["sq_per_launch"] = per
+            # the dominant kernel's issue-rate figures, as bench.py quotes them (roofline.frac_valu_issue / mean_wave_residency / clock_ghz_measured):
+            #   clock_ghz = SQ_BUSY_CYCLES / 32 / kernel time (the counter sums 32 shader engines' busy cycles);
+            #   frac_valu_issue = SQ_INSTS_VALU x 2 cycles / (kernel time x clock x 1024 SIMDs): share of the VALU issue slots used;
+            #   mean_wave_residency = (SQ_WAVE_CYCLES x 4 / wavefronts of the launch) / (SQ_BUSY_CYCLES / 32): mean time a wavefront is resident /
+            #   the launch's duration (k_step only: one wavefront per arena, at most 4096 resident slots)
+            ks = ent.get("kernel_stats", {})
+            dom = max((k for k in per if k in ks), key=lambda k: ks[k]["total_ms"], default=None)
+            if dom and per[dom].get("SQ_BUSY_CYCLES") and ks[dom].get("avg_us"):
+                cnt, us = per[dom], ks[dom]["avg_us"]
+                clock = cnt["SQ_BUSY_CYCLES"] / 32.0 / (us * 1e-6)
+                iss = {"kernel": dom, "clock_ghz": clock / 1e9, "kernel_avg_us": us,
+                       "frac_valu_issue": cnt.get("SQ_INSTS_VALU", 0.0) * 2.0 / (us * 1e-6 * clock * 1024.0)}
+                if dom == "k_step" and cnt.get("SQ_WAVE_CYCLES"):
+                    waves = float(min(int(a), 4096))
+                    iss["mean_wave_residency"] = (cnt["SQ_WAVE_CYCLES"] * 4.0 / waves) / (cnt["SQ_BUSY_CYCLES"] / 32.0)
+                ent["issue"] = iss
         if tot and ent.get("steps_total"):
             st = ent["steps_total"]
             fetch = sum(v for (k, c), v in tot.items() if c == "FETCH_SIZE") * 1024.0 / st

@@ -10,6 +10,8 @@ from agarcl_amd.vec_env import VecEnvironment
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--workloads", default="C3m6,C5s,C5,C1,mid"); ap.add_argument("--ks", default="1,2,4,8")
+ap.add_argument("--stagger-us", type=float, default=400.0)
+ap.add_argument("--stagger", type=float, default=0.0, help="fraction of a step by which sub-batch j lags sub-batch j-1 at the start (GPU-side sleep)")
 ap.add_argument("--own", type=int, default=1, help="1: engine-owned HIP streams, 0: torch pool streams")
 ap.add_argument("--arenas", type=int, default=4096); ap.add_argument("--steps", type=int, default=100); ap.add_argument("--warmup", type=int, default=20)
 a = ap.parse_args()
@@ -57,11 +59,15 @@ for name in a.workloads.split(","):
         for s in range(W): step(s)
         for e in envs: e.sync()
         torch.cuda.synchronize()
+        if a.stagger > 0 and k > 1:     # sub-batch j starts j * stagger * (one lock-step step) late: its step then runs under its predecessor's observation kernel
+            for j in range(1, k):
+                with torch.cuda.stream(envs[j].torch_stream()):
+                    torch.cuda._sleep(int(a.stagger * j * a.stagger_us * 2.1e3))
         t0 = time.perf_counter()
         for s in range(W, W + K): step(s)
         for e in envs: e.sync()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        say("own=%d hwq=%s " % (a.own, os.environ.get("GPU_MAX_HW_QUEUES", "-")) + "%-6s arenas %6d  sub-batches %d: %9.2f us per %d arena-steps   %.4g env-steps/s" % (name, A, k, el / K * 1e6, A, A * 4 * K / el))
+        say("stagger=%.2f own=%d hwq=%s " % (a.stagger, a.own, os.environ.get("GPU_MAX_HW_QUEUES", "-")) + "%-6s arenas %6d  sub-batches %d: %9.2f us per %d arena-steps   %.4g env-steps/s" % (name, A, k, el / K * 1e6, A, A * 4 * K / el))
         for e in envs: e.close()
         del envs, obs, dxdy, act

@@ -10,6 +10,7 @@ from oracle import orabind
 from lockstep import run_batched_lockstep
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 bad = flagged = 0
+by_flag = {}     # flag word -> trials that ended with it: a regression in the capacity corner shows as a changed histogram, not only as a count
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     na = int(rng.choice([1, 1, 1, 1, 2, 3]))
     mode = int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 6, 7, 8, 9, 10]))
@@ -45,7 +46,8 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     ok, msg = run_batched_lockstep(eng, oras, 120, seeds=sd, policy_seed=ps, sticky=st, every=int(os.environ.get('SOAK_EVERY', 30)), ticks_per_step=tps)
     fl = eng.flags(); eng.close()
     if fl.any():   # an arena left the reference's unbounded containers / tables: flagged by design, not a parity failure
-        flagged += 1; print("flagged (capacity) trial", trial, cfg, "flags 0x%x" % int(np.bitwise_or.reduce(fl))); continue
+        w_ = int(np.bitwise_or.reduce(fl)); by_flag[w_] = by_flag.get(w_, 0) + 1
+        flagged += 1; print("flagged (capacity) trial", trial, cfg, "flags 0x%x" % w_); continue
     if not ok:
         bad += 1; print("MISMATCH trial", trial, cfg, pins, A, msg); break
-print("soak done:", trial + 1, "trials,", bad, "bad,", flagged, "flagged")
+print("soak done:", trial + 1, "trials,", bad, "bad,", flagged, "flagged", "by flag word: " + ", ".join("0x%x: %d" % kv for kv in sorted(by_flag.items())) if by_flag else "")

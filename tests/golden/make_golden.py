@@ -134,6 +134,15 @@ def main():
            500, seed=42, checkpoints=[0, 499])
     record("roll_multi3_mode6_s5", dict(num_agents=3, ticks_per_step=4, arena_size=250, num_pellets=500, num_viruses=10, mode=6),
            400, seed=5, sticky=8, checkpoints=[0, 399])
+    # the paper's tasks (values of /root/reference/bench/tasks_configs/mode_{1,4,7,10}.json via tests/golden/paper_tasks.json: 350 x 350 arena,
+    # 500 pellets, no viruses, one bot in modes 7-10), 300 steps each
+    tasks = json.load(open(os.path.join(HERE, "paper_tasks.json")))["tasks"]
+    for m, sd in ((1, 101), (4, 104), (7, 107), (10, 110)):
+        t = tasks[str(m)]
+        record("task_mode%d_s%d" % (m, sd), dict(num_agents=1, ticks_per_step=t["ticks_per_step"], arena_size=t["arena_size"], num_pellets=t["num_pellets"],
+                                                 num_viruses=t["num_viruses"], num_bots=t["num_bots"], mode=m, reward_type=t["reward_type"], c_death=t["c_death"],
+                                                 pellet_regen=bool(t["pellet_regen"])),
+               300, seed=sd, sticky=8, checkpoints=[0, 149, 299], note="bench/tasks_configs/mode_%d.json" % m)
     record("roll_mode9_bot_s2", dict(num_agents=1, ticks_per_step=4, arena_size=200, num_pellets=500, num_viruses=5, num_bots=1, mode=9), 300, seed=2, sticky=8)
 
     # ---- bench/main.cpp's Tick population (bench/main.cpp:14-38): N ExampleBots (agario/bots/ExampleBot.hpp:45-51) on the default 250 x 250

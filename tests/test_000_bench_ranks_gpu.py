@@ -9,8 +9,9 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--gather", "step"], ["--gather", "step", "--gather-obs", "screen", "--arenas", "1024"]],
-                         ids=["block", "step", "step+screen"])
+@pytest.mark.parametrize("extra", [[], ["--gather", "step"], ["--gather", "step", "--gather-obs", "screen", "--arenas", "1024"],
+                                   ["--sub-batches", "2"], ["--sub-batches", "2", "--gather", "step", "--gather-obs", "screen", "--arenas", "1024"]],
+                         ids=["block", "step", "step+screen", "pipe2", "pipe2+step+screen"])
 def test_bench_two_ranks_end_to_end_gpu(extra):
     """bench.py --gpus 2 end to end on a 1-GPU box: the self-spawning launcher (children are started before anything touches the GPU and
     nothing is ever re-exec'd), 2 ranks over gloo sharing GPU 0 (AGAR_BENCH_BACKEND: the driver's multi-GPU runs use nccl == RCCL, a branch
@@ -35,10 +36,12 @@ def test_bench_two_ranks_end_to_end_gpu(extra):
     assert [r["rank"] for r in b["ranks"]] == [0, 1]
     for r in b["ranks"]:
         assert r["ms_per_step"] > 0 and r["kernel_ms_per_step"] > 0 and r["gather_wait_ms_total"] >= 0
+        sub = 2 if "--sub-batches" in extra else 1       # every sub-batch gathers its own result ring: `sub` collectives where one engine makes one
+        assert ("sub-batches" in b["config"]["parallelism"]) == (sub > 1)
         if "--gather" in extra:   # one collective per step, 8 bytes per arena
-            assert r["result_collectives"] == 40 and r["result_bytes_sent"] == 40 * arenas * 8
+            assert r["result_collectives"] == 40 * sub and r["result_bytes_sent"] == 40 * arenas * 8
         else:                     # whole 32-step blocks of the result ring: steps 10 .. 49 complete block 0 and leave block 1 partial (flushed as a block)
-            assert r["result_collectives"] == 2 and r["result_bytes_sent"] == 2 * 32 * arenas * 8
+            assert r["result_collectives"] == 2 * sub and r["result_bytes_sent"] == 2 * 32 * arenas * 8
         assert r["obs_collectives"] == (40 if "--gather-obs" in extra else 0) and r["obs_bytes_sent"] == (40 * arenas * 84 * 84 * 3 if "--gather-obs" in extra else 0)
 
 
@@ -80,9 +83,15 @@ def test_bench_line_as_the_driver_runs_it_gpu():
     assert b["roofline_large"]["arenas"] == 65536 and b["roofline_xlarge"]["arenas"] == 262144
     assert [e["arenas"] for e in b["roofline_sweep"]] == [16384, 131072] and all("error" not in e and e["ms_per_step"] > 0 and 0 < e["frac"] <= 1 for e in b["roofline_sweep"])
     full = b["roofline_full"]
-    assert set(full) == {"C3m6@4096", "mid@4096", "C1@4096", "C5@4096", "C5s@4096"}     # every BASELINE config on the driver's clock
-    for v in full.values():
-        assert "error" not in v and v["kernel_ms"] > 0 and v["work_per_step"]["general_engine_arena_steps"] > 4000
+    base = {"C3m6@4096", "mid@4096", "C1@4096", "C5@4096", "C5s@4096"}                    # every BASELINE config on the driver's clock ...
+    assert {k for k in full if "/" not in k and not k.startswith("task")} == base | {"C3m6@32768"}
+    assert {k for k in full if "/pipe" in k} == {k + "/pipe2" for k in base} | {"C3m6@4096/pipe4", "mid@4096/pipe4"}     # ... and as independent sub-batches
+    assert {k for k in full if k.startswith("task")} == {"task%d@4096" % m for m in range(1, 11)}
+    for k, v in full.items():
+        assert "error" not in v, (k, v)
+        assert v["kernel_ms"] > 0 and v["work_per_step"]["general_engine_arena_steps"] > (4000 if not k.startswith("task") else -1)
+        if "/pipe" in k:
+            assert v["sub_batches"] == int(k[-1]) and v["sub_batches_concurrent"] == int(k[-1]), (k, v.get("sub_batches_concurrent"))
     assert full["C1@4096"]["cpu_reference_ticks_per_s_1core"] > 0                        # bench/main.cpp's population on the reference engine
     assert full["C5@4096"]["streaming_model_bytes_per_step"] > 4096 * 8 * 128 * 128 * 4 and "k_grid_obs" in full["C5@4096"]["kernel"]
     assert "k_screen_obs" in full["C5s@4096"]["kernel"]
@@ -101,3 +110,21 @@ def test_bench_line_as_the_driver_runs_it_gpu():
         assert "error" not in v and v["gpu_env_steps_per_s"] > 0 and v["cpu_ticks_per_s_1core"] > 0 and v["cpu_kind"] in ("reference", "port")
     assert full["mid@4096"]["mean_counts_pellets_viruses_foods_cells"][3] > 1.5      # the agents have grown and split
     assert b["capacity_flags_raised"] == 0
+    # everything the driver's parse keeps lives inside `roofline`: one compact row per workload measured in this run, the issue-rate
+    # figures that bind the general engine (None until the round's SQ pass is committed for this kernel source), the tasks table, the
+    # vector surface
+    cols = r["by_workload_columns"]
+    assert cols[:2] == ["ms_per_step", "env_steps_per_s"] and "frac_valu_issue" in cols and "mean_wave_residency" in cols and "cpu_reference_env_steps_per_s" in cols
+    by = r["by_workload"]
+    want = ({"C2@%d" % a for a in (4096, 16384, 65536, 131072, 262144)} | set(full) | set(tick))
+    assert set(by) == want, sorted(set(by) ^ want)
+    for k, row in by.items():
+        assert isinstance(row, list) and len(row) == len(cols) and row[0] > 0 and row[1] > 0, (k, row)
+    assert by["C2@4096"][cols.index("cpu_reference_env_steps_per_s")] == c["value"] and by["C3m6@4096"][cols.index("cpu_reference_env_steps_per_s")] == c["c3m6_value"]
+    for k in ("frac_valu_issue", "mean_wave_residency", "clock_ghz_measured", "guide_copy_GBs", "frac_of_guide_copy", "frac_of_measured_copy"):
+        assert k in r, k
+    assert r["guide_copy_GBs"] == 6300.0
+    assert set(r["tasks"]["rows"]) == {"task%d" % m for m in range(1, 11)} and all(row[1] > 0 and row[6] > 0 for row in r["tasks"]["rows"].values())
+    gv = r["gym_vector"]
+    assert set(gv) == {"no_obs", "ram_obs", "screen_obs_84"} and all(v["host_us_per_step"] > 0 and v["gym_vector_steps_per_s"] > 0 for v in gv.values())
+    assert b["gym_vector_steps_per_s"] == gv["no_obs"]["gym_vector_steps_per_s"] and "gym_vector_pipe2" in r

@@ -12,6 +12,12 @@ CASES = [
     (dict(arena_size=300, num_pellets=300, num_viruses=5, mode=1), 200, 8),
     (dict(arena_size=1200, num_pellets=800, num_viruses=15, mode=3), 200, 8),
     (dict(arena_size=60, num_pellets=200, num_viruses=0, mode=0), 200, 8),
+    (dict(arena_size=50, num_pellets=200, num_viruses=0, mode=0), 300, 8),      # the gym "trivial" preset (AgarioEnv.py:329-338) ...
+    (dict(arena_size=50, num_pellets=200, num_viruses=0, mode=6), 300, 8),      # ... and with a mass-1000 agent: a sixth of the arena under one cell
+    # the soak's capacity corner: 80 x 80 with 1300 pellets -- a mass-1000 cell has ~200 pellets within its radius, a few such cells
+    # ate more than the 256 events per tick the fixed arrays held (flag 0x8): dense arenas spill the further events to HBM now (16 861 in one tick here)
+    (dict(arena_size=80, num_pellets=1300, num_viruses=0, mode=6), 150, 8),
+    (dict(num_agents=2, arena_size=80, num_pellets=1300, num_viruses=0, num_bots=2, mode=0), 150, 8),
     # several players per arena: bots (mode 0, modes 7-10) and multi-agent (cell-eats-cell, map order)
     (dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0), 600, 4),
     (dict(num_agents=3, arena_size=250, num_pellets=500, num_viruses=10, mode=6), 500, 8),

@@ -29,6 +29,12 @@ def test_hip_matches_reference_golden(hip_engine_cls, path):
     (dict(arena_size=300, num_pellets=300, num_viruses=5, mode=2), 300, 8),
     (dict(arena_size=1200, num_pellets=800, num_viruses=15, mode=3), 300, 8),
     (dict(arena_size=60, num_pellets=200, num_viruses=0, mode=0), 300, 8),   # "trivial" difficulty-like tiny arena
+    # the gym "trivial" preset itself (AgarioEnv.py:329-338: 50 x 50, 200 pellets): next to the capacity corner of the dense small arenas
+    (dict(arena_size=50, num_pellets=200, num_viruses=0, mode=0), 400, 8),
+    (dict(arena_size=50, num_pellets=200, num_viruses=0, mode=6), 400, 8),
+    # the capacity corner of the dense small arenas: more than 256 eat events in one tick: candidates up to the pellet capacity, further events spilled to HBM
+    (dict(arena_size=80, num_pellets=1300, num_viruses=0, mode=6), 300, 8),
+    (dict(num_agents=2, arena_size=80, num_pellets=1300, num_viruses=0, num_bots=2, mode=0), 300, 8),    # four players: 37 821 eat events in one tick
     (dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode=6, reward_type=0), 200, 8),
     # several players per arena: bots, multi-agent, map-order rehash
     (dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0), 600, 4),

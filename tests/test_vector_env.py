@@ -219,3 +219,7 @@ def test_rollout_example_runs(hip_engine_cls):
     assert int(line.split(";")[1].split()[0]) >= 64 * 2      # 30 steps of 10-step episodes: every arena ended at least twice
     out = subprocess.run([sys.executable, os.path.join(root, "examples", "vector_rollout.py"), "--envs", "64", "--steps", "10", "--obs", "none", "--bare"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "step() alone" in out.stdout, out.stderr[-2000:]
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "vector_rollout.py"), "--envs", "96", "--steps", "25", "--obs", "ram", "--number-steps", "10",
+                          "--sub-batches", "2", "--halves", "--mode", "6"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "as 2 ranges (recv / send halves)" in out.stdout, out.stderr[-2000:]
+    assert int(out.stdout.strip().splitlines()[-1].split(";")[1].split()[0]) >= 96      # every arena ended at least once
