@@ -1728,34 +1728,70 @@ template <int NS, bool AV> AG_DEV unsigned simple_turns(AgCtx<NS, AV> &c) {
   if (SR(c, AR_NFOOD) != 0) return 0u;   // ejected food somewhere: the per-player food test decides (Engine.hpp:520-525)
   const int nv = SR(c, AR_NVIR), np = SR(c, AR_NPEL);
   const bool decays = c.gs->g.mass_decay != 0;
-  unsigned dead = 0u;
+  // one look at every player's words and cell, a lane per player: the candidate, dead and ejecting players as three masks
   UBlock bx, by, br;
-  ub_fill(bx, [&](int l) { return l < P ? f2u(cells_of(c, l).x[0]) : 0; });
-  ub_fill(by, [&](int l) { return l < P ? f2u(cells_of(c, l).y[0]) : 0; });
-  ub_fill(br, [&](int l) { if (l >= P) return 0; const Cells s = cells_of(c, l); return f2u(cell_rad(c, s, 0)); });
-  unsigned cand = wave_or(P, [&](int p) -> unsigned {
+#ifdef AGAR_CPU_EMU
+  unsigned codes[AG_MAX_PLAYERS];
+#else
+  unsigned mycode = 0u; int myx = 0, myy = 0, myr = 0;
+#endif
+  AG_LANES(p, P) {
     const int *PL = PLS(c, p); const int n = PL[PL_NCELLS];
-    if (n != 1) return 0u;
-    const unsigned m = cells_of(c, p).m[0];
+    const Cells s = cells_of(c, p);
+    const unsigned m = s.m[0];
     const int el = PL[PL_ELAPSED] + 1, fcd = PL[PL_FEED_CD], scd = PL[PL_SPLIT_CD], act = PL[PL_ACTION];
-    const bool ok = m < AG_MAX_MASS && (nv == 0 || m < 111u) && !(decays && el % 60 == 0) &&
-                    !(act == 1 && (fcd > 0 ? fcd - 1 : fcd) == 0) && !(act == 2 && (scd > 0 ? scd - 1 : scd) == 0);
-    return ok ? 1u << p : 0u;
-  });
-  dead = wave_or(P, [&](int p) -> unsigned { return PLS(c, p)[PL_NCELLS] == 0 ? 1u << p : 0u; });
-  if (np > 0) {
-    for (unsigned todo = cand; todo; todo &= todo - 1u) {   // pellets_eat's fast path for the player's one cell: nothing inside the current radius
+    const bool feed_due = act == 1 && (fcd > 0 ? fcd - 1 : fcd) == 0;
+    // (the cell's cached radius must be the radius of its mass -- move_cell leaves it so; otherwise the player takes its ordinary turn)
+    const bool ok = n == 1 && s.cmc[0] == m && m < AG_MAX_MASS && (nv == 0 || m < 111u) && !(decays && el % 60 == 0) && !feed_due && !(act == 2 && (scd > 0 ? scd - 1 : scd) == 0);
+    const unsigned code = (ok ? 1u : 0u) | (n == 0 ? 2u : 0u) | (n > 0 && feed_due ? 4u : 0u);
+#ifdef AGAR_CPU_EMU
+    bx.w[p] = f2u(s.x[0]); by.w[p] = f2u(s.y[0]); br.w[p] = f2u(s.crad[0]); codes[p] = code;
+#else
+    myx = f2u(s.x[0]); myy = f2u(s.y[0]); myr = f2u(s.crad[0]); mycode = code;
+#endif
+  }
+  unsigned cand, dead, ejectors;
+#ifdef AGAR_CPU_EMU
+  cand = dead = ejectors = 0u;
+  for (int p = 0; p < P; p++) { const unsigned code = codes[p]; cand |= (code & 1u) << p; dead |= ((code >> 1) & 1u) << p; ejectors |= ((code >> 2) & 1u) << p; }
+#else
+  bx.v = myx; by.v = myy; br.v = myr;
+  cand = (unsigned)__ballot((mycode & 1u) != 0u); dead = (unsigned)__ballot((mycode & 2u) != 0u); ejectors = (unsigned)__ballot((mycode & 4u) != 0u);   // (players are lanes 0 .. P-1 <= 31)
+#endif
+  // ... unless somebody ejects food on this tick (maybe_emit_food: action feed with the cooldown run out): the food appears in the middle of the
+  // tick and every player BEHIND the ejector in the iteration order tests it -- such a tick is played in order, player by player
+  if (ejectors) return dead;
+  if (np > 0 && cand) {
+    // pellets_eat's fast path for each candidate's one cell -- nothing inside the current radius --, for ALL candidates in one sweep: every lane
+    // tests its pellet slots against candidate after candidate and keeps a bit per candidate; ONE reduction at the end instead of a ballot and
+    // a branch per player
+    unsigned seen = 0u;
+#ifdef AGAR_CPU_EMU
+    for (unsigned todo = cand; todo; todo &= todo - 1u) {
+#else
+    unsigned mine = 0u;
+    for (unsigned todo = cand; todo; todo &= todo - 1u) {
+#endif
       const int p = __builtin_ctz(todo);
       const float x = u2f(ub_get(bx, p)), y = u2f(ub_get(by, p)), r0 = u2f(ub_get(br, p)); const float rr0 = r0 * r0;
       const int gx = f2i(x) / AG_PELLET_GRID, gy = f2i(y) / AG_PELLET_GRID;
-      const bool hit = pel_any(c, [&](float qx, float qy, int) {
+      auto hits = [&](float qx, float qy) -> bool {
         bool ok = rr0 >= sqr_dist(x, y, qx, qy);
         if constexpr (!AV) { int ddx = f2i(qx) / AG_PELLET_GRID - gx, ddy = f2i(qy) / AG_PELLET_GRID - gy; ok = ok && ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1; }
         return ok;
-      });
-      if (hit) cand &= ~(1u << p);
+      };
       (void)gx; (void)gy;
+#ifdef AGAR_CPU_EMU
+      if (pel_any(c, [&](float qx, float qy, int) { return hits(qx, qy); })) seen |= 1u << p;
     }
+#else
+      bool a = false;
+      AG_PEL_FOR(s_, lane_, i_) { a = a | hits(PELX(c, s_, lane_), PELY(c, s_, lane_)); }
+      mine |= a ? 1u << p : 0u;
+    }
+    seen = wred_or(mine);
+#endif
+    cand &= ~seen;
   }
   if (cand) {
     AG_LANES(p, P) {
@@ -2219,12 +2255,19 @@ template <int NS, bool AV> AG_DEV void arena_tick(AgCtx<NS, AV> &c) {
 #endif
   AG_T(c, 1);
   // (several players, kinematics done: the turns that are pure bookkeeping are performed for all such players at once -- simple_turns)
+#ifdef AG_NO_SIMPLE_TURNS   // (measurement / bisection builds)
+  const unsigned done_ = 0u;
+#else
   const unsigned done_ = c.moved_all ? simple_turns(c) : 0u;
+#endif
   for (int k = 0; k < c.P; k++) { const int p_ = SR(c, AR_ORDER0 + k); if (!((done_ >> p_) & 1u)) tick_player(c, p_); }
   remove_pellets(c);
   remove_viruses(c);
   AG_T(c, 13);
 #ifndef AG_ABL_SORT
+  if (c.P > 1) {   // (a player with fewer than two cells has nothing to sort: one parallel look at the counts instead of a dependent LDS read per player)
+    for (unsigned todo = wave_or(c.P, [&](int p) -> unsigned { return PLS(c, p)[PL_NCELLS] >= 2 ? 1u << p : 0u; }); todo; todo &= todo - 1u) sort_cells_by_id(c, __builtin_ctz(todo));
+  } else
   for (int k = 0; k < c.P; k++) sort_cells_by_id(c, SR(c, AR_ORDER0 + k));
 #endif
   AG_T(c, 14);

@@ -269,7 +269,9 @@ template <int NS, bool AV, int TSLG> __device__ __attribute__((noinline)) void g
   AgCtx<NS, AV> c; ag_ctx_init(c, gs, arena, ag_lds + lds_off, act_dxdy, act, slot);
   c.ts_lg = TSLG;
   arena_load(c, true);
-  env_step(c, ticks, with_env != 0, qd, qb);
+  // general ticks only, as k_step runs them (r05): the front part has played the quiet ticks it could; with the quiet run inlined here as well the
+  // callee needed 860 bytes of scratch per lane instead of 484 for the same times (C2 at 4096 / 65 536 / 131 072 arenas: 9.10 / 16.7 / 22.5 us either way)
+  env_step<NS, AV, false>(c, ticks, with_env != 0, qd, qb);
   arena_store(c);
   ag_lds_order();
 }

@@ -218,6 +218,9 @@ template <int NS, bool AV> AG_DEV void players_collision(AgCtx<NS, AV> &c) {
       const double eat_thr = (double)ma * 1.1; const bool eater = act && ma > 25u; const double dma = (double)ma;
       const int tlo = (int)(unsigned)(__builtin_bit_cast(unsigned long long, eat_thr) & 0xffffffffull), thi = (int)(unsigned)(__builtin_bit_cast(unsigned long long, eat_thr) >> 32);
       bool hit = false;
+      // (nobody can eat anybody while the heaviest cell is not 1.1 x the lightest one -- bench/main.cpp's ExampleBots, all of about the same mass)
+      const unsigned mmax = wred_max(act ? ma : 0u), mmin = wred_min(act ? ma : 0xffffffffu);
+      if (cell_can_eat_cell(mmax, mmin))
       for (int b = 0; b < T; b++) {
         const int pb = __builtin_amdgcn_readlane(pa, b);
         const float xb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xa), b)), yb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ya), b));

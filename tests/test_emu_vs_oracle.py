@@ -223,3 +223,16 @@ def test_emulated_mass_beyond_tables_is_flagged(emu_lib):
     fl = eng.flags()
     assert fl[0] & 32 and fl[1] & 32 and fl[2] == 0, fl
     eng.close()
+
+
+def test_batched_simple_turns_keep_the_iteration_order_where_it_matters(emu_lib, oracle_lib):
+    """several players per arena: the turns that are pure bookkeeping are performed for all such players at once (agar_core.inl simple_turns),
+    out of the engine's iteration order -- except on ticks on which a player ejects food, which the players behind it must test.  16 crowded
+    arenas, agents that feed and split at random: the first form of the batching, without that exception, diverged here at step 94."""
+    from agarcl_amd import _capi
+    cfg = dict(num_agents=2, arena_size=80, num_pellets=1300, num_viruses=0, num_bots=2, mode=0)
+    A = 16
+    eng = _capi.BatchedEngine(A, lib=emu_lib, **cfg)
+    oras = [oracle_lib.OraEnv(**cfg) for _ in range(A)]
+    ok, msg = run_batched_lockstep(eng, oras, 130, seeds=np.arange(500, 500 + A), sticky=8, every=5)
+    assert ok, msg
