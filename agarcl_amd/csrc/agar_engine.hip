@@ -183,7 +183,11 @@ __device__ __forceinline__ int ag_xcd_swizzle(int bid, int nwg) {
 // use_q: k_quiet ran in front of this launch and left a work list (qlist / qcount) of the arenas it did not finish; only
 // those are visited, resuming where the front part stopped.  A quiet-dominated step therefore costs this launch one
 // scalar load per workgroup whatever the arena count.
-template <int NS, bool AV, int TSLG> __global__ void __launch_bounds__(64) AG_KSTEP_ATTR k_step(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int use_q, int parity, int sp, const int32_t *order) {
+// MP: the arenas hold several players (or none).  The single-player instantiation tells the compiler so (c.P = 1 below): everything that exists for
+// several players only -- the batched simple turns, move_all_players, players_collision, the bots, the per-player loops -- folds away instead of
+// sitting, never executed, in the register allocation of the single-player engine (with simple_turns inlined into ONE k_step the 16-slot
+// instantiation went from 20 to 88 bytes of scratch per lane and wrote 26 MB instead of 9 MB per 4096-arena launch of mode 6: PMC WRITE_SIZE).
+template <int NS, bool AV, int TSLG, bool MP> __global__ void __launch_bounds__(64) AG_KSTEP_ATTR k_step(const AgState *__restrict__ gs, const float *act_dxdy, const int32_t *act, int ticks, int with_env, int slot, int use_q, int parity, int sp, const int32_t *order) {
   const int A = gs->d.A;
   int total = A;
   if (use_q) {
@@ -214,6 +218,7 @@ template <int NS, bool AV, int TSLG> __global__ void __launch_bounds__(64) AG_KS
     }
     AgCtx<NS, AV> c; ag_ctx_init(c, gs, arena, ag_lds, act_dxdy, act, slot);
     c.ts_lg = TSLG;   // (== gs->d.ts_lg, as a constant: the array strides fold into the address arithmetic)
+    if constexpr (!MP) c.P = 1;   // (== gs->d.P: launch_step picks the instantiation)
 #ifdef AGAR_PROFILE
     for (int i = 0; i < AG_NPROF; i++) c.tacc[i] = 0;
     c.tlast = ag_clock32();
@@ -268,6 +273,7 @@ template <int NS, bool AV, int QG, int TSLG> __global__ void __launch_bounds__(2
 template <int NS, bool AV, int TSLG> __device__ __attribute__((noinline)) void general_arena_step(const AgState *gs, int arena, int lds_off, const float *act_dxdy, const int32_t *act, int slot, int ticks, int with_env, int qd, int qb) {
   AgCtx<NS, AV> c; ag_ctx_init(c, gs, arena, ag_lds + lds_off, act_dxdy, act, slot);
   c.ts_lg = TSLG;
+  c.P = 1;   // (k_fused serves single-player envs only -- fused_ok --: the several-player code folds away, as in k_step<.., MP = false>)
   arena_load(c, true);
   // general ticks only, as k_step runs them (r05): the front part has played the quiet ticks it could; with the quiet run inlined here as well the
   // callee needed 860 bytes of scratch per lane instead of 484 for the same times (C2 at 4096 / 65 536 / 131 072 arenas: 9.10 / 16.7 / 22.5 us either way)
@@ -370,7 +376,8 @@ __global__ void k_tile_scatter(uint32_t *dst, const uint32_t *src, int R, int ag
 // front of k_step's loops does not fit 128 registers and is spilled on the spot).  The same source without these macros still builds as a
 // single unit.
 #if !defined(AGAR_CPU_EMU) && (defined(AG_PART_NS) || defined(AG_SPLIT_BUILD))
-#define AG_INST_STEP(X, N, V, T) X template __global__ void k_step<N, V, T>(const AgState *__restrict__, const float *, const int32_t *, int, int, int, int, int, int, const int32_t *);
+#define AG_INST_STEP1(X, N, V, T, M) X template __global__ void k_step<N, V, T, M>(const AgState *__restrict__, const float *, const int32_t *, int, int, int, int, int, int, const int32_t *);
+#define AG_INST_STEP(X, N, V, T) AG_INST_STEP1(X, N, V, T, false) AG_INST_STEP1(X, N, V, T, true)
 #define AG_INST_FRONT(X, N, V, Q, T) \
   X template __global__ void k_quiet<N, V, Q, T>(const AgHot, const AgState *__restrict__, const float *, const int32_t *, int, int, int, int); \
   X template __global__ void k_fused<N, V, Q, T>(const AgHot, const AgState *__restrict__, const float *, const int32_t *, int, int, int, int);
@@ -504,7 +511,8 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
 #undef CALL
 #undef CALLQ
   }
-#define CALL(N, V) hipLaunchKernelGGL((k_step<N, V, T>), dim3(kgrid), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, use_q, e->parity, e->sched_parity, order)
+#define CALLM(N, V, M) hipLaunchKernelGGL((k_step<N, V, T, M>), dim3(kgrid), dim3(64), e->lds_bytes, e->stream, e->d_state, e->act_dxdy, e->act, ticks, with_env, e->slot, use_q, e->parity, e->sched_parity, order)
+#define CALL(N, V) do { if (e->d.P == 1) CALLM(N, V, false); else CALLM(N, V, true); } while (0)
   // grid of k_step: every arena (grid-stride from 4096 workgroups on), or -- working off a list the statistics say is short --
   // 256 workgroups, which dispatch faster (the loop still visits every listed arena if the list is long after all)
   const int kfull = e->d.A < e->kstep_grid ? e->d.A : e->kstep_grid, kgrid = use_q && e->few_unfinished && kfull > AG_KSTEP_SMALL_GRID ? AG_KSTEP_SMALL_GRID : kfull;
@@ -523,6 +531,7 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
   if (!tiled) AG_DISPATCH_NS(e->ns, CALL);
 #undef T
 #undef CALL
+#undef CALLM
   if (use_q) e->parity ^= 1;
   e->sched_parity ^= 1;
   HIPCHK(hipGetLastError());
@@ -722,7 +731,10 @@ static int create_env(const agarcl_config *cfg, int32_t num_arenas, int32_t devi
   { const char *no = getenv("AGARCL_NO_ORDER"); e->no_order = no && no[0] == '1'; }
   // k_step's grid: 4096 single-wave workgroups is what stays resident (4 per SIMD).  AGARCL_KSTEP_GRID=<n> caps it lower: soaks and tests use it to
   // put small batches through the several-items-per-workgroup path (work counter, cost order)
-  e->kstep_grid = 4096; { const char *kg = getenv("AGARCL_KSTEP_GRID"); if (kg) { int v = atoi(kg); if (v >= 1 && v <= 4096) e->kstep_grid = v; } }
+#ifndef AG_KSTEP_MAXGRID
+#define AG_KSTEP_MAXGRID 4096   // (measurement builds with another AG_KSTEP_ATTR: waves per SIMD x 1024)
+#endif
+  e->kstep_grid = AG_KSTEP_MAXGRID; { const char *kg = getenv("AGARCL_KSTEP_GRID"); if (kg) { int v = atoi(kg); if (v >= 1 && v <= AG_KSTEP_MAXGRID) e->kstep_grid = v; } }
   s.qlist = alloc<int32_t>(e, 2 * (size_t)d.A);
   { const char *nf = getenv("AGARCL_NO_FRONT"); e->no_front = nf && nf[0] == '1'; }
   // modes 0-4 start agents at mass 25 (quiet-dominated); 5 and 6 start at mass 1000 (general path every step)

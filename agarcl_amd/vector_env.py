@@ -40,8 +40,12 @@ double-buffered sampling (the policy works on range j's observations while the o
 
     venv.async_reset(seed=0)
     for j in cycle(range(k)):
-        obs_j, reward_j, term_j, trunc_j, info_j = venv.recv(j)       # rows of range j (views of the full tensors)
-        venv.send(policy(obs_j), j)
+        with torch.cuda.stream(venv.stream(j)):                       # range j's policy on range j's own stream: nothing to order across streams
+            obs_j, reward_j, term_j, trunc_j, info_j = venv.recv(j)   # rows of range j (views of the full tensors)
+            venv.send(policy(obs_j), j)
+
+(The full-batch step() of a pipelined env orders every range against the caller's stream twice per step -- two HIP calls of ~7 us and a
+device-side hand-over each way -- and is slower than the lock-step env; the halves on their own streams are what sub-batches are for.)
 
 Returned tensors are CUDA tensors owned by the environment and rewritten in place by the next `step()` -- copy what must outlive it (a
 rollout buffer does that anyway).  With one agent per arena the agent axis is dropped: obs [N, ...], reward [N]; with several agents
@@ -292,6 +296,11 @@ class AgarioVectorEnv:
         obs, reward, terminated, truncated, info"""
         self._parts[j].order_current_after()
         return self._ret(j)
+
+    def stream(self, j=0):
+        """the torch stream sub-batch j launches on: `with torch.cuda.stream(venv.stream(j)):` around recv(j) / policy / send(.., j) keeps range
+        j's whole loop on ONE stream -- no cross-stream ordering at all, which is what makes sub-batches pay"""
+        return self._parts[j].torch_stream()
 
     @property
     def ranges(self):

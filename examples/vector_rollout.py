@@ -43,18 +43,19 @@ if a.halves:   # every range on its own: range j's policy output is computed fro
     def policy_j(n):
         return torch.rand((n, 2), generator=g, device=dev) * 2 - 1, torch.randint(0, 3, (n,), generator=g, device=dev, dtype=torch.int32)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    episodes = torch.zeros((), dtype=torch.int64, device=dev)
+    ended = [torch.zeros((), dtype=torch.int64, device=dev) for _ in range(k)]
     for t in range(a.steps):
         for j in range(k):
-            obs_j, rew_j, term_j, trunc_j, info_j = venv.recv(j)      # the current stream now waits for range j only
-            lo, cnt = venv.ranges[j]
-            if buf_obs is not None: buf_obs[t, lo:lo + cnt].copy_(obs_j)
-            buf_rew[t, lo:lo + cnt].copy_(rew_j); buf_done[t, lo:lo + cnt].copy_(term_j)
-            episodes += info_j["ended"].sum()
-            venv.send(policy_j(cnt), j)
+            with torch.cuda.stream(venv.stream(j)):                   # range j's copies and policy on range j's own stream: no cross-stream ordering
+                obs_j, rew_j, term_j, trunc_j, info_j = venv.recv(j)
+                lo, cnt = venv.ranges[j]
+                if buf_obs is not None: buf_obs[t, lo:lo + cnt].copy_(obs_j)
+                buf_rew[t, lo:lo + cnt].copy_(rew_j); buf_done[t, lo:lo + cnt].copy_(term_j)
+                ended[j] += info_j["ended"].sum()
+                venv.send(policy_j(cnt), j)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print("%d envs x %d steps as %d ranges (recv / send halves), obs=%s: %.3g env-steps/s (%.1f us per vector step); %d episodes ended"
-          % (a.envs, a.steps, k, a.obs, a.envs * a.steps / dt, dt / a.steps * 1e6, int(episodes.item())))
+          % (a.envs, a.steps, k, a.obs, a.envs * a.steps / dt, dt / a.steps * 1e6, sum(int(e.item()) for e in ended)))
     venv.close(); sys.exit(0)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 episodes = torch.zeros((), dtype=torch.int64, device=dev); ret_sum = torch.zeros((), dtype=torch.float32, device=dev)
