@@ -166,7 +166,8 @@ __global__ void __launch_bounds__(256) k_screen_obs_pixelwise(const AgState *__r
 #endif
 // TAB: capacity of the per-column / per-row tables (256 for frames up to 256 x 256 -- with it the kernel holds 31 KB of LDS and FIVE workgroups
 // share a compute unit --, 1024 beyond)
-template <int TAB> __global__ void __launch_bounds__(256) k_screen_obs(const AgState *__restrict__ gs, AgScreenCfg o, uint8_t *out) {
+// AGV: the 4-channel agent-view frame (a template parameter since r05: the plain frame carries none of its tests)
+template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs(const AgState *__restrict__ gs, AgScreenCfg o, uint8_t *out) {
   __shared__ float ex[AG_SCR_CAP], ey[AG_SCR_CAP], er[AG_SCR_CAP];
   __shared__ unsigned ec[AG_SCR_CAP];  // 0x00BBGGRR | nsides << 24
   __shared__ unsigned fb[AG_SCR_BAND];  // 0xAABBGGRR of the band's pixels
@@ -175,8 +176,9 @@ template <int TAB> __global__ void __launch_bounds__(256) k_screen_obs(const AgS
   __shared__ float eapo[AG_SCR_CAP];                 // apothem of an entity's polygon
   __shared__ unsigned ebx[AG_SCR_CAP], eby[AG_SCR_CAP];   // pixel box of an entity: first | last << 16 column / row (one pixel of margin; empty: first > last)
   __shared__ int n_list;
+  __shared__ unsigned long long pp_chunks;   // agent view: the band's 64-pixel chunks that may hold a 255-pixel (bit c = chunk c; a band has <= 56)
   const int na = gs->d.n_agents, arena = (int)blockIdx.x / na, agent = (int)blockIdx.x % na, P = gs->d.P;
-  const int CH = o.agent_view ? 4 : 3;
+  constexpr int CH = AGV ? 4 : 3;
   uint8_t *dst = out + (size_t)blockIdx.x * o.W * o.H * CH;
   float px, py; unsigned mass;
   obs_player(gs, arena, agent, px, py, mass);
@@ -198,7 +200,7 @@ template <int TAB> __global__ void __launch_bounds__(256) k_screen_obs(const AgS
     const float *pxy = gs->pel_xy + (size_t)arena * gs->d.PC * 2; const int32_t *pid = gs->pel_id + (size_t)arena * gs->d.PC;
     const int np = ar[AG_TW(AR_NPEL)], nf = ar[AG_TW(AR_NFOOD)], nv = ar[AG_TW(AR_NVIR)];
     const float r_pel = gs->lut_r[AG_PELLET_MASS], r_food = gs->lut_r[AG_FOOD_MASS];
-    const bool av = o.agent_view != 0;
+    constexpr bool av = AGV;
     for (int b0 = 0; b0 < np; b0 += 16 * 64) {   // 16 chunks of pellets at a time: every load is issued before the first ballot (one round trip, not 16)
       float xs[16], ys[16]; int ids[16];
 #pragma unroll
@@ -264,11 +266,15 @@ template <int TAB> __global__ void __launch_bounds__(256) k_screen_obs(const AgS
       if (cidx >= o.W) { cidx -= o.W; r += 1; }
       const uint8_t cf = colflag[cidx], rf = rowflag[row0 + r];
       const bool grid = ((cf & 1) && (rf & 2)) || ((rf & 1) && (cf & 2));
-      fb[q] = grid ? 0xFF00001Au : (o.agent_view ? 0u : 0x00FFFFFFu);   // (0.1, 0, 0) -> 26; alpha byte: a fragment was written
+      // (0.1, 0, 0) -> 26; alpha byte: a fragment was written.  Agent view (r05): the pixel is written in the form post_processing_frame_data leaves
+      // it in -- a value <= 230 moves into alpha and the channel is cleared, whatever lies around it -- so that no pass over the band has to do it
+      fb[q] = grid ? (AGV ? 0x1A000000u : 0xFF00001Au) : (AGV ? 0u : 0x00FFFFFFu);
     }
+    if (threadIdx.x == 0) pp_chunks = 0ull;
     __syncthreads();
     // entities in draw order; a wavefront paints only its own rows, so later entities overwrite earlier ones without any exchange
     const int rpw = (rows + 3) >> 2, wr0 = row0 + wave * rpw, wr1 = (wr0 + rpw < row0 + rows ? wr0 + rpw : row0 + rows) - 1;
+    unsigned long long mybits = 0ull;   // agent view: chunks this wavefront painted 255-pixels into
     if (wr0 <= wr1) for (int k = 0; k < n; k++) {
       const unsigned bx = ebx[k], by = eby[k];
       const int c0 = (int)(bx & 0xFFFFu), c1 = (int)(bx >> 16);
@@ -276,90 +282,89 @@ template <int TAB> __global__ void __launch_bounds__(256) k_screen_obs(const AgS
       r0 = r0 < wr0 ? wr0 : r0; r1 = r1 > wr1 ? wr1 : r1;
       if (c0 > c1 || r0 > r1) continue;   // (wave-uniform)
       const float x = ex[k], y = ey[k], r = er[k], apo = eapo[k]; const unsigned e = ec[k];
+      // agent view: the main agent's 230 is written as post-processed (alpha 230, no colour); a 255-colour stays a 255-pixel, and the 64-pixel
+      // chunks of the band it may fall into are marked for the run pass below (a superset: a later draw may paint over it)
+      const bool keep255 = CH == 4 && (e & 0xFFFFFFu) > 230u;
+      const unsigned paint = (CH == 4 && !keep255) ? ((e & 0xFFu) << 24) : ((e & 0xFFFFFFu) | 0xFF000000u);
+      if (keep255) {   // (wave-uniform arithmetic: every chunk from the box's first pixel to its last -- a superset of the chunks it touches)
+        const int lo = ((r0 - row0) * o.W + c0) >> 6, hi = ((r1 - row0) * o.W + c1) >> 6;
+        mybits |= ((hi - lo >= 63) ? ~0ull : ((1ull << (hi - lo + 1)) - 1ull)) << lo;
+      }
       for (int ty = r0; ty <= r1; ty += 8) for (int tx = c0; tx <= c1; tx += 8) {   // 8 x 8 pixel tiles of the box, a lane per pixel
         const int rr = ty + (lane >> 3), cc = tx + (lane & 7);
-        if (rr <= r1 && cc <= c1 && scr_inside_apo(colx[cc] - x, rowy[rr] - y, r, apo, (int)(e >> 24))) fb[(rr - row0) * o.W + cc] = (e & 0xFFFFFFu) | 0xFF000000u;
+        if (rr <= r1 && cc <= c1 && scr_inside_apo(colx[cc] - x, rowy[rr] - y, r, apo, (int)(e >> 24))) fb[(rr - row0) * o.W + cc] = paint;
       }
     }
+    if (CH == 4 && lane == 0 && mybits) atomicOr(&pp_chunks, mybits);
     __syncthreads();
     if (CH == 4) {  // ScreenObservation::post_processing_frame_data (ScreenEnvironment.hpp:48-88): a sequential pass over the flat buffer
       // With the colours this kernel paints (one non-zero channel per pixel: 26 grid, 230 main agent, 255 pellets / others / viruses) the
-      // pass has a closed form.  A pixel whose channel is <= 230 moves it into alpha: no dependence.  A 255-pixel keeps alpha 255 unless
-      // the two previous FINAL alphas are both <= 30, then it takes the previous one; so a run of consecutive 255-pixels takes ONE value,
-      // decided at its first pixel -- 255, or the alpha in front of the run -- and only run starts are sequential: a dozen per frame instead
-      // of 7056 pixels.  (Any other pixel -- none can occur -- sends the band through the literal loop below.)
-      __shared__ int pp_irregular, pp_carry[2];
-      if (threadIdx.x == 0) { pp_irregular = 0; }
-      __syncthreads();
-      for (int q = (int)threadIdx.x; q < npix; q += 256) {   // phase 1: everything that does not depend on a neighbour
-        const unsigned w = fb[q]; const unsigned r_ = w & 0xFFu, g_ = (w >> 8) & 0xFFu, b_ = (w >> 16) & 0xFFu, al = w >> 24;
-        const int nz = (r_ != 0) + (g_ != 0) + (b_ != 0); const unsigned v = r_ | g_ | b_;
-        if (nz == 0) continue;                                  // background: alpha stays what it is
-        if (nz > 1 || (v > 230u && (v != 255u || al != 255u))) { pp_irregular = 1; continue; }
-        if (v <= 230u) fb[q] = v << 24;                         // the value moves into alpha, the channel is cleared
-      }
-      __syncthreads();
-      if (pp_irregular == 0) {
-        if (threadIdx.x < 64) {   // phase 2 (one wavefront, in pixel order): runs of 255-pixels
-          int run_val = -1;       // value of the run that reaches into the current chunk from the left (-1: none)
-          for (int c0_ = 0; c0_ < npix; c0_ += 64) {
-            const int q = c0_ + lane; const bool in = q < npix;
-            const unsigned w = in ? fb[q] : 0u;
-            const bool X = in && (w & 0xFFFFFFu) != 0u;            // after phase 1 only 255-pixels still carry a colour
-            unsigned long long xm = __ballot(X);
-            // final alphas of the two pixels in front of every lane's pixel, as far as they are NOT 255-pixels (those are resolved below)
-            unsigned long long done = 0ull;                       // 255-pixels of this chunk whose alpha has been decided
-            unsigned long long todo = xm;
-            int carry_val = run_val;
-            while (todo) {
-              const int s_ = (int)__builtin_ctzll(todo);           // first undecided 255-pixel: a run start, or the continuation of the left run
-              // length of the run inside this chunk
-              const unsigned long long from = xm >> s_; const int len = (~from) ? (int)__builtin_ctzll(~from) : 64 - s_;
-              int val;
-              if (s_ == 0 && carry_val >= 0) val = carry_val;     // the run started in an earlier chunk
-              else {
-                const int p = row0 * o.W + c0_ + s_;              // flat pixel index of the run start
-                int f1, f2;                                        // final alphas of pixels p - 1 and p - 2
-                if (c0_ + s_ >= 1) f1 = (int)(fb[c0_ + s_ - 1] >> 24); else f1 = a1;
-                if (c0_ + s_ >= 2) f2 = (int)(fb[c0_ + s_ - 2] >> 24); else f2 = (c0_ + s_ == 1) ? a1 : a2;
-                val = (p >= 2 && f2 <= 30 && f1 <= 30) ? f1 : 255;
-              }
-              if (lane >= s_ && lane < s_ + len) fb[q] = (w & 0xFFFFFFu) | ((unsigned)val << 24);
-              ag_lds_order();
-              const unsigned long long runmask = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << s_;
-              todo &= ~runmask; done |= runmask;
-              carry_val = -1;
-              run_val = (s_ + len == 64) ? val : -1;               // the run touches the chunk's right edge: it may continue
+      // pass has a closed form.  A pixel whose channel is <= 230 moves it into alpha: no dependence -- since r05 the painter writes such pixels
+      // in that form at once (the kernel is bound by issued instructions: a pass over every pixel of the band cost as much as painting it).
+      // A 255-pixel keeps alpha 255 unless the two previous FINAL alphas are both <= 30, then it takes the previous one; so a run of consecutive
+      // 255-pixels takes ONE value, decided at its first pixel -- 255, or the alpha in front of the run -- and only run starts are sequential: a
+      // dozen per frame instead of 7056 pixels.  One wavefront walks them in pixel order (on four wavefronts the pass issued more instructions
+      // and was slower: 352 -> 380 us per 4096 frames of 128 x 128), and since r05 only through the 64-pixel chunks the painter marked as
+      // holding a 255-pixel (pp_chunks) instead of through every chunk of the band.
+      __shared__ int pp_carry[2];
+      if (threadIdx.x < 64) {
+        int run_val = -1, prev_c = -2;   // value of the run that reaches into the current chunk from the left (-1: none); the chunk visited before this one
+        for (unsigned long long cm = pp_chunks; cm; cm &= cm - 1ull) {
+          const int cch = (int)__builtin_ctzll(cm), c0_ = cch << 6;
+          if (cch != prev_c + 1) run_val = -1;                     // (the chunks in between hold no 255-pixel: no run crosses them)
+          prev_c = cch;
+          const int q = c0_ + lane; const bool in = q < npix;
+          const unsigned w = in ? fb[q] : 0u;
+          const bool X = in && (w & 0xFFFFFFu) != 0u;            // only 255-pixels carry a colour
+          unsigned long long xm = __ballot(X);
+          unsigned long long todo = xm;
+          int carry_val = run_val;
+          while (todo) {
+            const int s_ = (int)__builtin_ctzll(todo);           // first undecided 255-pixel: a run start, or the continuation of the left run
+            const unsigned long long from = xm >> s_; const int len = (~from) ? (int)__builtin_ctzll(~from) : 64 - s_;   // length of the run inside this chunk
+            int val;
+            if (s_ == 0 && carry_val >= 0) val = carry_val;     // the run started in an earlier chunk
+            else {
+              const int p = row0 * o.W + c0_ + s_;              // flat pixel index of the run start
+              int f1, f2;                                        // final alphas of pixels p - 1 and p - 2
+              if (c0_ + s_ >= 1) f1 = (int)(fb[c0_ + s_ - 1] >> 24); else f1 = a1;
+              if (c0_ + s_ >= 2) f2 = (int)(fb[c0_ + s_ - 2] >> 24); else f2 = (c0_ + s_ == 1) ? a1 : a2;
+              val = (p >= 2 && f2 <= 30 && f1 <= 30) ? f1 : 255;
             }
-            if (!(xm >> 63)) run_val = -1;
+            if (lane >= s_ && lane < s_ + len) fb[q] = (w & 0xFFFFFFu) | ((unsigned)val << 24);
+            ag_lds_order();
+            const unsigned long long runmask = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << s_;
+            todo &= ~runmask;
+            carry_val = -1;
+            run_val = (s_ + len == 64) ? val : -1;               // the run touches the chunk's right edge: it may continue
           }
-          // the band's last two final alphas, for the next band
-          ag_lds_order();
-          if (lane == 0) { const int l1 = (int)(fb[npix - 1] >> 24), l2 = npix >= 2 ? (int)(fb[npix - 2] >> 24) : a1; pp_carry[0] = l1; pp_carry[1] = l2; }
+          if (!(xm >> 63)) run_val = -1;
         }
-        __syncthreads();
-        a2 = pp_carry[1]; a1 = pp_carry[0];
-      } else if (threadIdx.x == 0) {
-        for (int q = 0; q < npix; q++) {
-          unsigned w = fb[q]; int alpha = (int)(w >> 24); unsigned rgb = w & 0xFFFFFFu;
-          const int p = row0 * o.W + q;
-          for (int ch = 0; ch < 3; ch++) {
-            const int v = (int)((rgb >> (8 * ch)) & 0xFFu);
-            if (v == 0) continue;
-            if (v <= 230) { alpha = v; rgb &= ~(0xFFu << (8 * ch)); }
-            else if (p >= 2 && a2 <= 30 && a1 <= 30) alpha = a1;
-          }
-          fb[q] = rgb | ((unsigned)alpha << 24);
-          a2 = a1; a1 = alpha;
-        }
-        pp_carry[0] = a1; pp_carry[1] = a2;
+        // the band's last two final alphas, for the next band
+        ag_lds_order();
+        if (lane == 0) { const int l1 = (int)(fb[npix - 1] >> 24), l2 = npix >= 2 ? (int)(fb[npix - 2] >> 24) : a1; pp_carry[0] = l1; pp_carry[1] = l2; }
       }
       __syncthreads();
-      if (pp_irregular != 0) { a1 = pp_carry[0]; a2 = pp_carry[1]; }
+      a2 = pp_carry[1]; a1 = pp_carry[0];
     }
     // the band leaves LDS as one coalesced byte stream
     uint8_t *bd = dst + (size_t)row0 * o.W * CH; const int nbytes = npix * CH;
-    if (CH == 4) { for (int b = (int)threadIdx.x; b < nbytes; b += 256) bd[b] = (uint8_t)((fb[b >> 2] >> (8 * (b & 3))) & 0xFFu); }
+    // (r05: whole 32-bit words instead of one byte per lane and store -- a 128 x 128 x 4 frame left as 256 byte-stores per thread.  A packed RGBA
+    // pixel IS its four output bytes (0xAABBGGRR, little endian); three-channel frames assemble each output word from the two pixels it spans.
+    // Frames and bands start on 4-byte boundaries when their byte counts say so; anything else takes the byte loop.)
+    if (CH == 4 && (((size_t)bd) & 3) == 0) { unsigned *bw = (unsigned *)bd; for (int q = (int)threadIdx.x; q < npix; q += 256) bw[q] = fb[q]; }
+    else if (CH == 3 && (((size_t)bd) & 3) == 0) {
+      unsigned *bw = (unsigned *)bd; const int nwords = nbytes >> 2;
+      for (int j = (int)threadIdx.x; j < nwords; j += 256) {
+        // output bytes 4j .. 4j+3 = channels (4j + t) % 3 of pixels (4j + t) / 3: 4j = 3 q0 + c0
+        const int b0 = 4 * j, q0 = b0 / 3, c0 = b0 - 3 * q0;
+        // (c0 <= 2: the word's last byte is byte 5 of the two pixels' six)
+        const unsigned long long two = (unsigned long long)(fb[q0] & 0xFFFFFFu) | ((unsigned long long)(fb[q0 + 1 < npix ? q0 + 1 : q0] & 0xFFFFFFu) << 24);
+        bw[j] = (unsigned)(two >> (8 * c0));
+      }
+      for (int b = 4 * nwords + (int)threadIdx.x; b < nbytes; b += 256) { const int q = b / 3, ch = b - q * 3; bd[b] = (uint8_t)((fb[q] >> (8 * ch)) & 0xFFu); }
+    }
+    else if (CH == 4) { for (int b = (int)threadIdx.x; b < nbytes; b += 256) bd[b] = (uint8_t)((fb[b >> 2] >> (8 * (b & 3))) & 0xFFu); }
     else { for (int b = (int)threadIdx.x; b < nbytes; b += 256) { const int q = b / 3, ch = b - q * 3; bd[b] = (uint8_t)((fb[q] >> (8 * ch)) & 0xFFu); } }
     __syncthreads();
   }

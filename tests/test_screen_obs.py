@@ -180,7 +180,8 @@ def test_band_rasteriser_equals_the_pixelwise_kernel(hip_engine_cls, monkeypatch
     rng = np.random.RandomState(6)
     for t in range(steps):
         eng.set_actions(rng.uniform(-1, 1, size=(A, na, 2)).astype(np.float32), rng.randint(0, 3, size=(A, na)).astype(np.int32)); eng.step()
-    for (W, H, av) in ((84, 84, False), (96, 64, False), (512, 512, False), (84, 84, True), (200, 120, True), (1024, 33, False)):
+    for (W, H, av) in ((84, 84, False), (96, 64, False), (512, 512, False), (84, 84, True), (200, 120, True), (1024, 33, False),
+                       (128, 128, True), (50, 37, False), (77, 31, False), (33, 45, True)):   # (the paper's task frame; byte counts that leave frames / bands off 4-byte boundaries: the word-wide and the byte-wise output loops)
         monkeypatch.delenv("AGARCL_SCREEN_PIXELWISE", raising=False)
         new = eng.screen_obs(W, H, agent_view=av)
         monkeypatch.setenv("AGARCL_SCREEN_PIXELWISE", "1")
