@@ -170,8 +170,8 @@ __global__ void __launch_bounds__(256) k_screen_obs_pixelwise(const AgState *__r
 template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs(const AgState *__restrict__ gs, AgScreenCfg o, uint8_t *out) {
   __shared__ float ex[AG_SCR_CAP], ey[AG_SCR_CAP], er[AG_SCR_CAP];
   __shared__ unsigned ec[AG_SCR_CAP];  // 0x00BBGGRR | nsides << 24
-  __shared__ unsigned fb[AG_SCR_BAND];  // 0xAABBGGRR of the band's pixels
-  __shared__ uint8_t colflag[TAB], rowflag[TAB];   // bit 0: a grid line falls into this pixel column / row; bit 1: the column / row lies inside the arena
+  __shared__ __align__(16) unsigned fb[AG_SCR_BAND];  // 0xAABBGGRR of the band's pixels
+  __shared__ __align__(4) uint8_t colflag[TAB], rowflag[TAB];   // bit 0: a grid line falls into this pixel column / row; bit 1: the column / row lies inside the arena
   __shared__ float colx[TAB], rowy[TAB];           // world coordinate of every pixel column's / row's centre
   __shared__ float eapo[AG_SCR_CAP];                 // apothem of an entity's polygon
   __shared__ unsigned ebx[AG_SCR_CAP], eby[AG_SCR_CAP];   // pixel box of an entity: first | last << 16 column / row (one pixel of margin; empty: first > last)
@@ -261,14 +261,29 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs
   for (int row0 = 0; row0 < o.H; row0 += band_rows) {   // row 0 = bottom (glReadPixels)
     const int rows = o.H - row0 < band_rows ? o.H - row0 : band_rows, npix = rows * o.W;
     // background + grid
+    constexpr unsigned GRIDV = AGV ? 0x1A000000u : 0xFF00001Au, BACKV = AGV ? 0u : 0x00FFFFFFu;
+    // (0.1, 0, 0) -> 26; alpha byte: a fragment was written.  Agent view (r05): the pixel is written in the form post_processing_frame_data leaves
+    // it in -- a value <= 230 moves into alpha and the channel is cleared, whatever lies around it -- so that no pass over the band has to do it
+    if ((o.W & 3) == 0) {   // four pixels of a row per lane and store (r05): one row flag, the four column flags as one word, a 16-byte LDS store
+      typedef unsigned v4u __attribute__((ext_vector_type(4)));
+      const int gpr = o.W >> 2, ngrp = npix >> 2;   // groups per row, groups in the band
+      const int step_r = 256 / gpr, step_c = 256 - step_r * gpr;
+      for (int g = (int)threadIdx.x, r = (int)threadIdx.x / gpr, gc = (int)threadIdx.x - r * gpr; g < ngrp; g += 256, r += step_r, gc += step_c) {
+        if (gc >= gpr) { gc -= gpr; r += 1; }
+        const unsigned cf4 = *(const unsigned *)&colflag[gc << 2]; const unsigned rf = rowflag[row0 + r];
+        const unsigned line = (rf & 2u) ? 0x01010101u : 0u, inside = (rf & 1u) ? 0x02020202u : 0u;     // a column's line shows in rows inside the arena; a row's line in columns inside
+        const unsigned m = (cf4 & line) | ((cf4 & inside) >> 1);                                        // byte i: pixel i of the group is a grid pixel
+        v4u v; v.x = (m & 0x01u) ? GRIDV : BACKV; v.y = (m & 0x0100u) ? GRIDV : BACKV; v.z = (m & 0x010000u) ? GRIDV : BACKV; v.w = (m & 0x01000000u) ? GRIDV : BACKV;
+        *(v4u *)&fb[g << 2] = v;
+      }
+    } else {
     const int step_r = 256 / o.W, step_c = 256 - step_r * o.W;   // (one division: the loop below walks rows and columns by addition)
     for (int q = (int)threadIdx.x, r = (int)threadIdx.x / o.W, cidx = (int)threadIdx.x - r * o.W; q < npix; q += 256, r += step_r, cidx += step_c) {
       if (cidx >= o.W) { cidx -= o.W; r += 1; }
       const uint8_t cf = colflag[cidx], rf = rowflag[row0 + r];
       const bool grid = ((cf & 1) && (rf & 2)) || ((rf & 1) && (cf & 2));
-      // (0.1, 0, 0) -> 26; alpha byte: a fragment was written.  Agent view (r05): the pixel is written in the form post_processing_frame_data leaves
-      // it in -- a value <= 230 moves into alpha and the channel is cleared, whatever lies around it -- so that no pass over the band has to do it
-      fb[q] = grid ? (AGV ? 0x1A000000u : 0xFF00001Au) : (AGV ? 0u : 0x00FFFFFFu);
+      fb[q] = grid ? GRIDV : BACKV;
+    }
     }
     if (threadIdx.x == 0) pp_chunks = 0ull;
     __syncthreads();
