@@ -130,6 +130,10 @@ if __name__ == "__main__":
     if "--profile" in sys.argv:
         os.makedirs(os.path.join(HERE, "..", "build_variants"), exist_ok=True)
         print(build(True, "-v" in sys.argv, ["-DAGAR_PROFILE"], os.path.join(HERE, "..", "build_variants", "lib_PROF.so")))
+    elif "--variant" in sys.argv:   # diagnostic builds:  build.py --variant NAME -DFOO [-DBAR ...]  ->  build_variants/lib_NAME.so
+        os.makedirs(os.path.join(HERE, "..", "build_variants"), exist_ok=True)
+        name = sys.argv[sys.argv.index("--variant") + 1]
+        print(build(True, "-v" in sys.argv, [a for a in sys.argv if a.startswith("-D")], os.path.join(HERE, "..", "build_variants", "lib_%s.so" % name)))
     elif "--resources" in sys.argv:
         print(resource_table(sys.argv[sys.argv.index("--resources") + 1]), "kernels")
     elif "--pybind" in sys.argv:

@@ -436,7 +436,7 @@ template <class GT, class LT> AG_DEV void ag_glds4(GT *g, LT *lds_base) {
 template <int NS, bool AV> AG_DEV void arena_load(AgCtx<NS, AV> &c, bool want_pellets = false) {
   // Every load below is independent of every other (no count is needed to form an address), so the arena arrives in
   // ONE round trip to HBM: arena words, player words, and all AG_CC cell slots of every player incl. the persisted
-  // radius / speed cache (slots >= n_cells are never read).
+  // radius / speed cache (slots >= n_cells are never read).  (More than two players: their LIVE cells in a second trip, below.)
   // (pellets are NOT loaded here: ensure_pellets() fetches them on first use, and a launch whose cell provably stays
   // out of reach of every pellet -- AR_SAFE budget -- never touches them)
   // (want_pellets: the caller knows a general tick is coming -- k_step resuming after k_quiet -- so the pellet loads
@@ -447,6 +447,9 @@ template <int NS, bool AV> AG_DEV void arena_load(AgCtx<NS, AV> &c, bool want_pe
   ub_load_t(c.S, g_ar(c), AR_WORDS, ag_ts_lg);
   auto gpl = g_pl(c);
   AG_LANES(i, c.P * PL_WORDS) PLS(c, 0)[i] = gpl[AG_TW(i)];
+#ifndef AGAR_CPU_EMU
+  if (c.P <= 2)
+#endif
   for (int p = 0; p < c.P; p++) {
     auto g = g_cells(c, p); uint32_t *l = (uint32_t *)(c.lds + c.cells_off + p * CELL_STRIDE);
     AG_LANES(i, AG_CC) {
@@ -477,6 +480,25 @@ template <int NS, bool AV> AG_DEV void arena_load(AgCtx<NS, AV> &c, bool want_pe
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (an LDS-DMA is a pending LDS write on the VM counter)
 #endif
     ag_lds_order();
+#ifndef AGAR_CPU_EMU
+    if (c.P > 2) {
+      // Several players (r05): only the LIVE cells, a lane each over the flat list of all players' cells.  All AG_CC slots of every player in one
+      // round trip (above) is right for one or two players; thirty single-cell players made it 360 load instructions and 46 KB per arena for 1.4 KB
+      // of cells (23 % of a Tick/30 launch with the store, scripts/gpu_phase_multi.py).  The counts cost a second round trip: the player words
+      // are in LDS by now.  (Slots >= n_cells are never read; a created cell is written whole.)
+      const int ncl = AG_LANE < c.P ? PLS(c, AG_LANE)[PL_NCELLS] : 0;   // (P <= 32 players: a lane each)
+      for (int base = 0;; base += 64) {
+        const int t = base + AG_LANE; int p = -1, i = 0, st = 0;
+        for (int q = 0; q < c.P; q++) { const int nq = __builtin_amdgcn_readlane(ncl, q); if (t >= st && t < st + nq) { p = q; i = t - st; } st += nq; }
+        if (p >= 0) {
+          auto g = g_cells(c, p); uint32_t *l = (uint32_t *)(c.lds + c.cells_off + p * CELL_STRIDE);
+#pragma unroll
+          for (int f = 0; f < CF_ALL; f++) l[f * AG_CC + i] = g[AG_CELL_W(f, i)];
+        }
+        if (base + 64 >= st) break;
+      }
+    }
+#endif
     AG_LANES(i, c.VC) { const unsigned m = V.m[i]; V.r[i] = m == AG_VIRUS_MASS ? r100 : lut(g_lut_r(c), m); }
     const int nf = SR(c, AR_NFOOD);
     if (AG_RARE(nf > 64)) { for (int i = 64 + AG_LANE_OR_0; i < nf; i += AG_LANE_STEP) { F.x[i] = fx[i]; F.y[i] = fy[i]; F.vx[i] = fvx[i]; F.vy[i] = fvy[i]; } }
@@ -514,6 +536,22 @@ template <int NS, bool AV> AG_DEV void arena_store(AgCtx<NS, AV> &c) {
   int np = SR(c, AR_NPEL);
   pellets_store(c);
   int total_cells = 0;
+#ifndef AGAR_CPU_EMU
+  if (c.P > 2) {   // several players: a lane per live cell over the flat list (as arena_load) instead of a dependent LDS read and twelve stores per player
+    const int ncl = AG_LANE < c.P ? PLS(c, AG_LANE)[PL_NCELLS] : 0;
+    for (int base = 0;; base += 64) {
+      const int t = base + AG_LANE; int p = -1, i = 0, st = 0;
+      for (int q = 0; q < c.P; q++) { const int nq = __builtin_amdgcn_readlane(ncl, q); if (t >= st && t < st + nq) { p = q; i = t - st; } st += nq; }
+      if (p >= 0) {
+        auto g = g_cells(c, p); const uint32_t *l = (const uint32_t *)(c.lds + c.cells_off + p * CELL_STRIDE);
+#pragma unroll
+        for (int f = 0; f < CF_ALL; f++) g[AG_CELL_W(f, i)] = l[f * AG_CC + i];
+      }
+      total_cells = st;
+      if (base + 64 >= st) break;
+    }
+  } else
+#endif
   for (int p = 0; p < c.P; p++) {
     int n = ag_uni(PLS(c, p)[PL_NCELLS]);
     total_cells += n;

@@ -685,9 +685,11 @@ static int create_env(const agarcl_config *cfg, int32_t num_arenas, int32_t devi
   // spill area in HBM for the events beyond 256: a pellet under k overlapping cells is eaten k times in one tick (the stale-index quirk) -- a
   // mass-1000 agent split into 13 cells produced 16 861 events in ONE tick of an 80 x 80 / 1300 arena, four players 37 821 (measured on the
   // emulation).  Spill = 64 eats per pellet slot, at most 65 536 entries (256 KB per arena, only there).
-  { const double dens = (double)npel / ((double)g.W * (double)g.W); const bool dense = dens > 0.016;
+  // A CROWDED arena spills too (no LDS cost): five mass-1000 agents and sixteen bots in a 150 x 150 / 200 arena (0.009 pellets per unit area, 22
+  // players) overflowed the 256 events in the crowded soak -- pellets per unit area x (1 + players) > 0.06.
+  { const double dens = (double)npel / ((double)g.W * (double)g.W); const bool dense = dens > 0.016, crowded = dens * (double)(1 + d.P) > 0.06;
     const int pc = d.PC <= 256 ? 256 : d.PC <= 512 ? 512 : d.PC <= 1024 ? 1024 : 2048;
-    d.EC = AG_EV_MIN; d.KC = dense ? pc : AG_EV_MIN; d.EX = dense ? (64 * pc < 65536 ? 64 * pc : 65536) : 0; }
+    d.EC = AG_EV_MIN; d.KC = dense ? pc : AG_EV_MIN; d.EX = (dense || crowded) ? (64 * pc < 65536 ? 64 * pc : 65536) : 0; }
   // ejected foods live in LDS during a launch, 16 bytes each: 128 keep the single-player layout within the 10 KB per wavefront that 16 resident
   // wavefronts per CU leave (nominal play: <= ~60 in 20k-tick mode-6 roll-outs); arenas with many players feed more: 16 per player
   if (cfg->cap_foods <= 0 && d.P * 16 > d.FC) d.FC = d.P * 16;

@@ -190,6 +190,7 @@ template <int NS, bool AV> AG_DEV void players_collision(AgCtx<NS, AV> &c) {
   auto locate = [&](int g, int &p, int &i) { int k = 0; while (g >= off[k + 1]) k++; p = ordl[k]; i = g - off[k]; };
   // wave-parallel necessary condition: solve() can only report (collides && can_eat) pairs of different players
   bool any; int T;
+  int chk_found = -1; (void)chk_found;
 #ifndef AGAR_CPU_EMU
   {
     // Lane k < P holds order position k (its player slot and cell count, one parallel LDS read); every lane then finds its own cell of the flat
@@ -230,6 +231,61 @@ template <int NS, bool AV> AG_DEV void players_collision(AgCtx<NS, AV> &c) {
       }
       any = ag_any(hit);
       if (!any) return;
+      // The strip scan itself, a lane per eater (r05).  The test above is necessary, not sufficient: solve() finds a (collides, can eat) pair only
+      // where its strips lead it -- the scan of a strip starts at a binary search of the y keys for the eater's x - r and ends at the first cell of
+      // the eater's own player (utils/collision_detection.hpp:33-60) --, so two players can overlap tick after tick without an eat, and every such
+      // tick went through the lane-0 replay below over HBM scratch: ~70 k cycles per tick, 250-300 k of the 330-400 k cycles of the slowest arenas
+      // of a C1 launch (scripts/gpu_arena_spread_c1.py) -- the arenas the whole launch waits for.  Here every lane walks the strips of ITS cell over
+      // tables in LDS and reports whether the scan would record anything; only then (an eat does happen) the replay runs, unchanged.
+      // Strips of up to 16 cells: std::sort is the plain insertion sort there, i.e. the stable order by the y key (fill order = flat order).
+      {
+        const float W_ = c.gs->g.W;
+        float t_ = xa / W_; t_ = t_ * 100.0f;
+        const int row_ = act ? f2i(t_) : -1; const bool inrow = act && row_ >= 0 && row_ <= 101; const int rowk = inrow ? row_ : -1;
+        int cnt = 0, rank = 0;
+        for (int b = 0; b < T; b++) {
+          const int rb = __builtin_amdgcn_readlane(rowk, b); const float yb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ya), b));
+          const bool same = inrow && rb == rowk;
+          cnt += same ? 1 : 0; rank += (same && (yb < ya || (yb == ya && b < lane))) ? 1 : 0;
+        }
+        if (!ag_any(cnt > 16)) {
+          // tables: strip counts [104] and members [102][16] (flat indices, bytes), the players' slots [64] -- in the candidate records of the pellet
+          // replay (>= 2 KB, free between two pellets_eat) --; x, y, radius, mass by flat index in the created-cells block (free outside a turn)
+          unsigned char *sc = (unsigned char *)(c.lds + ag_cand_off(c)), *se = sc + 104, *gpb = se + 102 * 16;
+          float *gx = (float *)(c.lds + L_NEW), *gy = gx + 64, *gr = gy + 64; unsigned *gmm = (unsigned *)(gr + 64);
+          if (lane < 26) ((int *)sc)[lane] = 0;
+          ag_lds_order();
+          if (inrow) { se[rowk * 16 + rank] = (unsigned char)lane; sc[rowk] = (unsigned char)cnt; }
+          if (act) { gx[lane] = xa; gy[lane] = ya; gr[lane] = ra; gmm[lane] = ma; gpb[lane] = (unsigned char)pa; }
+          ag_lds_order();
+          bool found = false;
+          if (eater) {   // (cell_can_eat_cell needs the eater's mass > 25)
+            const float left = xa - ra, right = xa + ra;
+            float t = left / W_; t = t * 100.0f; int top = f2i(t);
+            t = right / W_; t = t * 100.0f; int bottom = f2i(t);
+            if (top < 0) top = 0;
+            if (bottom > 101) bottom = 101;
+            for (int i = top; i <= bottom && !found; i++) {
+              const int l = sc[i];
+              if (l == 0) continue;
+              const unsigned char *el = se + i * 16; int start = 0;
+              for (int j = 4; j >= 0; j--) if (start + (1 << j) < l && gy[el[start + (1 << j)]] < left) start += (1 << j);
+              for (int j = start; j < l; j++) {
+                const int g2 = el[j];
+                if ((int)gpb[g2] == pa) break;
+                if (collides(xa, ya, ra, gx[g2], gy[g2], gr[g2]) && cell_can_eat_cell(ma, gmm[g2])) { found = true; break; }
+              }
+            }
+          }
+          const bool found_any = ag_any(found);
+          ag_lds_order();
+#ifdef AG_PLCOL_CHECK   // (diagnostic build: the replay runs anyway and its result count is compared -- flag 0x4000 on a difference)
+          chk_found = found_any ? 1 : 0;
+#else
+          if (!found_any) return;
+#endif
+        }
+      }
       (void)build_tables();      // the rare path below reads the LDS tables
     } else {
       (void)build_tables();
@@ -313,9 +369,15 @@ template <int NS, bool AV> AG_DEV void players_collision(AgCtx<NS, AV> &c) {
       }
     }
     Tm[0] = flags;
+#ifdef AG_PLCOL_CHECK
+    Tm[1] = nres;
+#endif
   }
   ag_mem_fence();
   int fl = ag_uni(Tm[0]); if (fl) flag(c, (unsigned)fl);
+#ifdef AG_PLCOL_CHECK
+  if (chk_found >= 0 && (ag_uni(Tm[1]) > 0) != (chk_found != 0)) flag(c, 0x4000u);
+#endif
 }
 
 // ---- bots.  R: agario/bots/Bot.hpp, HungryBot.hpp, HungryShyBot.hpp, AggressiveBot.hpp, AggressiveShyBot.hpp -------------------

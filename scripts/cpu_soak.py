@@ -58,5 +58,5 @@ if __name__ == "__main__":
             except mp.TimeoutError:
                 kind, cfg, msg = "HANG", "trial %d" % k, ""
             counts[kind] = counts.get(kind, 0) + 1
-            if kind in ("MISMATCH", "HANG"): print(kind, "seed", seed, "trial", k, cfg, msg, flush=True)
+            if kind in ("MISMATCH", "HANG", "flagged"): print(kind, "seed", seed, "trial", k, cfg, msg, flush=True)   # (flagged trials with their flag word: the capacity corner)
     print("cpu soak seed", seed, counts, flush=True)
