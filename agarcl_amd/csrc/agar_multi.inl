@@ -236,8 +236,10 @@ template <int NS, bool AV> AG_DEV void players_collision(AgCtx<NS, AV> &c) {
       // the eater's own player (utils/collision_detection.hpp:33-60) --, so two players can overlap tick after tick without an eat, and every such
       // tick went through the lane-0 replay below over HBM scratch: ~70 k cycles per tick, 250-300 k of the 330-400 k cycles of the slowest arenas
       // of a C1 launch (scripts/gpu_arena_spread_c1.py) -- the arenas the whole launch waits for.  Here every lane walks the strips of ITS cell over
-      // tables in LDS and reports whether the scan would record anything; only then (an eat does happen) the replay runs, unchanged.
+      // tables in LDS and records what the scan would; an eat (rare) is then applied from these records.  The replay remains for what the tables do
+      // not cover: more than 64 cells in the arena, a strip of more than 16, more than four victims of one eater, more than 13 eaters (and the host build).
       // Strips of up to 16 cells: std::sort is the plain insertion sort there, i.e. the stable order by the y key (fill order = flat order).
+#ifndef AG_PLCOL_REPLAY_ONLY   // (differential builds: the replay alone, scripts/gpu_plcol_diff.py)
       {
         const float W_ = c.gs->g.W;
         float t_ = xa / W_; t_ = t_ * 100.0f;
@@ -258,14 +260,15 @@ template <int NS, bool AV> AG_DEV void players_collision(AgCtx<NS, AV> &c) {
           if (inrow) { se[rowk * 16 + rank] = (unsigned char)lane; sc[rowk] = (unsigned char)cnt; }
           if (act) { gx[lane] = xa; gy[lane] = ya; gr[lane] = ra; gmm[lane] = ma; gpb[lane] = (unsigned char)pa; }
           ag_lds_order();
-          bool found = false;
+          // every lane records what the scan of ITS cell would (up to four victims, in the scan's order: strips ascending, then along the strip)
+          int nh = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0;
           if (eater) {   // (cell_can_eat_cell needs the eater's mass > 25)
             const float left = xa - ra, right = xa + ra;
             float t = left / W_; t = t * 100.0f; int top = f2i(t);
             t = right / W_; t = t * 100.0f; int bottom = f2i(t);
             if (top < 0) top = 0;
             if (bottom > 101) bottom = 101;
-            for (int i = top; i <= bottom && !found; i++) {
+            for (int i = top; i <= bottom; i++) {
               const int l = sc[i];
               if (l == 0) continue;
               const unsigned char *el = se + i * 16; int start = 0;
@@ -273,19 +276,66 @@ template <int NS, bool AV> AG_DEV void players_collision(AgCtx<NS, AV> &c) {
               for (int j = start; j < l; j++) {
                 const int g2 = el[j];
                 if ((int)gpb[g2] == pa) break;
-                if (collides(xa, ya, ra, gx[g2], gy[g2], gr[g2]) && cell_can_eat_cell(ma, gmm[g2])) { found = true; break; }
+                if (collides(xa, ya, ra, gx[g2], gy[g2], gr[g2]) && cell_can_eat_cell(ma, gmm[g2])) {
+                  v0 = nh == 0 ? g2 : v0; v1 = nh == 1 ? g2 : v1; v2 = nh == 2 ? g2 : v2; v3 = nh == 3 ? g2 : v3; nh++;
+                }
               }
             }
           }
-          const bool found_any = ag_any(found);
+          const unsigned long long hitm = __ballot(nh > 0);
           ag_lds_order();
 #ifdef AG_PLCOL_CHECK   // (diagnostic build: the replay runs anyway and its result count is compared -- flag 0x4000 on a difference)
-          chk_found = found_any ? 1 : 0;
+          chk_found = hitm != 0ull ? 1 : 0;
 #else
-          if (!found_any) return;
+          if (hitm == 0ull) return;
+          const int ne_ = __popcll(hitm);
+          if (!ag_any(nh > 4) && ne_ <= 13) {
+            // An eat does happen (rare): applied from the lanes' records instead of the replay's HBM tables (~90 k cycles of dependent loads for
+            // one eat -- after the scan above, the arenas a C1 launch waited for).  Engine.hpp:168-194: the results map (an unordered_map keyed by
+            // the eater's flat index, filled in ascending order) is walked in ITS iteration order, each eater's victims in the order recorded;
+            // eater and victim are looked up by the ids of the snapshot (lower_bound over cells that may have been erased meanwhile: kept as is).
+            const int ida = act ? A.id[ia] : 0;
+            int *Tm = L_I(c, L_TMP);
+            if (ne_ > 1) {
+              auto scr = g_scratch(c);
+              AG_SERIAL {
+                AgHMap rm; rm.bucket_count = 1; rm.next_resize = 0; rm.n = 0; rm.head = -1; rm.key = scr + AGM_HK; rm.next = scr + AGM_HN; rm.before = scr + AGM_HB;
+                rm.before[0] = -2;
+                for (unsigned long long m = hitm; m; m &= m - 1ull) ag_hm_insert(rm, (int)__builtin_ctzll(m));
+                int k = 0;
+                for (int nd = rm.head; nd != -1; nd = rm.next[nd]) Tm[k++] = rm.key[nd];
+              }
+              ag_mem_fence();
+            }
+            for (int k = 0; k < ne_; k++) {
+              const int id = ne_ == 1 ? (int)__builtin_ctzll(hitm) : ag_uni(Tm[k]);
+              const int nhid = __builtin_amdgcn_readlane(nh, id), pe = __builtin_amdgcn_readlane(pa, id), gide = __builtin_amdgcn_readlane(ida, id);
+              for (int e = 0; e < nhid; e++) {
+                const int v = e == 0 ? __builtin_amdgcn_readlane(v0, id) : e == 1 ? __builtin_amdgcn_readlane(v1, id) : e == 2 ? __builtin_amdgcn_readlane(v2, id) : __builtin_amdgcn_readlane(v3, id);
+                const int pv = __builtin_amdgcn_readlane(pa, v), gidv = __builtin_amdgcn_readlane(ida, v); const unsigned gmv = (unsigned)__builtin_amdgcn_readlane((int)ma, v);
+                AG_SERIAL {
+                  Cells E = cells_of(c, pe), V = cells_of(c, pv);
+                  int *PE = PLS(c, pe), *PV = PLS(c, pv);
+                  int ne = PE[PL_NCELLS], it_ = 0;
+                  while (it_ < ne && E.id[it_] < gide) it_++;  // lower_bound by id
+                  if (it_ != ne) { E.m[it_] = clamp_mass(E.m[it_] + gmv); PE[PL_CELLS_EATEN] += 1; }
+                  int nv = PV[PL_NCELLS], ei = 0;
+                  while (ei < nv && V.id[ei] < gidv) ei++;
+                  if (ei != nv) {  // vector::erase
+                    for (int j = ei; j + 1 < nv; j++) { V.x[j] = V.x[j + 1]; V.y[j] = V.y[j + 1]; V.vx[j] = V.vx[j + 1]; V.vy[j] = V.vy[j + 1]; V.sx[j] = V.sx[j + 1]; V.sy[j] = V.sy[j + 1];
+                      V.m[j] = V.m[j + 1]; V.id[j] = V.id[j + 1]; V.dl[j] = V.dl[j + 1]; V.cmc[j] = 0u; }
+                    PV[PL_NCELLS] = nv - 1;
+                  }
+                }
+                ag_lds_order();
+              }
+            }
+            return;
+          }
 #endif
         }
       }
+#endif
       (void)build_tables();      // the rare path below reads the LDS tables
     } else {
       (void)build_tables();
