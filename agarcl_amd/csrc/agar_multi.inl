@@ -451,27 +451,20 @@ template <int NS, bool AV> AG_DEV void nearest_pellet(AgCtx<NS, AV> &c, float sx
     ag_mem_fence();
     ox = (float)ag_uni(T[0]); oy = (float)ag_uni(T[1]); return;
   }
-  unsigned best = UINT_MAX;
+  // ONE pass (r05: there were two, each with the correctly rounded square root per pellet): every lane keeps its nearest pellet and that one's
+  // index (its indices ascend, the strict < keeps the first), the wave takes the least distance and then the least index among the lanes that
+  // attain it.  (double)d > 0.01 of the reference is d > 0.01f exactly: the float nearest to 0.01 lies below it.
+  unsigned best = UINT_MAX, bi = UINT_MAX;
   {
-    unsigned lane_best = UINT_MAX;
-    AG_PEL_FOR(s, lane, i) { if (i < np) { float d = dist_to(PELX(c, s, lane), PELY(c, s, lane), sx, sy); if ((double)d > 0.01) { unsigned b = (unsigned)f2u(d); lane_best = b < lane_best ? b : lane_best; } } }
+    unsigned lane_best = UINT_MAX, lane_bi = UINT_MAX;
+    AG_PEL_FOR(s, lane, i) { if (i < np) { float d = dist_to(PELX(c, s, lane), PELY(c, s, lane), sx, sy); if (d > 0.01f) { unsigned b = (unsigned)f2u(d); if (b < lane_best) { lane_best = b; lane_bi = (unsigned)i; } } } }
 #ifdef AGAR_CPU_EMU
-    best = lane_best;
+    best = lane_best; bi = lane_bi;
 #else
-    best = wred_min(lane_best);
+    best = wred_min(lane_best); bi = wred_min(lane_best == best ? lane_bi : UINT_MAX);
 #endif
   }
   if (best == UINT_MAX) { ox = 0.0f; oy = 0.0f; return; }  // default-constructed Location, min_distance stays max
-  unsigned bi = UINT_MAX;
-  {
-    unsigned lane_bi = UINT_MAX;
-    AG_PEL_FOR(s, lane, i) { if (i < np) { float d = dist_to(PELX(c, s, lane), PELY(c, s, lane), sx, sy); if ((double)d > 0.01 && (unsigned)f2u(d) == best) lane_bi = (unsigned)i < lane_bi ? (unsigned)i : lane_bi; } }
-#ifdef AGAR_CPU_EMU
-    bi = lane_bi;
-#else
-    bi = wred_min(lane_bi);
-#endif
-  }
   pel_get(c, (int)bi, ox, oy);
 }
 #ifdef AGAR_CPU_EMU
@@ -512,6 +505,52 @@ template <int NS, bool AV> AG_DEV bool bot_aggressive_check(AgCtx<NS, AV> &c, in
   }
   return false;
 }
+#ifndef AGAR_CPU_EMU
+// The two checks above for all other players at once, a lane per order position (r05): each lane sums ITS player's centroid (and, for the
+// aggressive kinds, the part of it the bot's largest cell can eat) in cell order -- the same fp32 sums --, and the first position that
+// satisfies the test is taken with a ballot.  The serial forms walk the players one after the other with three dependent LDS reads per cell,
+// twice for the aggressive-shy kind: 8.5 k cycles per decision, 42 k of the 125 k cycles of a C1 arena-step that holds a bot tick
+// (scripts/gpu_arena_spread_c1.py).
+template <int NS, bool AV> AG_DEV bool bot_checks_lanes(AgCtx<NS, AV> &c, int p, float sx, float sy, bool shy, bool aggressive, float &tx, float &ty) {
+  const int lane = AG_LANE, P = c.P;
+  const int o = __builtin_amdgcn_ds_bpermute((AR_ORDER0 + (lane < P ? lane : 0)) << 2, c.S.v);   // word AR_ORDER0 + lane of the arena block
+  const bool on = lane < P && o != p;
+  const int no = on ? PLS(c, o)[PL_NCELLS] : 0;
+  const Cells oc = cells_of(c, on ? o : p);
+  unsigned lm = 0u;
+  if (aggressive) { const int n = ag_uni(PLS(c, p)[PL_NCELLS]); const Cells me = cells_of(c, p); lm = wave_max(n, [&](int i) { return me.m[i]; }); }
+  float cx = 0.0f, cy = 0.0f, ax = 0.0f, ay = 0.0f; unsigned tm = 0u, edible = 0u;
+  const int nmax = (int)wred_max((unsigned)no);
+  for (int i = 0; i < nmax; i++) {
+    if (i < no) {
+      const unsigned m = oc.m[i]; const float fm = (float)m; const float qx = oc.x[i] * fm, qy = oc.y[i] * fm;
+      cx += qx; cy += qy; tm += m;
+      if (aggressive && cell_can_eat_cell(lm, m)) { ax += qx; ay += qy; edible += m; }
+    }
+  }
+  const float ox = ag_divf(cx, (float)tm), oy = ag_divf(cy, (float)tm);
+  const float d = dist_to(sx, sy, ox, oy);
+  if (shy) {
+    const unsigned long long hm = __ballot(on && d < 25.0f && tm > 0u);
+    if (hm) {
+      const int k = (int)__builtin_ctzll(hm);
+      const float hx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ox), k)), hy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(oy), k));
+      const float dx = hx - sx, dy = hy - sy; tx = sx - dx; ty = sy - dy; return true;
+    }
+  }
+  if (aggressive) {
+    const unsigned long long hm = __ballot(on && d <= 20.0f && edible > 0u);
+    if (hm) {
+      const int k = (int)__builtin_ctzll(hm);
+      const float fm = (float)edible; const float qx = ag_divf(ax, fm), qy = ag_divf(ay, fm);
+      const float hx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), k)), hy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), k));
+      const float dsx = hx - sx, dsy = hy - sy; const float ex = dsx * 3.0f, ey = dsy * 3.0f;
+      tx = sx + ex; ty = sy + ey; return true;
+    }
+  }
+  return false;
+}
+#endif
 // Player::take_action override of the bot in slot p (called every 10th tick).  Operates on the register copy c.PB.
 template <int NS, bool AV> AG_DEV void bot_take_action(AgCtx<NS, AV> &c, int p) {
   int kind = PR(c, PL_KIND);
@@ -520,9 +559,15 @@ template <int NS, bool AV> AG_DEV void bot_take_action(AgCtx<NS, AV> &c, int p) 
   float tx = PRF(c, PL_TX), ty = PRF(c, PL_TY); int action = PR(c, PL_ACTION);
   bool done = false;
   if (kind == AG_KIND_EXAMPLE) { PW(c, PL_ACTION, 0); PW(c, PL_TX, f2u(sx)); PW(c, PL_TY, f2u(sy)); return; }   // R: ExampleBot.hpp:45-51
+#ifndef AGAR_CPU_EMU
+  if (kind == AG_KIND_HUNGRY_SHY) { action = 0; done = bot_checks_lanes(c, p, sx, sy, true, false, tx, ty); }
+  else if (kind == AG_KIND_AGGRESSIVE) done = bot_checks_lanes(c, p, sx, sy, false, true, tx, ty);
+  else if (kind == AG_KIND_AGGRESSIVE_SHY) done = bot_checks_lanes(c, p, sx, sy, true, true, tx, ty);
+#else
   if (kind == AG_KIND_HUNGRY_SHY) { action = 0; done = bot_shy_check(c, p, sx, sy, tx, ty); }
   else if (kind == AG_KIND_AGGRESSIVE) done = bot_aggressive_check(c, p, sx, sy, tx, ty);
   else if (kind == AG_KIND_AGGRESSIVE_SHY) { done = bot_shy_check(c, p, sx, sy, tx, ty); if (!done) done = bot_aggressive_check(c, p, sx, sy, tx, ty); }
+#endif
   if (!done) { action = 0; nearest_pellet(c, sx, sy, tx, ty); }
   PW(c, PL_ACTION, action); PW(c, PL_TX, f2u(tx)); PW(c, PL_TY, f2u(ty));
 }
