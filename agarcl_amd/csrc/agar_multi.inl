@@ -214,7 +214,7 @@ template <int NS, bool AV> AG_DEV void players_collision(AgCtx<NS, AV> &c) {
     if (T <= 64) {
       const bool act = lane < T;
       const Cells A = cells_of(c, pa);
-      const unsigned ma = act ? A.m[ia] : 0u; const float xa = act ? A.x[ia] : 0.0f, ya = act ? A.y[ia] : 0.0f; const float ra = act ? radius_of(c, ma) : 0.0f;
+      const unsigned ma = act ? A.m[ia] : 0u; const float xa = act ? A.x[ia] : 0.0f, ya = act ? A.y[ia] : 0.0f; const float ra = act ? cell_rad(c, A, ia) : 0.0f;   // (the cell's cached table entry when it is valid: no trip to the table in L2)
       // can_eat(a, b) = a > 25 && (double)a > (double)b * 1.1 (Entities.hpp:148-151, Ball.hpp:45-47): the victim's side of it once per lane
       const double eat_thr = (double)ma * 1.1; const bool eater = act && ma > 25u; const double dma = (double)ma;
       const int tlo = (int)(unsigned)(__builtin_bit_cast(unsigned long long, eat_thr) & 0xffffffffull), thi = (int)(unsigned)(__builtin_bit_cast(unsigned long long, eat_thr) >> 32);
