@@ -686,6 +686,8 @@ template <int NS, bool AV> AG_DEV void add_pellets(AgCtx<NS, AV> &c, int n) {
   }
   SW(c, AR_NPEL, np + n); SW(c, AR_IDC, idc + n);
   c.pel_dirty = true;
+  // (several players: the remembered "no pellet inside this cell" verdicts of simple_turns hold only while pellets disappear)
+  if (c.P > 1) { AG_LANES(p, c.P) PLS(c, p)[PL_CAND_IDX] = -1; ag_lds_order(); }
 }
 template <int NS, bool AV> AG_DEV void add_viruses(AgCtx<NS, AV> &c, int n) {
   if (n <= 0) return;
@@ -1781,34 +1783,39 @@ template <int NS, bool AV> AG_DEV unsigned simple_turns(AgCtx<NS, AV> &c) {
     const bool feed_due = act == 1 && (fcd > 0 ? fcd - 1 : fcd) == 0;
     // (the cell's cached radius must be the radius of its mass -- move_cell leaves it so; otherwise the player takes its ordinary turn)
     const bool ok = n == 1 && s.cmc[0] == m && m < AG_MAX_MASS && (nv == 0 || m < 111u) && !(decays && el % 60 == 0) && !feed_due && !(act == 2 && (scd > 0 ? scd - 1 : scd) == 0);
-    const unsigned code = (ok ? 1u : 0u) | (n == 0 ? 2u : 0u) | (n > 0 && feed_due ? 4u : 0u);
+    // (the pellet test's verdict "nothing inside" is remembered with the cell it was made for -- x, y, mass, bit for bit; it holds for that very
+    // cell for as long as pellets only disappear: add_pellets forgets all of them.  bench/main.cpp's ExampleBots never move: their test runs once
+    // per regeneration instead of every tick -- 40 k of the 186 k cycles of a Tick/30 launch, scripts/gpu_phase_multi.py)
+    const bool known = PL[PL_CAND_IDX] == (int)m && PL[PL_SAFE_X] == (int)f2u(s.x[0]) && PL[PL_SAFE_Y] == (int)f2u(s.y[0]);
+    const unsigned code = (ok ? 1u : 0u) | (n == 0 ? 2u : 0u) | (n > 0 && feed_due ? 4u : 0u) | (known ? 8u : 0u);
 #ifdef AGAR_CPU_EMU
     bx.w[p] = f2u(s.x[0]); by.w[p] = f2u(s.y[0]); br.w[p] = f2u(s.crad[0]); codes[p] = code;
 #else
     myx = f2u(s.x[0]); myy = f2u(s.y[0]); myr = f2u(s.crad[0]); mycode = code;
 #endif
   }
-  unsigned cand, dead, ejectors;
+  unsigned cand, dead, ejectors, known;
 #ifdef AGAR_CPU_EMU
-  cand = dead = ejectors = 0u;
-  for (int p = 0; p < P; p++) { const unsigned code = codes[p]; cand |= (code & 1u) << p; dead |= ((code >> 1) & 1u) << p; ejectors |= ((code >> 2) & 1u) << p; }
+  cand = dead = ejectors = known = 0u;
+  for (int p = 0; p < P; p++) { const unsigned code = codes[p]; cand |= (code & 1u) << p; dead |= ((code >> 1) & 1u) << p; ejectors |= ((code >> 2) & 1u) << p; known |= ((code >> 3) & 1u) << p; }
 #else
   bx.v = myx; by.v = myy; br.v = myr;
   cand = (unsigned)__ballot((mycode & 1u) != 0u); dead = (unsigned)__ballot((mycode & 2u) != 0u); ejectors = (unsigned)__ballot((mycode & 4u) != 0u);   // (players are lanes 0 .. P-1 <= 31)
+  known = (unsigned)__ballot((mycode & 8u) != 0u);
 #endif
   // ... unless somebody ejects food on this tick (maybe_emit_food: action feed with the cooldown run out): the food appears in the middle of the
   // tick and every player BEHIND the ejector in the iteration order tests it -- such a tick is played in order, player by player
   if (ejectors) return dead;
-  if (np > 0 && cand) {
+  if (np > 0 && (cand & ~known)) {
     // pellets_eat's fast path for each candidate's one cell -- nothing inside the current radius --, for ALL candidates in one sweep: every lane
     // tests its pellet slots against candidate after candidate and keeps a bit per candidate; ONE reduction at the end instead of a ballot and
     // a branch per player
     unsigned seen = 0u;
 #ifdef AGAR_CPU_EMU
-    for (unsigned todo = cand; todo; todo &= todo - 1u) {
+    for (unsigned todo = cand & ~known; todo; todo &= todo - 1u) {
 #else
     unsigned mine = 0u;
-    for (unsigned todo = cand; todo; todo &= todo - 1u) {
+    for (unsigned todo = cand & ~known; todo; todo &= todo - 1u) {
 #endif
       const int p = __builtin_ctz(todo);
       const float x = u2f(ub_get(bx, p)), y = u2f(ub_get(by, p)), r0 = u2f(ub_get(br, p)); const float rr0 = r0 * r0;
@@ -1829,6 +1836,8 @@ template <int NS, bool AV> AG_DEV unsigned simple_turns(AgCtx<NS, AV> &c) {
     }
     seen = wred_or(mine);
 #endif
+    const unsigned fresh = cand & ~known & ~seen;   // verdicts made now: remembered with their cells
+    AG_LANES(p, P) { if ((fresh >> p) & 1u) { int *PL = PLS(c, p); const Cells s = cells_of(c, p); PL[PL_SAFE_X] = (int)f2u(s.x[0]); PL[PL_SAFE_Y] = (int)f2u(s.y[0]); PL[PL_CAND_IDX] = (int)s.m[0]; } }
     cand &= ~seen;
   }
   if (cand) {
