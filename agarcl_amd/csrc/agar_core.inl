@@ -1657,7 +1657,7 @@ template <int NS, bool AV> AG_DEV void tick_player(AgCtx<NS, AV> &c, int p) {
   if (n == 0) return;  // dead players are skipped (Engine.hpp:216)
   Cells s = cells_of(c, p);
   PW(c, PL_ELAPSED, PR(c, PL_ELAPSED) + 1);
-  if (c.P > 1 && SR(c, AR_TICKS) % 10 == 0) bot_take_action(c, p);  // Engine.hpp:498-499
+  if (c.P > 1 && SR(c, AR_TICKS) % 10 == 0 && !c.moved_all) bot_take_action(c, p);  // Engine.hpp:498-499  (moved_all on a bot tick: bot_tick_unordered has decided)
   AG_T(c, 2);
 #ifndef AG_ABLATE_MOVE
   move_player(c, s, n);
@@ -2290,6 +2290,38 @@ template <int NS, bool AV> AG_DEV int quiet_run(AgCtx<NS, AV> &c, int max_ticks)
   return q.done;
 }
 
+// A bot tick (every 10th: Engine.hpp:498-499) without a bot that LOOKS at anybody: the four scripted kinds read the other players' cells as they
+// are when their turn comes, which is what keeps such a tick in the reference's player order; an agent decides nothing and an ExampleBot
+// (agario/bots/ExampleBot.hpp:45-51: no action, target = its own centroid) reads only itself.  With no live player of the four kinds the tick is an
+// ordinary one -- kinematics for everybody, simple turns at once -- after the ExampleBots' targets have been set here, a lane per player
+// (r05: bench/main.cpp's Tick/N populations and the multi-agent arenas paid a whole ordered round of turns on every bot tick: 44 % of a Tick/30
+// launch for a tenth of its ticks).
+template <int NS, bool AV> AG_DEV bool bot_tick_unordered(AgCtx<NS, AV> &c) {
+  const int P = c.P;
+  unsigned deciders = 0u, examples = 0u;
+#ifdef AGAR_CPU_EMU
+  for (int p = 0; p < P; p++) { const int *PL = PLS(c, p); const int kind = PL[PL_KIND]; const bool alive = PL[PL_NCELLS] > 0;
+    if (alive && kind >= AG_KIND_HUNGRY && kind <= AG_KIND_AGGRESSIVE_SHY) deciders |= 1u << p;
+    if (alive && kind == AG_KIND_EXAMPLE) examples |= 1u << p; }
+#else
+  { const int lane = AG_LANE; const int kind = lane < P ? PLS(c, lane)[PL_KIND] : 0; const bool alive = lane < P && PLS(c, lane)[PL_NCELLS] > 0;
+    deciders = (unsigned)__ballot(alive && kind >= AG_KIND_HUNGRY && kind <= AG_KIND_AGGRESSIVE_SHY); examples = (unsigned)__ballot(alive && kind == AG_KIND_EXAMPLE); }
+#endif
+  if (deciders) return false;
+  if (examples) {
+    AG_LANES(p, P) {
+      if ((examples >> p) & 1u) {   // Player::x / y (core/Player.hpp:102-126): sequential fp32 sums in cell order, as player_centroid
+        int *PL = PLS(c, p); const int n = PL[PL_NCELLS]; const Cells s = cells_of(c, p);
+        float sx = 0.0f, sy = 0.0f; unsigned tm = 0u;
+        for (int i = 0; i < n; i++) { const unsigned m = s.m[i]; const float fm = (float)m; float t = s.x[i] * fm; sx += t; t = s.y[i] * fm; sy += t; tm += m; }
+        PL[PL_ACTION] = 0; PL[PL_TX] = (int)f2u(ag_divf(sx, (float)tm)); PL[PL_TY] = (int)f2u(ag_divf(sy, (float)tm));
+      }
+    }
+    ag_lds_order();
+  }
+  return true;
+}
+
 // ---- Engine::tick.  R: Engine.hpp:208-240 --------------------------------------------------------------------
 template <int NS, bool AV> AG_DEV void arena_tick(AgCtx<NS, AV> &c) {
   ensure_pellets(c);
@@ -2298,7 +2330,7 @@ template <int NS, bool AV> AG_DEV void arena_tick(AgCtx<NS, AV> &c) {
   SW(c, AR_NEVP, 0); SW(c, AR_NEVV, 0);
   c.lut_risk = false; c.mass_sum = 0u; c.moved_all = false;
 #ifndef AG_NO_MOVE_ALL
-  if (c.P > 1 && SR(c, AR_TICKS) % 10 != 0) move_all_players(c);
+  if (c.P > 1 && (SR(c, AR_TICKS) % 10 != 0 || bot_tick_unordered(c))) move_all_players(c);
 #endif
   AG_T(c, 1);
   // (several players, kinematics done: the turns that are pure bookkeeping are performed for all such players at once -- simple_turns)
