@@ -98,11 +98,12 @@ def requested_bytes(work, counts, P, n_agents, ticks, pellet_cap):
     # front part, per arena-step: loads cell 0 (48) + 18 player words (72) + 9 arena words (36) + action (12);
     # stores cell (40) + player (64) + arena (40) + counts (16) + results f64/i32/u8/packed (21) + hand-over (8)
     front = 168.0 + 189.0
-    # general engine, per arena-step: arena words r+w (256), player words r+w (192 P), all 32 cell slots read (1536 P) +
-    # live cells written (48 N_c), results (29 A) + counts (16) + its cycle count (4); viruses and foods are staged in LDS ONCE per launch
+    # general engine, per arena-step: arena words r+w (256), player words r+w (192 P), all 32 cell slots read (1536 P) with one or two players,
+    # only the live cells (48 N_c) with more (r05: arena_load) + live cells written (48 N_c), results (29 A) + counts (16) + its cycle count (4);
+    # viruses and foods are staged in LDS ONCE per launch
     # (round 4): x / y / mass of the whole virus table (12 (N_v + 64): the capacity, no count is known when the loads are issued), the first
     # 64 foods (x, y, vx, vy: 1024) read, the live foods written back (16 N_f)
-    general = 256.0 + 192.0 * P + 1536.0 * P + 48.0 * n_cells + 29.0 * n_agents + 20.0 + 12.0 * (round(n_vir) + 64.0) + 1024.0 + 16.0 * n_food
+    general = 256.0 + 192.0 * P + (1536.0 * P if P <= 2 else 48.0 * n_cells) + 48.0 * n_cells + 29.0 * n_agents + 20.0 + 12.0 * (round(n_vir) + 64.0) + 1024.0 + 16.0 * n_food
     return front * front_steps + general * general_steps + pellet_moves * pellet_cap * 8.0
 
 

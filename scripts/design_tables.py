@@ -20,7 +20,7 @@ for k in bd:
     ms = g(r, "ms_per_step")
     print("| %s | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s |" % (
         k, "%.1f" % (ms * 1e3) if ms else "-", "%.4g" % g(r, "env_steps_per_s") if ms else "-", "%.1f" % (g(r2, "ms_per_step") * 1e3) if isinstance(r2, list) else "-",
-        "%.1f MB" % (tr / 1e6) if tr else "-", "%.2f" % (tr / rq) if tr and rq else "-", "%.3f" % (tr / (ms * 1e-3) / 8e12) if tr and ms else "-",
+        "%.1f MB" % (tr / 1e6) if tr else "-", ("%.2f" % g(r, "traffic_over_requested")) if g(r, "traffic_over_requested") else ("%.2f" % (tr / rq) if tr and rq else "-"), "%.3f" % (tr / (ms * 1e-3) / 8e12) if tr and ms else "-",
         "%.2f" % iss["frac_valu_issue"] if iss.get("frac_valu_issue") else "-", "%.2f" % iss["mean_wave_residency"] if iss.get("mean_wave_residency") else "-",
         "%.2f" % iss["clock_ghz"] if iss.get("clock_ghz") else "-",
         ("%.3g (%d)" % (g(r, "cpu_reference_env_steps_per_s"), g(r, "cpu_reference_cores"))) if g(r, "cpu_reference_env_steps_per_s") else "-"))

@@ -32,6 +32,9 @@ CASES = [
     (dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0, example_bots=12), 300, 4),
     (dict(num_agents=0, arena_size=250, num_pellets=500, num_viruses=10, mode=0, example_bots=0), 100, 4),      # Tick/0: an engine without players
     (dict(num_agents=0, arena_size=250, num_pellets=500, num_viruses=10, mode=0, example_bots=5), 100, 4),      # Tick/5
+    # crowded: players eat each other all the time; bot ticks with and without scripted bots; the remembered pellet verdicts across a regeneration (tick 120)
+    (dict(num_agents=3, arena_size=120, num_pellets=300, num_viruses=4, num_bots=6, mode=0), 200, 4),
+    (dict(num_agents=4, arena_size=250, num_pellets=500, num_viruses=10, mode=6, example_bots=20), 120, 4),
 ]
 
 

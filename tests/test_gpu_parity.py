@@ -51,6 +51,11 @@ def test_hip_matches_reference_golden(hip_engine_cls, path):
     (dict(num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0, example_bots=12), 300, 4),
     (dict(num_agents=0, arena_size=250, num_pellets=500, num_viruses=10, mode=0, example_bots=0), 100, 4),      # Tick/0: an engine without players
     (dict(num_agents=0, arena_size=250, num_pellets=500, num_viruses=10, mode=0, example_bots=30), 150, 4),     # Tick/30
+    # crowded arenas in which players eat each other all the time: players_collision's lane-parallel strip scan and the eats applied from its records
+    # (r05; the oracle replays the reference's sequential solve()), the scripted bots' lane-parallel checks, bot ticks with and without them
+    (dict(num_agents=3, arena_size=120, num_pellets=300, num_viruses=4, num_bots=6, mode=0), 400, 4),
+    (dict(num_agents=2, arena_size=200, num_pellets=400, num_viruses=5, num_bots=12, mode=0, example_bots=8), 300, 4),
+    (dict(num_agents=4, arena_size=250, num_pellets=500, num_viruses=10, mode=6, example_bots=20), 200, 4),
 ])
 def test_hip_vs_oracle_lockstep(hip_engine_cls, oracle_lib, cfg, steps, sticky):
     A = 16
