@@ -331,10 +331,21 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs
       // dozen per frame instead of 7056 pixels.  One wavefront walks them in pixel order (on four wavefronts the pass issued more instructions
       // and was slower: 352 -> 380 us per 4096 frames of 128 x 128), and since r05 only through the 64-pixel chunks the painter marked as
       // holding a 255-pixel (pp_chunks) instead of through every chunk of the band.
-      __shared__ int pp_carry[2];
-      if (threadIdx.x < 64) {
+      // All four wavefronts share the pass (r05): the kernel is bound by what a SIMD issues and a workgroup's wavefronts sit on different SIMDs, so a
+      // pass on wavefront 0 alone is issued by one SIMD in four.  The band's chunks are cut into four runs of consecutive chunks at SAFE boundaries --
+      // the two pixels in front of the boundary carry no colour: no run crosses it and a start behind it reads final alphas -- found with one ballot
+      // (lane c looks at the two pixels in front of chunk c); every wavefront walks its chunks in order exactly as the single wavefront did.
+      {
+        const int nch = (npix + 63) >> 6, per = (nch + 3) >> 2;
+        bool sf = false;
+        if (lane >= 1 && lane < nch) sf = (fb[64 * lane - 1] & 0xFFFFFFu) == 0u && (fb[64 * lane - 2] & 0xFFFFFFu) == 0u;
+        const unsigned long long safe = __ballot(sf);
+        auto cut = [&](int t) -> int { if (t <= 0) return 0; if (t >= nch) return nch; const unsigned long long m = safe >> t; return m ? t + (int)__builtin_ctzll(m) : nch; };   // first safe boundary >= t
+        const int lo_c = cut(wave * per), hi_c = cut((wave + 1) * per);
+        const unsigned long long seg = (hi_c >= 64 ? ~0ull : ((1ull << hi_c) - 1ull)) & ~((1ull << lo_c) - 1ull);
         int run_val = -1, prev_c = -2;   // value of the run that reaches into the current chunk from the left (-1: none); the chunk visited before this one
-        for (unsigned long long cm = pp_chunks; cm; cm &= cm - 1ull) {
+        const unsigned long long lt_lane = (1ull << lane) - 1ull;
+        for (unsigned long long cm = pp_chunks & seg; cm; cm &= cm - 1ull) {
           const int cch = (int)__builtin_ctzll(cm), c0_ = cch << 6;
           if (cch != prev_c + 1) run_val = -1;                     // (the chunks in between hold no 255-pixel: no run crosses them)
           prev_c = cch;
@@ -342,6 +353,34 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs
           const unsigned w = in ? fb[q] : 0u;
           const bool X = in && (w & 0xFFFFFFu) != 0u;            // only 255-pixels carry a colour
           unsigned long long xm = __ballot(X);
+          if (xm == 0ull) { run_val = -1; continue; }
+          // All runs of the chunk at once (r05): a 255-pixel finds the start of its run in the ballot (the highest non-255 pixel below it), the
+          // start decides the run's value from the two pixels in front of it -- final already unless the second one is a 255-pixel of THIS chunk
+          // (two runs one pixel apart: the chunk then takes the run-by-run loop below) -- and hands it to the run with one ds_bpermute.
+          // (Measured: 128 x 128 x 4 on a task-3 state 203 -> 199 us; marking the chunks row by row so that fewer are visited: 413 us on task 1's
+          // pattern -- the painter's scalar instructions --; neighbours from registers instead of LDS: 218 us.  The kernel is bound by what it issues.)
+          {
+            const unsigned long long below = ~xm & lt_lane;
+            const int sp = below ? 64 - (int)__builtin_clzll(below) : 0;            // chunk position at which this lane's run starts (0: it reaches the left edge)
+            const bool from_left = !below && run_val >= 0;                           // ... and continues the run of the chunk before
+            const bool start = X && sp == lane && !from_left;
+            // (two runs one pixel apart somewhere in the chunk -- X[i], !X[i-1], X[i-2] --: scalar arithmetic on the ballot)
+            if (!((xm & ~(xm << 1)) & (xm << 2))) {
+              int val = 255;
+              if (start) {
+                const int p = row0 * o.W + q;
+                const int f1 = q >= 1 ? (int)(fb[q - 1] >> 24) : a1;
+                const int f2 = q >= 2 ? (int)(fb[q - 2] >> 24) : (q == 1 ? a1 : a2);
+                val = (p >= 2 && f2 <= 30 && f1 <= 30) ? f1 : 255;
+              }
+              int mine = __builtin_amdgcn_ds_bpermute(sp << 2, val);
+              if (from_left) mine = run_val;
+              if (X) fb[q] = (w & 0xFFFFFFu) | ((unsigned)mine << 24);
+              ag_lds_order();
+              run_val = (xm >> 63) ? __builtin_amdgcn_readlane(mine, 63) : -1;
+              continue;
+            }
+          }
           unsigned long long todo = xm;
           int carry_val = run_val;
           while (todo) {
@@ -365,19 +404,28 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs
           }
           if (!(xm >> 63)) run_val = -1;
         }
-        // the band's last two final alphas, for the next band
-        ag_lds_order();
-        if (lane == 0) { const int l1 = (int)(fb[npix - 1] >> 24), l2 = npix >= 2 ? (int)(fb[npix - 2] >> 24) : a1; pp_carry[0] = l1; pp_carry[1] = l2; }
       }
       __syncthreads();
-      a2 = pp_carry[1]; a1 = pp_carry[0];
+      // the band's last two final alphas, for the next band
+      { const int l1 = (int)(fb[npix - 1] >> 24), l2 = npix >= 2 ? (int)(fb[npix - 2] >> 24) : a1; a2 = l2; a1 = l1; }
     }
     // the band leaves LDS as one coalesced byte stream
     uint8_t *bd = dst + (size_t)row0 * o.W * CH; const int nbytes = npix * CH;
     // (r05: whole 32-bit words instead of one byte per lane and store -- a 128 x 128 x 4 frame left as 256 byte-stores per thread.  A packed RGBA
     // pixel IS its four output bytes (0xAABBGGRR, little endian); three-channel frames assemble each output word from the two pixels it spans.
     // Frames and bands start on 4-byte boundaries when their byte counts say so; anything else takes the byte loop.)
-    if (CH == 4 && (((size_t)bd) & 3) == 0) { unsigned *bw = (unsigned *)bd; for (int q = (int)threadIdx.x; q < npix; q += 256) bw[q] = fb[q]; }
+    // (r05, second pass: four pixels per lane -- one 16-byte LDS read; the agent view stores them as they are, 16 bytes; a three-channel frame packs
+    // them into three words instead of assembling every output word with a division by three)
+    typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+    if (CH == 4 && (((size_t)bd) & 15) == 0 && (npix & 3) == 0) { v4u_ *bw = (v4u_ *)bd; const v4u_ *fw = (const v4u_ *)fb; for (int g = (int)threadIdx.x; g < (npix >> 2); g += 256) bw[g] = fw[g]; }
+    else if (CH == 3 && (((size_t)bd) & 3) == 0 && (npix & 3) == 0) {
+      unsigned *bw = (unsigned *)bd; const v4u_ *fw = (const v4u_ *)fb;
+      for (int g = (int)threadIdx.x; g < (npix >> 2); g += 256) {
+        const v4u_ v = fw[g]; const unsigned p0 = v.x & 0xFFFFFFu, p1 = v.y & 0xFFFFFFu, p2 = v.z & 0xFFFFFFu, p3 = v.w & 0xFFFFFFu;
+        bw[3 * g] = p0 | (p1 << 24); bw[3 * g + 1] = (p1 >> 8) | (p2 << 16); bw[3 * g + 2] = (p2 >> 16) | (p3 << 8);
+      }
+    }
+    else if (CH == 4 && (((size_t)bd) & 3) == 0) { unsigned *bw = (unsigned *)bd; for (int q = (int)threadIdx.x; q < npix; q += 256) bw[q] = fb[q]; }
     else if (CH == 3 && (((size_t)bd) & 3) == 0) {
       unsigned *bw = (unsigned *)bd; const int nwords = nbytes >> 2;
       for (int j = (int)threadIdx.x; j < nwords; j += 256) {
