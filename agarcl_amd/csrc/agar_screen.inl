@@ -187,9 +187,41 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs
   const float Wd = gs->g.W;
   const int ag_ts_lg = gs->d.ts_lg;
   const int32_t *ar = AG_AR_PTR(gs, arena);
-  if (threadIdx.x < 64) {  // ---- wave 0: visible entities in draw order ----
+  // ---- visible entities in draw order ----
+  // The pellets -- most of the list -- are compacted by all four wavefronts (r05: the kernel is bound by what a SIMD issues, a workgroup's
+  // wavefronts sit on different SIMDs, and work that only wavefront 0 does is issued by one SIMD in four): each takes a quarter of the 64-pellet
+  // chunks, counts what it will list, and writes behind the wavefronts in front of it.  Foods, cells and viruses follow on wavefront 0.
+  __shared__ int wcnt[4];
+  const float *pxy = gs->pel_xy + (size_t)arena * gs->d.PC * 2; const int32_t *pid = gs->pel_id + (size_t)arena * gs->d.PC;
+  const int np = ar[AG_TW(AR_NPEL)];
+  const float r_pel = gs->lut_r[AG_PELLET_MASS];
+  constexpr bool av = AGV;
+  int listed_pellets;
+  {
+    const int lw = (int)threadIdx.x >> 6, ll = (int)threadIdx.x & 63; const unsigned long long llt = (1ull << ll) - 1ull;
+    const int nchk = (np + 63) >> 6, per = (nchk + 3) >> 2, c_lo = lw * per, c_hi = (lw + 1) * per < nchk ? (lw + 1) * per : nchk;   // (<= 2048 pellets: per <= 8)
+    float xs[8], ys[8]; int ids[8]; unsigned long long vm[8]; int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { xs[j] = 0.f; ys[j] = 0.f; ids[j] = 0; vm[j] = 0ull;
+      if (j < per) { const int i = (c_lo + j) * 64 + ll; const bool v = c_lo + j < c_hi && i < np; if (v) { xs[j] = pxy[2 * i]; ys[j] = pxy[2 * i + 1]; if (!av) ids[j] = pid[i]; } } }
+#pragma unroll
+    for (int j = 0; j < 8; j++) if (j < per) { const int i = (c_lo + j) * 64 + ll; const bool v = c_lo + j < c_hi && i < np;
+      vm[j] = __ballot(v && fabsf(xs[j] - px) <= half_w + r_pel && fabsf(ys[j] - py) <= half_h + r_pel); cnt += __popcll(vm[j]); }
+    if (ll == 0) wcnt[lw] = cnt;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < lw; w++) base += wcnt[w];
+    listed_pellets = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+#pragma unroll
+    for (int j = 0; j < 8; j++) if (j < per && vm[j]) {
+      const int slot = base + __popcll(vm[j] & llt);
+      if (((vm[j] >> ll) & 1ull) && slot < AG_SCR_CAP) { ex[slot] = xs[j]; ey[slot] = ys[j]; er[slot] = r_pel; ec[slot] = (av ? 0x0000FFu : scr_palette(ids[j])) | (5u << 24); }
+      base += __popcll(vm[j]);
+    }
+  }
+  if (threadIdx.x < 64) {
     const int lane = (int)threadIdx.x; const unsigned long long lt = (1ull << lane) - 1ull;
-    int count = 0;
+    int count = listed_pellets;
     auto emit = [&](bool valid, float x, float y, float r, unsigned col) {
       bool vis = valid && fabsf(x - px) <= half_w + r && fabsf(y - py) <= half_h + r;
       unsigned long long m = __ballot(vis);
@@ -197,17 +229,8 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs
       if (vis && slot < AG_SCR_CAP) { ex[slot] = x; ey[slot] = y; er[slot] = r; ec[slot] = col; }
       count += __popcll(m);
     };
-    const float *pxy = gs->pel_xy + (size_t)arena * gs->d.PC * 2; const int32_t *pid = gs->pel_id + (size_t)arena * gs->d.PC;
-    const int np = ar[AG_TW(AR_NPEL)], nf = ar[AG_TW(AR_NFOOD)], nv = ar[AG_TW(AR_NVIR)];
-    const float r_pel = gs->lut_r[AG_PELLET_MASS], r_food = gs->lut_r[AG_FOOD_MASS];
-    constexpr bool av = AGV;
-    for (int b0 = 0; b0 < np; b0 += 16 * 64) {   // 16 chunks of pellets at a time: every load is issued before the first ballot (one round trip, not 16)
-      float xs[16], ys[16]; int ids[16];
-#pragma unroll
-      for (int j = 0; j < 16; j++) { const int i = b0 + j * 64 + lane; const bool v = i < np; xs[j] = v ? pxy[2 * i] : 0.f; ys[j] = v ? pxy[2 * i + 1] : 0.f; ids[j] = (v && !av) ? pid[i] : 0; }
-#pragma unroll
-      for (int j = 0; j < 16; j++) { const int i = b0 + j * 64 + lane; const bool v = i < np; if (b0 + j * 64 < np) emit(v, xs[j], ys[j], r_pel, v ? ((av ? 0x0000FFu : scr_palette(ids[j])) | (5u << 24)) : 0u); }
-    }
+    const int nf = ar[AG_TW(AR_NFOOD)], nv = ar[AG_TW(AR_NVIR)];
+    const float r_food = gs->lut_r[AG_FOOD_MASS];
     { size_t fo = (size_t)arena * gs->d.FC;
       for (int b = 0; b < nf; b += 64) { int i = b + lane; bool v = i < nf; emit(v, v ? gs->food_x[fo + i] : 0.f, v ? gs->food_y[fo + i] : 0.f, r_food, v ? ((av ? 0x0000FFu : scr_palette(gs->food_id[fo + i])) | (7u << 24)) : 0u); } }
     const int main_slot = na - 1;  // state.main_agent_pid: the last agent added
