@@ -196,7 +196,15 @@ OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o,
   int ch = 0;
   if (o.pellets) {  // ch+1: "at least one" (= mass 1), ch+2: count
     int32_t *a1 = out + (size_t)(ch + 1) * GG, *a2 = out + (size_t)(ch + 2) * GG;
-    auto pellet = [&](float qx, float qy) { int gx, gy; if (w2g(qx, qy, gx, gy)) { a1[gx * G + gy] = 1; OBS_ATOMIC_ADD(&a2[gx * G + gy], 1); rec((ch + 1) * GG + gx * G + gy); rec((ch + 2) * GG + gx * G + gy); } };
+    // (r05: nine pellets in ten lie outside the window -- a comparison decides that before the two correctly rounded divisions of the reference's
+    // formula: |d| > view (1/2 + 2/G) maps beyond the grid by more than a cell on either side, whatever the rounding)
+    const float p_lim = view * (0.5f + 2.0f / (float)G) * 1.001f;
+#ifdef AG_GRID_NOCULL   // (measurement builds)
+    const bool p_cull = false;
+#else
+    const bool p_cull = true;
+#endif
+    auto pellet = [&](float qx, float qy) { if (p_cull && !(fabsf(qx - px) <= p_lim && fabsf(qy - py) <= p_lim)) return; int gx, gy; if (w2g(qx, qy, gx, gy)) { a1[gx * G + gy] = 1; OBS_ATOMIC_ADD(&a2[gx * G + gy], 1); rec((ch + 1) * GG + gx * G + gy); rec((ch + 2) * GG + gx * G + gy); } };
 #ifndef AGAR_CPU_EMU
     const int np = pf_np;
 #pragma unroll
@@ -267,11 +275,16 @@ OBS_DEV void grid_obs_agent(const AgState *gs, int arena, int agent, AgObsCfg o,
     const int idx = e_idx[k], kind = e_kind[k];
     if (idx < 0) continue;
     bool first = true; int last = k, sum = 0, mn = 0x7fffffff, mx = 0;
+    // (branch-free and unrolled: the LDS reads of four entities are in flight together -- with a `continue` in it the loop was one dependent LDS
+    // round trip per entity on the one wavefront that holds the entities)
+#if !defined(AGAR_CPU_EMU) && !defined(AG_GRID_NOUNROLL)
+#pragma unroll 4
+#endif
     for (int j = 0; j < E; j++) {
-      if (e_idx[j] != idx || e_kind[j] != kind) continue;
-      if (j < k) first = false;
-      if (j > last) last = j;
-      const int m = e_mass[j]; sum += m; mn = m < mn ? m : mn; mx = m > mx ? m : mx;
+      const bool same = e_idx[j] == idx && e_kind[j] == kind; const int m = e_mass[j];
+      first = first && !(same && j < k);
+      last = (same && j > last) ? j : last;
+      sum += same ? m : 0; mn = (same && m < mn) ? m : mn; mx = (same && m > mx) ? m : mx;
     }
     if (!first) continue;
     if (kind == 0) { v1[idx] = e_mass[last]; v2[idx] = sum; rec((int)(v1 - out) + idx); rec((int)(v2 - out) + idx); }
