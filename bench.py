@@ -764,7 +764,7 @@ def main():
                 if name == "C1" and rf is not None and cpu:
                     rf["cpu_reference_ticks_per_s_1core"] = cpu["c1_ticks_per_s_1core"]
                 measure(name, c2, A, fk, fw, sub=PIPE_K, cpu_rate=cr[0], cpu_cores=cr[1], label=(lab % A) + " -- as %d sub-batches" % PIPE_K, **kw)
-                if name in ("C3m6", "mid"):      # ... and as four (GPU_MAX_HW_QUEUES was raised above: four queues beside torch's streams)
+                if True:                         # ... and as four (GPU_MAX_HW_QUEUES was raised above: four queues beside torch's streams)
                     measure(name, c2, A, fk, fw, sub=4, cpu_rate=cr[0], cpu_cores=cr[1], label=(lab % A) + " -- as 4 sub-batches", **kw)
             c2, kw, lab = wl_args("C3m6")
             measure("C3m6", c2, 32768, 40, 10, cpu_rate=c6cpu[0], cpu_cores=c6cpu[1], label=lab % 32768, **kw)
