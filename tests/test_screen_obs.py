@@ -169,6 +169,10 @@ def test_screen_obs_device_buffer_4096(hip_engine_cls):
     (dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode=6), 40),
     (dict(num_agents=2, arena_size=200, num_pellets=300, num_viruses=5, num_bots=3, mode=0), 60),
     (dict(arena_size=60, num_pellets=100, num_viruses=2, mode=0), 10),
+    # the paper's task 1 (squared pellet pattern: the view full of pellets, runs of 255-pixels one pixel apart -- the run pass's run-by-run path -- and
+    # next to each other across chunk boundaries) and a dense small arena (several hundred listed pellets: every wavefront's share of the list)
+    (dict(arena_size=350, num_pellets=500, num_viruses=0, mode=1), 30),
+    (dict(arena_size=80, num_pellets=1300, num_viruses=0, mode=6), 20),
 ])
 def test_band_rasteriser_equals_the_pixelwise_kernel(hip_engine_cls, monkeypatch, cfg, steps):
     """k_screen_obs paints bounding boxes into an LDS band; k_screen_obs_pixelwise shades every pixel against every entity: the same rules,
