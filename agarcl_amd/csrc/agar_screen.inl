@@ -198,7 +198,8 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs
   constexpr bool av = AGV;
   int listed_pellets;
   {
-    const int lw = (int)threadIdx.x >> 6, ll = (int)threadIdx.x & 63; const unsigned long long llt = (1ull << ll) - 1ull;
+    // (the wavefront's number is wave-uniform: said so, or the compiler keeps everything derived from it in vector registers and walks the loops with exec masks)
+    const int lw = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), ll = (int)threadIdx.x & 63; const unsigned long long llt = (1ull << ll) - 1ull;
     const int nchk = (np + 63) >> 6, per = (nchk + 3) >> 2, c_lo = lw * per, c_hi = (lw + 1) * per < nchk ? (lw + 1) * per : nchk;   // (<= 2048 pellets: per <= 8)
     float xs[8], ys[8]; int ids[8]; unsigned long long vm[8]; int cnt = 0;
 #pragma unroll
@@ -278,7 +279,9 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs
     { const float step = 6.28318530717958647692f / (float)(int)(ec[k] >> 24); eapo[k] = r * cosf(0.5f * step); }
   }
   __syncthreads();
-  const int n = n_list, wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  // (wave-uniform values the compiler cannot know to be uniform -- the wavefront's number, what comes out of LDS at a uniform address -- go through
+  // v_readfirstlane: the painter's loops over entities, boxes and tiles are then scalar loops, not vector compares and exec masks)
+  const int n = __builtin_amdgcn_readfirstlane(n_list), wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
   const int band_rows = AG_SCR_BAND / o.W > 0 ? (AG_SCR_BAND / o.W < o.H ? AG_SCR_BAND / o.W : o.H) : 1;
   int a1 = 255, a2 = 255;   // agent view: final alphas of the two previous pixels (thread 0 carries them from band to band)
   for (int row0 = 0; row0 < o.H; row0 += band_rows) {   // row 0 = bottom (glReadPixels)
@@ -324,11 +327,11 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs
         hits = __ballot(in_ && (int)(bx_ & 0xFFFFu) <= (int)(bx_ >> 16) && (r0_ < wr0 ? wr0 : r0_) <= (r1_ > wr1 ? wr1 : r1_)); }
       for (; hits; hits &= hits - 1ull) {
       const int k = k0 + (int)__builtin_ctzll(hits);
-      const unsigned bx = ebx[k], by = eby[k];
+      const unsigned bx = (unsigned)__builtin_amdgcn_readfirstlane((int)ebx[k]), by = (unsigned)__builtin_amdgcn_readfirstlane((int)eby[k]);
       const int c0 = (int)(bx & 0xFFFFu), c1 = (int)(bx >> 16);
       int r0 = (int)(by & 0xFFFFu), r1 = (int)(by >> 16);
       r0 = r0 < wr0 ? wr0 : r0; r1 = r1 > wr1 ? wr1 : r1;
-      const float x = ex[k], y = ey[k], r = er[k], apo = eapo[k]; const unsigned e = ec[k];
+      const float x = ex[k], y = ey[k], r = er[k], apo = eapo[k]; const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)ec[k]);
       // agent view: the main agent's 230 is written as post-processed (alpha 230, no colour); a 255-colour stays a 255-pixel, and the 64-pixel
       // chunks of the band it may fall into are marked for the run pass below (a superset: a later draw may paint over it)
       const bool keep255 = CH == 4 && (e & 0xFFFFFFu) > 230u;
@@ -368,12 +371,15 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs
         const unsigned long long seg = (hi_c >= 64 ? ~0ull : ((1ull << hi_c) - 1ull)) & ~((1ull << lo_c) - 1ull);
         int run_val = -1, prev_c = -2;   // value of the run that reaches into the current chunk from the left (-1: none); the chunk visited before this one
         const unsigned long long lt_lane = (1ull << lane) - 1ull;
-        for (unsigned long long cm = pp_chunks & seg; cm; cm &= cm - 1ull) {
+        // (pp_chunks comes out of LDS: a vector register to the compiler, which then walked the chunks with vector compares and exec masks)
+        const unsigned long long cm0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pp_chunks >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pp_chunks);
+        for (unsigned long long cm = cm0 & seg; cm; cm &= cm - 1ull) {
           const int cch = (int)__builtin_ctzll(cm), c0_ = cch << 6;
           if (cch != prev_c + 1) run_val = -1;                     // (the chunks in between hold no 255-pixel: no run crosses them)
           prev_c = cch;
-          const int q = c0_ + lane; const bool in = q < npix;
-          const unsigned w = in ? fb[q] : 0u;
+          const int q = c0_ + lane; const bool in = q < npix; const int qi = in ? q : 0;
+          // the chunk's words and, for the lanes that turn out to start a run, the two pixels in front: three reads in one round trip, no branches
+          const unsigned w = fb[qi], wl1 = fb[qi >= 1 ? qi - 1 : 0], wl2 = fb[qi >= 2 ? qi - 2 : 0];
           const bool X = in && (w & 0xFFFFFFu) != 0u;            // only 255-pixels carry a colour
           unsigned long long xm = __ballot(X);
           if (xm == 0ull) { run_val = -1; continue; }
@@ -382,27 +388,19 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs
           // (two runs one pixel apart: the chunk then takes the run-by-run loop below) -- and hands it to the run with one ds_bpermute.
           // (Measured: 128 x 128 x 4 on a task-3 state 203 -> 199 us; marking the chunks row by row so that fewer are visited: 413 us on task 1's
           // pattern -- the painter's scalar instructions --; neighbours from registers instead of LDS: 218 us.  The kernel is bound by what it issues.)
-          {
+          if (!((xm & ~(xm << 1)) & (xm << 2))) {   // (no two runs one pixel apart -- X[i], !X[i-1], X[i-2] --: scalar arithmetic on the ballot)
             const unsigned long long below = ~xm & lt_lane;
             const int sp = below ? 64 - (int)__builtin_clzll(below) : 0;            // chunk position at which this lane's run starts (0: it reaches the left edge)
             const bool from_left = !below && run_val >= 0;                           // ... and continues the run of the chunk before
             const bool start = X && sp == lane && !from_left;
-            // (two runs one pixel apart somewhere in the chunk -- X[i], !X[i-1], X[i-2] --: scalar arithmetic on the ballot)
-            if (!((xm & ~(xm << 1)) & (xm << 2))) {
-              int val = 255;
-              if (start) {
-                const int p = row0 * o.W + q;
-                const int f1 = q >= 1 ? (int)(fb[q - 1] >> 24) : a1;
-                const int f2 = q >= 2 ? (int)(fb[q - 2] >> 24) : (q == 1 ? a1 : a2);
-                val = (p >= 2 && f2 <= 30 && f1 <= 30) ? f1 : 255;
-              }
-              int mine = __builtin_amdgcn_ds_bpermute(sp << 2, val);
-              if (from_left) mine = run_val;
-              if (X) fb[q] = (w & 0xFFFFFFu) | ((unsigned)mine << 24);
-              ag_lds_order();
-              run_val = (xm >> 63) ? __builtin_amdgcn_readlane(mine, 63) : -1;
-              continue;
-            }
+            const int f1 = q >= 1 ? (int)(wl1 >> 24) : a1, f2 = q >= 2 ? (int)(wl2 >> 24) : (q == 1 ? a1 : a2);
+            const int val = (start && row0 * o.W + q >= 2 && f2 <= 30 && f1 <= 30) ? f1 : 255;
+            int mine = __builtin_amdgcn_ds_bpermute(sp << 2, val);
+            if (from_left) mine = run_val;
+            if (X) fb[q] = (w & 0xFFFFFFu) | ((unsigned)mine << 24);
+            ag_lds_order();
+            run_val = (xm >> 63) ? __builtin_amdgcn_readlane(mine, 63) : -1;
+            continue;
           }
           unsigned long long todo = xm;
           int carry_val = run_val;
