@@ -42,16 +42,42 @@ __device__ __forceinline__ unsigned scr_palette(int k) {  // core/color.hpp:4-12
   const unsigned pal[6] = {0x0000FFu /*red*/, 0x00A6FFu /*orange 1,.65,0*/, 0x00FFFFu /*yellow*/, 0x00FF00u /*green*/, 0xFF0000u /*blue*/, 0xCC3399u /*purple .6,.2,.8*/};
   return pal[((k % 6) + 6) % 6];
 }
-__device__ __forceinline__ bool scr_inside(float dx, float dy, float r, int nsides) {
-  float d2 = dx * dx + dy * dy;
-  if (d2 > r * r) return false;
+// Between the inscribed and the circumscribed circle the polygon's edge decides: the pixel is inside iff its projection on the outward normal of
+// the edge of ITS sector -- at angle (k + 1/2) step -- is at most the apothem.  That edge is the one with the LARGEST projection, so for the two
+// small polygons (pellets: 5 sides, foods: 7; a pentagon's ring between the circles is a third of its disc, nearly every pellet tile has a pixel
+// in it) the test is the maximum over the edges with their normals as constants, mirrored in y: seven instructions instead of atan2f, cosf and
+// sinf (~200, which every lane of the tile sat through: found in the ISA, r05).  Cells (50 sides) and viruses (150) keep the sector form.
+__device__ __forceinline__ bool scr_edge_inside(float dx, float dy, float apo, int nsides) {
+  if (nsides == 5) {   // normals at 36, 108, 180 degrees and their mirror images
+    const float ay = fabsf(dy);
+    const float p1 = dx * 0.8090169943749475f + ay * 0.5877852522924731f, p2 = dx * -0.30901699437494734f + ay * 0.9510565162951536f;
+    return fmaxf(fmaxf(p1, p2), -dx) <= apo;
+  }
+  if (nsides == 7) {   // normals at 25.71, 77.14, 128.57, 180 degrees and their mirror images
+    const float ay = fabsf(dy);
+    const float p1 = dx * 0.9009688679024191f + ay * 0.4338837391175581f, p2 = dx * 0.2225209339563144f + ay * 0.9749279121818236f, p3 = dx * -0.6234898018587335f + ay * 0.7818314824680298f;
+    return fmaxf(fmaxf(p1, p2), fmaxf(p3, -dx)) <= apo;
+  }
   const float step = 6.28318530717958647692f / (float)nsides;
-  float apo = r * cosf(0.5f * step);
-  if (d2 <= apo * apo) return true;
   float th = atan2f(dy, dx); if (th < 0.0f) th += 6.28318530717958647692f;
   float k = floorf(th / step);
   float phi = (k + 0.5f) * step;
   return dx * cosf(phi) + dy * sinf(phi) <= apo;
+}
+// cos(pi / nsides): the apothem of a unit polygon -- constants for the four polygons the renderer draws (core/Entities.hpp:13-16), cosf otherwise
+__device__ __forceinline__ float scr_cos_half_step(int nsides) {
+  if (nsides == 5) return 0.8090169943749475f;
+  if (nsides == 7) return 0.9009688679024191f;
+  if (nsides == 50) return 0.9980267284282716f;
+  if (nsides == 150) return 0.9997806834748455f;
+  return cosf(0.5f * (6.28318530717958647692f / (float)nsides));
+}
+__device__ __forceinline__ bool scr_inside(float dx, float dy, float r, int nsides) {
+  float d2 = dx * dx + dy * dy;
+  if (d2 > r * r) return false;
+  float apo = r * scr_cos_half_step(nsides);
+  if (d2 <= apo * apo) return true;
+  return scr_edge_inside(dx, dy, apo, nsides);
 }
 
 // the same test with the apothem r * cos(pi / nsides) handed in (computed once per entity by the band kernel)
@@ -59,11 +85,7 @@ __device__ __forceinline__ bool scr_inside_apo(float dx, float dy, float r, floa
   float d2 = dx * dx + dy * dy;
   if (d2 > r * r) return false;
   if (d2 <= apo * apo) return true;
-  const float step = 6.28318530717958647692f / (float)nsides;
-  float th = atan2f(dy, dx); if (th < 0.0f) th += 6.28318530717958647692f;
-  float k = floorf(th / step);
-  float phi = (k + 0.5f) * step;
-  return dx * cosf(phi) + dy * sinf(phi) <= apo;
+  return scr_edge_inside(dx, dy, apo, nsides);
 }
 
 __global__ void __launch_bounds__(256) k_screen_obs_pixelwise(const AgState *__restrict__ gs, AgScreenCfg o, uint8_t *out) {
@@ -254,18 +276,23 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs
   }
   // grid lines: the pixel column / row a line falls into (one pixel wide), and which columns / rows lie inside the arena
   const float sx_scale = (float)o.W * 0.5f / half_w, sy_scale = (float)o.H * 0.5f / half_h, spacing = Wd / 7.0f;
+  // (r05: the eight lines' pixel columns / rows are eight numbers -- every thread takes them from the same expression and compares; each column / row
+  // used to evaluate the eight floors for itself)
+  int gcol[8], grow[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { const float g = (float)i * spacing; gcol[i] = (int)floorf((g - px) * sx_scale + (float)o.W * 0.5f); grow[i] = (int)floorf((g - py) * sy_scale + (float)o.H * 0.5f); }
   for (int k = (int)threadIdx.x; k < o.W; k += 256) {
     const float wx = px + (((float)k + 0.5f) / (float)o.W * 2.0f - 1.0f) * half_w;
     uint8_t f = (wx >= 0.0f && wx <= Wd) ? 2 : 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) { float g = (float)i * spacing; if ((int)floorf((g - px) * sx_scale + (float)o.W * 0.5f) == k) f |= 1; }
+    for (int i = 0; i < 8; i++) if (gcol[i] == k) f |= 1;
     colflag[k] = f; colx[k] = wx;
   }
   for (int k = (int)threadIdx.x; k < o.H; k += 256) {
     const float wy = py + (((float)k + 0.5f) / (float)o.H * 2.0f - 1.0f) * half_h;
     uint8_t f = (wy >= 0.0f && wy <= Wd) ? 2 : 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) { float g = (float)i * spacing; if ((int)floorf((g - py) * sy_scale + (float)o.H * 0.5f) == k) f |= 1; }
+    for (int i = 0; i < 8; i++) if (grow[i] == k) f |= 1;
     rowflag[k] = f; rowy[k] = wy;
   }
   __syncthreads();
@@ -276,7 +303,7 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs
     c0 = c0 < 0 ? 0 : c0; c1 = c1 > o.W - 1 ? o.W - 1 : c1; r0 = r0 < 0 ? 0 : r0; r1 = r1 > o.H - 1 ? o.H - 1 : r1;
     if (c0 > c1 || r0 > r1) { c0 = 1; c1 = 0; r0 = 1; r1 = 0; }
     ebx[k] = (unsigned)c0 | ((unsigned)c1 << 16); eby[k] = (unsigned)r0 | ((unsigned)r1 << 16);
-    { const float step = 6.28318530717958647692f / (float)(int)(ec[k] >> 24); eapo[k] = r * cosf(0.5f * step); }
+    eapo[k] = r * scr_cos_half_step((int)(ec[k] >> 24));
   }
   __syncthreads();
   // (wave-uniform values the compiler cannot know to be uniform -- the wavefront's number, what comes out of LDS at a uniform address -- go through
