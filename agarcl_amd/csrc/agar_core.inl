@@ -202,8 +202,11 @@ AG_DEV unsigned clamp_mass(unsigned m) { return m > AG_CELL_MIN_SIZE ? m : AG_CE
 #define L_EVV 0                                    // int[AG_EVV_CAP]  virus eat events of the tick
 #define L_TMP (L_EVV + 4 * AG_EVV_CAP)             // int[128] mailbox / scratch
 #define L_NEW (L_TMP + 4 * 128)                    // created cells [CF_FIELDS][AG_CC]; also the RNG draw buffer (128 x u64)
-#define L_PLS (L_NEW + 4 * CF_FIELDS * AG_CC)     // int[P][PL_WORDS]
-#define CELL_STRIDE (4 * (CF_FIELDS + 3) * AG_CC) // per player: 9 fields + (cached-for mass, radius, max speed)
+#define L_PLS (L_NEW + 4 * CF_FIELDS * AG_CC)     // int[P][PL_LDS_STRIDE]
+// (+ 4 bytes: without them every player's block starts in the same LDS bank, and a lane-per-player access -- move_all_players, simple_turns, the
+// collision pre-test: field f of cell 0 of thirty players -- is a thirty-way bank conflict)
+#define CELL_STRIDE (4 * (CF_FIELDS + 3) * AG_CC + 4) // per player: 9 fields + (cached-for mass, radius, max speed)
+#define PL_LDS_STRIDE (PL_WORDS + 1)                // the player words in LDS: 25 words apart (24 would put eight players on each of four banks)
 #ifdef AGAR_CPU_EMU
 static inline
 #else
@@ -217,9 +220,9 @@ __host__ __device__ inline
 // held at fixed offsets until round 4 -- 3-5 % of the soak's default draw ended flagged.  At the end of the block their size costs the
 // default arenas nothing (EC = 256 as before) and the dense ones LDS, not correctness.
 size_t ag_lds_layout(int P, int VC, int FC, int EC, int KC, int *cells_off, int *vir_off = nullptr, int *food_off = nullptr, int *evp_off = nullptr, int *cand_off = nullptr) {
-  int co = L_PLS + 4 * P * PL_WORDS;
+  int co = L_PLS + 4 * P * PL_LDS_STRIDE;
   if (cells_off) *cells_off = co;
-  int vo = co + P * CELL_STRIDE, fo = vo + 16 * VC, eo = fo + 16 * FC, ko = eo + 4 * EC;
+  int vo = (co + P * CELL_STRIDE + 15) & ~15, fo = vo + 16 * VC, eo = fo + 16 * FC, ko = eo + 4 * EC;
   if (vir_off) *vir_off = vo;
   if (food_off) *food_off = fo;
   if (evp_off) *evp_off = eo;
@@ -304,7 +307,7 @@ template <int NS, bool AV> AG_DEV int ag_evp_off(const AgCtx<NS, AV> &c) { retur
 template <int NS, bool AV> AG_DEV int ag_cand_off(const AgCtx<NS, AV> &c) { return c.food_off + 16 * c.FC + 4 * c.gs->d.EC; }
 // the arena's event list in HBM: [0, EC) = the LDS events as arena_store exports them (agarcl_get_events), [EC, EC + EX) = the spill area
 template <int NS, bool AV> AG_DEV AG_GLOBAL int32_t *g_evp(const AgCtx<NS, AV> &c) { return (AG_GLOBAL int32_t *)(c.gs->ev_p + (size_t)c.arena * (size_t)(c.gs->d.EC + c.gs->d.EX)); }
-template <int NS, bool AV> AG_DEV int *PLS(const AgCtx<NS, AV> &c, int p) { return (int *)(c.lds + L_PLS) + p * PL_WORDS; }
+template <int NS, bool AV> AG_DEV int *PLS(const AgCtx<NS, AV> &c, int p) { return (int *)(c.lds + L_PLS) + p * PL_LDS_STRIDE; }
 template <int NS, bool AV> AG_DEV Cells cells_of(const AgCtx<NS, AV> &c, int p) {
   float *b = (float *)(c.lds + c.cells_off + p * CELL_STRIDE);
   Cells k;
@@ -446,7 +449,7 @@ template <int NS, bool AV> AG_DEV void arena_load(AgCtx<NS, AV> &c, bool want_pe
   if (want_pellets) { auto gxy = g_pxy(c); AG_PEL_FOR(s, lane, i) { PELX(c, s, lane) = gxy[2 * i]; PELY(c, s, lane) = gxy[2 * i + 1]; } c.pel_loaded = true; }
   ub_load_t(c.S, g_ar(c), AR_WORDS, ag_ts_lg);
   auto gpl = g_pl(c);
-  AG_LANES(i, c.P * PL_WORDS) PLS(c, 0)[i] = gpl[AG_TW(i)];
+  AG_LANES(i, c.P * PL_WORDS) PLS(c, 0)[i + i / PL_WORDS] = gpl[AG_TW(i)];   // (word w of player p: LDS word p * PL_LDS_STRIDE + w)
 #ifndef AGAR_CPU_EMU
   if (c.P <= 2)
 #endif
@@ -487,9 +490,11 @@ template <int NS, bool AV> AG_DEV void arena_load(AgCtx<NS, AV> &c, bool want_pe
       // of cells (23 % of a Tick/30 launch with the store, scripts/gpu_phase_multi.py).  The counts cost a second round trip: the player words
       // are in LDS by now.  (Slots >= n_cells are never read; a created cell is written whole.)
       const int ncl = AG_LANE < c.P ? PLS(c, AG_LANE)[PL_NCELLS] : 0;   // (P <= 32 players: a lane each)
+      const bool one_each = __ballot(AG_LANE < c.P && ncl != 1) == 0ull;
       for (int base = 0;; base += 64) {
         const int t = base + AG_LANE; int p = -1, i = 0, st = 0;
-        for (int q = 0; q < c.P; q++) { const int nq = __builtin_amdgcn_readlane(ncl, q); if (t >= st && t < st + nq) { p = q; i = t - st; } st += nq; }
+        if (one_each) { p = t < c.P ? t : -1; st = c.P; }   // (every player has exactly one cell: the flat list IS the player list)
+        else for (int q = 0; q < c.P; q++) { const int nq = __builtin_amdgcn_readlane(ncl, q); if (t >= st && t < st + nq) { p = q; i = t - st; } st += nq; }
         if (p >= 0) {
           auto g = g_cells(c, p); uint32_t *l = (uint32_t *)(c.lds + c.cells_off + p * CELL_STRIDE);
 #pragma unroll
@@ -539,9 +544,11 @@ template <int NS, bool AV> AG_DEV void arena_store(AgCtx<NS, AV> &c) {
 #ifndef AGAR_CPU_EMU
   if (c.P > 2) {   // several players: a lane per live cell over the flat list (as arena_load) instead of a dependent LDS read and twelve stores per player
     const int ncl = AG_LANE < c.P ? PLS(c, AG_LANE)[PL_NCELLS] : 0;
+    const bool one_each = __ballot(AG_LANE < c.P && ncl != 1) == 0ull;
     for (int base = 0;; base += 64) {
       const int t = base + AG_LANE; int p = -1, i = 0, st = 0;
-      for (int q = 0; q < c.P; q++) { const int nq = __builtin_amdgcn_readlane(ncl, q); if (t >= st && t < st + nq) { p = q; i = t - st; } st += nq; }
+      if (one_each) { p = t < c.P ? t : -1; st = c.P; }   // (every player has exactly one cell -- bench/main.cpp's populations, most of C1's ticks: the flat list IS the player list)
+      else for (int q = 0; q < c.P; q++) { const int nq = __builtin_amdgcn_readlane(ncl, q); if (t >= st && t < st + nq) { p = q; i = t - st; } st += nq; }
       if (p >= 0) {
         auto g = g_cells(c, p); const uint32_t *l = (const uint32_t *)(c.lds + c.cells_off + p * CELL_STRIDE);
 #pragma unroll
@@ -575,7 +582,7 @@ template <int NS, bool AV> AG_DEV void arena_store(AgCtx<NS, AV> &c) {
     if (AG_RARE(fl != 0)) { AG_SERIAL { ag_atomic_or(c.gs->qstat + 1, fl); } }
   }
   auto gpl = g_pl(c);
-  AG_LANES(i, c.P * PL_WORDS) gpl[AG_TW(i)] = PLS(c, 0)[i];
+  AG_LANES(i, c.P * PL_WORDS) gpl[AG_TW(i)] = PLS(c, 0)[i + i / PL_WORDS];
   int nevp = SR(c, AR_NEVP), nevv = SR(c, AR_NEVV);
   if (nevp > 0) { const int EC = c.gs->d.EC; auto ge = g_evp(c); int lim = nevp < EC ? nevp : EC; AG_LANES(i, lim) ge[i] = L_I(c, ag_evp_off(c))[i]; }
   if (nevv > 0) { auto ge = (AG_GLOBAL int32_t *)(c.gs->ev_v + (size_t)c.arena * AG_EVV_CAP); int lim = nevv < AG_EVV_CAP ? nevv : AG_EVV_CAP; AG_LANES(i, lim) ge[i] = L_I(c, L_EVV)[i]; }
@@ -1227,9 +1234,11 @@ template <int NS, bool AV> AG_DEV void move_all_players(AgCtx<NS, AV> &c) {
   }
 #else
   const int ncl = AG_LANE < c.P ? PLS(c, AG_LANE)[PL_NCELLS] : 0;   // (P <= 32 players: a lane each)
+  const bool one_each = __ballot(AG_LANE < c.P && ncl != 1) == 0ull;
   for (int base = 0;; base += 64) {
     const int t = base + AG_LANE; int p = -1, i = 0, st = 0;
-    for (int q = 0; q < c.P; q++) { const int nq = __builtin_amdgcn_readlane(ncl, q); if (t >= st && t < st + nq) { p = q; i = t - st; } st += nq; }
+    if (one_each) { p = t < c.P ? t : -1; st = c.P; }   // (every player has exactly one cell: the flat list IS the player list)
+    else for (int q = 0; q < c.P; q++) { const int nq = __builtin_amdgcn_readlane(ncl, q); if (t >= st && t < st + nq) { p = q; i = t - st; } st += nq; }
     if (p >= 0) { const int *PLp = PLS(c, p); Cells s = cells_of(c, p); big = big | move_cell(c, s, i, u2f(PLp[PL_TX]), u2f(PLp[PL_TY]), dt, W); }
     if (base + 64 >= st) break;
   }

@@ -203,7 +203,8 @@ template <int NS, bool AV> AG_DEV void players_collision(AgCtx<NS, AV> &c) {
     const int myslot = __builtin_amdgcn_ds_bpermute((AR_ORDER0 + (lane < P ? lane : 0)) << 2, c.S.v);     // word AR_ORDER0 + lane of the arena block
     const int mycnt = lane < P ? PLS(c, myslot)[PL_NCELLS] : 0;
     int acc = 0, pa = 0, ia = 0;
-    for (int k = 0; k < P; k++) {
+    if (__ballot(lane < P && mycnt != 1) == 0ull) { pa = lane < P ? myslot : 0; acc = P; }   // (every player has exactly one cell: lane k holds the cell of order position k)
+    else for (int k = 0; k < P; k++) {
       const int nk = __builtin_amdgcn_readlane(mycnt, k), sk = __builtin_amdgcn_readlane(myslot, k);
       const bool mine = lane >= acc && lane < acc + nk;
       pa = mine ? sk : pa; ia = mine ? lane - acc : ia;
