@@ -2348,7 +2348,9 @@ template <int NS, bool AV> AG_DEV void arena_tick(AgCtx<NS, AV> &c) {
 #else
   const unsigned done_ = c.moved_all ? simple_turns(c) : 0u;
 #endif
-  for (int k = 0; k < c.P; k++) { const int p_ = SR(c, AR_ORDER0 + k); if (!((done_ >> p_) & 1u)) tick_player(c, p_); }
+  // (nobody left -- bench/main.cpp's populations on nearly every tick --: the walk over the iteration order is skipped, not made P times in vain)
+  if (c.P > 32 || (~done_ & (c.P >= 32 ? ~0u : (1u << c.P) - 1u)) != 0u)
+    for (int k = 0; k < c.P; k++) { const int p_ = SR(c, AR_ORDER0 + k); if (!((done_ >> p_) & 1u)) tick_player(c, p_); }
   remove_pellets(c);
   remove_viruses(c);
   AG_T(c, 13);
