@@ -462,6 +462,15 @@ template <int NS, bool AV> AG_DEV void arena_load(AgCtx<NS, AV> &c, bool want_pe
       for (int f = 0; f < CF_ALL; f++) l[f * AG_CC + i] = g[AG_CELL_W(f, i)];
     }
   }
+#ifndef AGAR_CPU_EMU
+  else if (AG_LANE < c.P) {
+    // more than two players: cell 0 of every player, a lane each, in THIS round trip -- its address needs no count, and it is the only cell of
+    // most players (all of bench/main.cpp's); the cells behind it follow in the second trip below, if there are any
+    auto g = g_cells(c, AG_LANE); uint32_t *l = (uint32_t *)(c.lds + c.cells_off + AG_LANE * CELL_STRIDE);
+#pragma unroll
+    for (int f = 0; f < CF_ALL; f++) l[f * AG_CC] = g[AG_CELL_W(f, 0)];
+  }
+#endif
   // viruses (x, y, mass -> radius) and the first 64 foods: their addresses need no count either, and on the device the words go STRAIGHT
   // into LDS (global_load_lds: wave-uniform LDS base + lane * 4, per-lane source address) -- no destination registers, so the arena's
   // other loads (46 registers in flight with 1000 pellets) keep theirs.  An unfed virus weighs 100, so its radius is the one table entry
@@ -489,12 +498,12 @@ template <int NS, bool AV> AG_DEV void arena_load(AgCtx<NS, AV> &c, bool want_pe
       // round trip (above) is right for one or two players; thirty single-cell players made it 360 load instructions and 46 KB per arena for 1.4 KB
       // of cells (23 % of a Tick/30 launch with the store, scripts/gpu_phase_multi.py).  The counts cost a second round trip: the player words
       // are in LDS by now.  (Slots >= n_cells are never read; a created cell is written whole.)
-      const int ncl = AG_LANE < c.P ? PLS(c, AG_LANE)[PL_NCELLS] : 0;   // (P <= 32 players: a lane each)
-      const bool one_each = __ballot(AG_LANE < c.P && ncl != 1) == 0ull;
+      const int ncl0 = AG_LANE < c.P ? PLS(c, AG_LANE)[PL_NCELLS] : 0;   // (P <= 32 players: a lane each)
+      const int ncl = ncl0 > 1 ? ncl0 - 1 : 0;                            // cells behind cell 0 (which arrived with the first trip)
+      if (__ballot(ncl != 0) != 0ull)
       for (int base = 0;; base += 64) {
         const int t = base + AG_LANE; int p = -1, i = 0, st = 0;
-        if (one_each) { p = t < c.P ? t : -1; st = c.P; }   // (every player has exactly one cell: the flat list IS the player list)
-        else for (int q = 0; q < c.P; q++) { const int nq = __builtin_amdgcn_readlane(ncl, q); if (t >= st && t < st + nq) { p = q; i = t - st; } st += nq; }
+        for (int q = 0; q < c.P; q++) { const int nq = __builtin_amdgcn_readlane(ncl, q); if (t >= st && t < st + nq) { p = q; i = 1 + t - st; } st += nq; }
         if (p >= 0) {
           auto g = g_cells(c, p); uint32_t *l = (uint32_t *)(c.lds + c.cells_off + p * CELL_STRIDE);
 #pragma unroll
