@@ -81,6 +81,7 @@ SYMBOLS = [
     ("agarcl_num_arenas", C.c_int, [C.c_void_p]),
     ("agarcl_players_per_arena", C.c_int, [C.c_void_p]),
     ("agarcl_state_bytes", C.c_int64, [C.c_void_p]),
+    ("agarcl_device_bytes", C.c_int64, [C.c_void_p]),
     ("agarcl_get_stream", C.c_void_p, [C.c_void_p]),
     ("agarcl_stream_wait", C.c_int, [C.c_void_p, C.c_void_p]),
     ("agarcl_stream_signal", C.c_int, [C.c_void_p, C.c_void_p]),
@@ -399,6 +400,10 @@ class BatchedEngine:
 
     def state_bytes(self):
         return int(self.L.agarcl_state_bytes(self.h))
+
+    def device_bytes(self):
+        """HBM the engine has allocated (incl. the event spill of dense / crowded configurations)"""
+        return int(self.L.agarcl_device_bytes(self.h))
 
     # -- state exchange -------------------------------------------------------------------------
     def dump(self, arena=0):

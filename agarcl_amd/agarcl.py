@@ -224,3 +224,8 @@ class GoBiggerEnvironment(_Environment):
     def get_frame(self):                      # bindings.cpp:354-363: uint8 (1, 512, 512, 3) from the last agent's perspective
         f = self._engine.screen_obs(512, 512)
         return f[0, self._num_agents - 1].reshape(1, 512, 512, 3)
+
+
+# the GoBigger value classes and GoBiggerObservation as module attributes (bindings.cpp:184-318), as the compiled module carries them
+from .gobigger import (CloneInfo, FoodInfo, GlobalState, GoBiggerObservation, PlayerState, PlayerStates, SporeInfo,  # noqa: E402,F401
+                       VirusInfo)

@@ -77,7 +77,7 @@ struct agarcl_env {
   ag_stream_t stream; bool own_stream;
   size_t lds_bytes; int ns; bool all_vis;
   int slot;  // ring index of the packed result buffer written by the NEXT step
-  std::vector<void *> allocs;
+  std::vector<void *> allocs; size_t alloc_bytes = 0; bool alloc_failed = false;   // (any alloc<>() that returned null: checked once, before the first upload or launch)
   float *d_act_dxdy; int32_t *d_act;  // env-owned action buffers (host-copy path)
   float *lut_r, *lut_ms, *lut_ss, *lut_anti;
   void *timer_ev[2];               // agarcl_timer_mark / agarcl_timer_elapsed_ms
@@ -569,7 +569,7 @@ static int launch_respawn(agarcl_env *e) {
 }
 
 // ---- host helpers -------------------------------------------------------------------------------------
-template <class T> static T *alloc(agarcl_env *e, size_t n) { T *p = (T *)dmalloc(n * sizeof(T), e->stream); if (p) e->allocs.push_back(p); return p; }
+template <class T> static T *alloc(agarcl_env *e, size_t n) { T *p = (T *)dmalloc(n * sizeof(T), e->stream); if (p) { e->allocs.push_back(p); e->alloc_bytes += n * sizeof(T); } else e->alloc_failed = true; return p; }
 
 // glibc srand(): TYPE_3 additive-feedback state after the 310 discarded outputs, as the 34-word ring the device
 // continues (agar_multi.inl: ag_rand_next).  Engine::seed calls std::srand(s) (Engine.hpp:242-245).
@@ -689,7 +689,10 @@ static int create_env(const agarcl_config *cfg, int32_t num_arenas, int32_t devi
   // players) overflowed the 256 events in the crowded soak -- pellets per unit area x (1 + players) > 0.06.
   { const double dens = (double)npel / ((double)g.W * (double)g.W); const bool dense = dens > 0.016, crowded = dens * (double)(1 + d.P) > 0.06;
     const int pc = d.PC <= 256 ? 256 : d.PC <= 512 ? 512 : d.PC <= 1024 ? 1024 : 2048;
-    d.EC = AG_EV_MIN; d.KC = dense ? pc : AG_EV_MIN; d.EX = (dense || crowded) ? (64 * pc < 65536 ? 64 * pc : 65536) : 0; }
+    // (a crowded but sparse arena -- Tick/30, C1 -- cannot repeat the dense corner's counts: its events are bounded by the pellets its
+    // cells cover, a few per pellet slot.  8 per slot there (Tick/30: 16 KB per arena instead of 128 KB, 64 MB instead of 0.5 GB at 4096 arenas);
+    // flag 8 still reports an overflow, and the soak draws these configurations)
+    d.EC = AG_EV_MIN; d.KC = dense ? pc : AG_EV_MIN; d.EX = dense ? (64 * pc < 65536 ? 64 * pc : 65536) : crowded ? 8 * pc : 0; }
   // ejected foods live in LDS during a launch, 16 bytes each: 128 keep the single-player layout within the 10 KB per wavefront that 16 resident
   // wavefronts per CU leave (nominal play: <= ~60 in 20k-tick mode-6 roll-outs); arenas with many players feed more: 16 per player
   if (cfg->cap_foods <= 0 && d.P * 16 > d.FC) d.FC = d.P * 16;
@@ -738,6 +741,9 @@ static int create_env(const agarcl_config *cfg, int32_t num_arenas, int32_t devi
 #endif
   e->kstep_grid = AG_KSTEP_MAXGRID; { const char *kg = getenv("AGARCL_KSTEP_GRID"); if (kg) { int v = atoi(kg); if (v >= 1 && v <= AG_KSTEP_MAXGRID) e->kstep_grid = v; } }
   s.qlist = alloc<int32_t>(e, 2 * (size_t)d.A);
+  s.qstat = alloc<int32_t>(e, 16); e->d_mask = alloc<uint8_t>(e, (size_t)d.A);
+  // every array above is written through by some kernel (the event spill ev_p by pellets_eat / arena_store / k_quiet): one check for all
+  if (e->alloc_failed) { agarcl_destroy(e); return fail(AGARCL_E_NOMEM, "device allocation failed"); }
   { const char *nf = getenv("AGARCL_NO_FRONT"); e->no_front = nf && nf[0] == '1'; }
   // modes 0-4 start agents at mass 25 (quiet-dominated); 5 and 6 start at mass 1000 (general path every step)
   // single launch (k_fused) wherever the batch fits 2048 wavefronts -- the 2 per SIMD its register footprint admits -- at
@@ -753,10 +759,9 @@ static int create_env(const agarcl_config *cfg, int32_t num_arenas, int32_t devi
   e->fused = e->fused_ok && cfg->mode_number <= 4;  // starting point; poll_stats follows what the arenas actually do
   e->front_off = d.P == 1 && cfg->mode_number > 4; e->few_unfinished = false;
   e->work_step0 = e->work_front0 = 0; e->work_unf0 = 0; e->work_pass0 = 0;
-  e->flags_seen = 0; e->d_mask = alloc<uint8_t>(e, (size_t)d.A);
+  e->flags_seen = 0;
   e->fused_fixed = false; e->h_stat = nullptr; e->stat_ev = nullptr; e->next_poll = 2; e->poll_gap = 2; e->stat_pending = e->stat_stale_flags = false; e->step_no = e->front_runs = e->stat_req_front = e->stat_last_front = 0; e->stat_last_total = 0;
   { const char *fu = getenv("AGARCL_FUSED"); if (fu && (fu[0] == '0' || fu[0] == '1')) { e->fused = fu[0] == '1' && e->fused_ok; e->fused_fixed = true; } }
-  s.qstat = alloc<int32_t>(e, 16);
   // Lanes per arena of the lean front kernel.  The quiet tick is per-lane code that every lane of an arena's group carries
   // redundantly and a pellet pass is wave-wide whatever the group size, so the group size only sets how many wavefronts the
   // arenas make -- and from ~16k arenas on the launch is bound by issued wave-instructions.  Measured (MI355X, C2, us per
@@ -1040,13 +1045,23 @@ extern "C" int agarcl_get_events(agarcl_env *e, int32_t *n_events_host, int32_t 
   if (!e || !n_events_host) return fail(AGARCL_E_INVALID, "agarcl_get_events: null pointer");
   size_t A = (size_t)e->d.A; const int ag_ts_lg = e->d.ts_lg;
   const size_t EC = (size_t)(e->d.EC + e->d.EX);   // (the arena's stride: exported LDS events, then the spill area)
-  std::vector<int32_t> ar(AG_TILE_ARENAS(A) * AR_WORDS), evp(A * EC), evv(A * AG_EVV_CAP);
-  if (d2h(ar.data(), e->s.ar, ar.size() * 4, e->stream) || d2h(evp.data(), e->s.ev_p, evp.size() * 4, e->stream) || d2h(evv.data(), e->s.ev_v, evv.size() * 4, e->stream))
-    return fail(AGARCL_E_HIP, "copy failed");
+  // only the first min(cap, stride) entries of every arena travel (one strided copy): the spill area of a dense batch is gigabytes, the caller's
+  // buffer says how much of it is wanted
+  const size_t W = !pellet_idx_host || cap <= 0 ? 0 : ((size_t)cap < EC ? (size_t)cap : EC);
+  std::vector<int32_t> ar(AG_TILE_ARENAS(A) * AR_WORDS), evp(A * W), evv(A * AG_EVV_CAP);
+  if (d2h(ar.data(), e->s.ar, ar.size() * 4, e->stream) || d2h(evv.data(), e->s.ev_v, evv.size() * 4, e->stream)) return fail(AGARCL_E_HIP, "copy failed");
+  if (W) {
+#ifdef AGAR_CPU_EMU
+    for (size_t a = 0; a < A; a++) memcpy(&evp[a * W], e->s.ev_p + a * EC, W * 4);
+#else
+    if (hipMemcpy2DAsync(evp.data(), W * 4, e->s.ev_p, EC * 4, W * 4, A, hipMemcpyDeviceToHost, e->stream) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
+      return fail(AGARCL_E_HIP, "copy failed");
+#endif
+  }
   for (size_t a = 0; a < A; a++) {
     int np = ar[tix(ag_ts_lg, a, AR_WORDS, AR_NEVP)], nv = ar[tix(ag_ts_lg, a, AR_WORDS, AR_NEVV)];
     n_events_host[2 * a] = np; n_events_host[2 * a + 1] = nv;
-    if (pellet_idx_host) for (int i = 0; i < np && i < cap && i < (int)EC; i++) pellet_idx_host[a * cap + i] = evp[a * EC + i];
+    if (pellet_idx_host) for (int i = 0; i < np && i < (int)W; i++) pellet_idx_host[a * cap + i] = evp[a * W + i];
     if (virus_idx_host) for (int i = 0; i < nv && i < cap_v && i < AG_EVV_CAP; i++) virus_idx_host[a * cap_v + i] = evv[a * AG_EVV_CAP + i];
   }
   return AGARCL_OK;
@@ -1259,6 +1274,9 @@ extern "C" int64_t agarcl_state_bytes(agarcl_env *e) {
   return 8LL * e->cfg.num_pellets + 12LL * e->cfg.num_viruses + 72LL * 1 + 112LL * e->d.P + 24LL * e->d.n_agents;
 }
 
+// HBM the env holds (every array of agarcl_create incl. the event spill of dense / crowded arenas; observation scratch is added when first used)
+extern "C" int64_t agarcl_device_bytes(agarcl_env *e) { return e ? (int64_t)e->alloc_bytes : 0; }
+
 #ifndef AGAR_CPU_EMU
 #ifndef AG_GRID_WAVES
 #define AG_GRID_WAVES 6   // (waves per SIMD the register budget is cut for: 80 VGPRs, no spills; 8 -- all that LDS admits -- spills 20 registers for the same time, the uncapped 111 VGPRs leave 4 waves and cost 6 us)
@@ -1375,6 +1393,9 @@ extern "C" int agarcl_screen_obs(agarcl_env *e, int32_t width, int32_t height, i
     e->undo_out = nullptr;   // (as above)
   }
   AgScreenCfg o; o.W = width; o.H = height; o.agent_view = agent_view != 0;
+#ifdef AG_SCR_ABL
+  { const char *ab = getenv("AGARCL_SCR_ABL"); o.abl = ab ? atoi(ab) : 0; }
+#endif
   { const char *pw = getenv("AGARCL_SCREEN_PIXELWISE");   // the pixel-wise kernel: cross-check only (agar_screen.inl)
     if (pw && pw[0] == '1') hipLaunchKernelGGL(k_screen_obs_pixelwise, dim3((unsigned)n), dim3(256), 0, e->stream, e->d_state, o, dst);
     else if (o.W <= 256 && o.H <= 256) { if (o.agent_view) hipLaunchKernelGGL((k_screen_obs<256, true>), dim3((unsigned)n), dim3(256), 0, e->stream, e->d_state, o, dst); else hipLaunchKernelGGL((k_screen_obs<256, false>), dim3((unsigned)n), dim3(256), 0, e->stream, e->d_state, o, dst); }

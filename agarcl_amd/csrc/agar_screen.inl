@@ -35,7 +35,16 @@
 
 #define AG_SCR_CAP 512  // visible entities kept per frame (more are dropped from the END of the draw order)
 
-struct AgScreenCfg { int W, H, agent_view; };  // agent_view: the 4-channel frame of Renderer::multi_channel_render_screen
+struct AgScreenCfg { int W, H, agent_view;   // agent_view: the 4-channel frame of Renderer::multi_channel_render_screen
+#ifdef AG_SCR_ABL   // measurement builds only (build.py --variant SCRABL -DAG_SCR_ABL): AGARCL_SCR_ABL=<bits> switches parts of k_screen_obs off
+  int abl;          // 1 no entity list, 2 no painting, 4 no post-processing pass, 8 no global stores, 16 no background fill
+#endif
+};
+#ifdef AG_SCR_ABL
+#define SCR_ABL(bit) (o.abl & (bit))
+#else
+#define SCR_ABL(bit) 0
+#endif
 
 #ifndef AGAR_CPU_EMU
 __device__ __forceinline__ unsigned scr_palette(int k) {  // core/color.hpp:4-12 as 0xBBGGRR bytes (GL rounds c * 255 to nearest)
@@ -272,7 +281,7 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs
     { size_t vo = (size_t)arena * gs->d.VC;
       for (int b = 0; b < nv; b += 64) { int i = b + lane; bool v = i < nv; unsigned m = v ? (unsigned)gs->vir_mass[vo + i] : 0u;
         emit(v, v ? gs->vir_x[vo + i] : 0.f, v ? gs->vir_y[vo + i] : 0.f, v ? gs->lut_r[m < AG_LUT_SIZE ? m : AG_LUT_SIZE - 1] : 0.f, (av ? 0xFF0000u : scr_palette(3)) | (150u << 24)); } }
-    if (lane == 0) n_list = count < AG_SCR_CAP ? count : AG_SCR_CAP;
+    if (lane == 0) n_list = SCR_ABL(1) ? 0 : (count < AG_SCR_CAP ? count : AG_SCR_CAP);
   }
   // grid lines: the pixel column / row a line falls into (one pixel wide), and which columns / rows lie inside the arena
   const float sx_scale = (float)o.W * 0.5f / half_w, sy_scale = (float)o.H * 0.5f / half_h, spacing = Wd / 7.0f;
@@ -317,6 +326,7 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs
     constexpr unsigned GRIDV = AGV ? 0x1A000000u : 0xFF00001Au, BACKV = AGV ? 0u : 0x00FFFFFFu;
     // (0.1, 0, 0) -> 26; alpha byte: a fragment was written.  Agent view (r05): the pixel is written in the form post_processing_frame_data leaves
     // it in -- a value <= 230 moves into alpha and the channel is cleared, whatever lies around it -- so that no pass over the band has to do it
+    if (SCR_ABL(16)) {} else
     if ((o.W & 3) == 0) {   // four pixels of a row per lane and store (r05): one row flag, the four column flags as one word, a 16-byte LDS store
       typedef unsigned v4u __attribute__((ext_vector_type(4)));
       const int gpr = o.W >> 2, ngrp = npix >> 2;   // groups per row, groups in the band
@@ -346,7 +356,7 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs
     // (r05: which entities reach into this wavefront's rows is decided for 64 entities at a time, a lane each, and only those are visited -- in
     // list order, so later draws still overwrite earlier ones.  Walking the whole list with a uniform box test per entity, wavefront and band was
     // a third of the kernel's instructions at 128 x 128, where a frame is five bands and a wavefront owns 7 of its rows: ~3 of ~40 entities hit.)
-    if (wr0 <= wr1) for (int k0 = 0; k0 < n; k0 += 64) {
+    if (wr0 <= wr1 && !SCR_ABL(2)) for (int k0 = 0; k0 < n; k0 += 64) {
       unsigned long long hits;
       { const int kk = k0 + lane; const bool in_ = kk < n;
         const unsigned bx_ = in_ ? ebx[kk] : 1u, by_ = in_ ? eby[kk] : 1u;   // (1 = first 1, last 0: empty)
@@ -375,7 +385,7 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs
     }
     if (CH == 4 && lane == 0 && mybits) atomicOr(&pp_chunks, mybits);
     __syncthreads();
-    if (CH == 4) {  // ScreenObservation::post_processing_frame_data (ScreenEnvironment.hpp:48-88): a sequential pass over the flat buffer
+    if (CH == 4 && !SCR_ABL(4)) {  // ScreenObservation::post_processing_frame_data (ScreenEnvironment.hpp:48-88): a sequential pass over the flat buffer
       // With the colours this kernel paints (one non-zero channel per pixel: 26 grid, 230 main agent, 255 pellets / others / viruses) the
       // pass has a closed form.  A pixel whose channel is <= 230 moves it into alpha: no dependence -- since r05 the painter writes such pixels
       // in that form at once (the kernel is bound by issued instructions: a pass over every pixel of the band cost as much as painting it).
@@ -465,6 +475,7 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs
     // (r05, second pass: four pixels per lane -- one 16-byte LDS read; the agent view stores them as they are, 16 bytes; a three-channel frame packs
     // them into three words instead of assembling every output word with a division by three)
     typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+    if (SCR_ABL(8)) {} else
     if (CH == 4 && (((size_t)bd) & 15) == 0 && (npix & 3) == 0) { v4u_ *bw = (v4u_ *)bd; const v4u_ *fw = (const v4u_ *)fb; for (int g = (int)threadIdx.x; g < (npix >> 2); g += 256) bw[g] = fw[g]; }
     else if (CH == 3 && (((size_t)bd) & 3) == 0 && (npix & 3) == 0) {
       unsigned *bw = (unsigned *)bd; const v4u_ *fw = (const v4u_ *)fb;

@@ -273,9 +273,9 @@ PYBIND11_MODULE(agarcl, module) {
       .def("save_env_state", &ScreenEnvironment::save_env_state);
   module.attr("has_screen_env") = py::bool_(true);   // frames come from the rule-based HIP rasteriser, not from OpenGL
 
-  // GoBigger value classes (bindings.cpp:184-318): the Python classes of agarcl_amd/gobigger.py under the reference's names
+  // GoBigger value classes and GoBiggerObservation (bindings.cpp:184-318): the Python classes of agarcl_amd/gobigger.py under the reference's names
   py::module_ gb = py::module_::import("agarcl_amd.gobigger");
-  for (const char *n : {"FoodInfo", "VirusInfo", "SporeInfo", "CloneInfo", "GlobalState", "PlayerState", "PlayerStates"}) module.attr(n) = gb.attr(n);
+  for (const char *n : {"FoodInfo", "VirusInfo", "SporeInfo", "CloneInfo", "GlobalState", "PlayerState", "PlayerStates", "GoBiggerObservation"}) module.attr(n) = gb.attr(n);
 
   py::class_<GoBiggerEnvironment>(module, "GoBiggerEnvironment")
       .def(py::init<int, int, int, int, int, int, bool, int, int, int, bool, int, int, bool, bool>(),

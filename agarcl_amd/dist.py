@@ -104,16 +104,25 @@ class ResultGatherer:
 
 
 class TensorGatherer:
-    """Per-step gather of one fixed-shape tensor per rank to rank 0 -- the observation path of a learner that lives on
+    """Per-step gather of one tensor per rank to rank 0 -- the observation path of a learner that lives on
     rank 0 (uint8 screen frames are 21 KB per arena; the int32 grid tensor, 512 KB per arena, is better left
-    on the producing GPU).  One collective in flight: gather(t) starts it, wait() completes it before `t` is reused."""
+    on the producing GPU).  One collective in flight: gather(t) starts it, wait() completes it before `t` is reused.
+    `shape` is THIS rank's shape, first axis = its arenas: with unequal shards (total % world != 0) every rank sends the largest shard's rows
+    (a smaller one through a padded staging buffer) and rank 0 drops the padding again, as ResultGatherer does."""
 
     def __init__(self, shape, dtype, device, group=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        self.recv = [torch.empty(tuple(shape), dtype=dtype, device=device) for _ in range(self.world)] if self.rank == 0 else None
+        shape = tuple(int(x) for x in shape)
+        sizes = [None] * self.world
+        dist.all_gather_object(sizes, shape[0], group=group)
+        self.sizes = [int(x) for x in sizes]
+        self.n_local, self.n_max = shape[0], max(self.sizes)
+        padded = (self.n_max,) + shape[1:]
+        self.stage = torch.zeros(padded, dtype=dtype, device=device) if self.n_local != self.n_max else None
+        self.recv = [torch.empty(padded, dtype=dtype, device=device) for _ in range(self.world)] if self.rank == 0 else None
         self.work = None
         self.reset_stats()
 
@@ -122,8 +131,11 @@ class TensorGatherer:
 
     def gather(self, tensor):
         self.wait()
-        self.work = self.dist.gather(tensor, self.recv, dst=0, group=self.group, async_op=True)
         self.calls += 1; self.bytes_sent += tensor.numel() * tensor.element_size()
+        if self.stage is not None:
+            self.stage[:self.n_local].copy_(tensor)
+            tensor = self.stage
+        self.work = self.dist.gather(tensor, self.recv, dst=0, group=self.group, async_op=True)
 
     def wait(self):
         if self.work is not None:
@@ -134,5 +146,9 @@ class TensorGatherer:
             self.work = None
 
     def gathered(self):
-        """rank 0: [world * A_local, ...] after wait()"""
-        return self.torch.cat(self.recv, dim=0) if self.rank == 0 else None
+        """rank 0: [sum of the shards' rows, ...] after wait(), padding rows dropped"""
+        if self.rank != 0:
+            return None
+        if self.n_max * self.world == sum(self.sizes):
+            return self.torch.cat(self.recv, dim=0)
+        return self.torch.cat([r[:n] for r, n in zip(self.recv, self.sizes)], dim=0)

@@ -130,6 +130,40 @@ class PlayerStates:                  # :216-259, bindings.cpp:275-296
         return out
 
 
+class GoBiggerObservation:           # :251-548 as pybind exposes it, bindings.cpp:297-318 (the module-level class; the env builds its states itself)
+    def __init__(self, map_width, map_height, frame_limit, last_frame, team_num):
+        self._global = GlobalState(map_width, map_height, frame_limit, last_frame, team_num)
+        self._players = PlayerStates({})                  # :301-302: starts empty
+
+    def update_global_state(self, frame_count):           # :344-346
+        self._global.update_last_frame_count(frame_count)
+
+    def update_player_state(self, player_id, food_infos, virus_infos, spore_infos, clone_infos, team_name, score, can_eject, can_split):
+        # :350-372 (both pybind overloads bind this one function; the second differs in keyword names only, accepted below)
+        self._players.update_player_state(player_id, PlayerState(player_id, food_infos, virus_infos, spore_infos, clone_infos, team_name, score, can_eject, can_split))
+        print("Updated player state for player ID: %d" % int(player_id))   # :370: the reference prints this line
+
+    def get_global_state(self):                           # :374
+        return self._global
+
+    def get_player_states(self):                          # :375
+        return self._players
+
+
+def _second_overload(fn):
+    """bindings.cpp:312-315: the same function under the keyword names food_positions / thorn_positions / spore_positions / clone_positions"""
+    def update_player_state(self, *a, **kw):
+        for new, old in (("food_positions", "food_infos"), ("thorn_positions", "virus_infos"), ("spore_positions", "spore_infos"), ("clone_positions", "clone_infos")):
+            if new in kw:
+                kw[old] = kw.pop(new)
+        return fn(self, *a, **kw)
+    update_player_state.__doc__ = fn.__doc__
+    return update_player_state
+
+
+GoBiggerObservation.update_player_state = _second_overload(GoBiggerObservation.update_player_state)
+
+
 def add_frame(player_states, tensors, arena=0):
     """GoBiggerObservation::add_frame (:519-541) for one arena from the tensors of BatchedEngine.gobigger_obs(): the entity
     lists of every player whose row is marked committed are replaced (the reference commits a refreshed state only when at

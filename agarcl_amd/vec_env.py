@@ -26,6 +26,9 @@ class VecEnvironment:
         """engine: an existing _capi.BatchedEngine to wrap instead of creating one (a sub-batch of a PipelinedVecEnvironment: it keeps its
         own, verified-concurrent stream, so use_torch_stream must be False for it)"""
         import torch
+        if engine is not None and use_torch_stream:
+            # agarcl_set_stream on an adopted sub-batch would replace the stream agarcl_pipe_create verified to be concurrent (and silently serialise the pipe)
+            raise ValueError("VecEnvironment(engine=...) wraps a sub-batch that keeps its own stream: pass use_torch_stream=False")
         self.torch = torch
         self.device = torch.device("cuda", device)
         self.num_arenas, self.num_agents, self.ticks_per_step = num_arenas, num_agents, ticks_per_step
@@ -76,12 +79,10 @@ class VecEnvironment:
         host arrays.  Action enum as in the reference: 0 none, 1 feed, 2 split (core/types.hpp:59-61)."""
         torch = self.torch
         if isinstance(dxdy, torch.Tensor):
-            if dxdy.device != self.device or act.device != self.device:
-                raise ValueError("action tensors must live on %s" % self.device)
-            dxdy = dxdy.to(torch.float32).contiguous()
-            act = act.to(torch.int32).contiguous()
-            if dxdy.numel() != self.num_arenas * self.num_agents * 2 or act.numel() != self.num_arenas * self.num_agents:
-                raise RuntimeError("Number of actions does not match number of agents")  # BaseEnvironment.hpp:142-144
+            dxdy, act = self._device_actions(dxdy, act)
+            if self._current_raw_stream() != self.stream_handle:
+                # a conversion above (int64 -> int32, a non-contiguous slice) ran on torch's CURRENT stream: the engine's stream waits for it
+                self.order_after_current()
             self._act_keep = (dxdy, act)
             self.engine.set_actions_device(dxdy.data_ptr(), act.data_ptr())
         else:
@@ -90,6 +91,18 @@ class VecEnvironment:
             if dxdy.size != self.num_arenas * self.num_agents * 2 or act.size != self.num_arenas * self.num_agents:
                 raise RuntimeError("Number of actions does not match number of agents")
             self.engine.set_actions(dxdy, act)
+
+    def _device_actions(self, dxdy, act):
+        """CUDA action tensors in the layout the kernels read (f32 / i32, contiguous).  Any conversion is a torch kernel on the CURRENT stream:
+        callers order the engine's stream after it (order_after_current / pipe.fork) AFTER this returns, never before."""
+        torch = self.torch
+        if dxdy.device != self.device or act.device != self.device:
+            raise ValueError("action tensors must live on %s" % self.device)
+        dxdy = dxdy.to(torch.float32).contiguous()
+        act = act.to(torch.int32).contiguous()
+        if dxdy.numel() != self.num_arenas * self.num_agents * 2 or act.numel() != self.num_arenas * self.num_agents:
+            raise RuntimeError("Number of actions does not match number of agents")  # BaseEnvironment.hpp:142-144
+        return dxdy, act
 
     def step(self, ticks=0):
         """Enqueue one env step (ticks_per_step engine ticks); results land in self.rewards /
@@ -199,6 +212,18 @@ class VecEnvironment:
         self.engine.close()
 
 
+def default_sub_batches(num_arenas, num_agents=1, num_bots=0, mode_number=0, **_):
+    """How many independent sub-batches a batch of this configuration is stepped as when the caller does not say.
+
+    4 where the general engine (k_step) handles most arena-steps -- several players per arena (bots or several agents), or an agent that
+    starts at mass 1000 (modes 5 and 6): a launch lasts as long as its slowest arena, and four ranges on streams of their own stop 3/4 of the
+    arenas from waiting for it (measured at 4096 arenas, DESIGN.md section 5: mode 6 351 -> 303 us per step, C1 90 -> 67 us).
+    1 for the quiet configurations (one mass-25 agent per arena: the front kernel finishes nearly every arena-step in ~10 us): there the
+    fork / join of a pipelined step costs more than the step.  Small batches stay whole (a range below 256 arenas cannot fill the chip)."""
+    heavy = (int(num_agents) + int(num_bots) > 1) or int(mode_number) in (5, 6)
+    return 4 if heavy and int(num_arenas) >= 1024 else 1
+
+
 class PipelinedVecEnvironment:
     """`num_arenas` arenas as `sub_batches` independent sub-batches (include/agarcl_batch.h agarcl_pipe_*): contiguous arena ranges, each a
     VecEnvironment (`parts[j]`, arenas `ranges[j] = (first, count)`) on a HIP stream of its own that was verified to run concurrently with
@@ -212,9 +237,11 @@ class PipelinedVecEnvironment:
 
     Arena first_j + a computes exactly what arena first_j + a of one VecEnvironment over all arenas computes (seeds by global index)."""
 
-    def __init__(self, num_arenas, sub_batches=2, num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True, num_pellets=1000,
+    def __init__(self, num_arenas, sub_batches="auto", num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True, num_pellets=1000,
                  num_viruses=0, num_bots=0, reward_type=1, c_death=0, mode_number=0, device=0, dt=1.0 / 30, strict_flags=True, **caps):
         import torch
+        if sub_batches == "auto":      # by workload (default_sub_batches); a quiet configuration becomes ONE range: the lock-step env behind this surface
+            sub_batches = default_sub_batches(num_arenas, num_agents, num_bots, mode_number)
         self.torch = torch
         self.device = torch.device("cuda", device)
         self.num_arenas, self.num_agents, self.sub_batches = num_arenas, num_agents, sub_batches
@@ -235,8 +262,14 @@ class PipelinedVecEnvironment:
 
     def send(self, j, dxdy, act, ticks=0):
         p = self.parts[j]
-        p.order_after_current()
-        p.take_actions(dxdy, act)
+        if isinstance(dxdy, self.torch.Tensor):
+            dxdy, act = p._device_actions(dxdy, act)      # convert FIRST (torch kernels on the current stream) ...
+            p.order_after_current()                       # ... then order the sub-batch's stream after the current one: the event covers them
+            p._act_keep = (dxdy, act)
+            p.engine.set_actions_device(dxdy.data_ptr(), act.data_ptr())
+        else:
+            p.order_after_current()
+            p.take_actions(dxdy, act)
         p.step(ticks)
 
     def recv(self, j):
@@ -245,13 +278,38 @@ class PipelinedVecEnvironment:
         return p
 
     def step(self, dxdy, act, ticks=0):
+        torch = self.torch
         cur = self.parts[0]._current_raw_stream()
-        self.pipe.fork(cur)                                   # one event on the current stream, every sub-batch waits for it (one host call)
-        for j, (lo, n) in enumerate(self.ranges):
-            p = self.parts[j]
-            p.take_actions(dxdy[lo:lo + n], act[lo:lo + n])
-            p.step(ticks)
+        if isinstance(dxdy, torch.Tensor):
+            # convert the FULL-batch tensors first (torch kernels on the current stream), then fork: the event covers the conversion
+            A, n = self.num_arenas, self.num_agents
+            if dxdy.device != self.device or act.device != self.device:
+                raise ValueError("action tensors must live on %s" % self.device)
+            if dxdy.numel() != A * n * 2 or act.numel() != A * n:
+                raise RuntimeError("Number of actions does not match number of agents")
+            dxdy = dxdy.to(torch.float32).reshape(A, n, 2).contiguous(); act = act.to(torch.int32).reshape(A, n).contiguous()
+            self._act_keep = (dxdy, act)
+            self.pipe.fork(cur)                               # one event on the current stream, every sub-batch waits for it (one host call)
+            for j, (lo, cnt) in enumerate(self.ranges):
+                p = self.parts[j]
+                p.engine.set_actions_device(dxdy.data_ptr() + lo * n * 8, act.data_ptr() + lo * n * 4)
+        else:
+            self.pipe.fork(cur)
+            for j, (lo, cnt) in enumerate(self.ranges):
+                self.parts[j].take_actions(dxdy[lo:lo + cnt], act[lo:lo + cnt])
+        # every sub-batch is stepped and the caller's stream joined even when one of them reports a capacity flag: the ranges stay in
+        # lock-step and ordered; the flag is raised once, after the join
+        err = None
+        for p in self.parts:
+            try:
+                p.step(ticks)
+            except _capi.AgarclError as ex:
+                if ex.code != -6:
+                    raise
+                err = err or ex
         self.pipe.join(cur)
+        if err is not None:
+            raise err
         return list(self.parts)
 
     def sync(self):

@@ -58,15 +58,17 @@ import numpy as np
 from . import _capi
 from . import gym_agario as _single
 from . import spaces as _spaces
-from .vec_env import PipelinedVecEnvironment, VecEnvironment
+from .vec_env import PipelinedVecEnvironment, VecEnvironment, default_sub_batches
 
 
 class AgarioVectorEnv:
     metadata = {"render_modes": [], "autoreset_mode": "same_step"}
 
-    def __init__(self, num_envs, obs_type="grid", device=0, channels_last=False, sub_batches=1, **kwargs):
+    def __init__(self, num_envs, obs_type="grid", device=0, channels_last=False, sub_batches="auto", **kwargs):
         """num_envs arenas; obs_type "grid" | "screen" | "ram" | "gobigger" | "none"; channels_last: grid observations as a [.., G, G, C]
-        VIEW (what AgarioEnv hands out per arena) instead of the engine's channel-first layout; sub_batches: see the module text; every other
+        VIEW (what AgarioEnv hands out per arena) instead of the engine's channel-first layout; sub_batches: an int, or "auto" (the default) =
+        vec_env.default_sub_batches: 4 where the general engine handles most arena-steps (bots / several agents / modes 5 and 6), 1 for quiet
+        batches and for the GoBigger observation -- see the module text; every other
         keyword as AgarioEnv takes it (difficulty, ticks_per_step, arena_size, num_pellets, num_viruses, num_bots, pellet_regen, reward_type,
         c_death, mode, num_agents, number_steps, env_type, grid_size, observe_*, screen_len, agent_view, k_cells / k_pellets / k_viruses /
         k_others)."""
@@ -79,6 +81,8 @@ class AgarioVectorEnv:
         self.num_agents, self.multi_agent = o["num_agents"], o["multi_agent"]
         self.number_of_steps, self.env_type = o["number_steps"], o["env_type"]
         self.channels_last = bool(channels_last)
+        if sub_batches == "auto":
+            sub_batches = 1 if obs_type == "gobigger" else default_sub_batches(self.num_envs, o["num_agents"], o["num_bots"], o["mode"])
         self.sub_batches = int(sub_batches)
         if self.sub_batches < 1 or self.sub_batches > self.num_envs:
             raise ValueError("sub_batches must be in [1, num_envs]")
@@ -234,17 +238,17 @@ class AgarioVectorEnv:
         rc = self._vec_step(self._handles[j], sp, bf, move_ptr, kind_ptr, self._flags_ref)
         if rc != 0:
             self._chk(rc)
-        if self._flags.value:
-            self._check_flags()
+        return self._flags.value
 
     # ---- the vector-env surface -------------------------------------------------------------------------------------------------
     def reset(self, seed=None, options=None):
         """all arenas start a new episode.  seed: None (the arenas' random streams continue), an int s (arena a gets seed s + a, as
         num_envs separate `env.seed(s + a)` calls would give), or a sequence of num_envs seeds."""
         self.async_reset(seed)
+        obs = self._ret()[0]                                       # (GoBigger: enqueues its observation kernel -- before the current stream is ordered after the engine's)
         for p in self._parts:
             p.order_current_after()
-        return self._ret()[0], {}
+        return obs, {}
 
     def step(self, actions):
         """actions = (move, kind): move f32 [N, 2] (or [N, num_agents, 2]) in [-1, 1]^2, kind int [N] (or [N, num_agents]) in {0 none, 1 feed,
@@ -262,16 +266,22 @@ class AgarioVectorEnv:
             cur = p._current_raw_stream()
             if cur != p.stream_handle:                             # (stepping under another torch stream than the one the engine was bound to)
                 p.engine.stream_wait(cur)
-            self._step_part(0, mp, kp)
+            flags = self._step_part(0, mp, kp)
+            ret = self._ret()                                      # (GoBigger: its observation kernel is enqueued here, BEFORE the caller's stream is ordered after the engine's)
             if cur != p.stream_handle:
                 p.engine.stream_signal(cur)
         else:
             cur = self._parts[0]._current_raw_stream()
             self.pipe.pipe.fork(cur)                               # the actions were produced on the current stream: one event, every sub-batch waits for it
-            for j, (lo, cnt) in enumerate(self._ranges):
-                self._step_part(j, mp + lo * n * 8, kp + lo * n * 4)
+            flags = 0
+            for j, (lo, cnt) in enumerate(self._ranges):           # every range is stepped and joined even when one reports a flag: they stay in lock-step
+                flags |= self._step_part(j, mp + lo * n * 8, kp + lo * n * 4)
             self.pipe.pipe.join(cur)
-        return self._ret()
+            ret = self._ret()
+        if flags:
+            self._flags.value = flags
+            self._check_flags()                                    # raises once, after everything launched has been ordered (strict_flags)
+        return ret
 
     # ---- the two halves, per sub-batch (double-buffered sampling) ---------------------------------------------------------------------
     def async_reset(self, seed=None):
@@ -289,7 +299,8 @@ class AgarioVectorEnv:
         move = self._as_device(actions[0], self.torch.float32, (cnt, n, 2)); kind = self._as_device(actions[1], self.torch.int32, (cnt, n))
         self._act_keep[j] = (move, kind)
         self._parts[j].order_after_current()                      # the actions were produced on the current stream (no-op when that is the engine's)
-        self._step_part(j, move.data_ptr(), kind.data_ptr())
+        if self._step_part(j, move.data_ptr(), kind.data_ptr()):
+            self._check_flags()
 
     def recv(self, j=0):
         """the current stream waits (on the device) for sub-batch j's last reset / step; returns its rows (views of the full tensors):

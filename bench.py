@@ -32,7 +32,7 @@ CFG = dict(num_agents=1, ticks_per_step=4, arena_size=1000, pellet_regen=True, n
            num_bots=0, reward_type=1, c_death=0, mode_number=0)
 # The headline line is C2.  The other SURVEY 8(d) workloads are selectable for DESIGN.md's measurement table only.
 WORKLOADS = {
-    "C2": dict(desc="C2: %d arenas/GPU x 1 agent, 1000x1000 arena, 1000 pellets, 0 viruses, mode 0, 4 ticks/step, random (dx,dy), action none"),
+    "C2": dict(desc="C2: %d arenas/GPU x 1 agent, 1000x1000, 1000 pellets, 0 viruses, mode 0, 4 ticks/step, random (dx,dy), action none"),
     "C3m0": dict(num_viruses=25, rand_act=True,
                  desc="C3/mode 0: %d arenas/GPU x 1 agent, 1000x1000, 1000 pellets, 25 viruses, mode 0, 4 ticks/step, random (dx,dy), action ~ U{0,1,2}"),
     "C3m6": dict(num_viruses=25, mode_number=6, rand_act=True,
@@ -54,7 +54,7 @@ WORKLOADS = {
 TRAFFIC_FILE = "r05_pmc_traffic.json"   # PMC FETCH_SIZE / WRITE_SIZE (+ one SQ pass) per step of the bench workloads, recorded by scripts/profile_round.sh
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
 GUIDE_COPY_GBS = 6300.0   # the achievable device copy rate the guide quotes (MI355X_MICROARCH.md), beside the copy timed in this process
-PIPE_K = 2                # sub-batches of the "<workload>/pipe2" entries (agarcl_pipe_*: independent arena ranges on streams of their own)
+PIPE_K = 4                # sub-batches of the "<workload>/pipe4" entries (agarcl_pipe_*: independent arena ranges on streams of their own)
 TASKS_FIXTURE = os.path.join(ROOT, "tests", "golden", "paper_tasks.json")   # values of the reference's bench/tasks_configs/mode_{1..10}.json
 
 
@@ -107,7 +107,7 @@ def requested_bytes(work, counts, P, n_agents, ticks, pellet_cap):
     return front * front_steps + general * general_steps + pellet_moves * pellet_cap * 8.0
 
 
-def cpu_baseline(seconds_budget=12.0, c3_budget=6.0):
+def cpu_baseline(seconds_budget=10.0, c3_budget=5.0):
     """The same per-arena workload on the host cores, timed on a bounded sample.
     kind "reference": oracle/_ref/libagar_ref.so = the unmodified reference engine (prebuilt from
     /root/reference); otherwise kind "port": the plain-C restatement."""
@@ -196,8 +196,7 @@ def cpu_baseline(seconds_budget=12.0, c3_budget=6.0):
             "c3m6_value": sum(done6) / el6, "c3m6_cores": cores,
             "c3m6_sample": "%.0f s of C3 / mode 6 (1000x1000, 1000 pellets, 25 viruses, agent mass 1000, random dx/dy, action ~ U{0,1,2}), one engine per host "
                            "thread, %d threads, %d arena-ticks in total" % (c3_budget, cores, sum(done6)),
-            "sample": "%.0f s of the C2 workload (1000x1000, 1000 pellets, 1 agent, random dx/dy, action none), one engine "
-                      "per host thread, %d threads, %d arena-ticks in total; single-thread rate %.0f ticks/s"
+            "sample": "%.0f s of C2 on the host: one engine per thread, %d threads, %d arena-ticks; one thread alone: %.0f ticks/s"
                       % (seconds_budget, cores, total, rate1),
             "c1_ticks_per_s_1core": c1_rate,
             "c1_sample": "BASELINE configs[0] as bench/main.cpp runs it: 250x250, 500 pellets, 10 viruses, agent + 4 bot kinds, "
@@ -431,7 +430,13 @@ def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, 
     # per-rank record (so that a poor scaling curve can be read off the line): this rank's own wall time and step time by HIP events,
     # the host time it spent waiting for collectives, the payload bytes it contributed
     gl = gathers or []
-    rank_info = {"rank": rank, "ms_per_step": elapsed_own / K * 1e3, "kernel_ms_per_step": kernel_ms,
+    # bytes this rank's kernels requested per step, from ITS OWN work counters (the PMC traffic of profiles/ is a single-GPU recording and is
+    # not quoted for N > 1 lines)
+    own_work = sum(e_.work() for e_ in engs)
+    own_counts = sum(e_.counts().astype(np.float64).sum(axis=0) for e_ in engs) / float(A)
+    own_req = requested_bytes(own_work, own_counts, eng.players, cfg["num_agents"], cfg["ticks_per_step"], (cfg["num_pellets"] + 63) // 64 * 64) / K
+    rank_info = {"rank": rank, "ms_per_step": elapsed_own / K * 1e3, "kernel_ms_per_step": kernel_ms, "requested_bytes_per_step": own_req,
+                 "requested_GBs": own_req / (kernel_ms * 1e-3) / 1e9,
                  "gather_wait_ms_total": sum(g_.wait_s for g_ in gl) * 1e3 + (obs_gather.wait_s if obs_gather is not None else 0.0) * 1e3,
                  "result_collectives": sum(g_.calls for g_ in gl), "result_bytes_sent": sum(g_.bytes_sent for g_ in gl),
                  "obs_collectives": obs_gather.calls if obs_gather is not None else 0, "obs_bytes_sent": obs_gather.bytes_sent if obs_gather is not None else 0}
@@ -442,8 +447,8 @@ def run_workload(torch, np, env_cls, agdist, dev, dev_index, rank, world, A, K, 
         elapsed = float(tmax.item())
         ranks = [None] * world
         dist.all_gather_object(ranks, rank_info)
-    counts = sum(e_.counts().astype(np.float64).sum(axis=0) for e_ in engs) / float(A)
-    res = dict(elapsed=elapsed, kernel_ms=kernel_ms, ranks=ranks, work=sum(e_.work() for e_ in engs), flags=np.concatenate([e_.flags() for e_ in engs]),
+    counts = own_counts
+    res = dict(elapsed=elapsed, kernel_ms=kernel_ms, ranks=ranks, world=world, work=own_work, flags=np.concatenate([e_.flags() for e_ in engs]),
                counts=counts, players=eng.players, fused=int(eng.L.agarcl_debug_fused(eng.h)),
                pellet_cap=(cfg["num_pellets"] + 63) // 64 * 64, sub_batches=len(engs), concurrent=(penv.concurrent if penv is not None else 1))
     (penv if penv is not None else env).close()
@@ -482,7 +487,7 @@ def roofline_block(res, A, K, ticks, cfg, workload, extra_bytes=0.0, kernel=None
     try:  # HBM bytes per step from the PMC counters, recorded separately by scripts/profile_round.sh on THIS kernel source
         tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
         ent = tj["runs"].get("%s@%d" % (workload, A))
-        if ent and tj.get("source_sha") == source_sha() and res.get("sub_batches", 1) == 1:
+        if ent and tj.get("source_sha") == source_sha() and res.get("sub_batches", 1) == 1 and res.get("world", 1) == 1:
             traffic, tag = ent["traffic_bytes_per_step"], "%s, source %s" % (tj.get("recorded", "?"), tj["source_sha"])
             issue = ent.get("issue")   # scripts/collect_profiles.py: the dominant kernel's SQ counters condensed (see "issue" below)
     except Exception:
@@ -533,6 +538,95 @@ def compact(rf, value, ms, cpu=None, cpu_cores=None):
 
 BY_WORKLOAD_COLUMNS = ["ms_per_step", "env_steps_per_s", "frac_hbm_traffic", "traffic_over_requested", "frac_valu_issue", "mean_wave_residency",
                        "cpu_reference_env_steps_per_s", "cpu_reference_cores"]
+
+
+LINE_LIMIT = 6000          # the driver keeps an 8 KB tail of stdout + stderr: the ONE line stays well inside it (round 5's 52 KB line was lost)
+FULL_RECORD = os.path.join(ROOT, "bench_full.json")   # everything else measured in the run (full roofline blocks, per-rank records, the vector surface)
+
+
+def sig(x, n=4):
+    """numbers of the printed line carry n significant digits (the full record keeps them all)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (str, int)):
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (n, x))
+    if isinstance(x, dict):
+        return {k: sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [sig(v, n) for v in x]
+    return x
+
+
+ROOF_KEEP = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "arenas", "algorithmic_bytes_per_step", "requested_bytes_per_step",
+             "frac_of_requested", "frac_hbm_traffic", "frac_streaming_model", "streaming_model_bytes_per_step", "frac_valu_issue", "mean_wave_residency",
+             "clock_ghz_measured", "measured_copy_GBs", "frac_of_measured_copy", "guide_copy_GBs", "frac_of_guide_copy", "traffic_source", "sub_batches")
+CPU_KEEP = ("value", "unit", "cores", "kind", "sample", "c3m6_value", "c1_ticks_per_s_1core", "ticks_per_s_1core")
+
+
+def compact_line(out):
+    """The ONE line rank 0 prints: the contract's fields exactly as measured, `roofline` (the headline kernel's fields + one compact row per
+    other workload of the run) and `cpu_baseline`; strings <= 120 characters, side figures at 4 significant digits.  Everything is in
+    bench_full.json."""
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfgd = dict(out["config"]); cfgd["workload"] = cfgd["workload"][:120]; cfgd["parallelism"] = cfgd["parallelism"][:120]
+    line["config"] = cfgd
+    full_roof = out["roofline"]
+    roof = {k: sig(full_roof[k]) for k in ROOF_KEEP if k in full_roof}
+    roof["kernel"] = str(roof.get("kernel", ""))[:120]
+    by = full_roof.get("by_workload")
+    if by:
+        # flat copies of the rows the round's targets are stated on (should a reader keep only the scalars of `roofline`)
+        for key, name in (("C3m6@%d" % full_roof["arenas"], "C3m6"), ("C3m6@%d/pipe4" % full_roof["arenas"], "C3m6_pipe4"), ("mid@%d" % full_roof["arenas"], "mid"),
+                          ("C1@%d" % full_roof["arenas"], "C1"), ("C5@%d" % full_roof["arenas"], "C5"), ("C5s@%d" % full_roof["arenas"], "C5s"),
+                          ("task5@%d" % full_roof["arenas"], "task5"), ("task6@%d" % full_roof["arenas"], "task6"), ("task10@%d" % full_roof["arenas"], "task10"),
+                          ("Tick/30@%d" % full_roof["arenas"], "tick30"), ("C2@65536", "C2_65536"), ("C3m6@32768", "C3m6_32768")):
+            row = by.get(key)
+            if isinstance(row, list):
+                roof["ms_" + name] = sig(row[0])
+        roof["by_workload_columns"] = full_roof["by_workload_columns"]
+        roof["by_workload"] = {k: (sig(v) if isinstance(v, list) else {"error": str(v.get("error"))[:80]}) for k, v in by.items()}
+    gv = full_roof.get("gym_vector")
+    if isinstance(gv, dict) and "error" not in gv:
+        # the RL surface: [host us per step, us per step] un-pipelined, then with the sub-batching AgarioVectorEnv picks by itself
+        roof["gym_vector_us"] = {k: sig([v["host_us_per_step"], v["us_per_step"]], 3) for k, v in gv.items()}
+        ga = full_roof.get("gym_vector_auto")
+        if isinstance(ga, dict) and "error" not in ga:
+            roof["gym_vector_auto_us"] = {k: sig([v["host_us_per_step"], v["us_per_step"]], 3) for k, v in ga.items()}
+    line["roofline"] = roof
+    if out.get("cpu_baseline"):
+        cb = {k: sig(out["cpu_baseline"][k], 5) for k in CPU_KEEP if k in out["cpu_baseline"]}
+        cb["sample"] = cb["sample"][:120]
+        line["cpu_baseline"] = cb
+    line["capacity_flags_raised"] = out.get("capacity_flags_raised")
+    if out.get("world_size", 1) > 1:
+        line["world_size"] = out["world_size"]; line["backend"] = out["backend"]; line["result_gather"] = out["result_gather"]; line["obs_gather_ran"] = out["obs_gather_ran"]
+        line["rank_devices"] = [str(d)[-24:] for d in out["rank_devices"]]
+        # per rank: [ms per step on its own clock, ms per step by HIP events, ms spent waiting for collectives in total, result collectives, obs collectives]
+        line["ranks_columns"] = ["ms_per_step", "kernel_ms_per_step", "gather_wait_ms_total", "result_collectives", "obs_collectives", "requested_GBs"]
+        line["ranks"] = [sig([r["ms_per_step"], r["kernel_ms_per_step"], r["gather_wait_ms_total"], r["result_collectives"], r["obs_collectives"], r.get("requested_GBs")]) for r in out["ranks"]]
+    line["full_record"] = os.path.basename(FULL_RECORD)
+    txt = json.dumps(line, separators=(",", ":"))
+    if len(txt) > LINE_LIMIT and "by_workload" in roof:       # never again a line the driver cannot keep: rows go first, the contract fields never
+        for k in [k for k in roof["by_workload"] if "/pipe" in k or k.startswith("Tick/") or k.startswith("task")]:
+            del roof["by_workload"][k]
+            txt = json.dumps(line, separators=(",", ":"))
+            if len(txt) <= LINE_LIMIT:
+                break
+    if len(txt) > LINE_LIMIT:
+        for k in ("by_workload", "by_workload_columns", "gym_vector_us", "gym_vector_auto_us"):
+            roof.pop(k, None)
+        txt = json.dumps(line, separators=(",", ":"))
+    return txt
+
+
+def emit(out):
+    """writes the full record beside bench.py and prints the one compact line (stdout carries nothing else that starts with '{')"""
+    try:
+        with open(FULL_RECORD, "w") as f:
+            json.dump(out, f, indent=1, default=float)
+    except OSError:
+        pass
+    print(compact_line(out))
 
 
 def reference_rate(cfg, seconds=0.5, dt=1.0 / 30):
@@ -625,7 +719,7 @@ def main():
         if not args.no_cpu_baseline:
             rate, kind = tick_reference_rate(nb, 2.0)
             out["cpu_baseline"] = {"value": rate, "unit": "env-steps/s", "cores": 1, "kind": kind, "sample": "2 s of Engine::tick at dt 1/60 s on the same population, one core"}
-        print(json.dumps(out))
+        emit(out)
         return
     screen = (84, 84, False)
     if args.workload.startswith("task"):
@@ -694,10 +788,10 @@ def main():
                         "source is committed.  by_workload: every other workload measured in this run on the same clock, one row each "
                         "(by_workload_columns); '<w>/pipe%d' = the same arenas as %d independent sub-batches on streams of their own" % (PIPE_K, PIPE_K))
         if world > 1:
-            par = "arena-sharded x%d; every step's (reward, done) gathered to rank 0 %s%s%s" % (
-                world, "in asynchronous blocks of %d steps" % args.gather_block if args.gather == "block" else "by one collective per step",
-                ", plus every step's uint8 screen frames" if args.gather_obs == "screen" else "",
-                ", %d sub-batches per rank" % args.sub_batches if args.sub_batches > 1 else "")
+            par = "arena-sharded x%d; (reward, done) -> rank 0 %s%s%s" % (
+                world, "in async blocks of %d steps" % args.gather_block if args.gather == "block" else "per step",
+                "; + uint8 screen frames per step" if args.gather_obs == "screen" else "",
+                "; %d sub-batches per rank" % args.sub_batches if args.sub_batches > 1 else "")
         else:
             par = "single GPU" + (", %d sub-batches on streams of their own" % args.sub_batches if args.sub_batches > 1 else "")
         out = {
@@ -763,9 +857,8 @@ def main():
                 rf = measure(name, c2, A, fk, fw, cpu_rate=cr[0], cpu_cores=cr[1], label=lab % A, **kw)
                 if name == "C1" and rf is not None and cpu:
                     rf["cpu_reference_ticks_per_s_1core"] = cpu["c1_ticks_per_s_1core"]
+                # ... and as PIPE_K independent sub-batches (GPU_MAX_HW_QUEUES was raised above: that many queues beside torch's streams)
                 measure(name, c2, A, fk, fw, sub=PIPE_K, cpu_rate=cr[0], cpu_cores=cr[1], label=(lab % A) + " -- as %d sub-batches" % PIPE_K, **kw)
-                if True:                         # ... and as four (GPU_MAX_HW_QUEUES was raised above: four queues beside torch's streams)
-                    measure(name, c2, A, fk, fw, sub=4, cpu_rate=cr[0], cpu_cores=cr[1], label=(lab % A) + " -- as 4 sub-batches", **kw)
             c2, kw, lab = wl_args("C3m6")
             measure("C3m6", c2, 32768, 40, 10, cpu_rate=c6cpu[0], cpu_cores=c6cpu[1], label=lab % 32768, **kw)
         if world == 1:  # measured roofline next to the nominal one: device stream copy and fill of 1 GiB
@@ -824,7 +917,7 @@ def main():
                 vs = vector_surface(torch, A, 200, 30, dev_index)
                 roof["gym_vector"] = vs
                 out["gym_vector_steps_per_s"] = vs["no_obs"]["gym_vector_steps_per_s"]
-                roof["gym_vector_pipe%d" % PIPE_K] = vector_surface(torch, A, 200, 30, dev_index, sub_batches=PIPE_K)
+                roof["gym_vector_auto"] = vector_surface(torch, A, 200, 30, dev_index, sub_batches="auto")   # the surface's own choice of sub-batching
             except Exception as ex:
                 roof["gym_vector"] = {"error": str(ex)}
         if headline and not args.no_full:
@@ -838,7 +931,7 @@ def main():
             roof["by_workload"] = by
         if cpu:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 

@@ -230,6 +230,9 @@ int agarcl_num_arenas(agarcl_env *env);
 int agarcl_players_per_arena(agarcl_env *env);
 /* HBM bytes the engine reads+writes per arena-tick under the streaming model of DESIGN.md */
 int64_t agarcl_state_bytes(agarcl_env *env);
+/* HBM bytes the env has allocated (all SoA arrays, result rings, tables, and the pellet-event spill area that dense / crowded arena
+ * configurations get: up to 256 KB per arena there) -- what `num_arenas` costs on this device */
+int64_t agarcl_device_bytes(agarcl_env *env);
 
 
 /* ---- stream ordering (the env's launches against work of the caller's own streams) --------------------------------------- */

@@ -1,10 +1,11 @@
-"""One rank of the 2-rank shard-equivalence tests (TEST INFRASTRUCTURE; started as a child process).
+"""One rank of the shard-equivalence tests (world size 2, 3, 8) (TEST INFRASTRUCTURE; started as a child process).
 
     python shard_worker.py RANK WORLD PORT TOTAL_ARENAS STEPS LIB OUTDIR        LIB = "hip" | "emu"
 
 Rank r owns the contiguous arena block agarcl_amd.dist.shard_bounds gives it, seeds it with arena_seeds (a function of
 the GLOBAL arena index), steps it with the slice of one global action stream, sends every step's (reward, done) to rank
-0 through ResultGatherer over gloo, and writes its arenas' final state blobs to OUTDIR/rank<r>.npz."""
+0 through ResultGatherer over gloo -- pack() and the zero-copy gather_packed() -- and every step's masses through TensorGatherer (both pad
+unequal shards), and writes its arenas' final state blobs to OUTDIR/rank<r>.npz."""
 import ctypes
 import os
 import sys
@@ -38,7 +39,7 @@ def run_shard(lib, lo, hi, total, steps, on_step=None):
         dxdy, act = actions(t, total)
         eng.set_actions(dxdy[lo:hi], act[lo:hi]); eng.step()
         if on_step:
-            on_step(t, eng.rewards(), eng.dones())
+            on_step(t, eng.rewards(), eng.dones(), eng.masses())
     assert not eng.flags().any()
     blobs = [eng.dump(a) for a in range(hi - lo)]
     eng.close()
@@ -55,13 +56,18 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = agdist.shard_bounds(total, world, rank)
     g = agdist.ResultGatherer(hi - lo, torch.device("cpu"), depth=2)
-    got = []
+    gz = agdist.ResultGatherer(hi - lo, torch.device("cpu"), depth=2)         # the zero-copy entry point bench.py uses
+    tg = agdist.TensorGatherer((hi - lo, 1), torch.int32, torch.device("cpu"))
+    got, got_z, got_m = [], [], []
 
-    def on_step(t, rewards, dones):
+    def on_step(t, rewards, dones, masses):
         slot = g.pack(t, torch.from_numpy(rewards), torch.from_numpy(dones.astype(np.uint8)))
         g.wait_slot(slot)
+        packed = torch.stack([torch.from_numpy(rewards[:, 0].astype(np.float32)), torch.from_numpy(dones[:, 0].astype(np.float32))], dim=1)
+        gz.gather_packed(t & 1, packed); gz.wait_slot(t & 1)
+        tg.gather(torch.from_numpy(masses.astype(np.int32).reshape(-1, 1))); tg.wait()
         if rank == 0:
-            got.append(g.gathered(slot).numpy().copy())
+            got.append(g.gathered(slot).numpy().copy()); got_z.append(gz.gathered(t & 1).numpy().copy()); got_m.append(tg.gathered().numpy().copy())
     blobs = run_shard(lib, lo, hi, total, steps, on_step)
     g.wait_all()
     dist.barrier(); dist.destroy_process_group()
@@ -70,6 +76,7 @@ def main():
         out["blob_%d" % i] = b
     if rank == 0:
         out["gathered"] = np.stack(got)      # [steps][total][2]
+        out["gathered_packed"] = np.stack(got_z); out["gathered_masses"] = np.stack(got_m)
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
 
 

@@ -15,21 +15,27 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 WORKER = os.path.join(HERE, "helpers", "shard_worker.py")
 
 
-def run_two_ranks(lib, total, steps):
+def run_ranks(lib, total, steps, world=2):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = tempfile.mkdtemp(prefix="agar_shard_")
-    procs = [subprocess.Popen([sys.executable, WORKER, str(r), "2", str(port), str(total), str(steps), lib, out]) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), str(total), str(steps), lib, out]) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=600) == 0
-    return [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(2)]
+    return [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(world)]
+
+
+def run_two_ranks(lib, total, steps):
+    return run_ranks(lib, total, steps, 2)
 
 
 def check_against_single_process(lib, parts, total, steps):
     sys.path.insert(0, os.path.join(HERE, "helpers"))
     import shard_worker
     rows = []
-    blobs = shard_worker.run_shard(lib, 0, total, total, steps, lambda t, r, d: rows.append(np.stack([r[:, 0].astype(np.float32), d[:, 0].astype(np.float32)], axis=1)))
-    assert parts[0]["lo"] == 0 and parts[0]["hi"] == parts[1]["lo"] and parts[1]["hi"] == total
+    masses = []
+    blobs = shard_worker.run_shard(lib, 0, total, total, steps, lambda t, r, d, m: (rows.append(np.stack([r[:, 0].astype(np.float32), d[:, 0].astype(np.float32)], axis=1)),
+                                                                                    masses.append(m.astype(np.int32).reshape(-1, 1))))
+    assert parts[0]["lo"] == 0 and parts[-1]["hi"] == total and all(parts[i]["hi"] == parts[i + 1]["lo"] for i in range(len(parts) - 1))
     k = 0
     for part in parts:
         for i in range(int(part["n"])):
@@ -37,6 +43,8 @@ def check_against_single_process(lib, parts, total, steps):
             k += 1
     assert k == total
     assert np.array_equal(parts[0]["gathered"], np.stack(rows))       # what rank 0 received == the single process's results, every step
+    assert np.array_equal(parts[0]["gathered_packed"], np.stack(rows))        # ... through the zero-copy entry point too
+    assert np.array_equal(parts[0]["gathered_masses"], np.stack(masses))      # ... and a tensor through TensorGatherer
 
 
 @pytest.mark.gpu
@@ -55,3 +63,13 @@ def test_two_rank_shards_equal_one_rank_run_emulated(emu_lib):
     parts = run_two_ranks("emu", total, steps)
     check_against_single_process("emu", parts, total, steps)
 
+
+@pytest.mark.parametrize("world,total", [(3, 11), (8, 11)])
+def test_unequal_shards_world_3_and_8_emulated(emu_lib, world, total):
+    """total % world != 0 at world size 3 and 8: shard_bounds hands the first ranks one arena more; ResultGatherer.pack /
+    gather_packed and TensorGatherer pad to the largest shard and rank 0 drops the padding -- every arena and every gathered row equals the
+    single-process run"""
+    steps = 24
+    parts = run_ranks("emu", total, steps, world)
+    assert sorted(int(p["n"]) for p in parts) == sorted([total // world + (1 if r < total % world else 0) for r in range(world)])
+    check_against_single_process("emu", parts, total, steps)

@@ -206,3 +206,26 @@ def test_gobigger_object_view(emu_lib, monkeypatch):
             assert all(abs(f.get_position_x()) <= view / 2 + 1e-3 and abs(f.get_position_y()) <= view / 2 + 1e-3 for f in s.get_food_infos())
     assert env.observation_shape()[1:] == (512, 512) and env.observation_shape()[0] == 41     # one frame per reset / step
     env.close()
+
+
+def test_gobigger_observation_class_is_a_module_attribute():
+    """bindings.cpp:297-318: GoBiggerObservation(map_width, map_height, frame_limit, last_frame, team_num) with update_global_state,
+    update_player_state (two keyword spellings), get_global_state, get_player_states -- on both forms of the module (CPU only: no engine)"""
+    import importlib
+    from agarcl_amd import agarcl as ct
+    mods = [ct]
+    try:
+        mods.append(importlib.import_module("agarcl"))       # the compiled pybind11 module, when built
+    except ImportError:
+        pass
+    for m in mods:
+        for name in ("FoodInfo", "VirusInfo", "SporeInfo", "CloneInfo", "GlobalState", "PlayerState", "PlayerStates", "GoBiggerObservation"):
+            assert hasattr(m, name), (m.__name__, name)
+        o = m.GoBiggerObservation(map_width=512, map_height=256, frame_limit=1000, last_frame=0, team_num=2)
+        assert (o.get_global_state().get_map_width(), o.get_global_state().get_map_height(), o.get_global_state().get_frame_limit(), o.get_global_state().get_team_num()) == (512, 256, 1000, 2)
+        assert o.get_player_states().get_all_player_states() == {}
+        o.update_global_state(7)
+        o.update_player_state(1, [], [], [], [], "t", 5.0, True, False)
+        o.update_player_state(player_id=0, food_positions=[], thorn_positions=[], spore_positions=[], clone_positions=[], team_name="u", score=2.0, can_eject=False, can_split=True)
+        ps = o.get_player_states()
+        assert sorted(ps.get_all_player_states()) == [0, 1] and ps.get_player_state(1).get_score() == 5.0 and ps.get_player_state(0).canSplit() and not ps.get_player_state(1).canSplit()
