@@ -111,7 +111,7 @@ OBS_NONE, OBS_GRID, OBS_SCREEN, OBS_RAM = 0, 1, 2, 3
 
 class VecSpec(C.Structure):
     _fields_ = [("number_steps", C.c_int32), ("episodic", C.c_int32), ("reset_ids", C.c_int32), ("obs_kind", C.c_int32), ("obs_arg", C.c_int32 * 6),
-                ("ticks", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("ticks", C.c_int32), ("reset_flagged", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class VecBuffers(C.Structure):

@@ -115,11 +115,15 @@ struct agarcl_env {
 struct AgVecPost {
   const uint8_t *dones; const double *rewards; int n, number_steps, episodic;
   int32_t *steps; float *reward; uint8_t *done, *trunc, *ended; float *ep_return, *final_return; int32_t *final_length;
+  const int32_t *ar; int ts_lg, reset_flagged;   // reset_flagged: an arena that carries a capacity flag ends here too (its rows are truncated)
 };
 AG_DEV bool ag_vec_post_arena(const AgVecPost &v, int a) {
   const int n = v.n, played = v.steps[a];
   const bool timeout = v.episodic != 0 && played >= v.number_steps;
   bool any = timeout;
+  // a capacity flag = the arena has left what this engine (or, mostly, the reference itself: README "capacity flags") can represent: with
+  // reset_flagged its episode is cut here like any other -- truncated, never terminated -- and the reset clears the flag
+  if (v.reset_flagged) { const int ag_ts_lg = v.ts_lg; any = any || v.ar[AG_TILE_BASE(a, AR_WORDS) + AG_TW(AR_FLAGS)] != 0; }
   for (int i = 0; i < n; i++) any = any || v.dones[(size_t)a * n + i] != 0;
   for (int i = 0; i < n; i++) {
     const size_t k = (size_t)a * n + i;
@@ -1501,6 +1505,7 @@ static int vec_args(agarcl_env *e, const agarcl_vec_spec *sp, const agarcl_vec_b
   v.dones = e->s.dones; v.rewards = e->s.rewards; v.n = e->d.n_agents; v.number_steps = sp->number_steps; v.episodic = sp->episodic;
   v.steps = b->steps; v.reward = b->reward; v.done = b->done; v.trunc = b->truncated; v.ended = b->ended;
   v.ep_return = b->ep_return; v.final_return = b->final_return; v.final_length = b->final_length;
+  v.ar = e->s.ar; v.ts_lg = e->d.ts_lg; v.reset_flagged = sp->reset_flagged != 0;
   return AGARCL_OK;
 }
 static int vec_observe(agarcl_env *e, const agarcl_vec_spec *sp, const agarcl_vec_buffers *b) {

@@ -47,6 +47,15 @@ struct AgScreenCfg { int W, H, agent_view;   // agent_view: the 4-channel frame 
 #endif
 
 #ifndef AGAR_CPU_EMU
+// Renderer::camera_z: clamp(100 + mass / 10, 100, 900) in double, then float (renderer.hpp:91-99).  In fp32 without the double division: for
+// mass < 8000 the float nearest to (1000 + mass) / 10 IS what the double expression rounds to -- (1000 + mass) / 10 is either a float itself or at
+// least 1 / (10 * 2^18) away from the nearest midpoint between two floats of that size, eleven orders of magnitude more than the double
+// expression's error -- and from 8000 on the clamp gives 900 (a wrapped mass of billions included)
+__device__ __forceinline__ float scr_camera_z(unsigned mass) {
+  if (mass >= 8000u) return 900.0f;
+  const float z = (float)(1000u + mass) / 10.0f;
+  return z < 100.0f ? 100.0f : z;
+}
 __device__ __forceinline__ unsigned scr_palette(int k) {  // core/color.hpp:4-12 as 0xBBGGRR bytes (GL rounds c * 255 to nearest)
   const unsigned pal[6] = {0x0000FFu /*red*/, 0x00A6FFu /*orange 1,.65,0*/, 0x00FFFFu /*yellow*/, 0x00FF00u /*green*/, 0xFF0000u /*blue*/, 0xCC3399u /*purple .6,.2,.8*/};
   return pal[((k % 6) + 6) % 6];
@@ -106,8 +115,7 @@ __global__ void __launch_bounds__(256) k_screen_obs_pixelwise(const AgState *__r
   uint8_t *dst = out + (size_t)blockIdx.x * o.W * o.H * CH;
   float px, py; unsigned mass;
   obs_player(gs, arena, agent, px, py, mass);
-  double zd = 100.0 + (double)mass / 10.0; zd = zd < 100.0 ? 100.0 : (zd > 900.0 ? 900.0 : zd);
-  const float z = (float)zd, half_h = z * 0.41421356237309504880f, half_w = half_h * ((float)o.W / (float)o.H);
+  const float z = scr_camera_z(mass), half_h = z * 0.41421356237309504880f, half_w = half_h * ((float)o.W / (float)o.H);
   const float Wd = gs->g.W;
   const int ag_ts_lg = gs->d.ts_lg;
   const int32_t *ar = AG_AR_PTR(gs, arena);
@@ -188,150 +196,228 @@ __global__ void __launch_bounds__(256) k_screen_obs_pixelwise(const AgState *__r
     }
   }
 }
-// pixels of one LDS band (14 KiB of packed RGBA): half an 84 x 84 frame.  With the whole frame in one band (7168 pixels, 28 KiB) the kernel
-// holds 52 KB of LDS and three workgroups share a compute unit; with two bands of 42 rows it holds 38 KB and four do -- the second pass over
-// the entity boxes costs less than the fourth workgroup brings: 4096 frames 215.8 -> 196.4 us, agent view 285.8 -> 254.8 (four bands of 21
-// rows, five workgroups: 214.2 / 269.9)
-#ifndef AG_SCR_BAND
-#define AG_SCR_BAND 3584
+// ---- round 6: every wavefront rasterises its own rows -----------------------------------------------------------------------------------------
+// Round 5's kernel walked a frame band by band, the four wavefronts sharing each band (four workgroup barriers per band); its ablation
+// (scripts/gpu_screen_ablate.py, 4096 frames of 128 x 128 x 4 on a task-3 state, 147 us) said where the time went: 24 us before the first pixel (a chain of dependent global loads: cell
+// count, then cells; arena words, then lists), 72 us painting ~35 entities (one dependent LDS round trip after another per entity, three wavefronts
+// waiting at the barrier for the one that has the entities), 50 us in the agent view's run pass, 38 us filling and storing -- latencies in series, not
+// instructions.  Here
+//   * everything a frame reads is requested at once (capacities, not counts, bound the loads), the camera centre is summed from registers;
+//   * after the entity list is complete a wavefront never waits for another: it owns H/4 consecutive rows and a private LDS band, fills, paints,
+//     post-processes and stores them band by band at its own pace -- wavefronts of a workgroup and of the workgroups sharing a SIMD drift apart and
+//     fill each other's latencies;
+//   * the painter takes 64 entities' parameters in one LDS round trip (a lane each) and hands them out with v_readlane;
+//   * the agent view's sequential pass needs the final alphas of the two pixels in front of a wavefront's first row: it paints those two pixels
+//     itself; only when one of them is a 255-pixel (its alpha then depends on the run it belongs to) does it wait for the wavefront above to publish
+//     them.
+// Same per-pixel rules and fp32 expressions as before: byte-identical to k_screen_obs_pixelwise (tests/test_screen_obs.py).
+#ifndef AG_SCR_WBAND
+#define AG_SCR_WBAND 924   // pixels of one wavefront's LDS band (3.6 KiB of packed RGBA): 7 rows of 128, 11 rows of 84 (a quarter of 84 rows = 21 = two bands)
 #endif
-// TAB: capacity of the per-column / per-row tables (256 for frames up to 256 x 256 -- with it the kernel holds 31 KB of LDS and FIVE workgroups
-// share a compute unit --, 1024 beyond)
-// AGV: the 4-channel agent-view frame (a template parameter since r05: the plain frame carries none of its tests)
-template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs(const AgState *__restrict__ gs, AgScreenCfg o, uint8_t *out) {
-  __shared__ float ex[AG_SCR_CAP], ey[AG_SCR_CAP], er[AG_SCR_CAP];
-  __shared__ unsigned ec[AG_SCR_CAP];  // 0x00BBGGRR | nsides << 24
-  __shared__ __align__(16) unsigned fb[AG_SCR_BAND];  // 0xAABBGGRR of the band's pixels
-  __shared__ __align__(4) uint8_t colflag[TAB], rowflag[TAB];   // bit 0: a grid line falls into this pixel column / row; bit 1: the column / row lies inside the arena
-  __shared__ float colx[TAB], rowy[TAB];           // world coordinate of every pixel column's / row's centre
-  __shared__ float eapo[AG_SCR_CAP];                 // apothem of an entity's polygon
-  __shared__ unsigned ebx[AG_SCR_CAP], eby[AG_SCR_CAP];   // pixel box of an entity: first | last << 16 column / row (one pixel of margin; empty: first > last)
-  __shared__ int n_list;
-  __shared__ unsigned long long pp_chunks;   // agent view: the band's 64-pixel chunks that may hold a 255-pixel (bit c = chunk c; a band has <= 56)
-  const int na = gs->d.n_agents, arena = (int)blockIdx.x / na, agent = (int)blockIdx.x % na, P = gs->d.P;
+// conservative pixel box of an entity, first | last << 16; empty: first > last.  Pixel column c's centre lies at px + ((c + 1/2) / W * 2 - 1) half_w, so
+// the disc spans columns (x -+ r - px) kx + W/2 - 1/2 with kx = W / (2 half_w): floor of the low end - 1 and floor of the high end + 2 (a pixel of
+// margin either side, far more than the rounding of these products: the inside test decides, the box only has to contain what it accepts)
+__device__ __forceinline__ void scr_box(float x, float y, float r, float px, float py, float kx, float ky, int W, int H, unsigned &bx, unsigned &by) {
+  const float ox = (float)W * 0.5f - 0.5f, oy = (float)H * 0.5f - 0.5f, dx = x - px, dy = y - py;
+  int c0 = (int)floorf((dx - r) * kx + ox) - 1, c1 = (int)floorf((dx + r) * kx + ox) + 2;
+  int r0 = (int)floorf((dy - r) * ky + oy) - 1, r1 = (int)floorf((dy + r) * ky + oy) + 2;
+  c0 = c0 < 0 ? 0 : c0; c1 = c1 > W - 1 ? W - 1 : c1; r0 = r0 < 0 ? 0 : r0; r1 = r1 > H - 1 ? H - 1 : r1;
+  if (c0 > c1 || r0 > r1) { c0 = 1; c1 = 0; r0 = 1; r1 = 0; }
+  bx = (unsigned)c0 | ((unsigned)c1 << 16); by = (unsigned)r0 | ((unsigned)r1 << 16);
+}
+// what a fragment of colour e (0xNNBBGGRR, NN = polygon sides) leaves in a packed pixel.  Agent view: a value <= 230 is written as
+// post_processing_frame_data leaves it (alpha = the value, channel cleared); a 255-colour stays a 255-pixel with alpha 255 until the run pass
+template <bool AGV> __device__ __forceinline__ unsigned scr_paint_word(unsigned e) {
+  return (AGV && (e & 0xFFFFFFu) <= 230u) ? ((e & 0xFFu) << 24) : ((e & 0xFFFFFFu) | 0xFF000000u);
+}
+template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) k_screen_obs(const AgState *__restrict__ gs, AgScreenCfg o, uint8_t *out) {
+  constexpr int WB = TAB > 256 ? 1024 : AG_SCR_WBAND;   // (a band holds at least one row)
   constexpr int CH = AGV ? 4 : 3;
+  constexpr unsigned GRIDV = AGV ? 0x1A000000u : 0xFF00001Au, BACKV = AGV ? 0u : 0x00FFFFFFu;   // (0.1, 0, 0) -> 26; alpha byte: a fragment was written
+  __shared__ float ex[AG_SCR_CAP], ey[AG_SCR_CAP], er[AG_SCR_CAP];
+  __shared__ unsigned ec[AG_SCR_CAP];                        // 0x00BBGGRR | nsides << 24
+  __shared__ unsigned ebx[AG_SCR_CAP], eby[AG_SCR_CAP];      // pixel box: first | last << 16 column / row
+  __shared__ __align__(16) unsigned fbw[4][WB + 4];          // per wavefront: [2], [3] = the two pixels in front of the band (agent view), [4 ..] = the band
+  __shared__ __align__(4) uint8_t colflag[TAB], rowflag[TAB];   // bit 0: a grid line falls into this pixel column / row; bit 1: the column / row lies inside the arena
+  __shared__ float colx[TAB], rowy[TAB];                     // world coordinate of every pixel column's / row's centre
+  __shared__ int wcnt[8];                                    // [0..3] pellets listed by wavefront w, [4] foods, [5] the whole list
+  __shared__ unsigned pp_last[4][2]; __shared__ int pp_done[4];   // agent view: a wavefront's last two FINAL pixels, and that they are there
+  const int na = gs->d.n_agents, arena = (int)blockIdx.x / na, agent = (int)blockIdx.x % na, P = gs->d.P;
+  const int tid = (int)threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
   uint8_t *dst = out + (size_t)blockIdx.x * o.W * o.H * CH;
-  float px, py; unsigned mass;
-  obs_player(gs, arena, agent, px, py, mass);
-  double zd = 100.0 + (double)mass / 10.0; zd = zd < 100.0 ? 100.0 : (zd > 900.0 ? 900.0 : zd);
-  const float z = (float)zd, half_h = z * 0.41421356237309504880f, half_w = half_h * ((float)o.W / (float)o.H);
-  const float Wd = gs->g.W;
   const int ag_ts_lg = gs->d.ts_lg;
   const int32_t *ar = AG_AR_PTR(gs, arena);
-  // ---- visible entities in draw order ----
-  // The pellets -- most of the list -- are compacted by all four wavefronts (r05: the kernel is bound by what a SIMD issues, a workgroup's
-  // wavefronts sit on different SIMDs, and work that only wavefront 0 does is issued by one SIMD in four): each takes a quarter of the 64-pellet
-  // chunks, counts what it will list, and writes behind the wavefronts in front of it.  Foods, cells and viruses follow on wavefront 0.
-  __shared__ int wcnt[4];
-  const float *pxy = gs->pel_xy + (size_t)arena * gs->d.PC * 2; const int32_t *pid = gs->pel_id + (size_t)arena * gs->d.PC;
-  const int np = ar[AG_TW(AR_NPEL)];
-  const float r_pel = gs->lut_r[AG_PELLET_MASS];
-  constexpr bool av = AGV;
-  int listed_pellets;
-  {
-    // (the wavefront's number is wave-uniform: said so, or the compiler keeps everything derived from it in vector registers and walks the loops with exec masks)
-    const int lw = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), ll = (int)threadIdx.x & 63; const unsigned long long llt = (1ull << ll) - 1ull;
-    const int nchk = (np + 63) >> 6, per = (nchk + 3) >> 2, c_lo = lw * per, c_hi = (lw + 1) * per < nchk ? (lw + 1) * per : nchk;   // (<= 2048 pellets: per <= 8)
-    float xs[8], ys[8]; int ids[8]; unsigned long long vm[8]; int cnt = 0;
+  // ---- everything the frame reads, requested together (slots behind a count hold valid memory: capacities bound the loads) ----
+  const int PCp = gs->d.PC, FCp = gs->d.FC, VCp = gs->d.VC;
+  const float *pxy = gs->pel_xy + (size_t)arena * PCp * 2; const int32_t *pid = gs->pel_id + (size_t)arena * PCp;
+  const int np = ar[AG_TW(AR_NPEL)], nf = ar[AG_TW(AR_NFOOD)], nv = ar[AG_TW(AR_NVIR)];
+  const int32_t *plA = AG_PL_PTR(gs, arena, agent); const uint32_t *CA = AG_CELLS_PTR(gs, arena, agent);
+  const int n_own = plA[AG_TW(PL_NCELLS)];
+  unsigned own_xu = 0u, own_yu = 0u, own_m = 0u;             // the observing agent's cell slots, a lane each (every wavefront: no exchange needed)
+  if (lane < AG_CC) { own_xu = CA[AG_CELL_W(CF_X, lane)]; own_yu = CA[AG_CELL_W(CF_Y, lane)]; own_m = CA[AG_CELL_W(CF_M, lane)]; }
+  // pellets: the 64-pellet chunks of the CAPACITY, a quarter per wavefront (<= 2048 pellets: <= 8 chunks each)
+  const int nchk = PCp >> 6, per = (nchk + 3) >> 2, c_lo = wave * per;
+  float pxs[8], pys[8]; int pids[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) { xs[j] = 0.f; ys[j] = 0.f; ids[j] = 0; vm[j] = 0ull;
-      if (j < per) { const int i = (c_lo + j) * 64 + ll; const bool v = c_lo + j < c_hi && i < np; if (v) { xs[j] = pxy[2 * i]; ys[j] = pxy[2 * i + 1]; if (!av) ids[j] = pid[i]; } } }
-#pragma unroll
-    for (int j = 0; j < 8; j++) if (j < per) { const int i = (c_lo + j) * 64 + ll; const bool v = c_lo + j < c_hi && i < np;
-      vm[j] = __ballot(v && fabsf(xs[j] - px) <= half_w + r_pel && fabsf(ys[j] - py) <= half_h + r_pel); cnt += __popcll(vm[j]); }
-    if (ll == 0) wcnt[lw] = cnt;
-    __syncthreads();
-    int base = 0;
-    for (int w = 0; w < lw; w++) base += wcnt[w];
-    listed_pellets = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-#pragma unroll
-    for (int j = 0; j < 8; j++) if (j < per && vm[j]) {
-      const int slot = base + __popcll(vm[j] & llt);
-      if (((vm[j] >> ll) & 1ull) && slot < AG_SCR_CAP) { ex[slot] = xs[j]; ey[slot] = ys[j]; er[slot] = r_pel; ec[slot] = (av ? 0x0000FFu : scr_palette(ids[j])) | (5u << 24); }
-      base += __popcll(vm[j]);
+  for (int j = 0; j < 8; j++) { pxs[j] = 0.f; pys[j] = 0.f; pids[j] = 0;
+    if (j < per && c_lo + j < nchk) { const int i = (c_lo + j) * 64 + lane; pxs[j] = pxy[2 * i]; pys[j] = pxy[2 * i + 1]; if (!AGV) pids[j] = pid[i]; } }
+  // foods (wavefront 1) and viruses (wavefront 0, which lists them behind the players): the first 128 / 64 slots in registers, the rest in the loops below
+  float fx0 = 0.f, fy0 = 0.f, fx1 = 0.f, fy1 = 0.f; int fi0 = 0, fi1 = 0;
+  const size_t fo = (size_t)arena * FCp, vo = (size_t)arena * VCp;
+  if (wave == 1) { if (lane < FCp) { fx0 = gs->food_x[fo + lane]; fy0 = gs->food_y[fo + lane]; if (!AGV) fi0 = gs->food_id[fo + lane]; }
+                   if (lane + 64 < FCp) { fx1 = gs->food_x[fo + lane + 64]; fy1 = gs->food_y[fo + lane + 64]; if (!AGV) fi1 = gs->food_id[fo + lane + 64]; } }
+  float vx0 = 0.f, vy0 = 0.f; unsigned vm0 = 0u;
+  if (wave == 0 && lane < VCp) { vx0 = gs->vir_x[vo + lane]; vy0 = gs->vir_y[vo + lane]; vm0 = (unsigned)gs->vir_mass[vo + lane]; }
+  const float r_pel = gs->lut_r[AG_PELLET_MASS], r_food = gs->lut_r[AG_FOOD_MASS];
+  const float Wd = gs->g.W;
+  // ---- camera: Player::x / y / mass (core/Player.hpp:102-126), sequential fp32 sums in cell order -- obs_player's arithmetic on the lanes' registers ----
+  float px, py; unsigned mass;
+  { float sx = 0.0f, sy = 0.0f; unsigned tm = 0;
+    for (int i = 0; i < n_own; i++) {
+      const float xi = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)own_xu, i)), yi = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)own_yu, i));
+      const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)own_m, i); const float fm = (float)m;
+      float t = xi * fm; sx += t; t = yi * fm; sy += t; tm += m;
     }
+    px = sx / (float)tm; py = sy / (float)tm; mass = tm; }
+  const float z = scr_camera_z(mass), half_h = z * 0.41421356237309504880f, half_w = half_h * ((float)o.W / (float)o.H);
+  // ---- which pixel columns / rows lie inside the arena, and their centres' world coordinates (the grid lines' bits follow behind the barrier) ----
+  const float sx_scale = (float)o.W * 0.5f / half_w, sy_scale = (float)o.H * 0.5f / half_h, spacing = Wd / 7.0f;
+  for (int k = tid; k < o.W; k += 256) { const float wx = px + (((float)k + 0.5f) / (float)o.W * 2.0f - 1.0f) * half_w; colflag[k] = (wx >= 0.0f && wx <= Wd) ? 2 : 0; colx[k] = wx; }
+  for (int k = tid; k < o.H; k += 256) { const float wy = py + (((float)k + 0.5f) / (float)o.H * 2.0f - 1.0f) * half_h; rowflag[k] = (wy >= 0.0f && wy <= Wd) ? 2 : 0; rowy[k] = wy; }
+  // ---- visible entities in draw order: pellets (all four wavefronts), foods (wavefront 1), players and viruses (wavefront 0) ----
+  unsigned long long pvm[8]; int pcnt = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) { pvm[j] = 0ull;
+    if (j < per) { const int i = (c_lo + j) * 64 + lane; pvm[j] = __ballot(i < np && fabsf(pxs[j] - px) <= half_w + r_pel && fabsf(pys[j] - py) <= half_h + r_pel); pcnt += __popcll(pvm[j]); } }
+  unsigned long long fvm0 = 0ull, fvm1 = 0ull;
+  if (wave == 1) {
+    fvm0 = __ballot(lane < nf && fabsf(fx0 - px) <= half_w + r_food && fabsf(fy0 - py) <= half_h + r_food);
+    fvm1 = __ballot(lane + 64 < nf && fabsf(fx1 - px) <= half_w + r_food && fabsf(fy1 - py) <= half_h + r_food);
+    int fc = __popcll(fvm0) + __popcll(fvm1);
+    for (int b = 128; b < nf; b += 64) { const int i = b + lane; const bool v = i < nf; const float x = v ? gs->food_x[fo + i] : 0.f, y = v ? gs->food_y[fo + i] : 0.f;
+      fc += __popcll(__ballot(v && fabsf(x - px) <= half_w + r_food && fabsf(y - py) <= half_h + r_food)); }
+    if (lane == 0) wcnt[4] = fc;
   }
-  if (threadIdx.x < 64) {
-    const int lane = (int)threadIdx.x; const unsigned long long lt = (1ull << lane) - 1ull;
-    int count = listed_pellets;
+  if (lane == 0) { wcnt[wave] = pcnt; pp_done[wave] = 0; }
+  if (SCR_ABL(1)) { pcnt = 0; }
+  __syncthreads();
+  auto put = [&](int slot, float x, float y, float r, unsigned col) {
+    if (slot < AG_SCR_CAP) { ex[slot] = x; ey[slot] = y; er[slot] = r; ec[slot] = col; unsigned bx, by; scr_box(x, y, r, px, py, sx_scale, sy_scale, o.W, o.H, bx, by); ebx[slot] = bx; eby[slot] = by; }
+  };
+  const int n_pel = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3], n_food = wcnt[4];
+  { int base = 0;
+    for (int w = 0; w < wave; w++) base += wcnt[w];
+#pragma unroll
+    for (int j = 0; j < 8; j++) if (j < per && pvm[j]) {
+      if ((pvm[j] >> lane) & 1ull) put(base + __popcll(pvm[j] & lt), pxs[j], pys[j], r_pel, (AGV ? 0x0000FFu : scr_palette(pids[j])) | (5u << 24));
+      base += __popcll(pvm[j]);
+    } }
+  if (wave == 3 && lane < 16) {   // grid lines: the pixel column / row a line falls into (one pixel wide) -- eight columns, eight rows, a lane each
+    const float g = (float)(lane & 7) * spacing;
+    if (lane < 8) { const int gc = (int)floorf((g - px) * sx_scale + (float)o.W * 0.5f); if (gc >= 0 && gc < o.W) colflag[gc] |= 1; }
+    else { const int gr = (int)floorf((g - py) * sy_scale + (float)o.H * 0.5f); if (gr >= 0 && gr < o.H) rowflag[gr] |= 1; }
+  }
+  if (wave == 1) {
+    int base = n_pel;
+    if ((fvm0 >> lane) & 1ull) put(base + __popcll(fvm0 & lt), fx0, fy0, r_food, (AGV ? 0x0000FFu : scr_palette(fi0)) | (7u << 24));
+    base += __popcll(fvm0);
+    if ((fvm1 >> lane) & 1ull) put(base + __popcll(fvm1 & lt), fx1, fy1, r_food, (AGV ? 0x0000FFu : scr_palette(fi1)) | (7u << 24));
+    base += __popcll(fvm1);
+    for (int b = 128; b < nf; b += 64) { const int i = b + lane; const bool v = i < nf; const float x = v ? gs->food_x[fo + i] : 0.f, y = v ? gs->food_y[fo + i] : 0.f;
+      const unsigned long long m = __ballot(v && fabsf(x - px) <= half_w + r_food && fabsf(y - py) <= half_h + r_food);
+      if ((m >> lane) & 1ull) put(base + __popcll(m & lt), x, y, r_food, (AGV ? 0x0000FFu : scr_palette(gs->food_id[fo + i])) | (7u << 24));
+      base += __popcll(m); }
+  }
+  if (wave == 0) {
+    int count = n_pel + n_food;
     auto emit = [&](bool valid, float x, float y, float r, unsigned col) {
-      bool vis = valid && fabsf(x - px) <= half_w + r && fabsf(y - py) <= half_h + r;
-      unsigned long long m = __ballot(vis);
-      int slot = count + __popcll(m & lt);
-      if (vis && slot < AG_SCR_CAP) { ex[slot] = x; ey[slot] = y; er[slot] = r; ec[slot] = col; }
+      const bool vis = valid && fabsf(x - px) <= half_w + r && fabsf(y - py) <= half_h + r;
+      const unsigned long long m = __ballot(vis);
+      if (vis) put(count + __popcll(m & lt), x, y, r, col);
       count += __popcll(m);
     };
-    const int nf = ar[AG_TW(AR_NFOOD)], nv = ar[AG_TW(AR_NVIR)];
-    const float r_food = gs->lut_r[AG_FOOD_MASS];
-    { size_t fo = (size_t)arena * gs->d.FC;
-      for (int b = 0; b < nf; b += 64) { int i = b + lane; bool v = i < nf; emit(v, v ? gs->food_x[fo + i] : 0.f, v ? gs->food_y[fo + i] : 0.f, r_food, v ? ((av ? 0x0000FFu : scr_palette(gs->food_id[fo + i])) | (7u << 24)) : 0u); } }
     const int main_slot = na - 1;  // state.main_agent_pid: the last agent added
-    for (int kk = av ? -1 : 0; kk < P; kk++) {  // players in the engine's iteration order (agent view: the main agent first), cells in vector order
+    for (int kk = AGV ? -1 : 0; kk < P; kk++) {  // players in the engine's iteration order (agent view: the main agent first), cells in vector order
       const int slot = kk < 0 ? main_slot : ar[AG_TW(AR_ORDER0 + kk)];
-      if (av && kk >= 0 && slot == main_slot) continue;
+      if (AGV && kk >= 0 && slot == main_slot) continue;
       const int32_t *pl = AG_PL_PTR(gs, arena, slot);
-      const uint32_t *C = AG_CELLS_PTR(gs, arena, slot);
-      const int n = pl[AG_TW(PL_NCELLS)], kind = pl[AG_TW(PL_KIND)];
-      const unsigned col = (av ? (kk < 0 ? 0x0000E6u /* 0.9 -> 230 */ : 0x00FF00u)
-                               : (kind == 0 ? scr_palette(pl[AG_TW(PL_PID)]) : kind == 1 ? scr_palette(4) : kind == 2 ? scr_palette(5) : kind == 3 ? scr_palette(0) : scr_palette(1))) | (50u << 24);
-      bool v = lane < n;
-      unsigned m = v ? C[AG_CELL_W(CF_M, lane)] : 0u;
-      emit(v, v ? __uint_as_float(C[AG_CELL_W(CF_X, lane)]) : 0.f, v ? __uint_as_float(C[AG_CELL_W(CF_Y, lane)]) : 0.f, v ? gs->lut_r[m < AG_LUT_SIZE ? m : AG_LUT_SIZE - 1] : 0.f, col);
+      const int kind = pl[AG_TW(PL_KIND)];
+      const unsigned col = (AGV ? (kk < 0 ? 0x0000E6u /* 0.9 -> 230 */ : 0x00FF00u)
+                                : (kind == 0 ? scr_palette(pl[AG_TW(PL_PID)]) : kind == 1 ? scr_palette(4) : kind == 2 ? scr_palette(5) : kind == 3 ? scr_palette(0) : scr_palette(1))) | (50u << 24);
+      int n; unsigned xu, yu, m;
+      if (slot == agent) { n = n_own; xu = own_xu; yu = own_yu; m = own_m; }   // (already in registers)
+      else { const uint32_t *C = AG_CELLS_PTR(gs, arena, slot); n = pl[AG_TW(PL_NCELLS)]; const bool v = lane < AG_CC;
+             xu = v ? C[AG_CELL_W(CF_X, lane)] : 0u; yu = v ? C[AG_CELL_W(CF_Y, lane)] : 0u; m = v ? C[AG_CELL_W(CF_M, lane)] : 0u; }
+      const bool v = lane < n;
+      emit(v, v ? __uint_as_float(xu) : 0.f, v ? __uint_as_float(yu) : 0.f, v ? gs->lut_r[m < AG_LUT_SIZE ? m : AG_LUT_SIZE - 1] : 0.f, col);
     }
-    { size_t vo = (size_t)arena * gs->d.VC;
-      for (int b = 0; b < nv; b += 64) { int i = b + lane; bool v = i < nv; unsigned m = v ? (unsigned)gs->vir_mass[vo + i] : 0u;
-        emit(v, v ? gs->vir_x[vo + i] : 0.f, v ? gs->vir_y[vo + i] : 0.f, v ? gs->lut_r[m < AG_LUT_SIZE ? m : AG_LUT_SIZE - 1] : 0.f, (av ? 0xFF0000u : scr_palette(3)) | (150u << 24)); } }
-    if (lane == 0) n_list = SCR_ABL(1) ? 0 : (count < AG_SCR_CAP ? count : AG_SCR_CAP);
+    { const unsigned vcol = (AGV ? 0xFF0000u : scr_palette(3)) | (150u << 24);
+      { const bool v = lane < nv; emit(v, vx0, vy0, v ? gs->lut_r[vm0 < AG_LUT_SIZE ? vm0 : AG_LUT_SIZE - 1] : 0.f, vcol); }
+      for (int b = 64; b < nv; b += 64) { const int i = b + lane; const bool v = i < nv; const unsigned m = v ? (unsigned)gs->vir_mass[vo + i] : 0u;
+        emit(v, v ? gs->vir_x[vo + i] : 0.f, v ? gs->vir_y[vo + i] : 0.f, v ? gs->lut_r[m < AG_LUT_SIZE ? m : AG_LUT_SIZE - 1] : 0.f, vcol); } }
+    if (lane == 0) wcnt[5] = SCR_ABL(1) ? 0 : (count < AG_SCR_CAP ? count : AG_SCR_CAP);
   }
-  // grid lines: the pixel column / row a line falls into (one pixel wide), and which columns / rows lie inside the arena
-  const float sx_scale = (float)o.W * 0.5f / half_w, sy_scale = (float)o.H * 0.5f / half_h, spacing = Wd / 7.0f;
-  // (r05: the eight lines' pixel columns / rows are eight numbers -- every thread takes them from the same expression and compares; each column / row
-  // used to evaluate the eight floors for itself)
-  int gcol[8], grow[8];
+  __syncthreads();   // the list is complete: from here on no wavefront waits for another (but for the rare hand-over of the run pass)
+  const int n = __builtin_amdgcn_readfirstlane(wcnt[5]);
+  // ---- this wavefront's rows, band by band ----
+  const int rpw = (o.H + 3) >> 2, wr0 = wave * rpw, wr1 = (wr0 + rpw < o.H ? wr0 + rpw : o.H) - 1;   // row 0 = bottom (glReadPixels)
+  if (wr0 > wr1) return;
+  unsigned *fb = &fbw[wave][4];
+  const int max_rows = WB / o.W > 0 ? WB / o.W : 1, wrows = wr1 - wr0 + 1, nbands = (wrows + max_rows - 1) / max_rows, band_rows = (wrows + nbands - 1) / nbands;
+  // one visible-entity batch: 64 entities' parameters, a lane each, in ONE LDS round trip; handed out with v_readlane
+  if (AGV) {   // the two pixels in front of this wavefront's first row, as painted (final unless a 255-pixel)
+    unsigned lb[2];
 #pragma unroll
-  for (int i = 0; i < 8; i++) { const float g = (float)i * spacing; gcol[i] = (int)floorf((g - px) * sx_scale + (float)o.W * 0.5f); grow[i] = (int)floorf((g - py) * sy_scale + (float)o.H * 0.5f); }
-  for (int k = (int)threadIdx.x; k < o.W; k += 256) {
-    const float wx = px + (((float)k + 0.5f) / (float)o.W * 2.0f - 1.0f) * half_w;
-    uint8_t f = (wx >= 0.0f && wx <= Wd) ? 2 : 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) if (gcol[i] == k) f |= 1;
-    colflag[k] = f; colx[k] = wx;
+    for (int t = 0; t < 2; t++) {
+      const int f = wr0 * o.W - 1 - t;                      // flat pixel index (t = 0: the previous pixel)
+      unsigned w = 0xFF000000u;                             // no such pixel: alpha 255 fails the run rule exactly as its p >= 2 test does
+      if (f >= 0) {
+        const int rr = f / o.W, cc = f - rr * o.W;
+        const uint8_t cf = colflag[cc], rf = rowflag[rr];
+        w = (((cf & 1) && (rf & 2)) || ((rf & 1) && (cf & 2))) ? GRIDV : BACKV;
+        const float wx = colx[cc], wy = rowy[rr];
+        for (int k0 = 0; k0 < n; k0 += 64) {
+          const int kk = k0 + lane; const bool in_ = kk < n; const int ki = in_ ? kk : 0;
+          const unsigned e = ec[ki]; const float r = er[ki];
+          const unsigned long long m = __ballot(in_ && scr_inside_apo(wx - ex[ki], wy - ey[ki], r, r * scr_cos_half_step((int)(e >> 24)), (int)(e >> 24)));
+          if (m) w = scr_paint_word<AGV>((unsigned)__builtin_amdgcn_readlane((int)e, 63 - (int)__builtin_clzll(m)));   // the LAST draw that covers the pixel
+        }
+      }
+      lb[t] = w;
+    }
+    if (((lb[0] | lb[1]) & 0xFFFFFFu) != 0u && !SCR_ABL(4)) {   // a 255-pixel: its alpha is its run's -- the wavefront above knows (rare: an entity at the frame's right edge of exactly that row)
+      while (__hip_atomic_load(&pp_done[wave - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(8);
+      lb[0] = pp_last[wave - 1][0]; lb[1] = pp_last[wave - 1][1];
+    }
+    if (lane == 0) { fb[-1] = lb[0]; fb[-2] = lb[1]; }
+    ag_lds_order();
   }
-  for (int k = (int)threadIdx.x; k < o.H; k += 256) {
-    const float wy = py + (((float)k + 0.5f) / (float)o.H * 2.0f - 1.0f) * half_h;
-    uint8_t f = (wy >= 0.0f && wy <= Wd) ? 2 : 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) if (grow[i] == k) f |= 1;
-    rowflag[k] = f; rowy[k] = wy;
-  }
-  __syncthreads();
-  for (int k = (int)threadIdx.x; k < n_list; k += 256) {   // conservative pixel box of every listed entity (one pixel of margin: the inside test decides)
-    const float x = ex[k], y = ey[k], r = er[k];
-    int c0 = (int)floorf(((x - r - px) / half_w + 1.0f) * 0.5f * (float)o.W - 0.5f) - 1, c1 = (int)floorf(((x + r - px) / half_w + 1.0f) * 0.5f * (float)o.W - 0.5f) + 2;
-    int r0 = (int)floorf(((y - r - py) / half_h + 1.0f) * 0.5f * (float)o.H - 0.5f) - 1, r1 = (int)floorf(((y + r - py) / half_h + 1.0f) * 0.5f * (float)o.H - 0.5f) + 2;
-    c0 = c0 < 0 ? 0 : c0; c1 = c1 > o.W - 1 ? o.W - 1 : c1; r0 = r0 < 0 ? 0 : r0; r1 = r1 > o.H - 1 ? o.H - 1 : r1;
-    if (c0 > c1 || r0 > r1) { c0 = 1; c1 = 0; r0 = 1; r1 = 0; }
-    ebx[k] = (unsigned)c0 | ((unsigned)c1 << 16); eby[k] = (unsigned)r0 | ((unsigned)r1 << 16);
-    eapo[k] = r * scr_cos_half_step((int)(ec[k] >> 24));
-  }
-  __syncthreads();
-  // (wave-uniform values the compiler cannot know to be uniform -- the wavefront's number, what comes out of LDS at a uniform address -- go through
-  // v_readfirstlane: the painter's loops over entities, boxes and tiles are then scalar loops, not vector compares and exec masks)
-  const int n = __builtin_amdgcn_readfirstlane(n_list), wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
-  const int band_rows = AG_SCR_BAND / o.W > 0 ? (AG_SCR_BAND / o.W < o.H ? AG_SCR_BAND / o.W : o.H) : 1;
-  int a1 = 255, a2 = 255;   // agent view: final alphas of the two previous pixels (thread 0 carries them from band to band)
-  for (int row0 = 0; row0 < o.H; row0 += band_rows) {   // row 0 = bottom (glReadPixels)
-    const int rows = o.H - row0 < band_rows ? o.H - row0 : band_rows, npix = rows * o.W;
-    // background + grid
-    constexpr unsigned GRIDV = AGV ? 0x1A000000u : 0xFF00001Au, BACKV = AGV ? 0u : 0x00FFFFFFu;
-    // (0.1, 0, 0) -> 26; alpha byte: a fragment was written.  Agent view (r05): the pixel is written in the form post_processing_frame_data leaves
-    // it in -- a value <= 230 moves into alpha and the channel is cleared, whatever lies around it -- so that no pass over the band has to do it
+  // rows of up to 256 pixels, a multiple of four: a pass of the fill covers whole rows -- 64 / (W / 4) of them, a lane per four pixels, the lanes
+  // beyond that idle (84 x 84: 63 of 64 work) -- so a lane's four columns never change.  Its masks: byte i = 1 where column i carries a grid line
+  // (shown in rows inside the arena) / lies inside the arena (where a row's line shows)
+  const int fc_gpr = o.W >> 2;
+  const bool fixed_cols = (o.W & 3) == 0 && fc_gpr >= 1 && fc_gpr <= 64;
+  unsigned fc_line = 0u, fc_inside = 0u; int fc_r = 0, fc_step = 1, fc_gc = 0; bool fc_on = false;
+  if (fixed_cols) { fc_step = 64 / fc_gpr; fc_r = lane / fc_gpr; fc_gc = lane - fc_r * fc_gpr; fc_on = fc_r < fc_step;
+                    const unsigned cf4 = *(const unsigned *)&colflag[fc_gc << 2]; fc_line = cf4 & 0x01010101u; fc_inside = (cf4 & 0x02020202u) >> 1; }
+  for (int row0 = wr0; row0 <= wr1; row0 += band_rows) {
+    const int rows = wr1 + 1 - row0 < band_rows ? wr1 + 1 - row0 : band_rows, npix = rows * o.W, rlast = row0 + rows - 1;
+    // background + grid: four pixels of a row per lane and store -- one row flag, the four column flags as one word, a 16-byte LDS store
     if (SCR_ABL(16)) {} else
-    if ((o.W & 3) == 0) {   // four pixels of a row per lane and store (r05): one row flag, the four column flags as one word, a 16-byte LDS store
+    if (fixed_cols) {   // the lane keeps its column group from pass to pass: its two column masks were taken once, in front of the band loop
+      typedef unsigned v4u __attribute__((ext_vector_type(4)));
+      if (fc_on) for (int rb = fc_r; rb < rows; rb += fc_step) {
+        const unsigned rf = rowflag[row0 + rb];
+        const unsigned m = ((rf & 2u) ? fc_line : 0u) | ((rf & 1u) ? fc_inside : 0u);                    // byte i: pixel i of the group is a grid pixel
+        v4u v; v.x = (m & 0x01u) ? GRIDV : BACKV; v.y = (m & 0x0100u) ? GRIDV : BACKV; v.z = (m & 0x010000u) ? GRIDV : BACKV; v.w = (m & 0x01000000u) ? GRIDV : BACKV;
+        *(v4u *)&fb[(rb * fc_gpr + fc_gc) << 2] = v;
+      }
+    } else if ((o.W & 3) == 0) {
       typedef unsigned v4u __attribute__((ext_vector_type(4)));
       const int gpr = o.W >> 2, ngrp = npix >> 2;   // groups per row, groups in the band
-      const int step_r = 256 / gpr, step_c = 256 - step_r * gpr;
-      for (int g = (int)threadIdx.x, r = (int)threadIdx.x / gpr, gc = (int)threadIdx.x - r * gpr; g < ngrp; g += 256, r += step_r, gc += step_c) {
+      const int step_r = 64 / gpr, step_c = 64 - step_r * gpr;
+      for (int g = lane, r = lane / gpr, gc = lane - r * gpr; g < ngrp; g += 64, r += step_r, gc += step_c) {
         if (gc >= gpr) { gc -= gpr; r += 1; }
         const unsigned cf4 = *(const unsigned *)&colflag[gc << 2]; const unsigned rf = rowflag[row0 + r];
         const unsigned line = (rf & 2u) ? 0x01010101u : 0u, inside = (rf & 1u) ? 0x02020202u : 0u;     // a column's line shows in rows inside the arena; a row's line in columns inside
@@ -340,165 +426,171 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) k_screen_obs
         *(v4u *)&fb[g << 2] = v;
       }
     } else {
-    const int step_r = 256 / o.W, step_c = 256 - step_r * o.W;   // (one division: the loop below walks rows and columns by addition)
-    for (int q = (int)threadIdx.x, r = (int)threadIdx.x / o.W, cidx = (int)threadIdx.x - r * o.W; q < npix; q += 256, r += step_r, cidx += step_c) {
-      if (cidx >= o.W) { cidx -= o.W; r += 1; }
-      const uint8_t cf = colflag[cidx], rf = rowflag[row0 + r];
-      const bool grid = ((cf & 1) && (rf & 2)) || ((rf & 1) && (cf & 2));
-      fb[q] = grid ? GRIDV : BACKV;
+      const int step_r = 64 / o.W, step_c = 64 - step_r * o.W;   // (one division: the loop walks rows and columns by addition)
+      for (int q = lane, r = lane / o.W, cidx = lane - r * o.W; q < npix; q += 64, r += step_r, cidx += step_c) {
+        while (cidx >= o.W) { cidx -= o.W; r += 1; }
+        const uint8_t cf = colflag[cidx], rf = rowflag[row0 + r];
+        fb[q] = (((cf & 1) && (rf & 2)) || ((rf & 1) && (cf & 2))) ? GRIDV : BACKV;
+      }
     }
-    }
-    if (threadIdx.x == 0) pp_chunks = 0ull;
-    __syncthreads();
-    // entities in draw order; a wavefront paints only its own rows, so later entities overwrite earlier ones without any exchange
-    const int rpw = (rows + 3) >> 2, wr0 = row0 + wave * rpw, wr1 = (wr0 + rpw < row0 + rows ? wr0 + rpw : row0 + rows) - 1;
-    unsigned long long mybits = 0ull;   // agent view: chunks this wavefront painted 255-pixels into
-    // (r05: which entities reach into this wavefront's rows is decided for 64 entities at a time, a lane each, and only those are visited -- in
-    // list order, so later draws still overwrite earlier ones.  Walking the whole list with a uniform box test per entity, wavefront and band was
-    // a third of the kernel's instructions at 128 x 128, where a frame is five bands and a wavefront owns 7 of its rows: ~3 of ~40 entities hit.)
-    if (wr0 <= wr1 && !SCR_ABL(2)) for (int k0 = 0; k0 < n; k0 += 64) {
+    ag_lds_order();
+    // entities in draw order: later draws overwrite earlier ones (one wavefront, in order: no exchange)
+    unsigned long long chunks255 = 0ull;   // agent view: the band's 64-pixel chunks that may hold a 255-pixel (bit c = chunk c; a band has <= 16)
+    if (!SCR_ABL(2)) for (int k0 = 0; k0 < n; k0 += 64) {
+      const int kk = k0 + lane; const bool in_ = kk < n; const int ki = in_ ? kk : 0;
+      const unsigned bx_ = in_ ? ebx[ki] : 1u, by_ = in_ ? eby[ki] : 1u;   // (1 = first 1, last 0: empty)
+      const float x_ = ex[ki], y_ = ey[ki], r_ = er[ki]; const unsigned e_ = ec[ki];
       unsigned long long hits;
-      { const int kk = k0 + lane; const bool in_ = kk < n;
-        const unsigned bx_ = in_ ? ebx[kk] : 1u, by_ = in_ ? eby[kk] : 1u;   // (1 = first 1, last 0: empty)
-        const int r0_ = (int)(by_ & 0xFFFFu), r1_ = (int)(by_ >> 16);
-        hits = __ballot(in_ && (int)(bx_ & 0xFFFFu) <= (int)(bx_ >> 16) && (r0_ < wr0 ? wr0 : r0_) <= (r1_ > wr1 ? wr1 : r1_)); }
-      for (; hits; hits &= hits - 1ull) {
-      const int k = k0 + (int)__builtin_ctzll(hits);
-      const unsigned bx = (unsigned)__builtin_amdgcn_readfirstlane((int)ebx[k]), by = (unsigned)__builtin_amdgcn_readfirstlane((int)eby[k]);
-      const int c0 = (int)(bx & 0xFFFFu), c1 = (int)(bx >> 16);
-      int r0 = (int)(by & 0xFFFFu), r1 = (int)(by >> 16);
-      r0 = r0 < wr0 ? wr0 : r0; r1 = r1 > wr1 ? wr1 : r1;
-      const float x = ex[k], y = ey[k], r = er[k], apo = eapo[k]; const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)ec[k]);
-      // agent view: the main agent's 230 is written as post-processed (alpha 230, no colour); a 255-colour stays a 255-pixel, and the 64-pixel
-      // chunks of the band it may fall into are marked for the run pass below (a superset: a later draw may paint over it)
-      const bool keep255 = CH == 4 && (e & 0xFFFFFFu) > 230u;
-      const unsigned paint = (CH == 4 && !keep255) ? ((e & 0xFFu) << 24) : ((e & 0xFFFFFFu) | 0xFF000000u);
-      if (keep255) {   // (wave-uniform arithmetic: every chunk from the box's first pixel to its last -- a superset of the chunks it touches)
-        const int lo = ((r0 - row0) * o.W + c0) >> 6, hi = ((r1 - row0) * o.W + c1) >> 6;
-        mybits |= ((hi - lo >= 63) ? ~0ull : ((1ull << (hi - lo + 1)) - 1ull)) << lo;
-      }
-      for (int ty = r0; ty <= r1; ty += 8) for (int tx = c0; tx <= c1; tx += 8) {   // 8 x 8 pixel tiles of the box, a lane per pixel
-        const int rr = ty + (lane >> 3), cc = tx + (lane & 7);
-        if (rr <= r1 && cc <= c1 && scr_inside_apo(colx[cc] - x, rowy[rr] - y, r, apo, (int)(e >> 24))) fb[(rr - row0) * o.W + cc] = paint;
-      }
-      }
-    }
-    if (CH == 4 && lane == 0 && mybits) atomicOr(&pp_chunks, mybits);
-    __syncthreads();
-    if (CH == 4 && !SCR_ABL(4)) {  // ScreenObservation::post_processing_frame_data (ScreenEnvironment.hpp:48-88): a sequential pass over the flat buffer
-      // With the colours this kernel paints (one non-zero channel per pixel: 26 grid, 230 main agent, 255 pellets / others / viruses) the
-      // pass has a closed form.  A pixel whose channel is <= 230 moves it into alpha: no dependence -- since r05 the painter writes such pixels
-      // in that form at once (the kernel is bound by issued instructions: a pass over every pixel of the band cost as much as painting it).
-      // A 255-pixel keeps alpha 255 unless the two previous FINAL alphas are both <= 30, then it takes the previous one; so a run of consecutive
-      // 255-pixels takes ONE value, decided at its first pixel -- 255, or the alpha in front of the run -- and only run starts are sequential: a
-      // dozen per frame instead of 7056 pixels.  One wavefront walks them in pixel order (on four wavefronts the pass issued more instructions
-      // and was slower: 352 -> 380 us per 4096 frames of 128 x 128), and since r05 only through the 64-pixel chunks the painter marked as
-      // holding a 255-pixel (pp_chunks) instead of through every chunk of the band.
-      // All four wavefronts share the pass (r05): the kernel is bound by what a SIMD issues and a workgroup's wavefronts sit on different SIMDs, so a
-      // pass on wavefront 0 alone is issued by one SIMD in four.  The band's chunks are cut into four runs of consecutive chunks at SAFE boundaries --
-      // the two pixels in front of the boundary carry no colour: no run crosses it and a start behind it reads final alphas -- found with one ballot
-      // (lane c looks at the two pixels in front of chunk c); every wavefront walks its chunks in order exactly as the single wavefront did.
-      {
-        const int nch = (npix + 63) >> 6, per = (nch + 3) >> 2;
-        bool sf = false;
-        if (lane >= 1 && lane < nch) sf = (fb[64 * lane - 1] & 0xFFFFFFu) == 0u && (fb[64 * lane - 2] & 0xFFFFFFu) == 0u;
-        const unsigned long long safe = __ballot(sf);
-        auto cut = [&](int t) -> int { if (t <= 0) return 0; if (t >= nch) return nch; const unsigned long long m = safe >> t; return m ? t + (int)__builtin_ctzll(m) : nch; };   // first safe boundary >= t
-        const int lo_c = cut(wave * per), hi_c = cut((wave + 1) * per);
-        const unsigned long long seg = (hi_c >= 64 ? ~0ull : ((1ull << hi_c) - 1ull)) & ~((1ull << lo_c) - 1ull);
-        int run_val = -1, prev_c = -2;   // value of the run that reaches into the current chunk from the left (-1: none); the chunk visited before this one
-        const unsigned long long lt_lane = (1ull << lane) - 1ull;
-        // (pp_chunks comes out of LDS: a vector register to the compiler, which then walked the chunks with vector compares and exec masks)
-        const unsigned long long cm0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pp_chunks >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pp_chunks);
-        for (unsigned long long cm = cm0 & seg; cm; cm &= cm - 1ull) {
-          const int cch = (int)__builtin_ctzll(cm), c0_ = cch << 6;
-          if (cch != prev_c + 1) run_val = -1;                     // (the chunks in between hold no 255-pixel: no run crosses them)
-          prev_c = cch;
-          const int q = c0_ + lane; const bool in = q < npix; const int qi = in ? q : 0;
-          // the chunk's words and, for the lanes that turn out to start a run, the two pixels in front: three reads in one round trip, no branches
-          const unsigned w = fb[qi], wl1 = fb[qi >= 1 ? qi - 1 : 0], wl2 = fb[qi >= 2 ? qi - 2 : 0];
-          const bool X = in && (w & 0xFFFFFFu) != 0u;            // only 255-pixels carry a colour
-          unsigned long long xm = __ballot(X);
-          if (xm == 0ull) { run_val = -1; continue; }
-          // All runs of the chunk at once (r05): a 255-pixel finds the start of its run in the ballot (the highest non-255 pixel below it), the
-          // start decides the run's value from the two pixels in front of it -- final already unless the second one is a 255-pixel of THIS chunk
-          // (two runs one pixel apart: the chunk then takes the run-by-run loop below) -- and hands it to the run with one ds_bpermute.
-          // (Measured: 128 x 128 x 4 on a task-3 state 203 -> 199 us; marking the chunks row by row so that fewer are visited: 413 us on task 1's
-          // pattern -- the painter's scalar instructions --; neighbours from registers instead of LDS: 218 us.  The kernel is bound by what it issues.)
-          if (!((xm & ~(xm << 1)) & (xm << 2))) {   // (no two runs one pixel apart -- X[i], !X[i-1], X[i-2] --: scalar arithmetic on the ballot)
-            const unsigned long long below = ~xm & lt_lane;
-            const int sp = below ? 64 - (int)__builtin_clzll(below) : 0;            // chunk position at which this lane's run starts (0: it reaches the left edge)
-            const bool from_left = !below && run_val >= 0;                           // ... and continues the run of the chunk before
-            const bool start = X && sp == lane && !from_left;
-            const int f1 = q >= 1 ? (int)(wl1 >> 24) : a1, f2 = q >= 2 ? (int)(wl2 >> 24) : (q == 1 ? a1 : a2);
-            const int val = (start && row0 * o.W + q >= 2 && f2 <= 30 && f1 <= 30) ? f1 : 255;
-            int mine = __builtin_amdgcn_ds_bpermute(sp << 2, val);
-            if (from_left) mine = run_val;
-            if (X) fb[q] = (w & 0xFFFFFFu) | ((unsigned)mine << 24);
-            ag_lds_order();
-            run_val = (xm >> 63) ? __builtin_amdgcn_readlane(mine, 63) : -1;
-            continue;
+      { const int r0_ = (int)(by_ & 0xFFFFu), r1_ = (int)(by_ >> 16);
+        hits = __ballot(in_ && (int)(bx_ & 0xFFFFu) <= (int)(bx_ >> 16) && (r0_ < row0 ? row0 : r0_) <= (r1_ > rlast ? rlast : r1_)); }
+      if (AGV && __popcll(hits) >= 5) {
+        // Many hits in one batch -- a line of pellets across the view (tasks 1 and 2 lay 350 of them along a square, one unit apart), a cloud of
+        // ejected food: when they all paint the same word and their boxes are small, the ORDER among them is immaterial, and every lane paints its own
+        // entity, <= 6 x 6 pixels, while the others paint theirs (one wavefront-wide loop instead of one tile pass per entity).  Tight box: the stored
+        // one without its margins (floor(low end) .. floor(high end) + 1 still contains every pixel the inside test can accept).
+        const bool mine = (hits >> lane) & 1ull;
+        const unsigned e0 = (unsigned)__builtin_amdgcn_readlane((int)e_, (int)__builtin_ctzll(hits));
+        const int c0s = (int)(bx_ & 0xFFFFu), c1s = (int)(bx_ >> 16), r0s = (int)(by_ & 0xFFFFu), r1s = (int)(by_ >> 16);
+        const int c0 = c0s == 0 ? 0 : c0s + 1, c1 = c1s == o.W - 1 ? c1s : c1s - 1;
+        int r0 = r0s == 0 ? 0 : r0s + 1, r1 = r1s == o.H - 1 ? r1s : r1s - 1;
+        r0 = r0 < row0 ? row0 : r0; r1 = r1 > rlast ? rlast : r1;
+        const int bw = c1 - c0 + 1, bh = r1 - r0 + 1;
+        if (__ballot(mine && (e_ != e0 || bw > 6 || bh > 6)) == 0ull) {
+          const int ns = (int)(e0 >> 24); const float apo = r_ * scr_cos_half_step(ns); const unsigned paint = scr_paint_word<AGV>(e0);
+          unsigned marks = 0u;   // the band's 64-pixel chunks this lane's entity can touch, row by row (a band has <= 16 chunks)
+          const bool is255 = (e0 & 0xFFFFFFu) > 230u;
+          float cx[6];
+#pragma unroll
+          for (int dx = 0; dx < 6; dx++) cx[dx] = colx[(mine && dx < bw) ? c0 + dx : 0] - x_;
+#pragma unroll
+          for (int dy = 0; dy < 6; dy++) {
+            if (__ballot(mine && dy < bh) == 0ull) break;
+            const bool rowok = mine && dy < bh; const float yy = rowy[rowok ? r0 + dy : 0] - y_; const int rb = (r0 + dy - row0) * o.W + c0;
+            if (is255 && rowok && bw > 0) { const int lo_ = rb >> 6, hi_ = (rb + bw - 1) >> 6; marks |= ((2u << (hi_ - lo_)) - 1u) << lo_; }
+#pragma unroll
+            for (int dx = 0; dx < 6; dx++) if (rowok && dx < bw && scr_inside_apo(cx[dx], yy, r_, apo, ns)) fb[rb + dx] = paint;
           }
-          unsigned long long todo = xm;
-          int carry_val = run_val;
-          while (todo) {
-            const int s_ = (int)__builtin_ctzll(todo);           // first undecided 255-pixel: a run start, or the continuation of the left run
-            const unsigned long long from = xm >> s_; const int len = (~from) ? (int)__builtin_ctzll(~from) : 64 - s_;   // length of the run inside this chunk
-            int val;
-            if (s_ == 0 && carry_val >= 0) val = carry_val;     // the run started in an earlier chunk
-            else {
-              const int p = row0 * o.W + c0_ + s_;              // flat pixel index of the run start
-              int f1, f2;                                        // final alphas of pixels p - 1 and p - 2
-              if (c0_ + s_ >= 1) f1 = (int)(fb[c0_ + s_ - 1] >> 24); else f1 = a1;
-              if (c0_ + s_ >= 2) f2 = (int)(fb[c0_ + s_ - 2] >> 24); else f2 = (c0_ + s_ == 1) ? a1 : a2;
-              val = (p >= 2 && f2 <= 30 && f1 <= 30) ? f1 : 255;
-            }
-            if (lane >= s_ && lane < s_ + len) fb[q] = (w & 0xFFFFFFu) | ((unsigned)val << 24);
-            ag_lds_order();
-            const unsigned long long runmask = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << s_;
-            todo &= ~runmask;
-            carry_val = -1;
-            run_val = (s_ + len == 64) ? val : -1;               // the run touches the chunk's right edge: it may continue
+          if (is255) {
+            for (int sft = 32; sft; sft >>= 1) marks |= (unsigned)__shfl_xor((int)marks, sft, 64);
+            chunks255 |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)marks);
           }
-          if (!(xm >> 63)) run_val = -1;
+          hits = 0ull;
         }
       }
-      __syncthreads();
-      // the band's last two final alphas, for the next band
-      { const int l1 = (int)(fb[npix - 1] >> 24), l2 = npix >= 2 ? (int)(fb[npix - 2] >> 24) : a1; a2 = l2; a1 = l1; }
+      for (; hits; hits &= hits - 1ull) {
+        const int j = (int)__builtin_ctzll(hits);
+        const unsigned bx = (unsigned)__builtin_amdgcn_readlane((int)bx_, j), by = (unsigned)__builtin_amdgcn_readlane((int)by_, j);
+        const int c0 = (int)(bx & 0xFFFFu), c1 = (int)(bx >> 16);
+        int r0 = (int)(by & 0xFFFFu), r1 = (int)(by >> 16);
+        r0 = r0 < row0 ? row0 : r0; r1 = r1 > rlast ? rlast : r1;
+        const float x = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(x_), j)), y = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(y_), j));
+        const float r = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(r_), j)); const unsigned e = (unsigned)__builtin_amdgcn_readlane((int)e_, j);
+        const int ns = (int)(e >> 24); const float apo = r * scr_cos_half_step(ns);
+        const unsigned paint = scr_paint_word<AGV>(e);
+        if (AGV && (e & 0xFFFFFFu) > 230u) {   // (wave-uniform arithmetic: every chunk from the box's first pixel to its last -- a superset of the chunks it touches;
+          // marking a small entity's chunks row by row leaves the run pass fewer chunks, but costs more scalar instructions here than it saves there: measured)
+          const int lo = ((r0 - row0) * o.W + c0) >> 6, hi = ((r1 - row0) * o.W + c1) >> 6;
+          chunks255 |= ((hi - lo >= 63) ? ~0ull : ((1ull << (hi - lo + 1)) - 1ull)) << lo;
+        }
+        for (int ty = r0; ty <= r1; ty += 8) for (int tx = c0; tx <= c1; tx += 8) {   // 8 x 8 pixel tiles of the box, a lane per pixel
+          const int rr = ty + (lane >> 3), cc = tx + (lane & 7);
+          if (rr <= r1 && cc <= c1 && scr_inside_apo(colx[cc] - x, rowy[rr] - y, r, apo, ns)) fb[(rr - row0) * o.W + cc] = paint;
+        }
+      }
     }
-    // the band leaves LDS as one coalesced byte stream
+    ag_lds_order();
+    if (AGV && !SCR_ABL(4)) {
+      // ScreenObservation::post_processing_frame_data (ScreenEnvironment.hpp:48-88): a sequential pass over the flat buffer.  With the colours this kernel
+      // paints (one non-zero channel per pixel: 26 grid, 230 main agent, 255 pellets / others / viruses) the pass has a closed form.  A pixel whose
+      // channel is <= 230 moves it into alpha: no dependence -- the painter writes such pixels in that form at once.  A 255-pixel keeps alpha 255 unless
+      // the two previous FINAL alphas are both <= 30, then it takes the previous one; so a run of consecutive 255-pixels takes ONE value, decided at its
+      // first pixel -- 255, or the alpha in front of the run -- and only run starts are sequential.  The wavefront walks, in pixel order, the 64-pixel
+      // chunks the painter marked; fb[-1] / fb[-2] hold the two final pixels in front of the band, so the first pixels look back like any other.
+      int run_val = -1, prev_c = -2;   // value of the run that reaches into the current chunk from the left (-1: none); the chunk visited before this one
+      for (unsigned long long cm = chunks255; cm; cm &= cm - 1ull) {
+        const int cch = (int)__builtin_ctzll(cm), c0_ = cch << 6;
+        if (cch != prev_c + 1) run_val = -1;                     // (the chunks in between hold no 255-pixel: no run crosses them)
+        prev_c = cch;
+        const int q = c0_ + lane; const bool in = q < npix; const int qi = in ? q : 0;
+        // the chunk's words and, for the lanes that turn out to start a run, the two pixels in front: three reads in one round trip, no branches
+        const unsigned w = fb[qi], wl1 = fb[qi - 1], wl2 = fb[qi - 2];
+        const bool X = in && (w & 0xFFFFFFu) != 0u;            // only 255-pixels carry a colour
+        const unsigned long long xm = __ballot(X);
+        if (xm == 0ull) { run_val = -1; continue; }
+        // All runs of the chunk at once: a 255-pixel finds the start of its run in the ballot (the highest non-255 pixel below it), the start decides
+        // the run's value from the two pixels in front of it -- final already unless the second one is a 255-pixel of THIS chunk (two runs one pixel
+        // apart: the chunk then takes the run-by-run loop below) -- and hands it to the run with one ds_bpermute.
+        if (!((xm & ~(xm << 1)) & (xm << 2))) {   // (no two runs one pixel apart -- X[i], !X[i-1], X[i-2] --: scalar arithmetic on the ballot)
+          const unsigned long long below = ~xm & lt;
+          const int sp = below ? 64 - (int)__builtin_clzll(below) : 0;            // chunk position at which this lane's run starts (0: it reaches the left edge)
+          const bool from_left = !below && run_val >= 0;                           // ... and continues the run of the chunk before
+          const bool start = X && sp == lane && !from_left;
+          const int f1 = (int)(wl1 >> 24), f2 = (int)(wl2 >> 24);
+          const int val = (start && f2 <= 30 && f1 <= 30) ? f1 : 255;
+          int mine = __builtin_amdgcn_ds_bpermute(sp << 2, val);
+          if (from_left) mine = run_val;
+          if (X) fb[q] = (w & 0xFFFFFFu) | ((unsigned)mine << 24);
+          ag_lds_order();
+          run_val = (xm >> 63) ? __builtin_amdgcn_readlane(mine, 63) : -1;
+          continue;
+        }
+        unsigned long long todo = xm;
+        int carry_val = run_val;
+        while (todo) {
+          const int s_ = (int)__builtin_ctzll(todo);           // first undecided 255-pixel: a run start, or the continuation of the left run
+          const unsigned long long from = xm >> s_; const int len = (~from) ? (int)__builtin_ctzll(~from) : 64 - s_;   // length of the run inside this chunk
+          int val;
+          if (s_ == 0 && carry_val >= 0) val = carry_val;     // the run started in an earlier chunk
+          else {
+            const int f1 = (int)(fb[c0_ + s_ - 1] >> 24), f2 = (int)(fb[c0_ + s_ - 2] >> 24);   // final alphas of the two pixels in front of the run start
+            val = (f2 <= 30 && f1 <= 30) ? f1 : 255;
+          }
+          if (lane >= s_ && lane < s_ + len) fb[q] = (w & 0xFFFFFFu) | ((unsigned)val << 24);
+          ag_lds_order();
+          const unsigned long long runmask = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << s_;
+          todo &= ~runmask;
+          carry_val = -1;
+          run_val = (s_ + len == 64) ? val : -1;               // the run touches the chunk's right edge: it may continue
+        }
+        if (!(xm >> 63)) run_val = -1;
+      }
+      // the band's last two final pixels: in front of the next band, or published for the wavefront below
+      { const unsigned l1 = fb[npix - 1], l2 = fb[npix - 2];   // (npix == 1: fb[-1], the pixel in front of this band -- which is what lies two before the next)
+        ag_lds_order();
+        if (lane == 0) {
+          if (row0 + rows <= wr1) { fb[-1] = l1; fb[-2] = l2; }
+          else { pp_last[wave][0] = l1; pp_last[wave][1] = l2; __hip_atomic_store(&pp_done[wave], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        }
+        ag_lds_order(); }
+    }
+    // the band leaves LDS as one coalesced byte stream: whole 32-bit words (a packed RGBA pixel IS its four output bytes, 0xAABBGGRR little endian;
+    // three-channel frames pack four pixels into three words); frames and bands start on 4- / 16-byte boundaries when their byte counts say so,
+    // anything else takes the byte loop
     uint8_t *bd = dst + (size_t)row0 * o.W * CH; const int nbytes = npix * CH;
-    // (r05: whole 32-bit words instead of one byte per lane and store -- a 128 x 128 x 4 frame left as 256 byte-stores per thread.  A packed RGBA
-    // pixel IS its four output bytes (0xAABBGGRR, little endian); three-channel frames assemble each output word from the two pixels it spans.
-    // Frames and bands start on 4-byte boundaries when their byte counts say so; anything else takes the byte loop.)
-    // (r05, second pass: four pixels per lane -- one 16-byte LDS read; the agent view stores them as they are, 16 bytes; a three-channel frame packs
-    // them into three words instead of assembling every output word with a division by three)
     typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
     if (SCR_ABL(8)) {} else
-    if (CH == 4 && (((size_t)bd) & 15) == 0 && (npix & 3) == 0) { v4u_ *bw = (v4u_ *)bd; const v4u_ *fw = (const v4u_ *)fb; for (int g = (int)threadIdx.x; g < (npix >> 2); g += 256) bw[g] = fw[g]; }
+    if (CH == 4 && (((size_t)bd) & 15) == 0 && (npix & 3) == 0) { v4u_ *bw = (v4u_ *)bd; const v4u_ *fw = (const v4u_ *)fb; for (int g = lane; g < (npix >> 2); g += 64) bw[g] = fw[g]; }
     else if (CH == 3 && (((size_t)bd) & 3) == 0 && (npix & 3) == 0) {
       unsigned *bw = (unsigned *)bd; const v4u_ *fw = (const v4u_ *)fb;
-      for (int g = (int)threadIdx.x; g < (npix >> 2); g += 256) {
+      for (int g = lane; g < (npix >> 2); g += 64) {
         const v4u_ v = fw[g]; const unsigned p0 = v.x & 0xFFFFFFu, p1 = v.y & 0xFFFFFFu, p2 = v.z & 0xFFFFFFu, p3 = v.w & 0xFFFFFFu;
         bw[3 * g] = p0 | (p1 << 24); bw[3 * g + 1] = (p1 >> 8) | (p2 << 16); bw[3 * g + 2] = (p2 >> 16) | (p3 << 8);
       }
     }
-    else if (CH == 4 && (((size_t)bd) & 3) == 0) { unsigned *bw = (unsigned *)bd; for (int q = (int)threadIdx.x; q < npix; q += 256) bw[q] = fb[q]; }
+    else if (CH == 4 && (((size_t)bd) & 3) == 0) { unsigned *bw = (unsigned *)bd; for (int q = lane; q < npix; q += 64) bw[q] = fb[q]; }
     else if (CH == 3 && (((size_t)bd) & 3) == 0) {
       unsigned *bw = (unsigned *)bd; const int nwords = nbytes >> 2;
-      for (int j = (int)threadIdx.x; j < nwords; j += 256) {
-        // output bytes 4j .. 4j+3 = channels (4j + t) % 3 of pixels (4j + t) / 3: 4j = 3 q0 + c0
+      for (int j = lane; j < nwords; j += 64) {
+        // output bytes 4j .. 4j+3 = channels (4j + t) % 3 of pixels (4j + t) / 3: 4j = 3 q0 + c0  (c0 <= 2: the word's last byte is byte 5 of the two pixels' six)
         const int b0 = 4 * j, q0 = b0 / 3, c0 = b0 - 3 * q0;
-        // (c0 <= 2: the word's last byte is byte 5 of the two pixels' six)
         const unsigned long long two = (unsigned long long)(fb[q0] & 0xFFFFFFu) | ((unsigned long long)(fb[q0 + 1 < npix ? q0 + 1 : q0] & 0xFFFFFFu) << 24);
         bw[j] = (unsigned)(two >> (8 * c0));
       }
-      for (int b = 4 * nwords + (int)threadIdx.x; b < nbytes; b += 256) { const int q = b / 3, ch = b - q * 3; bd[b] = (uint8_t)((fb[q] >> (8 * ch)) & 0xFFu); }
+      for (int b = 4 * nwords + lane; b < nbytes; b += 64) { const int q = b / 3, ch = b - q * 3; bd[b] = (uint8_t)((fb[q] >> (8 * ch)) & 0xFFu); }
     }
-    else if (CH == 4) { for (int b = (int)threadIdx.x; b < nbytes; b += 256) bd[b] = (uint8_t)((fb[b >> 2] >> (8 * (b & 3))) & 0xFFu); }
-    else { for (int b = (int)threadIdx.x; b < nbytes; b += 256) { const int q = b / 3, ch = b - q * 3; bd[b] = (uint8_t)((fb[q] >> (8 * ch)) & 0xFFu); } }
-    __syncthreads();
+    else if (CH == 4) { for (int b = lane; b < nbytes; b += 64) bd[b] = (uint8_t)((fb[b >> 2] >> (8 * (b & 3))) & 0xFFu); }
+    else { for (int b = lane; b < nbytes; b += 64) { const int q = b / 3, ch = b - q * 3; bd[b] = (uint8_t)((fb[q] >> (8 * ch)) & 0xFFu); } }
+    ag_lds_order();   // (the next band's fill comes after these reads)
   }
 }
 #endif

@@ -64,15 +64,23 @@ from .vec_env import PipelinedVecEnvironment, VecEnvironment, default_sub_batche
 class AgarioVectorEnv:
     metadata = {"render_modes": [], "autoreset_mode": "same_step"}
 
-    def __init__(self, num_envs, obs_type="grid", device=0, channels_last=False, sub_batches="auto", **kwargs):
+    def __init__(self, num_envs, obs_type="grid", device=0, channels_last=False, sub_batches="auto", on_capacity_flag="raise", **kwargs):
         """num_envs arenas; obs_type "grid" | "screen" | "ram" | "gobigger" | "none"; channels_last: grid observations as a [.., G, G, C]
         VIEW (what AgarioEnv hands out per arena) instead of the engine's channel-first layout; sub_batches: an int, or "auto" (the default) =
         vec_env.default_sub_batches: 4 where the general engine handles most arena-steps (bots / several agents / modes 5 and 6), 1 for quiet
-        batches and for the GoBigger observation -- see the module text; every other
+        batches and for the GoBigger observation -- see the module text; on_capacity_flag: what happens to an arena that raises a capacity flag
+        (README "capacity flags": nearly always the reference's own arithmetic leaving its domain, e.g. the anti-team decay factor going
+        negative in a tiny arena full of viruses) -- "raise" (default: the next step() raises AgarclError -6 until reset()), "reset" (the arena is
+        reset inside the same step like an ended episode, its rows truncated = True: a diverged arena never feeds a learner) or "ignore"; every other
         keyword as AgarioEnv takes it (difficulty, ticks_per_step, arena_size, num_pellets, num_viruses, num_bots, pellet_regen, reward_type,
         c_death, mode, num_agents, number_steps, env_type, grid_size, observe_*, screen_len, agent_view, k_cells / k_pellets / k_viruses /
         k_others)."""
         import torch
+        if on_capacity_flag not in ("raise", "reset", "ignore"):
+            raise ValueError("on_capacity_flag must be 'raise', 'reset' or 'ignore'")
+        if on_capacity_flag != "raise":
+            kwargs = dict(kwargs, strict_flags=False)
+        self.on_capacity_flag = on_capacity_flag
         if obs_type not in _single.OBS_TYPES + ("none",):
             raise ValueError("obs_type must be one of %s, got %r" % (_single.OBS_TYPES + ("none",), obs_type))
         self.torch = torch
@@ -136,7 +144,8 @@ class AgarioVectorEnv:
         self._mask = torch.zeros(N, dtype=torch.uint8, device=self.device)        # "ended"
         self._started = False
         self._L = self._parts[0].engine.L
-        self._spec = _capi.VecSpec(int(self.number_of_steps), 1 if self.env_type == 0 else 0, 0, spec_kind, (ctypes.c_int32 * 6)(*[int(x) for x in arg]), 0)
+        self._spec = _capi.VecSpec(int(self.number_of_steps), 1 if self.env_type == 0 else 0, 0, spec_kind, (ctypes.c_int32 * 6)(*[int(x) for x in arg]), 0,
+                                   1 if on_capacity_flag == "reset" else 0)
         self._bufs = []
         for lo, cnt in self._ranges:
             off = lambda t, per_row: t.data_ptr() + lo * per_row

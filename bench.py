@@ -578,7 +578,8 @@ def compact_line(out):
         # flat copies of the rows the round's targets are stated on (should a reader keep only the scalars of `roofline`)
         for key, name in (("C3m6@%d" % full_roof["arenas"], "C3m6"), ("C3m6@%d/pipe4" % full_roof["arenas"], "C3m6_pipe4"), ("mid@%d" % full_roof["arenas"], "mid"),
                           ("C1@%d" % full_roof["arenas"], "C1"), ("C5@%d" % full_roof["arenas"], "C5"), ("C5s@%d" % full_roof["arenas"], "C5s"),
-                          ("task5@%d" % full_roof["arenas"], "task5"), ("task6@%d" % full_roof["arenas"], "task6"), ("task10@%d" % full_roof["arenas"], "task10"),
+                          ("task3@%d" % full_roof["arenas"], "task3"), ("task5@%d" % full_roof["arenas"], "task5"), ("task6@%d" % full_roof["arenas"], "task6"),
+                          ("task5@%d/pipe4" % full_roof["arenas"], "task5_pipe4"), ("task6@%d/pipe4" % full_roof["arenas"], "task6_pipe4"), ("task10@%d" % full_roof["arenas"], "task10"),
                           ("Tick/30@%d" % full_roof["arenas"], "tick30"), ("C2@65536", "C2_65536"), ("C3m6@32768", "C3m6_32768")):
             row = by.get(key)
             if isinstance(row, list):
@@ -764,7 +765,7 @@ def main():
         _hip_build.build()          # normally prebuilt by __graft_entry__.build(); never rebuilt when present
     if world > 1:
         dist.barrier()              # nobody loads the library while rank 0 may still be writing it
-    from agarcl_amd.vec_env import VecEnvironment
+    from agarcl_amd.vec_env import VecEnvironment, default_sub_batches
     from agarcl_amd import dist as agdist
 
     A, K, Wm = args.arenas, args.steps, args.warmup
@@ -911,6 +912,12 @@ def main():
                 rf = measure("task%d" % m, tcfg, A, 40, 10, ra=True, ws=True, scr=tscr, cpu_rate=cr[0], cpu_cores=cr[1], label=tdesc.replace("%%", "%") % (A, A))
                 if rf is not None:
                     tasks["task%d" % m] = by["task%d@%d" % (m, A)]
+                # ... and as AgarioVectorEnv steps it by default (vec_env.default_sub_batches: 4 ranges where the general engine does the work --
+                # modes 5 / 6, bots -- so that one range's frame kernel runs under another's step)
+                dsub = default_sub_batches(A, tcfg["num_agents"], tcfg["num_bots"], tcfg["mode_number"])
+                if dsub > 1:
+                    measure("task%d" % m, tcfg, A, 40, 10, ra=True, ws=True, scr=tscr, sub=dsub, cpu_rate=cr[0], cpu_cores=cr[1],
+                            label=tdesc.replace("%%", "%") % (A, A) + " -- as %d sub-batches (the vector env's default)" % dsub)
             roof["tasks"] = {"columns": BY_WORKLOAD_COLUMNS, "rows": tasks,
                              "what": "the reference's bench/tasks_configs/mode_{1..10}.json at %d arenas: k_step (+ k_quiet / k_fused) + k_screen_obs 128x128x4 per step" % A}
             try:   # the RL surface itself: AgarioVectorEnv.step = ONE agarcl_vec_step (step + bookkeeping / auto-reset + observation)

@@ -1,11 +1,13 @@
 """A rollout loop through the batched user surface (agarcl_amd/vector_env.py: AgarioVectorEnv): N arenas, a random policy on the device,
 T steps collected into a rollout buffer -- the shape of a PPO / IMPALA actor -- with nothing inside the loop that waits for the GPU.
 
-    python examples/vector_rollout.py [--envs 4096] [--steps 256] [--obs grid|ram|screen|none] [--difficulty normal] [--sub-batches 2 [--halves]]
+    python examples/vector_rollout.py [--envs 4096] [--steps 256] [--obs grid|ram|screen|none] [--difficulty normal] [--mode 6] [--sub-batches auto|k [--halves]]
 
 --sub-batches k: the arenas as k independent ranges on HIP streams of their own (a range never waits for the slowest arena of another, one
-range's observation kernel runs under another's step); --halves: double-buffered sampling through recv(j) / send(actions_j, j) -- the policy
-works on range j's observations while the other ranges step.
+range's observation kernel runs under another's step).  The default, "auto", is what AgarioVectorEnv picks by workload
+(agarcl_amd/vec_env.py default_sub_batches): 4 where the general engine handles most arena-steps -- bots, several agents, modes 5 / 6 (try
+--mode 6) --, 1 for quiet batches such as the default mode 0, where a pipelined step would cost more than the step itself.
+--halves: double-buffered sampling through recv(j) / send(actions_j, j) -- the policy works on range j's observations while the other ranges step.
 
 Prints env-steps per second of the whole loop (engine step + observation + Python), which is what a learner sees; `bench.py` times the
 engine alone."""
@@ -18,7 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--envs", type=int, default=4096); ap.add_argument("--steps", type=int, default=256)
 ap.add_argument("--obs", default="ram"); ap.add_argument("--difficulty", default="normal"); ap.add_argument("--number-steps", type=int, default=500)
 ap.add_argument("--bare", action="store_true", help="time venv.step alone: one fixed action batch, no rollout buffer")
-ap.add_argument("--sub-batches", type=int, default=1); ap.add_argument("--halves", action="store_true", help="recv / send per sub-batch instead of full-batch step()")
+ap.add_argument("--sub-batches", default="auto", type=lambda v: v if v == "auto" else int(v)); ap.add_argument("--halves", action="store_true", help="recv / send per sub-batch instead of full-batch step()")
 ap.add_argument("--mode", type=int, default=0)
 a = ap.parse_args()
 venv = AgarioVectorEnv(a.envs, obs_type=a.obs, difficulty=a.difficulty, number_steps=a.number_steps, env_type=0, sub_batches=a.sub_batches, mode=a.mode,

@@ -33,7 +33,9 @@ typedef struct agarcl_vec_spec {
   int32_t obs_kind;       /* AGARCL_OBS_* */
   int32_t obs_arg[6];
   int32_t ticks;          /* engine ticks per step; <= 0 -> the env's ticks_per_step */
-  int32_t reserved[5];
+  int32_t reset_flagged;  /* != 0: an arena that carries a capacity flag (agarcl_get_flags) is treated like an ended episode: reset in the same step,
+                             its rows truncated = 1 (unless done), final_return / final_length written -- a diverged arena never feeds a learner */
+  int32_t reserved[4];
 } agarcl_vec_spec;
 
 /* HBM buffers of the caller, A = agarcl_num_arenas(env), n = num_agents: all written by agarcl_vec_step / agarcl_vec_reset */

@@ -119,3 +119,39 @@ def _sync_then(fn, keep):
         torch.cuda.synchronize()
         return fn(t)
     return f
+
+
+def test_vec_step_resets_flagged_arenas_on_request(emu_lib):
+    """agarcl_vec_spec.reset_flagged: an arena that raised a capacity flag (here: two food slots, an agent that keeps ejecting) is cut like an ended
+    episode -- reset in the same step, its row truncated and not done, the flag gone -- instead of running on diverged; without the switch it
+    keeps its flag and is never reset"""
+    from agarcl_amd import _capi
+    cfg = dict(num_agents=1, arena_size=120, num_pellets=100, num_viruses=0, mode=6, cap_foods=2)
+    A = 4
+    for switch in (1, 0):
+        eng = _capi.BatchedEngine(A, lib=emu_lib, **cfg)
+        eng.seed(np.arange(40, 40 + A, dtype=np.uint32))
+        names = [("steps", (A,), np.int32), ("reward", (A, 1), np.float32), ("done", (A, 1), np.uint8), ("truncated", (A, 1), np.uint8), ("ended", (A,), np.uint8),
+                 ("ep_return", (A, 1), np.float32), ("final_return", (A, 1), np.float32), ("final_length", (A,), np.int32)]
+        bufs = {k: np.zeros(shape, dt) for k, shape, dt in names}
+        spec = _capi.VecSpec(1000, 0, 0, _capi.OBS_NONE, (C.c_int32 * 6)(0, 0, 0, 0, 0, 0), 0, switch)
+        vb = _capi.VecBuffers(*([C.c_void_p(bufs[k].ctypes.data) for k, _, _ in names] + [None]))
+        assert emu_lib.agarcl_vec_reset(eng.h, C.byref(spec), C.byref(vb)) == 0
+        move = np.zeros((A, 1, 2), np.float32); move[:, 0, 0] = 1.0
+        kind = np.ones((A, 1), np.int32)                       # feed, every step
+        cut = 0
+        for t in range(40):
+            fl = C.c_uint32(0)
+            assert emu_lib.agarcl_vec_step(eng.h, C.byref(spec), C.byref(vb), C.c_void_p(move.ctypes.data), C.c_void_p(kind.ctypes.data), C.byref(fl)) == 0
+            if switch:
+                assert not eng.flags().any(), "a flagged arena survived the step"
+                assert np.array_equal(bufs["truncated"][:, 0], bufs["ended"]) and not bufs["done"].any()
+                assert (bufs["steps"][bufs["ended"] != 0] == 0).all()
+                cut += int(bufs["ended"].sum())
+            else:
+                assert not bufs["ended"].any()
+        if switch:
+            assert cut >= 2, "no arena was cut (%d)" % cut
+        else:
+            assert (eng.flags() & 2).any(), "no arena overflowed its two food slots: the switch = 1 half proved nothing"
+        eng.close()
