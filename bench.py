@@ -51,7 +51,7 @@ WORKLOADS = {
     "C1r": dict(arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, dt=1.0 / 60, rand_act=True, ram_obs=True,
                 desc="C1 batched + ram observation: %d arenas/GPU x (1 agent + 4 bots), 250x250, 500 pellets, 10 viruses, mode 0, dt 1/60 s, 4 ticks/step, f32 [A][1][152] written once per step"),
 }
-TRAFFIC_FILE = "r05_pmc_traffic.json"   # PMC FETCH_SIZE / WRITE_SIZE (+ one SQ pass) per step of the bench workloads, recorded by scripts/profile_round.sh
+TRAFFIC_FILE = "r06_pmc_traffic.json"   # PMC FETCH_SIZE / WRITE_SIZE (+ one SQ pass) per step of the bench workloads, recorded by scripts/profile_round.sh
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
 GUIDE_COPY_GBS = 6300.0   # the achievable device copy rate the guide quotes (MI355X_MICROARCH.md), beside the copy timed in this process
 PIPE_K = 4                # sub-batches of the "<workload>/pipe4" entries (agarcl_pipe_*: independent arena ranges on streams of their own)

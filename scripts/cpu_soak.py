@@ -43,7 +43,11 @@ def trial(args):
       ok, msg = run_batched_lockstep(eng, oras, int(rng.choice([120, 300, 600])), seeds=rng.randint(1, 1 << 30, size=A), policy_seed=int(rng.randint(1, 1000)),
                                      sticky=int(rng.choice([1, 4, 8])), every=10, ticks_per_step=cfg.get("ticks_per_step", 4))
     fl = eng.flags(); eng.close()
-    if fl.any(): return ("flagged", cfg, "0x%x" % int(np.bitwise_or.reduce(fl)))
+    if fl.any():
+        # whose limit?  (as scripts/gpu_soak.py: a cell mass above 2^31 on the REFERENCE side = its unsigned arithmetic went below zero)
+        from oracle import blob
+        und = all(any((p_["anti_team"] >= 500.0 or (p_["n_cells"] and int(p_["cell_mass"].max()) >= (1 << 31))) for p_ in blob.parse(oras[int(a)].dump())["players"]) for a in np.nonzero(fl)[0])
+        return ("reference-undefined" if und else "flagged", cfg, "0x%x" % int(np.bitwise_or.reduce(fl)))
     return ("ok", cfg, "") if ok else ("MISMATCH", cfg, msg)
 
 

@@ -9,7 +9,7 @@ from agarcl_amd import _capi
 from oracle import orabind
 from lockstep import run_batched_lockstep
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
-bad = flagged = 0
+bad = flagged = ref_undefined = 0
 by_flag = {}     # flag word -> trials that ended with it: a regression in the capacity corner shows as a changed histogram, not only as a count
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     na = int(rng.choice([1, 1, 1, 1, 2, 3]))
@@ -46,8 +46,20 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     ok, msg = run_batched_lockstep(eng, oras, 120, seeds=sd, policy_seed=ps, sticky=st, every=int(os.environ.get('SOAK_EVERY', 30)), ticks_per_step=tps)
     fl = eng.flags(); eng.close()
     if fl.any():   # an arena left the reference's unbounded containers / tables: flagged by design, not a parity failure
-        w_ = int(np.bitwise_or.reduce(fl)); by_flag[w_] = by_flag.get(w_, 0) + 1
+        w_ = int(np.bitwise_or.reduce(fl))
+        # Whose limit was it?  In every flagged arena look at the REFERENCE side (the oracle kept running): an anti-team decay rate 0.002 * 1.1^(n-1) >= 1
+        # (the player's stored 1.1^(n-1) >= 500: >= 67 viruses eaten within 3600 ticks -- a tiny arena full of viruses) makes the decay factor negative
+        # and the reference's own unsigned mass wrap to ~2^32 (Engine.hpp:550-584, Entities.hpp:199-203); from there it grows cells without bound:
+        # nothing an engine can follow.  (The wrapped cells themselves may be gone again by the checkpoint at which the flag is seen.)
+        from oracle import blob
+        und = True
+        for a in np.nonzero(fl)[0]:
+            pl = blob.parse(oras[int(a)].dump())["players"]
+            und = und and any((p_["anti_team"] >= 500.0 or (p_["n_cells"] and int(p_["cell_mass"].max()) >= (1 << 31))) for p_ in pl)
+        if und:
+            ref_undefined += 1; print("reference left its domain (wrapped cell mass) trial", trial, cfg, "flags 0x%x" % w_); continue
+        by_flag[w_] = by_flag.get(w_, 0) + 1
         flagged += 1; print("flagged (capacity) trial", trial, cfg, "flags 0x%x" % w_); continue
     if not ok:
         bad += 1; print("MISMATCH trial", trial, cfg, pins, A, msg); break
-print("soak done:", trial + 1, "trials,", bad, "bad,", flagged, "flagged", "by flag word: " + ", ".join("0x%x: %d" % kv for kv in sorted(by_flag.items())) if by_flag else "")
+print("soak done:", trial + 1, "trials,", bad, "bad,", ref_undefined, "reference-undefined,", flagged, "flagged", "by flag word: " + ", ".join("0x%x: %d" % kv for kv in sorted(by_flag.items())) if by_flag else "")
