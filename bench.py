@@ -48,6 +48,9 @@ WORKLOADS = {
     # 250x250 arena, Engine::tick at dt = 1/60 s), 4 ticks per launch
     "C1": dict(arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, dt=1.0 / 60, rand_act=True,
                desc="C1 batched: %d arenas/GPU x (1 agent + 4 bots), 250x250, 500 pellets, 10 viruses, mode 0, dt 1/60 s, 4 ticks/step"),
+    # the 32-slot several-player instantiation (k_step<32, *, *, MP = true>: more than 1024 pellets with several players; VERDICT r5 weak #1e)
+    "P5big": dict(arena_size=400, num_pellets=1500, num_viruses=10, num_bots=4, rand_act=True,
+                  desc="P5big: %d arenas/GPU x (1 agent + 4 bots), 400x400, 1500 pellets, 10 viruses, mode 0, 4 ticks/step"),
     "C1r": dict(arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, dt=1.0 / 60, rand_act=True, ram_obs=True,
                 desc="C1 batched + ram observation: %d arenas/GPU x (1 agent + 4 bots), 250x250, 500 pellets, 10 viruses, mode 0, dt 1/60 s, 4 ticks/step, f32 [A][1][152] written once per step"),
 }
