@@ -64,11 +64,12 @@ from .vec_env import PipelinedVecEnvironment, VecEnvironment, default_sub_batche
 class AgarioVectorEnv:
     metadata = {"render_modes": [], "autoreset_mode": "same_step"}
 
-    def __init__(self, num_envs, obs_type="grid", device=0, channels_last=False, sub_batches="auto", on_capacity_flag="raise", **kwargs):
+    def __init__(self, num_envs, obs_type="grid", device=0, channels_last=False, sub_batches="auto", halves=False, on_capacity_flag="raise", **kwargs):
         """num_envs arenas; obs_type "grid" | "screen" | "ram" | "gobigger" | "none"; channels_last: grid observations as a [.., G, G, C]
-        VIEW (what AgarioEnv hands out per arena) instead of the engine's channel-first layout; sub_batches: an int, or "auto" (the default) =
-        vec_env.default_sub_batches: 4 where the general engine handles most arena-steps (bots / several agents / modes 5 and 6), 1 for quiet
-        batches and for the GoBigger observation -- see the module text; on_capacity_flag: what happens to an arena that raises a capacity flag
+        VIEW (what AgarioEnv hands out per arena) instead of the engine's channel-first layout; sub_batches: an int, or "auto" (the default): ONE range for the
+        full-batch step(); with halves=True (sampling through recv(j) / send(.., j) on the ranges' own streams) vec_env.default_sub_batches -- 4
+        where the general engine handles most arena-steps (bots / several agents / modes 5 and 6), 1 for quiet batches -- see the module text
+        and the measurement beside the choice below; on_capacity_flag: what happens to an arena that raises a capacity flag
         (README "capacity flags": nearly always the reference's own arithmetic leaving its domain, e.g. the anti-team decay factor going
         negative in a tiny arena full of viruses) -- "raise" (default: the next step() raises AgarclError -6 until reset()), "reset" (the arena is
         reset inside the same step like an ended episode, its rows truncated = True: a diverged arena never feeds a learner) or "ignore"; every other
@@ -90,7 +91,14 @@ class AgarioVectorEnv:
         self.number_of_steps, self.env_type = o["number_steps"], o["env_type"]
         self.channels_last = bool(channels_last)
         if sub_batches == "auto":
-            sub_batches = 1 if obs_type == "gobigger" else default_sub_batches(self.num_envs, o["num_agents"], o["num_bots"], o["mode"])
+            # The full-batch step() orders every range against the caller's stream twice per step (fork / join) and a learner's policy sits between
+            # two steps, so the ranges restart together every step: nothing is staggered, and the ordering costs more than a range's observation
+            # kernel under another's step brings -- measured at 4096 arenas, k = 1 / 2 / 4 (scripts/gpu_vec_pipe_ab.py, profiles/r06_vec_pipe_ab.txt):
+            # mode 6 366 / 411 / 731 us per vector step, task 6 with its 128 x 128 frame 550 / 760 / 900, C1-like 119 / 234 / 416.  So "auto" is ONE
+            # range for step(); ranges pay where nothing orders them against each other -- the recv(j) / send(.., j) halves on the ranges' own streams
+            # (halves=True: "auto" is then vec_env.default_sub_batches, 4 for bots / several agents / modes 5 and 6) and free-running engine loops
+            # (PipelinedVecEnvironment; bench.py's <workload>/pipe4 rows)
+            sub_batches = default_sub_batches(self.num_envs, o["num_agents"], o["num_bots"], o["mode"]) if (halves and obs_type != "gobigger") else 1
         self.sub_batches = int(sub_batches)
         if self.sub_batches < 1 or self.sub_batches > self.num_envs:
             raise ValueError("sub_batches must be in [1, num_envs]")

@@ -915,12 +915,13 @@ def main():
                 rf = measure("task%d" % m, tcfg, A, 40, 10, ra=True, ws=True, scr=tscr, cpu_rate=cr[0], cpu_cores=cr[1], label=tdesc.replace("%%", "%") % (A, A))
                 if rf is not None:
                     tasks["task%d" % m] = by["task%d@%d" % (m, A)]
-                # ... and as AgarioVectorEnv steps it by default (vec_env.default_sub_batches: 4 ranges where the general engine does the work --
-                # modes 5 / 6, bots -- so that one range's frame kernel runs under another's step)
+                # ... and as free-running ranges (vec_env.default_sub_batches: 4 where the general engine does the work -- modes 5 / 6, bots --: one
+                # range's frame kernel runs under another's step; what the recv / send halves of AgarioVectorEnv(halves=True) and
+                # PipelinedVecEnvironment give, NOT the full-batch step(), which stays one range: scripts/gpu_vec_pipe_ab.py)
                 dsub = default_sub_batches(A, tcfg["num_agents"], tcfg["num_bots"], tcfg["mode_number"])
                 if dsub > 1:
                     measure("task%d" % m, tcfg, A, 40, 10, ra=True, ws=True, scr=tscr, sub=dsub, cpu_rate=cr[0], cpu_cores=cr[1],
-                            label=tdesc.replace("%%", "%") % (A, A) + " -- as %d sub-batches (the vector env's default)" % dsub)
+                            label=tdesc.replace("%%", "%") % (A, A) + " -- as %d free-running sub-batches" % dsub)
             roof["tasks"] = {"columns": BY_WORKLOAD_COLUMNS, "rows": tasks,
                              "what": "the reference's bench/tasks_configs/mode_{1..10}.json at %d arenas: k_step (+ k_quiet / k_fused) + k_screen_obs 128x128x4 per step" % A}
             try:   # the RL surface itself: AgarioVectorEnv.step = ONE agarcl_vec_step (step + bookkeeping / auto-reset + observation)

@@ -4,9 +4,10 @@ T steps collected into a rollout buffer -- the shape of a PPO / IMPALA actor -- 
     python examples/vector_rollout.py [--envs 4096] [--steps 256] [--obs grid|ram|screen|none] [--difficulty normal] [--mode 6] [--sub-batches auto|k [--halves]]
 
 --sub-batches k: the arenas as k independent ranges on HIP streams of their own (a range never waits for the slowest arena of another, one
-range's observation kernel runs under another's step).  The default, "auto", is what AgarioVectorEnv picks by workload
-(agarcl_amd/vec_env.py default_sub_batches): 4 where the general engine handles most arena-steps -- bots, several agents, modes 5 / 6 (try
---mode 6) --, 1 for quiet batches such as the default mode 0, where a pipelined step would cost more than the step itself.
+range's observation kernel runs under another's step).  The default, "auto", is what AgarioVectorEnv picks: ONE range for the full-batch
+step() (which orders every range against the caller's stream every step: measured slower with ranges, scripts/gpu_vec_pipe_ab.py), and with
+--halves agarcl_amd/vec_env.py default_sub_batches: 4 where the general engine handles most arena-steps -- bots, several agents, modes 5 / 6
+(try --mode 6 --halves) --, 1 for quiet batches such as the default mode 0.
 --halves: double-buffered sampling through recv(j) / send(actions_j, j) -- the policy works on range j's observations while the other ranges step.
 
 Prints env-steps per second of the whole loop (engine step + observation + Python), which is what a learner sees; `bench.py` times the
@@ -23,7 +24,7 @@ ap.add_argument("--bare", action="store_true", help="time venv.step alone: one f
 ap.add_argument("--sub-batches", default="auto", type=lambda v: v if v == "auto" else int(v)); ap.add_argument("--halves", action="store_true", help="recv / send per sub-batch instead of full-batch step()")
 ap.add_argument("--mode", type=int, default=0)
 a = ap.parse_args()
-venv = AgarioVectorEnv(a.envs, obs_type=a.obs, difficulty=a.difficulty, number_steps=a.number_steps, env_type=0, sub_batches=a.sub_batches, mode=a.mode,
+venv = AgarioVectorEnv(a.envs, obs_type=a.obs, difficulty=a.difficulty, number_steps=a.number_steps, env_type=0, sub_batches=a.sub_batches, halves=a.halves, mode=a.mode,
                        **({"num_viruses": 25} if a.mode else {}))
 dev = venv.device
 obs, _ = venv.reset(seed=1)
