@@ -171,7 +171,12 @@ extern __shared__ __align__(16) unsigned char ag_lds[];
 // compiler spills ~290 rarely-live registers to scratch) is 1.32x faster, 3 waves 1.11x, 5 waves same as 4, 6 and 8 slower;
 // the quiet-dominated C2 step is unaffected (it runs in k_quiet).
 #ifndef AG_KSTEP_ATTR
-#define AG_KSTEP_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+// (the 32-slot several-player instantiation -- more than 1024 pellets with several players -- gets the registers of 2 wavefronts per SIMD: at 128 it
+// kept 1.5-4 KB per lane in scratch (1096 spilled registers) and a 1500-pellet five-player step took 1354 us; round 6)
+#ifndef AG_K32_SINGLE
+#define AG_K32_SINGLE false   // (measurement switch: the single-player 32-slot instantiation, 420-440 bytes of scratch at 128 registers, at 2 wavefronts per SIMD as well)
+#endif
+#define AG_KSTEP_ATTR __attribute__((amdgpu_waves_per_eu((NS == 32 && (MP || AG_K32_SINGLE)) ? 2 : 4, (NS == 32 && (MP || AG_K32_SINGLE)) ? 2 : 4)))
 #endif
 #define AG_KERNEL_PROLOGUE AgCtx<NS, AV> c; ag_ctx_init(c, gs, (int)blockIdx.x, ag_lds, act_dxdy, act);
 // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), and the per-arena word arrays are tile-transposed

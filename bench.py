@@ -51,6 +51,9 @@ WORKLOADS = {
     # the 32-slot several-player instantiation (k_step<32, *, *, MP = true>: more than 1024 pellets with several players; VERDICT r5 weak #1e)
     "P5big": dict(arena_size=400, num_pellets=1500, num_viruses=10, num_bots=4, rand_act=True,
                   desc="P5big: %d arenas/GPU x (1 agent + 4 bots), 400x400, 1500 pellets, 10 viruses, mode 0, 4 ticks/step"),
+    # ... and the single-player one (more than 1024 pellets under a mass-1000 agent)
+    "C3m6big": dict(num_pellets=1500, num_viruses=25, mode_number=6, rand_act=True,
+                    desc="C3m6big: %d arenas/GPU x 1 agent (mass 1000), 1000x1000, 1500 pellets, 25 viruses, mode 6, 4 ticks/step"),
     "C1r": dict(arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, dt=1.0 / 60, rand_act=True, ram_obs=True,
                 desc="C1 batched + ram observation: %d arenas/GPU x (1 agent + 4 bots), 250x250, 500 pellets, 10 viruses, mode 0, dt 1/60 s, 4 ticks/step, f32 [A][1][152] written once per step"),
 }

@@ -223,3 +223,34 @@ def test_rollout_example_runs(hip_engine_cls):
                           "--sub-batches", "2", "--halves", "--mode", "6"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "as 2 ranges (recv / send halves)" in out.stdout, out.stderr[-2000:]
     assert int(out.stdout.strip().splitlines()[-1].split(";")[1].split()[0]) >= 96      # every arena ended at least once
+
+
+@pytest.mark.gpu
+def test_vector_env_defaults_and_flagged_arenas_gpu(hip_engine_cls):
+    """(1) sub_batches="auto": ONE range for the full-batch step() whatever the workload, vec_env.default_sub_batches with halves=True (round 6: the
+    measurement beside the choice in vector_env.py).  (2) on_capacity_flag="reset": an arena that raises a capacity flag (two food slots, an agent that
+    keeps ejecting) is cut inside the step like an ended episode -- truncated, not terminated, its flag gone -- where the default raises."""
+    import torch
+    from agarcl_amd import _capi
+    from agarcl_amd.vector_env import AgarioVectorEnv
+    v = AgarioVectorEnv(1024, obs_type="none", mode=6, num_viruses=5); assert v.sub_batches == 1 and v.pipe is None; v.close()
+    v = AgarioVectorEnv(1024, obs_type="none", mode=6, num_viruses=5, halves=True); assert v.sub_batches == 4 and len(v.ranges) == 4; v.close()
+    v = AgarioVectorEnv(1024, obs_type="none", mode=0, halves=True); assert v.sub_batches == 1; v.close()
+    N = 64
+    kw = dict(obs_type="none", arena_size=120, num_pellets=100, num_viruses=0, mode=6, cap_foods=2, number_steps=100000)
+    move = torch.zeros((N, 2), device="cuda"); move[:, 0] = 1.0; feed = torch.ones(N, dtype=torch.int32, device="cuda")
+    v = AgarioVectorEnv(N, on_capacity_flag="reset", **kw); v.reset(seed=5)
+    cut = 0
+    for t in range(40):
+        obs, rew, term, trunc, info = v.step((move, feed))
+        torch.cuda.synchronize()
+        assert not bool(term.any()) and torch.equal(trunc, info["ended"])
+        cut += int(info["ended"].sum())
+        assert not v._parts[0].engine.flags().any(), "a flagged arena survived the step"
+    assert cut >= N // 2, cut
+    v.close()
+    v = AgarioVectorEnv(N, **kw); v.reset(seed=5)          # the default: the watch raises (asynchronously: within ~64 steps)
+    with pytest.raises(_capi.AgarclError):
+        for t in range(200):
+            v.step((move, feed))
+    v.close()
