@@ -171,12 +171,23 @@ extern __shared__ __align__(16) unsigned char ag_lds[];
 // compiler spills ~290 rarely-live registers to scratch) is 1.32x faster, 3 waves 1.11x, 5 waves same as 4, 6 and 8 slower;
 // the quiet-dominated C2 step is unaffected (it runs in k_quiet).
 #ifndef AG_KSTEP_ATTR
-// (the 32-slot several-player instantiation -- more than 1024 pellets with several players -- gets the registers of 2 wavefronts per SIMD: at 128 it
-// kept 1.5-4 KB per lane in scratch (1096 spilled registers) and a 1500-pellet five-player step took 1354 us; round 6)
+// Register budgets by instantiation (round 6, scripts/gpu_config_sweep.py): the several-player kernels with 16 or 32 pellet slots do not fit 128
+// registers -- 100-800 bytes of scratch per lane with 16 slots, 1.5-4 KB with 32 (1096 spilled registers) -- and scratch is what their step then costs:
+// agent + 3 bots in an 1100 x 1100 arena (16 slots, pellet grid larger than 2 x 2) 432 us per step at 4 wavefronts per SIMD, 135 us at 3; agent + 4 bots
+// with 1500 pellets (32 slots) 1155 us at 4, 143 us at 2.  Several players hold 12-58 KB of LDS per arena anyway, so the wave slots given up were
+// mostly not there to lose.  Up to 8 slots (C1, the paper's tasks: 0-12 bytes of scratch) and the single-player kernels keep 4 (the single-player
+// 32-slot form at 2: 397 -> 509 us).
 #ifndef AG_K32_SINGLE
-#define AG_K32_SINGLE false   // (measurement switch: the single-player 32-slot instantiation, 420-440 bytes of scratch at 128 registers, at 2 wavefronts per SIMD as well)
+#define AG_K32_SINGLE false   // (measurement switch: the single-player 32-slot instantiation at 2 wavefronts per SIMD as well)
 #endif
-#define AG_KSTEP_ATTR __attribute__((amdgpu_waves_per_eu((NS == 32 && (MP || AG_K32_SINGLE)) ? 2 : 4, (NS == 32 && (MP || AG_K32_SINGLE)) ? 2 : 4)))
+#ifndef AG_K32MP_WAVES
+#define AG_K32MP_WAVES 2
+#endif
+#ifndef AG_K16MP_WAVES
+#define AG_K16MP_WAVES 3
+#endif
+#define AG_KSTEP_WAVES ((NS == 32 && MP) ? AG_K32MP_WAVES : (NS == 32 && AG_K32_SINGLE) ? 2 : (NS == 16 && MP) ? AG_K16MP_WAVES : 4)
+#define AG_KSTEP_ATTR __attribute__((amdgpu_waves_per_eu(AG_KSTEP_WAVES, AG_KSTEP_WAVES)))
 #endif
 #define AG_KERNEL_PROLOGUE AgCtx<NS, AV> c; ag_ctx_init(c, gs, (int)blockIdx.x, ag_lds, act_dxdy, act);
 // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), and the per-arena word arrays are tile-transposed

@@ -2,6 +2,7 @@
 kinds), bench/main.cpp's Tick/N populations.  python scripts/gpu_phase_multi.py"""
 import sys, time, ctypes as C
 sys.path.insert(0, '.')
+import os
 import numpy as np
 from agarcl_amd import _capi
 lib = _capi.bind(C.CDLL('build_variants/lib_PROF.so'))
@@ -29,6 +30,11 @@ def run(tag, A, K=60, ticks=4, tick_only=False, **cfg):
     for n, v in zip(names, per): print('   %-22s %8.0f  %5.1f%%' % (n, v, 100 * v / per.sum()))
     print('   mean counts (pellets, viruses, foods, cells):', eng.counts().mean(axis=0))
     eng.close()
+if os.environ.get('PHASE_BIG'):   # round 6: the configurations scripts/gpu_config_sweep.py found slow
+    run('normal + 25 bots', 4096, K=20, num_agents=1, arena_size=1000, num_pellets=1000, num_viruses=0, num_bots=25, mode=0)
+    run('3 agents mode 6', 4096, K=20, num_agents=3, arena_size=1000, num_pellets=1000, num_viruses=25, mode=6)
+    run('normal + 4 bots', 4096, K=40, num_agents=1, arena_size=1000, num_pellets=1000, num_viruses=0, num_bots=4, mode=0)
+    sys.exit(0)
 run('C1', 4096, num_agents=1, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4, mode=0, dt=1.0 / 60)
 run('Tick/10', 4096, tick_only=True, num_agents=0, arena_size=250, num_pellets=500, num_viruses=10, mode=0, dt=1.0 / 60, example_bots=10)
 run('Tick/30', 4096, tick_only=True, num_agents=0, arena_size=250, num_pellets=500, num_viruses=10, mode=0, dt=1.0 / 60, example_bots=30)
