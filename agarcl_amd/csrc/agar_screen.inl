@@ -443,11 +443,14 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
       unsigned long long hits;
       { const int r0_ = (int)(by_ & 0xFFFFu), r1_ = (int)(by_ >> 16);
         hits = __ballot(in_ && (int)(bx_ & 0xFFFFu) <= (int)(bx_ >> 16) && (r0_ < row0 ? row0 : r0_) <= (r1_ > rlast ? rlast : r1_)); }
-      if (AGV && __popcll(hits) >= 5) {
+      if (__popcll(hits) >= 5) {
         // Many hits in one batch -- a line of pellets across the view (tasks 1 and 2 lay 350 of them along a square, one unit apart), a cloud of
-        // ejected food: when they all paint the same word and their boxes are small, the ORDER among them is immaterial, and every lane paints its own
-        // entity, <= 6 x 6 pixels, while the others paint theirs (one wavefront-wide loop instead of one tile pass per entity).  Tight box: the stored
-        // one without its margins (floor(low end) .. floor(high end) + 1 still contains every pixel the inside test can accept).
+        // ejected food: when their boxes are small every lane paints its own entity, <= 6 x 6 pixels, while the others paint theirs (one
+        // wavefront-wide loop instead of one tile pass per entity).  Tight box: the stored one without its margins (floor(low end) .. floor(high end)
+        // + 1 still contains every pixel the inside test can accept).  Agent view: the hits must all paint the same word -- then the ORDER among them
+        // is immaterial, plain stores.  Plain frame: colours differ by id, the latest draw must win a pixel two entities cover -- the alpha byte, which
+        // a three-channel frame never outputs, carries the lane: a first pass clears it on every covered pixel, a second pass takes the maximum of
+        // (lane + 1) << 24 | colour, which is the highest lane's, i.e. the latest entity's, word.
         const bool mine = (hits >> lane) & 1ull;
         const unsigned e0 = (unsigned)__builtin_amdgcn_readlane((int)e_, (int)__builtin_ctzll(hits));
         const int c0s = (int)(bx_ & 0xFFFFu), c1s = (int)(bx_ >> 16), r0s = (int)(by_ & 0xFFFFu), r1s = (int)(by_ >> 16);
@@ -455,24 +458,47 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
         int r0 = r0s == 0 ? 0 : r0s + 1, r1 = r1s == o.H - 1 ? r1s : r1s - 1;
         r0 = r0 < row0 ? row0 : r0; r1 = r1 > rlast ? rlast : r1;
         const int bw = c1 - c0 + 1, bh = r1 - r0 + 1;
-        if (__ballot(mine && (e_ != e0 || bw > 6 || bh > 6)) == 0ull) {
-          const int ns = (int)(e0 >> 24); const float apo = r_ * scr_cos_half_step(ns); const unsigned paint = scr_paint_word<AGV>(e0);
-          unsigned marks = 0u;   // the band's 64-pixel chunks this lane's entity can touch, row by row (a band has <= 16 chunks)
-          const bool is255 = (e0 & 0xFFFFFFu) > 230u;
+        const bool alike = AGV ? e_ == e0 : (e_ >> 24) == (e0 >> 24);   // (the polygon's side count is wave-uniform in the inside test)
+        if (__ballot(mine && (!alike || bw > 6 || bh > 6)) == 0ull) {
+          const int ns = (int)(e0 >> 24); const float apo = r_ * scr_cos_half_step(ns);
           float cx[6];
 #pragma unroll
           for (int dx = 0; dx < 6; dx++) cx[dx] = colx[(mine && dx < bw) ? c0 + dx : 0] - x_;
+          if (AGV) {
+            const unsigned paint = scr_paint_word<AGV>(e0);
+            unsigned marks = 0u;   // the band's 64-pixel chunks this lane's entity can touch, row by row (a band has <= 16 chunks)
+            const bool is255 = (e0 & 0xFFFFFFu) > 230u;
 #pragma unroll
-          for (int dy = 0; dy < 6; dy++) {
-            if (__ballot(mine && dy < bh) == 0ull) break;
-            const bool rowok = mine && dy < bh; const float yy = rowy[rowok ? r0 + dy : 0] - y_; const int rb = (r0 + dy - row0) * o.W + c0;
-            if (is255 && rowok && bw > 0) { const int lo_ = rb >> 6, hi_ = (rb + bw - 1) >> 6; marks |= ((2u << (hi_ - lo_)) - 1u) << lo_; }
+            for (int dy = 0; dy < 6; dy++) {
+              if (__ballot(mine && dy < bh) == 0ull) break;
+              const bool rowok = mine && dy < bh; const float yy = rowy[rowok ? r0 + dy : 0] - y_; const int rb = (r0 + dy - row0) * o.W + c0;
+              if (is255 && rowok && bw > 0) { const int lo_ = rb >> 6, hi_ = (rb + bw - 1) >> 6; marks |= ((2u << (hi_ - lo_)) - 1u) << lo_; }
 #pragma unroll
-            for (int dx = 0; dx < 6; dx++) if (rowok && dx < bw && scr_inside_apo(cx[dx], yy, r_, apo, ns)) fb[rb + dx] = paint;
-          }
-          if (is255) {
-            for (int sft = 32; sft; sft >>= 1) marks |= (unsigned)__shfl_xor((int)marks, sft, 64);
-            chunks255 |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)marks);
+              for (int dx = 0; dx < 6; dx++) if (rowok && dx < bw && scr_inside_apo(cx[dx], yy, r_, apo, ns)) fb[rb + dx] = paint;
+            }
+            if (is255) {
+              for (int sft = 32; sft; sft >>= 1) marks |= (unsigned)__shfl_xor((int)marks, sft, 64);
+              chunks255 |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)marks);
+            }
+          } else {
+            unsigned long long cover = 0ull;   // bit dy * 6 + dx: this lane's entity covers that pixel of its box
+#pragma unroll
+            for (int dy = 0; dy < 6; dy++) {
+              if (__ballot(mine && dy < bh) == 0ull) break;
+              const bool rowok = mine && dy < bh; const float yy = rowy[rowok ? r0 + dy : 0] - y_; const int rb = (r0 + dy - row0) * o.W + c0;
+#pragma unroll
+              for (int dx = 0; dx < 6; dx++) if (rowok && dx < bw && scr_inside_apo(cx[dx], yy, r_, apo, ns)) { cover |= 1ull << (dy * 6 + dx); atomicAnd(&fb[rb + dx], 0x00FFFFFFu); }
+            }
+            ag_lds_order();
+            const unsigned word = ((unsigned)(lane + 1) << 24) | (e_ & 0xFFFFFFu);
+#pragma unroll
+            for (int dy = 0; dy < 6; dy++) {
+              if (__ballot((cover >> (dy * 6)) & 63ull) == 0ull) continue;
+              const int rb = (r0 + dy - row0) * o.W + c0;
+#pragma unroll
+              for (int dx = 0; dx < 6; dx++) if ((cover >> (dy * 6 + dx)) & 1ull) atomicMax(&fb[rb + dx], word);
+            }
+            ag_lds_order();
           }
           hits = 0ull;
         }

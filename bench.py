@@ -473,6 +473,11 @@ def obs_bytes(res, A, cfg, with_obs, with_screen, with_ram, screen=(84, 84, Fals
         n_pel, n_vir, n_food, n_cells = res["counts"]
         vis = min(1.0, (300.0 / cfg["arena_size"]) ** 2)
         extra = A * (512.0 + 16.0 * (vis * 2 * (n_pel + n_vir) + 3 * n_cells))
+    if with_ram:
+        # k_ram_obs reads every live entity once to pick the K nearest (the pellets are not in registers there): those reads are what it requests
+        # (round 5 counted only the 608 bytes it writes and then read "2.17 x requested" off the PMC counters)
+        n_pel, n_vir, n_food, n_cells = res["counts"]
+        extra = model_extra + A * cfg["num_agents"] * (8.0 * n_pel + 12.0 * n_vir + 12.0 * n_cells)
     kernel = None
     if with_obs: kernel = "k_step + k_grid_obs (persistent tensor: incremental clear)"
     if with_screen: kernel = "k_step + k_screen_obs"
