@@ -443,7 +443,10 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
       unsigned long long hits;
       { const int r0_ = (int)(by_ & 0xFFFFu), r1_ = (int)(by_ >> 16);
         hits = __ballot(in_ && (int)(bx_ & 0xFFFFu) <= (int)(bx_ >> 16) && (r0_ < row0 ? row0 : r0_) <= (r1_ > rlast ? rlast : r1_)); }
-      if (__popcll(hits) >= 5) {
+#ifndef AG_SCR_LANE_MIN
+#define AG_SCR_LANE_MIN 3   // (hits of one batch from which the lane-parallel form pays: 2 / 3 / 5 / 8 measured -- task 3 128 x 128 x 4 129 / 128 / 132 / 136 us, task 6 197 / 197 / 198 / 208)
+#endif
+      if (__popcll(hits) >= AG_SCR_LANE_MIN) {
         // Many hits in one batch -- a line of pellets across the view (tasks 1 and 2 lay 350 of them along a square, one unit apart), a cloud of
         // ejected food: when their boxes are small every lane paints its own entity, <= 6 x 6 pixels, while the others paint theirs (one
         // wavefront-wide loop instead of one tile pass per entity).  Tight box: the stored one without its margins (floor(low end) .. floor(high end)
