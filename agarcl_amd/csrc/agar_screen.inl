@@ -37,7 +37,7 @@
 
 struct AgScreenCfg { int W, H, agent_view;   // agent_view: the 4-channel frame of Renderer::multi_channel_render_screen
 #ifdef AG_SCR_ABL   // measurement builds only (build.py --variant SCRABL -DAG_SCR_ABL): AGARCL_SCR_ABL=<bits> switches parts of k_screen_obs off
-  int abl;          // 1 no entity list, 2 no painting, 4 no post-processing pass, 8 no global stores, 16 no background fill
+  int abl;          // 1 no entity list, 2 no painting, 4 no post-processing pass, 8 no global stores, 16 no background fill, 32 return at once
 #endif
 };
 #ifdef AG_SCR_ABL
@@ -230,7 +230,7 @@ __device__ __forceinline__ void scr_box(float x, float y, float r, float px, flo
 template <bool AGV> __device__ __forceinline__ unsigned scr_paint_word(unsigned e) {
   return (AGV && (e & 0xFFFFFFu) <= 230u) ? ((e & 0xFFu) << 24) : ((e & 0xFFFFFFu) | 0xFF000000u);
 }
-template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) k_screen_obs(const AgState *__restrict__ gs, AgScreenCfg o, uint8_t *out) {
+template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TAB > 256 ? 4 : 5, TAB > 256 ? 4 : 5))) k_screen_obs(const AgState *__restrict__ gs, AgScreenCfg o, uint8_t *out) {
   constexpr int WB = TAB > 256 ? 1024 : AG_SCR_WBAND;   // (a band holds at least one row)
   constexpr int CH = AGV ? 4 : 3;
   constexpr unsigned GRIDV = AGV ? 0x1A000000u : 0xFF00001Au, BACKV = AGV ? 0u : 0x00FFFFFFu;   // (0.1, 0, 0) -> 26; alpha byte: a fragment was written
@@ -242,6 +242,7 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
   __shared__ float colx[TAB], rowy[TAB];                     // world coordinate of every pixel column's / row's centre
   __shared__ int wcnt[8];                                    // [0..3] pellets listed by wavefront w, [4] foods, [5] the whole list
   __shared__ unsigned pp_last[4][2]; __shared__ int pp_done[4];   // agent view: a wavefront's last two FINAL pixels, and that they are there
+  if (SCR_ABL(32)) { if (threadIdx.x == 0) fbw[0][0] = 1u; return; }   // (measurement: the launch alone -- workgroups, LDS, registers -- without a load)
   const int na = gs->d.n_agents, arena = (int)blockIdx.x / na, agent = (int)blockIdx.x % na, P = gs->d.P;
   const int tid = (int)threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const unsigned long long lt = (1ull << lane) - 1ull;
