@@ -13,7 +13,10 @@ CASES = (("mode 6, 1000x1000, 25 viruses, no obs", dict(obs_type="none", mode=6,
          ("task 10 (1 bot, mode 10, 128x128x4 agent view)", dict(obs_type="screen", screen_len=128, agent_view=True, mode=10, arena_size=350, num_pellets=500, num_viruses=0, num_bots=1)),
          ("C1-like (4 bots, 250x250, no obs)", dict(obs_type="none", mode=0, arena_size=250, num_pellets=500, num_viruses=10, num_bots=4)),
          ("task 3 (quiet, 128x128x4 agent view)", dict(obs_type="screen", screen_len=128, agent_view=True, mode=3, arena_size=350, num_pellets=500, num_viruses=0)))
-for name, kw in CASES:
+side = torch.cuda.Stream() if "--stream" in sys.argv else None      # --stream: the sampling loop on a stream of its own instead of the legacy default stream
+if side is not None:
+    torch.cuda.set_stream(side)
+for name, kw in CASES[:2] + CASES[3:4] if "--short" in sys.argv else CASES:
     row = []
     for k in (1, 2, 4):
         venv = AgarioVectorEnv(A, sub_batches=k, strict_flags=False, number_steps=100000, **kw)
@@ -27,6 +30,6 @@ for name, kw in CASES:
         for _ in range(100):
             a = policy(); h0 = time.perf_counter(); venv.step(a); host += time.perf_counter() - h0
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        row.append("k=%d: %6.1f us (host %5.1f)" % (k, dt / 100 * 1e6, host / 100 * 1e6))
+        row.append("k=%d (%d concurrent): %6.1f us (host %5.1f)" % (k, venv.concurrent_sub_batches, dt / 100 * 1e6, host / 100 * 1e6))
         venv.close()
     print("%-62s %s" % (name, "   ".join(row)), flush=True)
