@@ -88,6 +88,7 @@ SYMBOLS = [
     ("agarcl_pipe_create", C.c_int, [C.POINTER(Config), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     ("agarcl_pipe_destroy", C.c_int, [C.c_void_p]),
     ("agarcl_pipe_sub_batches", C.c_int, [C.c_void_p]),
+    ("agarcl_pipe_spin_timeouts", C.c_int, [C.c_void_p]),
     ("agarcl_pipe_env", C.c_void_p, [C.c_void_p, C.c_int32]),
     ("agarcl_pipe_range", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("agarcl_pipe_seed", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
@@ -471,6 +472,10 @@ class PipelinedEngine:
     def join(self, consumer_stream):
         """`consumer_stream` waits, on the device, for everything every sub-batch has enqueued so far: one call"""
         self._chk(self.L.agarcl_pipe_join(self.p, C.c_void_p(int(consumer_stream))))
+
+    def spin_timeouts(self):
+        """diagnostics: 1 if a spin of the flag-word fork / join ever ran into its time bound (synchronises the pipe)"""
+        return int(self.L.agarcl_pipe_spin_timeouts(self.p))
 
     def close(self):
         if getattr(self, "p", None) and self.p.value:

@@ -1575,7 +1575,9 @@ extern "C" int agarcl_vec_step(agarcl_env *e, const agarcl_vec_spec *sp, const a
 }
 
 // ---- sub-batch pipelining (include/agarcl_batch.h) ------------------------------------------------------------------------------------
-struct agarcl_pipe { std::vector<agarcl_env *> envs; std::vector<int32_t> first; int32_t A; int device; int concurrent; void *fork_ev; };
+struct agarcl_pipe { std::vector<agarcl_env *> envs; std::vector<int32_t> first; int32_t A; int device; int concurrent; void *fork_ev;
+  // fork / join through flag words in HBM instead of HIP events (see agarcl_pipe_fork): [0] the fork's epoch, [1 + j] sub-batch j's join epoch, [65] a spin ran into its time bound
+  int32_t *d_sync; int32_t epoch; void *spin_for; bool spin_ok, spin_off; };
 #ifndef AGAR_CPU_EMU
 // Do two streams execute concurrently?  The runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) and two
 // streams that share a queue run one after the other whatever the API says -- measured on MI355X: two 2048-arena sub-batches on streams that
@@ -1601,6 +1603,7 @@ extern "C" int agarcl_pipe_destroy(agarcl_pipe *p) {
   if (!p) return AGARCL_OK;
 #ifndef AGAR_CPU_EMU
   if (p->fork_ev) (void)hipEventDestroy((hipEvent_t)p->fork_ev);
+  if (p->d_sync) { for (agarcl_env *e : p->envs) (void)hipStreamSynchronize(e->stream); (void)hipFree(p->d_sync); }
 #endif
   for (agarcl_env *e : p->envs) agarcl_destroy(e);
   delete p;
@@ -1609,6 +1612,7 @@ extern "C" int agarcl_pipe_destroy(agarcl_pipe *p) {
 extern "C" int agarcl_pipe_create(const agarcl_config *cfg, int32_t num_arenas, int32_t sub_batches, int32_t device, agarcl_pipe **out) {
   if (!cfg || !out || num_arenas <= 0 || sub_batches < 1 || sub_batches > num_arenas || sub_batches > 64) return fail(AGARCL_E_INVALID, "agarcl_pipe_create: bad arguments (1 <= sub_batches <= min(num_arenas, 64))");
   agarcl_pipe *p = new agarcl_pipe(); p->A = num_arenas; p->device = device; p->concurrent = 1; p->fork_ev = nullptr;
+  p->d_sync = nullptr; p->epoch = 0; p->spin_for = nullptr; p->spin_ok = false; { const char *pe = getenv("AGARCL_PIPE_EVENTS"); p->spin_off = pe && pe[0] == '1'; }
   const int32_t base = num_arenas / sub_batches, rem = num_arenas % sub_batches;   // contiguous ranges, the first ones take the remainder (agarcl_amd/dist.py shard_bounds)
   for (int32_t j = 0; j < sub_batches; j++) {
     const int32_t lo = j * base + (j < rem ? j : rem), n = base + (j < rem ? 1 : 0);
@@ -1665,10 +1669,47 @@ extern "C" int agarcl_pipe_seed(agarcl_pipe *p, const uint32_t *seeds_host, uint
   return AGARCL_OK;
 }
 extern "C" int agarcl_pipe_concurrent(agarcl_pipe *p) { return p ? p->concurrent : 0; }
+#ifndef AGAR_CPU_EMU
+// Ordering the sub-batches against the caller's stream with HIP events costs ~40 us of device-side latency per hand-over on this stack (r05: fork + join
+// around a 10 us step took 170 us; round 6, k = 4: a mode-6 vector step 366 -> 731 us), which is why the full-batch step() of a pipelined env lost to
+// the lock-step one.  The same ordering through flag words: the producer's stream runs a one-lane kernel that publishes an epoch, every consumer stream
+// starts with a one-lane kernel that spins until it sees it.  Kernels of one stream run in order and a kernel's end releases what it wrote, so what
+// comes behind the spin sees what came in front of the flag.  A spinning kernel must never sit in front of the kernel it waits for in the SAME hardware
+// queue: the caller's stream is verified once to run beside every sub-batch stream (as the sub-batch streams were verified against each other);
+// otherwise, or with AGARCL_PIPE_EVENTS=1, events are used.  Every spin is bounded (200 ms): a time-out sets a word that the next call reports.
+__global__ void k_flag_set(int32_t *w, int32_t v) { __hip_atomic_store((AG_GLOBAL int32_t *)w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ void k_flag_wait(const int32_t *w, int n, int32_t v, int32_t *err) {   // lane i < n waits for w[i] to reach v (wrap-safe)
+  const int i = (int)threadIdx.x;
+  if (i < n) {
+    const long long t0 = (long long)wall_clock64();
+    while ((int32_t)(__hip_atomic_load((const AG_GLOBAL int32_t *)w + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - v) < 0) {
+      if ((long long)wall_clock64() - t0 > 20000000LL) { (void)__hip_atomic_fetch_or((AG_GLOBAL int32_t *)err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+}
+static bool pipe_spin_ready(agarcl_pipe *p, hipStream_t caller) {
+  if (p->spin_off) return false;
+  if (p->spin_for == (void *)caller && p->d_sync) return p->spin_ok;
+  if (!p->d_sync) { if (hipMalloc((void **)&p->d_sync, 66 * 4) != hipSuccess) { p->spin_off = true; return false; } (void)hipMemset(p->d_sync, 0, 66 * 4); }
+  int *d_two = nullptr; bool ok = hipMalloc((void **)&d_two, 8) == hipSuccess;
+  for (size_t j = 0; ok && j < p->envs.size(); j++) ok = p->envs[j]->stream != caller && streams_concurrent(caller, p->envs[j]->stream, d_two) == 1;
+  if (d_two) (void)hipFree(d_two);
+  p->spin_for = (void *)caller; p->spin_ok = ok;
+  return ok;
+}
+#endif
 extern "C" int agarcl_pipe_fork(agarcl_pipe *p, void *producer_stream) {
   if (!p) return fail(AGARCL_E_INVALID, "null pipe");
 #ifndef AGAR_CPU_EMU
   HIPCHK(hipSetDevice(p->device));
+  if (p->envs.size() <= 64 && pipe_spin_ready(p, (hipStream_t)producer_stream)) {
+    p->epoch += 1;
+    hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(1), 0, (hipStream_t)producer_stream, p->d_sync, p->epoch);
+    for (agarcl_env *e : p->envs) hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(1), 0, e->stream, (const int32_t *)p->d_sync, 1, p->epoch, p->d_sync + 65);
+    HIPCHK(hipGetLastError());
+    return AGARCL_OK;
+  }
   if (!p->fork_ev) { hipEvent_t ev = nullptr; HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence)); p->fork_ev = (void *)ev; }
   HIPCHK(hipEventRecord((hipEvent_t)p->fork_ev, (hipStream_t)producer_stream));
   for (agarcl_env *e : p->envs) if (e->stream != (hipStream_t)producer_stream) HIPCHK(hipStreamWaitEvent(e->stream, (hipEvent_t)p->fork_ev, 0));
@@ -1679,8 +1720,33 @@ extern "C" int agarcl_pipe_fork(agarcl_pipe *p, void *producer_stream) {
 }
 extern "C" int agarcl_pipe_join(agarcl_pipe *p, void *consumer_stream) {
   if (!p) return fail(AGARCL_E_INVALID, "null pipe");
+#ifndef AGAR_CPU_EMU
+  HIPCHK(hipSetDevice(p->device));
+  if (p->envs.size() <= 64 && pipe_spin_ready(p, (hipStream_t)consumer_stream)) {
+    // (the join's epoch is the last fork's: a join without a fork in front of it -- after a reset -- takes a fresh one)
+    p->epoch += 1;
+    for (size_t j = 0; j < p->envs.size(); j++) hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(1), 0, p->envs[j]->stream, p->d_sync + 1 + j, p->epoch);
+    hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, (hipStream_t)consumer_stream, (const int32_t *)(p->d_sync + 1), (int)p->envs.size(), p->epoch, p->d_sync + 65);
+    HIPCHK(hipGetLastError());
+    return AGARCL_OK;
+  }
+#endif
   for (agarcl_env *e : p->envs) { const int rc = agarcl_stream_signal(e, consumer_stream); if (rc) return rc; }
   return AGARCL_OK;
+}
+// 1 if a spin of the flag-word fork / join ever ran into its time bound (an ordering that was NOT enforced: a bug or two streams of one hardware queue
+// after all), else 0; synchronises the pipe (diagnostics / tests)
+extern "C" int agarcl_pipe_spin_timeouts(agarcl_pipe *p) {
+  if (!p) return -1;
+#ifndef AGAR_CPU_EMU
+  if (!p->d_sync) return 0;
+  for (agarcl_env *e : p->envs) (void)hipStreamSynchronize(e->stream);
+  int32_t w = 0;
+  if (hipMemcpy(&w, p->d_sync + 65, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return w != 0;
+#else
+  return 0;
+#endif
 }
 extern "C" int agarcl_pipe_sync(agarcl_pipe *p) {
   if (!p) return fail(AGARCL_E_INVALID, "null pipe");

@@ -92,12 +92,12 @@ class AgarioVectorEnv:
         self.channels_last = bool(channels_last)
         if sub_batches == "auto":
             # The full-batch step() orders every range against the caller's stream twice per step (fork / join) and a learner's policy sits between
-            # two steps, so the ranges restart together every step: nothing is staggered, and the ordering costs more than a range's observation
-            # kernel under another's step brings -- measured at 4096 arenas, k = 1 / 2 / 4 (scripts/gpu_vec_pipe_ab.py, profiles/r06_vec_pipe_ab.txt):
-            # mode 6 366 / 411 / 731 us per vector step, task 6 with its 128 x 128 frame 550 / 760 / 900, C1-like 119 / 234 / 416.  So "auto" is ONE
-            # range for step(); ranges pay where nothing orders them against each other -- the recv(j) / send(.., j) halves on the ranges' own streams
-            # (halves=True: "auto" is then vec_env.default_sub_batches, 4 for bots / several agents / modes 5 and 6) and free-running engine loops
-            # (PipelinedVecEnvironment; bench.py's <workload>/pipe4 rows)
+            # two steps, so the ranges restart together every step: nothing is staggered.  Measured at 4096 arenas, k = 1 / 2 / 4
+            # (scripts/gpu_vec_pipe_ab.py, profiles/r06_vec_pipe_ab.txt), with the flag-word fork / join of round 6 (HIP events in brackets): mode 6
+            # 366 / 370 / 554 us per vector step (411 / 731), mode 6 + 84 x 84 screen 450 / 591 / 666 (599 / 919), task 6 with its 128 x 128 frame
+            # 548 / 625 / 611 (760 / 900).  So "auto" is ONE range for step(); ranges pay where nothing orders them against each other -- the recv(j) /
+            # send(.., j) halves on the ranges' own streams (halves=True: "auto" is then vec_env.default_sub_batches, 4 for bots / several agents /
+            # modes 5 and 6) and free-running engine loops (PipelinedVecEnvironment; bench.py's <workload>/pipe4 rows)
             sub_batches = default_sub_batches(self.num_envs, o["num_agents"], o["num_bots"], o["mode"]) if (halves and obs_type != "gobigger") else 1
         self.sub_batches = int(sub_batches)
         if self.sub_batches < 1 or self.sub_batches > self.num_envs:

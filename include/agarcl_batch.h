@@ -269,10 +269,15 @@ int agarcl_pipe_seed(agarcl_pipe *pipe, const uint32_t *seeds_host, uint32_t bas
 int agarcl_pipe_concurrent(agarcl_pipe *pipe);
 /* waits for every sub-batch's stream (the reference's single pool.wait()) */
 int agarcl_pipe_sync(agarcl_pipe *pipe);
-/* agarcl_stream_wait for all sub-batches at once: ONE event recorded on `producer_stream`, every sub-batch's stream waits for it (device-side) */
+/* agarcl_stream_wait for all sub-batches at once: everything enqueued so far on `producer_stream` happens before whatever the sub-batches enqueue from
+ * now on (device-side).  Through a flag word in HBM -- a one-lane kernel on the producer's stream publishes an epoch, a one-lane kernel at the head of
+ * every sub-batch's stream spins until it sees it -- when the producer's stream was verified to run beside every sub-batch stream; through one HIP event
+ * otherwise (or with AGARCL_PIPE_EVENTS=1): ~40 us of device-side latency per hand-over on this stack, which is what the flag words avoid */
 int agarcl_pipe_fork(agarcl_pipe *pipe, void *producer_stream);
 /* agarcl_stream_signal for all sub-batches at once: `consumer_stream` waits (device-side) for everything every sub-batch has enqueued so far */
 int agarcl_pipe_join(agarcl_pipe *pipe, void *consumer_stream);
+/* diagnostics: 1 if a spin of the flag-word fork / join ever ran into its 200 ms bound (synchronises the pipe) */
+int agarcl_pipe_spin_timeouts(agarcl_pipe *pipe);
 
 
 /* ---- diagnostics (not part of the drop-in surface; used by tests/ and scripts/) --------------------------------------- */

@@ -27,9 +27,11 @@ for name, kw in CASES[:2] + CASES[3:4] if "--short" in sys.argv else CASES:
             return torch.rand((A, 2), generator=g, device=dev) * 2 - 1, torch.randint(0, 3, (A,), generator=g, device=dev, dtype=torch.int32)
         for _ in range(40): venv.step(policy())
         torch.cuda.synchronize(); t0 = time.perf_counter(); host = 0.0
+        fixed = policy() if "--fixed" in sys.argv else None      # --fixed: one action batch for every step (no policy kernels between the steps)
         for _ in range(100):
-            a = policy(); h0 = time.perf_counter(); venv.step(a); host += time.perf_counter() - h0
+            a = fixed if fixed is not None else policy(); h0 = time.perf_counter(); venv.step(a); host += time.perf_counter() - h0
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        row.append("k=%d (%d concurrent): %6.1f us (host %5.1f)" % (k, venv.concurrent_sub_batches, dt / 100 * 1e6, host / 100 * 1e6))
+        to = venv.pipe.pipe.spin_timeouts() if venv.pipe is not None else 0
+        row.append("k=%d (%d concurrent%s): %6.1f us (host %5.1f)" % (k, venv.concurrent_sub_batches, ", SPIN TIME-OUT" if to else "", dt / 100 * 1e6, host / 100 * 1e6))
         venv.close()
     print("%-62s %s" % (name, "   ".join(row)), flush=True)
