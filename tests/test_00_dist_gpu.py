@@ -57,6 +57,16 @@ def test_two_rank_shards_equal_one_rank_run_gpu():
     check_against_single_process("hip", parts, total, steps)
 
 
+@pytest.mark.gpu
+def test_rccl_branch_on_one_gpu():
+    """the "nccl" (= RCCL) backend with a process group of ONE rank on GPU 0: ResultGatherer.pack / gather_packed, TensorGatherer, the all-reduce and
+    the object gather bench.py makes -- the calls the driver's multi-GPU runs take, as far as a 1-GPU box can exercise them (a child process: this
+    process has not touched the GPU yet)"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    p = subprocess.run([sys.executable, os.path.join(HERE, "helpers", "nccl_one_rank.py"), str(port)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "nccl one-rank ok" in p.stdout, (p.stdout[-500:], p.stderr[-1500:])
+
+
 def test_two_rank_shards_equal_one_rank_run_emulated(emu_lib):
     """the same on the CPU with the test-only host build of the kernel source (world size 2, gloo)"""
     total, steps = 10, 60
