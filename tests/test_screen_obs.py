@@ -192,3 +192,24 @@ def test_band_rasteriser_equals_the_pixelwise_kernel(hip_engine_cls, monkeypatch
         old = eng.screen_obs(W, H, agent_view=av)
         assert np.array_equal(new, old), (W, H, av, float((new != old).mean()))
     eng.close()
+
+
+@pytest.mark.gpu
+def test_band_rasteriser_tiny_and_odd_frames(hip_engine_cls, monkeypatch):
+    """frames smaller than a wavefront's share -- 1 x 1, a single row, a single column, fewer rows than wavefronts -- and widths that are not a
+    multiple of four: the per-wavefront band loop, its look-back across wavefront boundaries (agent view) and the byte-wise output loops, against the
+    pixel-wise kernel"""
+    A = 6
+    eng = hip_engine_cls(A, arena_size=120, num_pellets=400, num_viruses=3, mode=6)
+    eng.seed(None, 17); eng.reset(reset_ids=True)
+    rng = np.random.RandomState(2)
+    for t in range(25):
+        eng.set_actions(rng.uniform(-1, 1, size=(A, 1, 2)).astype(np.float32), rng.randint(0, 3, size=(A, 1)).astype(np.int32)); eng.step()
+    for (W, H) in ((1, 1), (2, 1), (1, 7), (9, 1), (3, 2), (2, 5), (5, 3), (7, 7), (130, 3), (3, 130), (257, 5), (64, 64), (66, 9)):
+        for av in (False, True):
+            monkeypatch.delenv("AGARCL_SCREEN_PIXELWISE", raising=False)
+            new = eng.screen_obs(W, H, agent_view=av)
+            monkeypatch.setenv("AGARCL_SCREEN_PIXELWISE", "1")
+            old = eng.screen_obs(W, H, agent_view=av)
+            assert np.array_equal(new, old), (W, H, av, float((new != old).mean()))
+    eng.close()
