@@ -269,7 +269,13 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
   if (wave == 1) { if (lane < FCp) { fx0 = gs->food_x[fo + lane]; fy0 = gs->food_y[fo + lane]; if (!AGV) fi0 = gs->food_id[fo + lane]; }
                    if (lane + 64 < FCp) { fx1 = gs->food_x[fo + lane + 64]; fy1 = gs->food_y[fo + lane + 64]; if (!AGV) fi1 = gs->food_id[fo + lane + 64]; } }
   float vx0 = 0.f, vy0 = 0.f; unsigned vm0 = 0u;
-  if (wave == 0 && lane < VCp) { vx0 = gs->vir_x[vo + lane]; vy0 = gs->vir_y[vo + lane]; vm0 = (unsigned)gs->vir_mass[vo + lane]; }
+  // (wavefront 0 lists the players between the two barriers, where every round trip is on the workgroup's critical path: the iteration order and
+  // every player's kind / pid / cell count are requested here, a lane per position / slot, and handed out with v_readlane in the loop)
+  int pf_order = 0, pf_meta = 0;   // pf_meta = kind | cells << 4 | pid << 12
+  if (wave == 0) {
+    if (lane < VCp) { vx0 = gs->vir_x[vo + lane]; vy0 = gs->vir_y[vo + lane]; vm0 = (unsigned)gs->vir_mass[vo + lane]; }
+    if (lane < P) { pf_order = ar[AG_TW(AR_ORDER0 + lane)]; const int32_t *plq = AG_PL_PTR(gs, arena, lane); pf_meta = (plq[AG_TW(PL_KIND)] & 15) | (plq[AG_TW(PL_NCELLS)] & 255) << 4 | plq[AG_TW(PL_PID)] << 12; }
+  }
   const float r_pel = gs->lut_r[AG_PELLET_MASS], r_food = gs->lut_r[AG_FOOD_MASS];
   const float Wd = gs->g.W;
   // ---- camera: Player::x / y / mass (core/Player.hpp:102-126), sequential fp32 sums in cell order -- obs_player's arithmetic on the lanes' registers ----
@@ -282,6 +288,9 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
     }
     px = sx / (float)tm; py = sy / (float)tm; mass = tm; }
   const float z = scr_camera_z(mass), half_h = z * 0.41421356237309504880f, half_w = half_h * ((float)o.W / (float)o.H);
+  // (the masses have arrived: the radii of the agent's cells and of the first 64 viruses, second hop, requested now -- wavefront 0 uses them behind the barrier)
+  float own_r = 0.f, vr0 = 0.f;
+  if (wave == 0) { if (lane < AG_CC) own_r = gs->lut_r[own_m < AG_LUT_SIZE ? own_m : AG_LUT_SIZE - 1]; vr0 = gs->lut_r[vm0 < AG_LUT_SIZE ? vm0 : AG_LUT_SIZE - 1]; }
   // ---- which pixel columns / rows lie inside the arena, and their centres' world coordinates (the grid lines' bits follow behind the barrier) ----
   const float sx_scale = (float)o.W * 0.5f / half_w, sy_scale = (float)o.H * 0.5f / half_h, spacing = Wd / 7.0f;
   for (int k = tid; k < o.W; k += 256) { const float wx = px + (((float)k + 0.5f) / (float)o.W * 2.0f - 1.0f) * half_w; colflag[k] = (wx >= 0.0f && wx <= Wd) ? 2 : 0; colx[k] = wx; }
@@ -340,21 +349,21 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
     };
     const int main_slot = na - 1;  // state.main_agent_pid: the last agent added
     for (int kk = AGV ? -1 : 0; kk < P; kk++) {  // players in the engine's iteration order (agent view: the main agent first), cells in vector order
-      const int slot = kk < 0 ? main_slot : ar[AG_TW(AR_ORDER0 + kk)];
+      const int slot = kk < 0 ? main_slot : __builtin_amdgcn_readlane(pf_order, kk);
       if (AGV && kk >= 0 && slot == main_slot) continue;
-      const int32_t *pl = AG_PL_PTR(gs, arena, slot);
-      const int kind = pl[AG_TW(PL_KIND)];
+      const int meta = __builtin_amdgcn_readlane(pf_meta, slot), kind = meta & 15;
       const unsigned col = (AGV ? (kk < 0 ? 0x0000E6u /* 0.9 -> 230 */ : 0x00FF00u)
-                                : (kind == 0 ? scr_palette(pl[AG_TW(PL_PID)]) : kind == 1 ? scr_palette(4) : kind == 2 ? scr_palette(5) : kind == 3 ? scr_palette(0) : scr_palette(1))) | (50u << 24);
-      int n; unsigned xu, yu, m;
-      if (slot == agent) { n = n_own; xu = own_xu; yu = own_yu; m = own_m; }   // (already in registers)
-      else { const uint32_t *C = AG_CELLS_PTR(gs, arena, slot); n = pl[AG_TW(PL_NCELLS)]; const bool v = lane < AG_CC;
-             xu = v ? C[AG_CELL_W(CF_X, lane)] : 0u; yu = v ? C[AG_CELL_W(CF_Y, lane)] : 0u; m = v ? C[AG_CELL_W(CF_M, lane)] : 0u; }
+                                : (kind == 0 ? scr_palette(meta >> 12) : kind == 1 ? scr_palette(4) : kind == 2 ? scr_palette(5) : kind == 3 ? scr_palette(0) : scr_palette(1))) | (50u << 24);
+      int n; unsigned xu, yu, m; float rad;
+      if (slot == agent) { n = n_own; xu = own_xu; yu = own_yu; m = own_m; rad = own_r; }   // (already in registers)
+      else { const uint32_t *C = AG_CELLS_PTR(gs, arena, slot); n = (meta >> 4) & 255; const bool v = lane < AG_CC;
+             xu = v ? C[AG_CELL_W(CF_X, lane)] : 0u; yu = v ? C[AG_CELL_W(CF_Y, lane)] : 0u; m = v ? C[AG_CELL_W(CF_M, lane)] : 0u;
+             rad = lane < n ? gs->lut_r[m < AG_LUT_SIZE ? m : AG_LUT_SIZE - 1] : 0.f; }
       const bool v = lane < n;
-      emit(v, v ? __uint_as_float(xu) : 0.f, v ? __uint_as_float(yu) : 0.f, v ? gs->lut_r[m < AG_LUT_SIZE ? m : AG_LUT_SIZE - 1] : 0.f, col);
+      emit(v, v ? __uint_as_float(xu) : 0.f, v ? __uint_as_float(yu) : 0.f, v ? rad : 0.f, col);
     }
     { const unsigned vcol = (AGV ? 0xFF0000u : scr_palette(3)) | (150u << 24);
-      { const bool v = lane < nv; emit(v, vx0, vy0, v ? gs->lut_r[vm0 < AG_LUT_SIZE ? vm0 : AG_LUT_SIZE - 1] : 0.f, vcol); }
+      { const bool v = lane < nv; emit(v, vx0, vy0, v ? vr0 : 0.f, vcol); }
       for (int b = 64; b < nv; b += 64) { const int i = b + lane; const bool v = i < nv; const unsigned m = v ? (unsigned)gs->vir_mass[vo + i] : 0u;
         emit(v, v ? gs->vir_x[vo + i] : 0.f, v ? gs->vir_y[vo + i] : 0.f, v ? gs->lut_r[m < AG_LUT_SIZE ? m : AG_LUT_SIZE - 1] : 0.f, vcol); } }
     if (lane == 0) wcnt[5] = SCR_ABL(1) ? 0 : (count < AG_SCR_CAP ? count : AG_SCR_CAP);
@@ -441,29 +450,45 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
       const int kk = k0 + lane; const bool in_ = kk < n; const int ki = in_ ? kk : 0;
       const unsigned bx_ = in_ ? ebx[ki] : 1u, by_ = in_ ? eby[ki] : 1u;   // (1 = first 1, last 0: empty)
       const float x_ = ex[ki], y_ = ey[ki], r_ = er[ki]; const unsigned e_ = ec[ki];
-      unsigned long long hits;
-      { const int r0_ = (int)(by_ & 0xFFFFu), r1_ = (int)(by_ >> 16);
-        hits = __ballot(in_ && (int)(bx_ & 0xFFFFu) <= (int)(bx_ >> 16) && (r0_ < row0 ? row0 : r0_) <= (r1_ > rlast ? rlast : r1_)); }
 #ifndef AG_SCR_LANE_MIN
-#define AG_SCR_LANE_MIN 3   // (hits of one batch from which the lane-parallel form pays: 2 / 3 / 5 / 8 measured -- task 3 128 x 128 x 4 129 / 128 / 132 / 136 us, task 6 197 / 197 / 198 / 208)
+#define AG_SCR_LANE_MIN 3
 #endif
-      if (__popcll(hits) >= AG_SCR_LANE_MIN) {
-        // Many hits in one batch -- a line of pellets across the view (tasks 1 and 2 lay 350 of them along a square, one unit apart), a cloud of
-        // ejected food: when their boxes are small every lane paints its own entity, <= 6 x 6 pixels, while the others paint theirs (one
-        // wavefront-wide loop instead of one tile pass per entity).  Tight box: the stored one without its margins (floor(low end) .. floor(high end)
-        // + 1 still contains every pixel the inside test can accept).  Agent view: the hits must all paint the same word -- then the ORDER among them
-        // is immaterial, plain stores.  Plain frame: colours differ by id, the latest draw must win a pixel two entities cover -- the alpha byte, which
-        // a three-channel frame never outputs, carries the lane: a first pass clears it on every covered pixel, a second pass takes the maximum of
-        // (lane + 1) << 24 | colour, which is the highest lane's, i.e. the latest entity's, word.
-        const bool mine = (hits >> lane) & 1ull;
-        const unsigned e0 = (unsigned)__builtin_amdgcn_readlane((int)e_, (int)__builtin_ctzll(hits));
-        const int c0s = (int)(bx_ & 0xFFFFu), c1s = (int)(bx_ >> 16), r0s = (int)(by_ & 0xFFFFu), r1s = (int)(by_ >> 16);
+#ifndef AG_SCR_LANE_MIN_RGB
+#define AG_SCR_LANE_MIN_RGB 6   // (the plain frame's form takes two passes of LDS atomics)
+#endif
+      constexpr int LANE_MIN = AGV ? AG_SCR_LANE_MIN : AG_SCR_LANE_MIN_RGB;   // hits of one run from which the lane-parallel form pays
+      // This lane's entity's TIGHT box inside the band: the stored one without its margins (floor(low end) .. floor(high end) + 1 still contains
+      // every pixel the inside test can accept)
+      unsigned tbx, tby;   // first | last << 16 again (only lanes with a non-empty box are ever read)
+      unsigned long long hits;
+      { const int c0s = (int)(bx_ & 0xFFFFu), c1s = (int)(bx_ >> 16), r0s = (int)(by_ & 0xFFFFu), r1s = (int)(by_ >> 16);
         const int c0 = c0s == 0 ? 0 : c0s + 1, c1 = c1s == o.W - 1 ? c1s : c1s - 1;
         int r0 = r0s == 0 ? 0 : r0s + 1, r1 = r1s == o.H - 1 ? r1s : r1s - 1;
         r0 = r0 < row0 ? row0 : r0; r1 = r1 > rlast ? rlast : r1;
-        const int bw = c1 - c0 + 1, bh = r1 - r0 + 1;
-        const bool alike = AGV ? e_ == e0 : (e_ >> 24) == (e0 >> 24);   // (the polygon's side count is wave-uniform in the inside test)
-        if (__ballot(mine && (!alike || bw > 6 || bh > 6)) == 0ull) {
+        hits = __ballot(in_ && c0 <= c1 && r0 <= r1);
+        tbx = (unsigned)c0 | ((unsigned)c1 << 16); tby = (unsigned)r0 | ((unsigned)r1 << 16); }
+      while (hits) {
+        // Many hits in one batch -- a line of pellets across the view (tasks 1 and 2 lay 350 of them along a square, one unit apart), a cloud of
+        // ejected food, the pellets around a split agent: when their boxes are small every lane paints its own entity, <= 6 x 6 pixels, while the
+        // others paint theirs (one wavefront-wide loop instead of one tile pass per entity).  Taken for the longest RUN of hits, from the first one on,
+        // that are small and alike -- the draw order of the run against what comes before and behind it stays what it was.  Agent view: alike = all paint
+        // the same word -- then the ORDER among them is immaterial, plain stores.  Plain frame: alike = the same polygon; colours differ by id, the latest
+        // draw must win a pixel two entities cover -- the alpha byte, which a three-channel frame never outputs, carries the lane: a first pass clears it
+        // on every covered pixel, a second pass takes the maximum of (lane + 1) << 24 | colour, which is the highest lane's, i.e. the latest entity's, word.
+        const int j = (int)__builtin_ctzll(hits);
+        const unsigned e0 = (unsigned)__builtin_amdgcn_readlane((int)e_, j);
+        unsigned long long run = 0ull;
+        if (__popcll(hits) >= LANE_MIN) {
+          const bool alike = AGV ? e_ == e0 : (e_ >> 24) == (e0 >> 24);   // (the polygon's side count is wave-uniform in the inside test)
+          const unsigned long long bad = __ballot(((hits >> lane) & 1ull) && (!alike || (tbx >> 16) - (tbx & 0xFFFFu) > 5u || (tby >> 16) - (tby & 0xFFFFu) > 5u));
+          run = bad ? hits & ((1ull << (int)__builtin_ctzll(bad)) - 1ull) : hits;
+        }
+        if (__popcll(run) >= LANE_MIN) {
+          const bool mine = (run >> lane) & 1ull;
+          unsigned bxv = tbx, byv = tby;
+          asm volatile("" : "+v"(bxv), "+v"(byv));   // (opaque: keeps the unpacked box and everything derived from it inside this block instead of hoisted in front of the loop, where it cost 14 registers)
+          const int c0 = (int)(bxv & 0xFFFFu), r0 = (int)(byv & 0xFFFFu), bw = (int)(bxv >> 16) - c0 + 1, bh = (int)(byv >> 16) - r0 + 1;
+          {
           const int ns = (int)(e0 >> 24); const float apo = r_ * scr_cos_half_step(ns);
           float cx[6];
 #pragma unroll
@@ -504,17 +529,15 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
             }
             ag_lds_order();
           }
-          hits = 0ull;
-        }
-      }
-      for (; hits; hits &= hits - 1ull) {
-        const int j = (int)__builtin_ctzll(hits);
-        const unsigned bx = (unsigned)__builtin_amdgcn_readlane((int)bx_, j), by = (unsigned)__builtin_amdgcn_readlane((int)by_, j);
-        const int c0 = (int)(bx & 0xFFFFu), c1 = (int)(bx >> 16);
-        int r0 = (int)(by & 0xFFFFu), r1 = (int)(by >> 16);
-        r0 = r0 < row0 ? row0 : r0; r1 = r1 > rlast ? rlast : r1;
+          }
+          hits &= ~run;
+        } else {
+        // one entity, the wavefront's lanes over the pixels of its (tight) box
+        hits &= hits - 1ull;
+        const unsigned bx = (unsigned)__builtin_amdgcn_readlane((int)tbx, j), by = (unsigned)__builtin_amdgcn_readlane((int)tby, j);
+        const int c0 = (int)(bx & 0xFFFFu), c1 = (int)(bx >> 16), r0 = (int)(by & 0xFFFFu), r1 = (int)(by >> 16);
         const float x = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(x_), j)), y = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(y_), j));
-        const float r = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(r_), j)); const unsigned e = (unsigned)__builtin_amdgcn_readlane((int)e_, j);
+        const float r = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(r_), j)); const unsigned e = e0;
         const int ns = (int)(e >> 24); const float apo = r * scr_cos_half_step(ns);
         const unsigned paint = scr_paint_word<AGV>(e);
         if (AGV && (e & 0xFFFFFFu) > 230u) {   // (wave-uniform arithmetic: every chunk from the box's first pixel to its last -- a superset of the chunks it touches;
@@ -525,6 +548,7 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
         for (int ty = r0; ty <= r1; ty += 8) for (int tx = c0; tx <= c1; tx += 8) {   // 8 x 8 pixel tiles of the box, a lane per pixel
           const int rr = ty + (lane >> 3), cc = tx + (lane & 7);
           if (rr <= r1 && cc <= c1 && scr_inside_apo(colx[cc] - x, rowy[rr] - y, r, apo, ns)) fb[(rr - row0) * o.W + cc] = paint;
+        }
         }
       }
     }
