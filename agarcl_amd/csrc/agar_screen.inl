@@ -446,6 +446,7 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
     ag_lds_order();
     // entities in draw order: later draws overwrite earlier ones (one wavefront, in order: no exchange)
     unsigned long long chunks255 = 0ull;   // agent view: the band's 64-pixel chunks that may hold a 255-pixel (bit c = chunk c; a band has <= 16)
+    unsigned marks_acc = 0u;               // ... collected lane by lane, row by row (the chunks a box's row touches), OR-reduced once behind the painter
     if (!SCR_ABL(2)) for (int k0 = 0; k0 < n; k0 += 64) {
       const int kk = k0 + lane; const bool in_ = kk < n; const int ki = in_ ? kk : 0;
       const unsigned bx_ = in_ ? ebx[ki] : 1u, by_ = in_ ? eby[ki] : 1u;   // (1 = first 1, last 0: empty)
@@ -495,19 +496,14 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
           for (int dx = 0; dx < 6; dx++) cx[dx] = colx[(mine && dx < bw) ? c0 + dx : 0] - x_;
           if (AGV) {
             const unsigned paint = scr_paint_word<AGV>(e0);
-            unsigned marks = 0u;   // the band's 64-pixel chunks this lane's entity can touch, row by row (a band has <= 16 chunks)
             const bool is255 = (e0 & 0xFFFFFFu) > 230u;
 #pragma unroll
             for (int dy = 0; dy < 6; dy++) {
               if (__ballot(mine && dy < bh) == 0ull) break;
               const bool rowok = mine && dy < bh; const float yy = rowy[rowok ? r0 + dy : 0] - y_; const int rb = (r0 + dy - row0) * o.W + c0;
-              if (is255 && rowok && bw > 0) { const int lo_ = rb >> 6, hi_ = (rb + bw - 1) >> 6; marks |= ((2u << (hi_ - lo_)) - 1u) << lo_; }
+              if (is255 && rowok && bw > 0) { const int lo_ = rb >> 6, hi_ = (rb + bw - 1) >> 6; marks_acc |= ((2u << (hi_ - lo_)) - 1u) << lo_; }
 #pragma unroll
               for (int dx = 0; dx < 6; dx++) if (rowok && dx < bw && scr_inside_apo(cx[dx], yy, r_, apo, ns)) fb[rb + dx] = paint;
-            }
-            if (is255) {
-              for (int sft = 32; sft; sft >>= 1) marks |= (unsigned)__shfl_xor((int)marks, sft, 64);
-              chunks255 |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)marks);
             }
           } else {
             unsigned long long cover = 0ull;   // bit dy * 6 + dx: this lane's entity covers that pixel of its box
@@ -540,10 +536,13 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
         const float r = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(r_), j)); const unsigned e = e0;
         const int ns = (int)(e >> 24); const float apo = r * scr_cos_half_step(ns);
         const unsigned paint = scr_paint_word<AGV>(e);
-        if (AGV && (e & 0xFFFFFFu) > 230u) {   // (wave-uniform arithmetic: every chunk from the box's first pixel to its last -- a superset of the chunks it touches;
-          // marking a small entity's chunks row by row leaves the run pass fewer chunks, but costs more scalar instructions here than it saves there: measured)
-          const int lo = ((r0 - row0) * o.W + c0) >> 6, hi = ((r1 - row0) * o.W + c1) >> 6;
-          chunks255 |= ((hi - lo >= 63) ? ~0ull : ((1ull << (hi - lo + 1)) - 1ull)) << lo;
+        if (AGV && (e & 0xFFFFFFu) > 230u) {
+          if (r1 - r0 < 64) {   // a lane per row of the box: the chunks that row touches
+            if (lane <= r1 - r0) { const int rb = (r0 + lane - row0) * o.W + c0, lo_ = rb >> 6, hi_ = (rb + c1 - c0) >> 6; marks_acc |= ((hi_ - lo_ >= 31) ? ~0u : ((2u << (hi_ - lo_)) - 1u)) << lo_; }
+          } else {              // (bands of very narrow frames: every chunk from the box's first pixel to its last)
+            const int lo = ((r0 - row0) * o.W + c0) >> 6, hi = ((r1 - row0) * o.W + c1) >> 6;
+            chunks255 |= ((hi - lo >= 63) ? ~0ull : ((1ull << (hi - lo + 1)) - 1ull)) << lo;
+          }
         }
         for (int ty = r0; ty <= r1; ty += 8) for (int tx = c0; tx <= c1; tx += 8) {   // 8 x 8 pixel tiles of the box, a lane per pixel
           const int rr = ty + (lane >> 3), cc = tx + (lane & 7);
@@ -553,6 +552,7 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
       }
     }
     ag_lds_order();
+    if (AGV) chunks255 |= (unsigned long long)wred_or(marks_acc);
     if (AGV && !SCR_ABL(4)) {
       // ScreenObservation::post_processing_frame_data (ScreenEnvironment.hpp:48-88): a sequential pass over the flat buffer.  With the colours this kernel
       // paints (one non-zero channel per pixel: 26 grid, 230 main agent, 255 pellets / others / viruses) the pass has a closed form.  A pixel whose
