@@ -211,8 +211,14 @@ __global__ void __launch_bounds__(256) k_screen_obs_pixelwise(const AgState *__r
 //     itself; only when one of them is a 255-pixel (its alpha then depends on the run it belongs to) does it wait for the wavefront above to publish
 //     them.
 // Same per-pixel rules and fp32 expressions as before: byte-identical to k_screen_obs_pixelwise (tests/test_screen_obs.py).
+#ifndef AG_SCR_WAVES
+#define AG_SCR_WAVES 5   // wavefronts per SIMD = workgroups per compute unit the small-frame instantiation is built for
+#endif
 #ifndef AG_SCR_WBAND
-#define AG_SCR_WBAND 924   // pixels of one wavefront's LDS band (3.6 KiB of packed RGBA): 7 rows of 128, 11 rows of 84 (a quarter of 84 rows = 21 = two bands)
+#define AG_SCR_WBAND 1024  // pixels of one wavefront's LDS band (4 KiB of packed RGBA): 8 rows of 128 -- a wavefront's 32 rows are four bands --, 12 rows of 84 (a quarter of
+                           // 84 rows = 21 = two bands).  31.4 KB of LDS per workgroup: five per compute unit, what the 96 registers admit.  Every band costs a round of the
+                           // painter's list reads, a fill, a reduction of the marks, a run pass and a store loop: 924 pixels (7 rows of 128, five bands) measured
+                           // 121 / 142 / 174 us per 4096 frames of 128 x 128 x 4 on task-3 / 1 / 6 states against 113 / 134 / 160
 #endif
 // conservative pixel box of an entity, first | last << 16; empty: first > last.  Pixel column c's centre lies at px + ((c + 1/2) / W * 2 - 1) half_w, so
 // the disc spans columns (x -+ r - px) kx + W/2 - 1/2 with kx = W / (2 half_w): floor of the low end - 1 and floor of the high end + 2 (a pixel of
@@ -230,7 +236,7 @@ __device__ __forceinline__ void scr_box(float x, float y, float r, float px, flo
 template <bool AGV> __device__ __forceinline__ unsigned scr_paint_word(unsigned e) {
   return (AGV && (e & 0xFFFFFFu) <= 230u) ? ((e & 0xFFu) << 24) : ((e & 0xFFFFFFu) | 0xFF000000u);
 }
-template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TAB > 256 ? 4 : 5, TAB > 256 ? 4 : 5))) k_screen_obs(const AgState *__restrict__ gs, AgScreenCfg o, uint8_t *out) {
+template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TAB > 256 ? 4 : AG_SCR_WAVES, TAB > 256 ? 4 : AG_SCR_WAVES))) k_screen_obs(const AgState *__restrict__ gs, AgScreenCfg o, uint8_t *out) {
   constexpr int WB = TAB > 256 ? 1024 : AG_SCR_WBAND;   // (a band holds at least one row)
   constexpr int CH = AGV ? 4 : 3;
   constexpr unsigned GRIDV = AGV ? 0x1A000000u : 0xFF00001Au, BACKV = AGV ? 0u : 0x00FFFFFFu;   // (0.1, 0, 0) -> 26; alpha byte: a fragment was written
