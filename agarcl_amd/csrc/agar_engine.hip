@@ -1418,8 +1418,8 @@ extern "C" int agarcl_screen_obs(agarcl_env *e, int32_t width, int32_t height, i
 #endif
   { const char *pw = getenv("AGARCL_SCREEN_PIXELWISE");   // the pixel-wise kernel: cross-check only (agar_screen.inl)
     if (pw && pw[0] == '1') hipLaunchKernelGGL(k_screen_obs_pixelwise, dim3((unsigned)n), dim3(256), 0, e->stream, e->d_state, o, dst);
-    else if (o.W <= 256 && o.H <= 256) { if (o.agent_view) hipLaunchKernelGGL((k_screen_obs<256, true>), dim3((unsigned)n), dim3(256), 0, e->stream, e->d_state, o, dst); else hipLaunchKernelGGL((k_screen_obs<256, false>), dim3((unsigned)n), dim3(256), 0, e->stream, e->d_state, o, dst); }
-    else { if (o.agent_view) hipLaunchKernelGGL((k_screen_obs<1024, true>), dim3((unsigned)n), dim3(256), 0, e->stream, e->d_state, o, dst); else hipLaunchKernelGGL((k_screen_obs<1024, false>), dim3((unsigned)n), dim3(256), 0, e->stream, e->d_state, o, dst); } }
+    else if (o.W <= 256 && o.H <= 256) { if (o.agent_view) hipLaunchKernelGGL((k_screen_obs<256, true>), dim3((unsigned)n), dim3(256), 0, e->stream, e->s, o, dst); else hipLaunchKernelGGL((k_screen_obs<256, false>), dim3((unsigned)n), dim3(256), 0, e->stream, e->s, o, dst); }
+    else { if (o.agent_view) hipLaunchKernelGGL((k_screen_obs<1024, true>), dim3((unsigned)n), dim3(256), 0, e->stream, e->s, o, dst); else hipLaunchKernelGGL((k_screen_obs<1024, false>), dim3((unsigned)n), dim3(256), 0, e->stream, e->s, o, dst); } }
   HIPCHK(hipGetLastError());
   if (!on_device && d2h(out, dst, bytes, e->stream)) return fail(AGARCL_E_HIP, "agarcl_screen_obs: copy failed");
   return AGARCL_OK;

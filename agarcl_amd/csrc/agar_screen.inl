@@ -37,7 +37,7 @@
 
 struct AgScreenCfg { int W, H, agent_view;   // agent_view: the 4-channel frame of Renderer::multi_channel_render_screen
 #ifdef AG_SCR_ABL   // measurement builds only (build.py --variant SCRABL -DAG_SCR_ABL): AGARCL_SCR_ABL=<bits> switches parts of k_screen_obs off
-  int abl;          // 1 no entity list, 2 no painting, 4 no post-processing pass, 8 no global stores, 16 no background fill, 32 return at once
+  int abl;          // 1 no entity list, 2 no painting, 4 no post-processing pass, 8 no global stores, 16 no background fill, 32 return at once, 64 / 128 return behind the first / second barrier
 #endif
 };
 #ifdef AG_SCR_ABL
@@ -211,6 +211,13 @@ __global__ void __launch_bounds__(256) k_screen_obs_pixelwise(const AgState *__r
 //     itself; only when one of them is a 255-pixel (its alpha then depends on the run it belongs to) does it wait for the wavefront above to publish
 //     them.
 // Same per-pixel rules and fp32 expressions as before: byte-identical to k_screen_obs_pixelwise (tests/test_screen_obs.py).
+// A frame is written once and read by somebody else, later: non-temporal stores (they do not allocate in the L2 the engine's state lives in).  Measured on 4096
+// frames of 128 x 128 x 4, task-3 / 1 / 6 states: 114 / 132 / 158 -> 106 / 125 / 154 us
+#ifdef AG_SCR_PLAIN_STORES
+#define AG_SCR_STORE(p, v) (*(p) = (v))
+#else
+#define AG_SCR_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#endif
 #ifndef AG_SCR_WAVES
 #define AG_SCR_WAVES 5   // wavefronts per SIMD = workgroups per compute unit the small-frame instantiation is built for
 #endif
@@ -236,7 +243,10 @@ __device__ __forceinline__ void scr_box(float x, float y, float r, float px, flo
 template <bool AGV> __device__ __forceinline__ unsigned scr_paint_word(unsigned e) {
   return (AGV && (e & 0xFFFFFFu) <= 230u) ? ((e & 0xFFu) << 24) : ((e & 0xFFFFFFu) | 0xFF000000u);
 }
-template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TAB > 256 ? 4 : AG_SCR_WAVES, TAB > 256 ? 4 : AG_SCR_WAVES))) k_screen_obs(const AgState *__restrict__ gs, AgScreenCfg o, uint8_t *out) {
+template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TAB > 256 ? 4 : AG_SCR_WAVES, TAB > 256 ? 4 : AG_SCR_WAVES))) k_screen_obs(const AgState S, AgScreenCfg o, uint8_t *out) {
+  // (the env's descriptor travels BY VALUE: its fields are scalar loads from the kernel-argument segment, one round trip less in front of the first state load
+  // than through the descriptor's copy in HBM -- every workgroup's prologue is a chain of dependent round trips)
+  const AgState *const gs = &S;
   constexpr int WB = TAB > 256 ? 1024 : AG_SCR_WBAND;   // (a band holds at least one row)
   constexpr int CH = AGV ? 4 : 3;
   constexpr unsigned GRIDV = AGV ? 0x1A000000u : 0xFF00001Au, BACKV = AGV ? 0u : 0x00FFFFFFu;   // (0.1, 0, 0) -> 26; alpha byte: a fragment was written
@@ -318,6 +328,7 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
   if (lane == 0) { wcnt[wave] = pcnt; pp_done[wave] = 0; }
   if (SCR_ABL(1)) { pcnt = 0; }
   __syncthreads();
+  if (SCR_ABL(64)) { if (threadIdx.x == 0) out[blockIdx.x] = (uint8_t)wcnt[0]; return; }   // (measurement: everything in front of the first barrier)
   auto put = [&](int slot, float x, float y, float r, unsigned col) {
     if (slot < AG_SCR_CAP) { ex[slot] = x; ey[slot] = y; er[slot] = r; ec[slot] = col; unsigned bx, by; scr_box(x, y, r, px, py, sx_scale, sy_scale, o.W, o.H, bx, by); ebx[slot] = bx; eby[slot] = by; }
   };
@@ -375,6 +386,7 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
     if (lane == 0) wcnt[5] = SCR_ABL(1) ? 0 : (count < AG_SCR_CAP ? count : AG_SCR_CAP);
   }
   __syncthreads();   // the list is complete: from here on no wavefront waits for another (but for the rare hand-over of the run pass)
+  if (SCR_ABL(128)) { if (threadIdx.x == 0) out[blockIdx.x] = (uint8_t)wcnt[5]; return; }   // (measurement: ... and of the second)
   const int n = __builtin_amdgcn_readfirstlane(wcnt[5]);
   // ---- this wavefront's rows, band by band ----
   const int rpw = (o.H + 3) >> 2, wr0 = wave * rpw, wr1 = (wr0 + rpw < o.H ? wr0 + rpw : o.H) - 1;   // row 0 = bottom (glReadPixels)
@@ -629,12 +641,12 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
     uint8_t *bd = dst + (size_t)row0 * o.W * CH; const int nbytes = npix * CH;
     typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
     if (SCR_ABL(8)) {} else
-    if (CH == 4 && (((size_t)bd) & 15) == 0 && (npix & 3) == 0) { v4u_ *bw = (v4u_ *)bd; const v4u_ *fw = (const v4u_ *)fb; for (int g = lane; g < (npix >> 2); g += 64) bw[g] = fw[g]; }
+    if (CH == 4 && (((size_t)bd) & 15) == 0 && (npix & 3) == 0) { v4u_ *bw = (v4u_ *)bd; const v4u_ *fw = (const v4u_ *)fb; for (int g = lane; g < (npix >> 2); g += 64) AG_SCR_STORE(&bw[g], fw[g]); }
     else if (CH == 3 && (((size_t)bd) & 3) == 0 && (npix & 3) == 0) {
       unsigned *bw = (unsigned *)bd; const v4u_ *fw = (const v4u_ *)fb;
       for (int g = lane; g < (npix >> 2); g += 64) {
         const v4u_ v = fw[g]; const unsigned p0 = v.x & 0xFFFFFFu, p1 = v.y & 0xFFFFFFu, p2 = v.z & 0xFFFFFFu, p3 = v.w & 0xFFFFFFu;
-        bw[3 * g] = p0 | (p1 << 24); bw[3 * g + 1] = (p1 >> 8) | (p2 << 16); bw[3 * g + 2] = (p2 >> 16) | (p3 << 8);
+        AG_SCR_STORE(&bw[3 * g], p0 | (p1 << 24)); AG_SCR_STORE(&bw[3 * g + 1], (p1 >> 8) | (p2 << 16)); AG_SCR_STORE(&bw[3 * g + 2], (p2 >> 16) | (p3 << 8));
       }
     }
     else if (CH == 4 && (((size_t)bd) & 3) == 0) { unsigned *bw = (unsigned *)bd; for (int q = lane; q < npix; q += 64) bw[q] = fb[q]; }

@@ -1,6 +1,6 @@
 """Which part of k_screen_obs costs what: the kernel alone on task-like states with parts switched off (measurement build:
 python -m agarcl_amd.build --variant SCRABL -DAG_SCR_ABL; AGARCL_HIP_SO=build_variants/lib_SCRABL.so python scripts/gpu_screen_ablate.py).
-AGARCL_SCR_ABL bits: 1 no entity list, 2 no painting, 4 no post-processing pass, 8 no global stores, 16 no background fill, 32 return at once."""
+AGARCL_SCR_ABL bits: 1 no entity list, 2 no painting, 4 no post-processing pass, 8 no global stores, 16 no background fill, 32 return at once, 64 / 128 return behind the first / second barrier."""
 import os, sys, time
 sys.path.insert(0, '.')
 import torch
@@ -10,7 +10,7 @@ STATES = (("task3", dict(arena_size=350, num_pellets=500, num_viruses=0, mode_nu
           ("task1", dict(arena_size=350, num_pellets=500, num_viruses=0, mode_number=1)),
           ("task6", dict(arena_size=350, num_pellets=500, num_viruses=0, mode_number=6)),
           ("C3m6", dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode_number=6)))
-ABL = (0, 2, 4, 7, 15, 31, 32)
+ABL = (0, 2, 4, 7, 15, 31, 128, 64, 32)
 for name, cfg in STATES:
     env = VecEnvironment(A, strict_flags=False, **cfg); env.seed(base_seed=10000); env.reset()
     g = torch.Generator(device="cuda"); g.manual_seed(0)
