@@ -1412,7 +1412,7 @@ extern "C" int agarcl_screen_obs(agarcl_env *e, int32_t width, int32_t height, i
     dst = (uint8_t *)e->obs_buf;
     e->undo_out = nullptr;   // (as above)
   }
-  AgScreenCfg o; o.W = width; o.H = height; o.agent_view = agent_view != 0;
+  AgScreenCfg o; o.W = width; o.H = height; o.agent_view = agent_view != 0; scr_cfg_geometry(o);
 #ifdef AG_SCR_ABL
   { const char *ab = getenv("AGARCL_SCR_ABL"); o.abl = ab ? atoi(ab) : 0; }
 #endif

@@ -36,6 +36,7 @@
 #define AG_SCR_CAP 512  // visible entities kept per frame (more are dropped from the END of the draw order)
 
 struct AgScreenCfg { int W, H, agent_view;   // agent_view: the 4-channel frame of Renderer::multi_channel_render_screen
+  int rows_per_wave, band_rows, fc_mul, fc_step;   // host arithmetic (scr_cfg_geometry): a wavefront's share of the rows, the rows of one LDS band -- three integer divisions less per wavefront
 #ifdef AG_SCR_ABL   // measurement builds only (build.py --variant SCRABL -DAG_SCR_ABL): AGARCL_SCR_ABL=<bits> switches parts of k_screen_obs off
   int abl;          // 1 no entity list, 2 no painting, 4 no post-processing pass, 8 no global stores, 16 no background fill, 32 return at once, 64 / 128 return behind the first / second barrier
 #endif
@@ -227,6 +228,14 @@ __global__ void __launch_bounds__(256) k_screen_obs_pixelwise(const AgState *__r
                            // painter's list reads, a fill, a reduction of the marks, a run pass and a store loop: 924 pixels (7 rows of 128, five bands) measured
                            // 121 / 142 / 174 us per 4096 frames of 128 x 128 x 4 on task-3 / 1 / 6 states against 113 / 134 / 160
 #endif
+// the band geometry of a frame (host side, at launch): rows per wavefront, rows per band (bands of equal size: ceil(rows / ceil(rows / rows that fit)))
+static inline void scr_cfg_geometry(AgScreenCfg &o) {
+  const int WB = (o.W > 256 || o.H > 256) ? 1024 : AG_SCR_WBAND;
+  const int rpw = (o.H + 3) >> 2, max_rows = WB / o.W > 0 ? WB / o.W : 1, nbands = (rpw + max_rows - 1) / max_rows;
+  o.rows_per_wave = rpw; o.band_rows = (rpw + nbands - 1) / nbands;
+  const int gpr = o.W >> 2 > 0 ? o.W >> 2 : 1;            // the fill's groups of four pixels per row: lane / gpr as (lane * fc_mul) >> 16 (exact for lane < 64, gpr <= 64)
+  o.fc_mul = (65536 + gpr - 1) / gpr; o.fc_step = 64 / gpr;
+}
 // conservative pixel box of an entity, first | last << 16; empty: first > last.  Pixel column c's centre lies at px + ((c + 1/2) / W * 2 - 1) half_w, so
 // the disc spans columns (x -+ r - px) kx + W/2 - 1/2 with kx = W / (2 half_w): floor of the low end - 1 and floor of the high end + 2 (a pixel of
 // margin either side, far more than the rounding of these products: the inside test decides, the box only has to contain what it accepts)
@@ -389,14 +398,16 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
   if (SCR_ABL(128)) { if (threadIdx.x == 0) out[blockIdx.x] = (uint8_t)wcnt[5]; return; }   // (measurement: ... and of the second)
   const int n = __builtin_amdgcn_readfirstlane(wcnt[5]);
   // ---- this wavefront's rows, band by band ----
-  const int rpw = (o.H + 3) >> 2, wr0 = wave * rpw, wr1 = (wr0 + rpw < o.H ? wr0 + rpw : o.H) - 1;   // row 0 = bottom (glReadPixels)
+  const int rpw = o.rows_per_wave, wr0 = wave * rpw, wr1 = (wr0 + rpw < o.H ? wr0 + rpw : o.H) - 1;   // row 0 = bottom (glReadPixels)
   if (wr0 > wr1) return;
   unsigned *fb = &fbw[wave][4];
-  const int max_rows = WB / o.W > 0 ? WB / o.W : 1, wrows = wr1 - wr0 + 1, nbands = (wrows + max_rows - 1) / max_rows, band_rows = (wrows + nbands - 1) / nbands;
+  const int band_rows = o.band_rows;   // (scr_cfg_geometry)
   // one visible-entity batch: 64 entities' parameters, a lane each, in ONE LDS round trip; handed out with v_readlane
-  if (AGV) {   // the two pixels in front of this wavefront's first row, as painted (final unless a 255-pixel)
-    unsigned lb[2];
-#pragma unroll
+  // Agent view: the two pixels in front of this wavefront's first row, as painted (final unless a 255-pixel).  Only a 255-pixel among the first two of the
+  // wavefront's rows ever asks for them (the run pass below): computed only when the entity list allows for one -- for most wavefronts it does not
+  auto lookback = [&]() {
+    unsigned lb0 = 0u, lb1 = 0u;
+#pragma unroll 1
     for (int t = 0; t < 2; t++) {
       const int f = wr0 * o.W - 1 - t;                      // flat pixel index (t = 0: the previous pixel)
       unsigned w = 0xFF000000u;                             // no such pixel: alpha 255 fails the run rule exactly as its p >= 2 test does
@@ -412,14 +423,23 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
           if (m) w = scr_paint_word<AGV>((unsigned)__builtin_amdgcn_readlane((int)e, 63 - (int)__builtin_clzll(m)));   // the LAST draw that covers the pixel
         }
       }
-      lb[t] = w;
+      if (t == 0) lb0 = w; else lb1 = w;
     }
-    if (((lb[0] | lb[1]) & 0xFFFFFFu) != 0u && !SCR_ABL(4)) {   // a 255-pixel: its alpha is its run's -- the wavefront above knows (rare: an entity at the frame's right edge of exactly that row)
+    if (((lb0 | lb1) & 0xFFFFFFu) != 0u && !SCR_ABL(4)) {   // a 255-pixel: its alpha is its run's -- the wavefront above knows (rare: an entity at the frame's right edge of exactly that row)
       while (__hip_atomic_load(&pp_done[wave - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(8);
-      lb[0] = pp_last[wave - 1][0]; lb[1] = pp_last[wave - 1][1];
+      lb0 = pp_last[wave - 1][0]; lb1 = pp_last[wave - 1][1];
     }
-    if (lane == 0) { fb[-1] = lb[0]; fb[-2] = lb[1]; }
+    if (lane == 0) { fb[-1] = lb0; fb[-2] = lb1; }
     ag_lds_order();
+  };
+  if (AGV) {   // can a 255-coloured entity cover one of this wavefront's first two pixels?  (its box holds row wr0 and column 0 or 1; frames one pixel wide: always)
+    bool need = o.W < 2;
+    for (int k0 = 0; k0 < n && !need; k0 += 64) {
+      const int kk = k0 + lane; const bool in_ = kk < n; const int ki = in_ ? kk : 0;
+      const unsigned bx = ebx[ki], by = eby[ki], e = ec[ki];
+      need = __ballot(in_ && (e & 0xFFFFFFu) > 230u && (bx & 0xFFFFu) <= 1u && (bx & 0xFFFFu) <= (bx >> 16) && (int)(by & 0xFFFFu) <= wr0 && wr0 <= (int)(by >> 16)) != 0ull;
+    }
+    if (need) lookback();
   }
   // rows of up to 256 pixels, a multiple of four: a pass of the fill covers whole rows -- 64 / (W / 4) of them, a lane per four pixels, the lanes
   // beyond that idle (84 x 84: 63 of 64 work) -- so a lane's four columns never change.  Its masks: byte i = 1 where column i carries a grid line
@@ -427,7 +447,7 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
   const int fc_gpr = o.W >> 2;
   const bool fixed_cols = (o.W & 3) == 0 && fc_gpr >= 1 && fc_gpr <= 64;
   unsigned fc_line = 0u, fc_inside = 0u; int fc_r = 0, fc_step = 1, fc_gc = 0; bool fc_on = false;
-  if (fixed_cols) { fc_step = 64 / fc_gpr; fc_r = lane / fc_gpr; fc_gc = lane - fc_r * fc_gpr; fc_on = fc_r < fc_step;
+  if (fixed_cols) { fc_step = o.fc_step; fc_r = (lane * o.fc_mul) >> 16; fc_gc = lane - fc_r * fc_gpr; fc_on = fc_r < fc_step;
                     const unsigned cf4 = *(const unsigned *)&colflag[fc_gc << 2]; fc_line = cf4 & 0x01010101u; fc_inside = (cf4 & 0x02020202u) >> 1; }
   for (int row0 = wr0; row0 <= wr1; row0 += band_rows) {
     const int rows = wr1 + 1 - row0 < band_rows ? wr1 + 1 - row0 : band_rows, npix = rows * o.W, rlast = row0 + rows - 1;
