@@ -236,13 +236,19 @@ static inline void scr_cfg_geometry(AgScreenCfg &o) {
   const int gpr = o.W >> 2 > 0 ? o.W >> 2 : 1;            // the fill's groups of four pixels per row: lane / gpr as (lane * fc_mul) >> 16 (exact for lane < 64, gpr <= 64)
   o.fc_mul = (65536 + gpr - 1) / gpr; o.fc_step = 64 / gpr;
 }
-// conservative pixel box of an entity, first | last << 16; empty: first > last.  Pixel column c's centre lies at px + ((c + 1/2) / W * 2 - 1) half_w, so
-// the disc spans columns (x -+ r - px) kx + W/2 - 1/2 with kx = W / (2 half_w): floor of the low end - 1 and floor of the high end + 2 (a pixel of
-// margin either side, far more than the rounding of these products: the inside test decides, the box only has to contain what it accepts)
+// Pixel box of an entity, first | last << 16; empty: first > last.  Pixel column c's centre lies at px + ((c + 1/2) / W * 2 - 1) half_w, so in the coordinate
+// u = (x - px) kx + W/2 - 1/2, kx = W / (2 half_w), column c sits at u = c and the disc spans u -+ r kx: the columns ceil(low end) .. floor(high end), taken with
+// AG_SCR_BOX_EPS of a pixel either side -- the inside test decides (in world coordinates, from colx[] / rowy[]), the box only has to contain what it accepts,
+// and the two formulations differ by rounding: < 2e-3 pixel even for 1024-pixel frames of a 1000-unit arena.  A tight box is what makes small entities cheap: a
+// pellet seen by a mass-1000 agent has a radius of 0.43 pixels -- it covers one pixel centre or none (none: the entity is never looked at again), where the
+// box with a whole pixel of margin had nine candidates in three rows, each row a chunk for the agent view's run pass.
+#ifndef AG_SCR_BOX_EPS
+#define AG_SCR_BOX_EPS 0.03125f
+#endif
 __device__ __forceinline__ void scr_box(float x, float y, float r, float px, float py, float kx, float ky, int W, int H, unsigned &bx, unsigned &by) {
   const float ox = (float)W * 0.5f - 0.5f, oy = (float)H * 0.5f - 0.5f, dx = x - px, dy = y - py;
-  int c0 = (int)floorf((dx - r) * kx + ox) - 1, c1 = (int)floorf((dx + r) * kx + ox) + 2;
-  int r0 = (int)floorf((dy - r) * ky + oy) - 1, r1 = (int)floorf((dy + r) * ky + oy) + 2;
+  int c0 = (int)ceilf((dx - r) * kx + ox - AG_SCR_BOX_EPS), c1 = (int)floorf((dx + r) * kx + ox + AG_SCR_BOX_EPS);
+  int r0 = (int)ceilf((dy - r) * ky + oy - AG_SCR_BOX_EPS), r1 = (int)floorf((dy + r) * ky + oy + AG_SCR_BOX_EPS);
   c0 = c0 < 0 ? 0 : c0; c1 = c1 > W - 1 ? W - 1 : c1; r0 = r0 < 0 ? 0 : r0; r1 = r1 > H - 1 ? H - 1 : r1;
   if (c0 > c1 || r0 > r1) { c0 = 1; c1 = 0; r0 = 1; r1 = 0; }
   bx = (unsigned)c0 | ((unsigned)c1 << 16); by = (unsigned)r0 | ((unsigned)r1 << 16);
@@ -496,16 +502,13 @@ template <int TAB, bool AGV> __global__ void __launch_bounds__(256) __attribute_
 #define AG_SCR_LANE_MIN_RGB 6   // (the plain frame's form takes two passes of LDS atomics)
 #endif
       constexpr int LANE_MIN = AGV ? AG_SCR_LANE_MIN : AG_SCR_LANE_MIN_RGB;   // hits of one run from which the lane-parallel form pays
-      // This lane's entity's TIGHT box inside the band: the stored one without its margins (floor(low end) .. floor(high end) + 1 still contains
-      // every pixel the inside test can accept)
+      // this lane's entity's box inside the band
       unsigned tbx, tby;   // first | last << 16 again (only lanes with a non-empty box are ever read)
       unsigned long long hits;
-      { const int c0s = (int)(bx_ & 0xFFFFu), c1s = (int)(bx_ >> 16), r0s = (int)(by_ & 0xFFFFu), r1s = (int)(by_ >> 16);
-        const int c0 = c0s == 0 ? 0 : c0s + 1, c1 = c1s == o.W - 1 ? c1s : c1s - 1;
-        int r0 = r0s == 0 ? 0 : r0s + 1, r1 = r1s == o.H - 1 ? r1s : r1s - 1;
+      { const int c0 = (int)(bx_ & 0xFFFFu), c1 = (int)(bx_ >> 16); int r0 = (int)(by_ & 0xFFFFu), r1 = (int)(by_ >> 16);
         r0 = r0 < row0 ? row0 : r0; r1 = r1 > rlast ? rlast : r1;
         hits = __ballot(in_ && c0 <= c1 && r0 <= r1);
-        tbx = (unsigned)c0 | ((unsigned)c1 << 16); tby = (unsigned)r0 | ((unsigned)r1 << 16); }
+        tbx = bx_; tby = (unsigned)r0 | ((unsigned)r1 << 16); }
       while (hits) {
         // Many hits in one batch -- a line of pellets across the view (tasks 1 and 2 lay 350 of them along a square, one unit apart), a cloud of
         // ejected food, the pellets around a split agent: when their boxes are small every lane paints its own entity, <= 6 x 6 pixels, while the
