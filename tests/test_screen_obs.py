@@ -213,3 +213,25 @@ def test_band_rasteriser_tiny_and_odd_frames(hip_engine_cls, monkeypatch):
             old = eng.screen_obs(W, H, agent_view=av)
             assert np.array_equal(new, old), (W, H, av, float((new != old).mean()))
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(arena_size=350, num_pellets=500, num_viruses=0, mode=6), dict(arena_size=350, num_pellets=500, num_viruses=0, mode=3)])
+def test_band_rasteriser_many_frames_tight_boxes(hip_engine_cls, monkeypatch, cfg):
+    """round 6: entity boxes tight to 1/32 of a pixel (a far pellet covers one pixel centre or none), runs of alike hits painted a lane each, the look-back
+    pixels only on demand -- 768 frames of the paper's task frame and of the 84 x 84 frame at two points of the game against the pixel-wise kernel"""
+    A = 768
+    eng = hip_engine_cls(A, **cfg)
+    eng.seed(None, 4242); eng.reset(reset_ids=True)
+    rng = np.random.RandomState(11)
+    for steps in (5, 50):
+        for t in range(steps):
+            eng.set_actions(rng.uniform(-1, 1, size=(A, 1, 2)).astype(np.float32), rng.randint(0, 3, size=(A, 1)).astype(np.int32)); eng.step()
+        for (W, H, av) in ((128, 128, True), (84, 84, False), (84, 84, True), (128, 128, False)):
+            monkeypatch.delenv("AGARCL_SCREEN_PIXELWISE", raising=False)
+            new = eng.screen_obs(W, H, agent_view=av)
+            monkeypatch.setenv("AGARCL_SCREEN_PIXELWISE", "1")
+            old = eng.screen_obs(W, H, agent_view=av)
+            bad = (new.reshape(A, -1) != old.reshape(A, -1)).any(axis=1)
+            assert not bad.any(), (W, H, av, int(bad.sum()))
+    eng.close()
