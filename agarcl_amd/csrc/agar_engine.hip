@@ -468,9 +468,19 @@ static void poll_stats(agarcl_env *e, bool adapt) {
     if (adapt && steps > 0) {
       const double frac = (double)(uint32_t)(e->h_stat[0] - e->stat_last_total) / ((double)steps * (double)e->d.A);
       // (fused_ok: the batch fits the 2048 wavefronts k_fused keeps resident at its best lane-group size, see agarcl_create)
-      if (e->fused && frac > 0.05) e->fused = false; else if (!e->fused && frac < 0.01) e->fused = e->fused_ok;
-      // the two-kernel step's front launch is pure overhead when it finishes (almost) nothing: mass-1000 modes
-      e->front_off = !e->fused && frac > 0.99;
+      if (e->d.A <= e->kstep_grid) {
+        // Every arena fits ONE round of k_step: the general engine over all of them lasts as long as over the unfinished ones alone -- as long as its slowest
+        // arena -- so the work list buys nothing and the front launch in front of it only costs (the paper's task 1, 4096 arenas: k_quiet 18 + k_step 36 us
+        // against k_step alone 40; tasks 3 / 4 while the agents grow and split: k_fused 9.5 us when nothing is left over, 25-40 when one wavefront has to
+        // complete an arena or two, k_step alone 21).  The single launch pays only while a step usually leaves NO arena unfinished.
+        const double unfinished = frac * (double)e->d.A;   // arenas per step
+        if (e->fused && unfinished > 0.5) e->fused = false; else if (!e->fused && unfinished < 0.1) e->fused = e->fused_ok;   // (the tail of a single launch with one left-over arena: +15-30 us)
+        e->front_off = !e->fused;
+      } else {
+        if (e->fused && frac > 0.05) e->fused = false; else if (!e->fused && frac < 0.01) e->fused = e->fused_ok;
+        // the two-kernel step's front launch is pure overhead when it finishes (almost) nothing: mass-1000 modes
+        e->front_off = !e->fused && frac > 0.99;
+      }
       e->few_unfinished = frac * (double)e->d.A < 64.0;   // k_step's work list is short: a small grid dispatches faster
     }
     e->stat_last_total = e->h_stat[0]; e->stat_last_front = e->stat_req_front;
@@ -499,7 +509,8 @@ static int launch_step(agarcl_env *e, int ticks, int with_env) {
   poll_stats(e, front_ok && !e->fused_fixed);
   // front_off: the statistics say the front part finishes < 1 % of the arena-steps, so its launch is skipped; every 256th
   // step it runs again so that the statistics notice when the arenas have become quiet
-  const int use_q = front_ok && !(e->front_off && !e->fused && (e->step_no & 255) != 0);
+  // (one round of k_step: every 32nd step, the switch back to the single launch is worth noticing early)
+  const int use_q = front_ok && !(e->front_off && !e->fused && (e->step_no & (e->d.A <= e->kstep_grid ? 31 : 255)) != 0);
   if (use_q) e->front_runs++;
   const AgHot hot{e->s.ar, e->s.pl, e->s.cells};
   const bool tiled = e->d.ts_lg != 0;   // (0 or 6, agarcl_create)
