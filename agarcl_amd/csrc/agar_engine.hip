@@ -698,7 +698,9 @@ static int create_env(const agarcl_config *cfg, int32_t num_arenas, int32_t devi
   int npel = cfg->num_pellets;
   if (g.squared) { int pps = (int)(g.W / 2.0f); npel = 4 * pps; }
   d.PC = ((npel > 0 ? npel : 1) + 63) / 64 * 64;
-  d.VC = cfg->cap_viruses > 0 ? cfg->cap_viruses : cfg->num_viruses + 64;
+  // (an arena created without viruses never grows one -- they come from the regeneration target and from feeding an existing virus --: 16 slots, for states
+  // loaded into it, instead of 64; the 768 bytes are what a two-player arena needs to get under 10 KB of LDS, below)
+  d.VC = cfg->cap_viruses > 0 ? cfg->cap_viruses : cfg->num_viruses > 0 ? cfg->num_viruses + 64 : 16;
   // (foods live in LDS during a launch, 16 bytes each: 128 keep the single-player layout within the 10 KB per wavefront that 16 resident
   // wavefronts per CU leave; nominal play stays far below -- <= ~60 ejected foods in 20k-tick mode-6 roll-outs)
   d.FC = cfg->cap_foods > 0 ? cfg->cap_foods : 128;
@@ -727,6 +729,13 @@ static int create_env(const agarcl_config *cfg, int32_t num_arenas, int32_t devi
   // ejected foods live in LDS during a launch, 16 bytes each: 128 keep the single-player layout within the 10 KB per wavefront that 16 resident
   // wavefronts per CU leave (nominal play: <= ~60 in 20k-tick mode-6 roll-outs); arenas with many players feed more: 16 per player
   if (cfg->cap_foods <= 0 && d.P * 16 > d.FC) d.FC = d.P * 16;
+  // 16 arenas per compute unit -- 4096 resident at once, one round of k_step -- need <= 10 240 bytes of LDS each.  An arena a few hundred bytes above that
+  // (agent + 1 bot, the paper's tasks 7-10: 10 576) runs 4096 arenas as 3840 + a second round: 52.9 us per step against 38.5 at 3584 arenas.  Its default food
+  // capacity gives the difference back (128 -> 107 there; at most 32 slots, never below 96; an explicit cap_foods is left alone): 39.3 us.
+  if (cfg->cap_foods <= 0) {
+    const long over = (long)ag_lds_layout(d.P, d.VC, d.FC, d.EC, d.KC, nullptr) - 10240;
+    if (over > 0 && over <= 16 * 32 && d.FC - (int)((over + 15) / 16) >= 96) d.FC -= (int)((over + 15) / 16);
+  }
   e->d = d; e->g = g;
   e->lds_bytes = ag_lds_layout(d.P, d.VC, d.FC, d.EC, d.KC, nullptr);
   e->all_vis = g.pgw <= 2 && g.pgh <= 2;

@@ -30,6 +30,11 @@ def run(tag, A, K=60, ticks=4, tick_only=False, **cfg):
     for n, v in zip(names, per): print('   %-22s %8.0f  %5.1f%%' % (n, v, 100 * v / per.sum()))
     print('   mean counts (pellets, viruses, foods, cells):', eng.counts().mean(axis=0))
     eng.close()
+if os.environ.get('PHASE_LIGHT'):   # round 6: light single-player arenas through the general engine (run with AGARCL_NO_FRONT=1), the paper's tasks 1, 3, 7
+    run('task3 (mode 3)', 4096, K=100, arena_size=350, num_pellets=500, num_viruses=0, mode=3)
+    run('task1 (mode 1)', 4096, K=100, arena_size=350, num_pellets=500, num_viruses=0, mode=1)
+    run('task7 (mode 7 + bot)', 4096, K=100, arena_size=350, num_pellets=500, num_viruses=0, num_bots=1, mode=7)
+    sys.exit(0)
 if os.environ.get('PHASE_BIG'):   # round 6: the configurations scripts/gpu_config_sweep.py found slow
     run('normal + 25 bots', 4096, K=20, num_agents=1, arena_size=1000, num_pellets=1000, num_viruses=0, num_bots=25, mode=0)
     run('3 agents mode 6', 4096, K=20, num_agents=3, arena_size=1000, num_pellets=1000, num_viruses=25, mode=6)
