@@ -748,10 +748,6 @@ def main():
     # more hardware queues than the runtime's default 4, so that sub-batch streams (agarcl_pipe_*) find queues of their own beside torch's
     # streams; must be in the environment before the first HIP call (read by the HIP runtime, nothing else)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    if os.environ.get("AGARCL_BENCH_SPIN") == "1":   # (experiment, scripts/gpu_sync_edge.sh: the host spins in synchronize() instead of blocking on the completion signal)
-        import ctypes
-        _hip = ctypes.CDLL("libamdhip64.so"); _rc = _hip.hipSetDeviceFlags(ctypes.c_uint(1))   # hipDeviceScheduleSpin
-        sys.stderr.write("hipSetDeviceFlags(spin) rc=%d\n" % _rc)
     import torch
     import numpy as np
     rank = int(os.environ.get("RANK", "0"))
