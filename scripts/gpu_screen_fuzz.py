@@ -10,7 +10,7 @@ A = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 CONFIGS = (dict(arena_size=350, num_pellets=500, num_viruses=0, mode_number=3), dict(arena_size=350, num_pellets=500, num_viruses=0, mode_number=1),
            dict(arena_size=350, num_pellets=500, num_viruses=0, mode_number=6), dict(arena_size=1000, num_pellets=1000, num_viruses=25, mode_number=6),
            dict(arena_size=120, num_pellets=400, num_viruses=6, mode_number=6), dict(arena_size=250, num_pellets=250, num_viruses=10, mode_number=0, num_bots=4),
-           dict(arena_size=80, num_pellets=64, num_viruses=25, mode_number=6), dict(arena_size=1500, num_pellets=1200, num_viruses=40, mode_number=5))
+           dict(arena_size=80, num_pellets=64, num_viruses=25, mode_number=6), dict(arena_size=900, num_pellets=1200, num_viruses=40, mode_number=5))
 SHAPES = ((128, 128), (84, 84), (96, 72), (64, 200), (256, 256), (37, 53), (8, 8), (512, 384), (130, 66))
 bad_total = 0
 for ci, cfg in enumerate(CONFIGS):
