@@ -53,8 +53,9 @@ typedef struct agarcl_config {
   int32_t mode_number;    /* Engine.hpp:367-416 */
   double dt;              /* seconds per tick; 0 -> DEFAULT_DT = 1/30 (BaseEnvironment.hpp:14) */
   int32_t cap_cells;      /* cells per player, 0 -> 32 (reference: unbounded vector, nominal limit 14) */
-  int32_t cap_viruses;    /* 0 -> num_viruses + 64 */
-  int32_t cap_foods;      /* 0 -> max(128, 16 per player) (ejected foods live in LDS during a launch: 16 bytes each) */
+  int32_t cap_viruses;    /* 0 -> num_viruses + 64; 16 when num_viruses == 0 (such an arena never grows a virus; a state LOADED into it may bring up to 16) */
+  int32_t cap_foods;      /* 0 -> max(128, 16 per player), less up to 32 where that puts an arena's LDS block under 10 240 bytes = 16 arenas per compute unit
+                           *      (agent + 1 bot: 107) (ejected foods live in LDS during a launch: 16 bytes each) */
   /* ScreenEnvironment semantics (environment/envs/ScreenEnvironment.hpp:233-243): a dead agent is respawned right
    * after the ticks of a step in EVERY mode, and that step's rewards get + c_death (BaseEnvironment.hpp:116-120) */
   int32_t screen_respawn;
